@@ -1,0 +1,275 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Dev-container tool: needs /root/reference (read-only) and is never run on the GPU box.  It imports
+the reference through `_ref_shim`, feeds it deterministic synthetic inputs (graphs, feature
+tables and parameters all come from seeded numpy legacy streams via `oracle/` helpers, so the
+fixtures store only the reference's OUTPUTS plus the small inputs that are not re-derivable), and
+writes `*.npz` files.  Run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_shim  # noqa: E402
+
+_ref_shim.install()
+
+import networkx as nx  # noqa: E402
+from pmgt.optimizers import DenseSparseAdamW  # noqa: E402  (reference)
+from pmgt.pmgt.configuration_pmgt import PMGTConfig  # noqa: E402
+from pmgt.pmgt.datasets import PMGTDataset, _sample_context_neigh, pmgt_collate_fn  # noqa: E402
+from pmgt.pmgt.models import PMGT  # noqa: E402
+
+from oracle import pmgt_oracle as po  # noqa: E402
+from oracle import sampler_oracle as so  # noqa: E402
+
+BIG = 3000           # tensors above this many elements are stored strided (+ their L2 norm)
+STRIDE = 37
+
+
+def build_nx(n_nodes, edges, weights):
+    g = nx.Graph()
+    g.add_nodes_from(range(2, n_nodes + 2))
+    for (u, v), w in zip(edges.tolist(), weights.tolist()):
+        g.add_edge(u, v, weight=w)
+    return g
+
+
+GRAPHS = {
+    "A": dict(n=60, e=200, seed=1),
+    "B": dict(n=40, e=44, seed=2),      # sparse: contexts get padded
+    "C": dict(n=300, e=1500, seed=3),
+}
+
+
+def graph(name):
+    spec = GRAPHS[name]
+    edges, w = so.synth_graph(spec["n"], spec["e"], spec["seed"])
+    return spec["n"], edges, w, build_nx(spec["n"], edges, w)
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+def collated_to_np(prefix, coll, out):
+    tgt, pair, num_pairs, labels = coll
+    out[prefix + "tgt_ids"] = t2n(tgt["node_ids"])
+    out[prefix + "tgt_mask"] = t2n(tgt["attention_mask"])
+    out[prefix + "pair_ids"] = t2n(pair["node_ids"])
+    out[prefix + "pair_mask"] = t2n(pair["attention_mask"])
+    out[prefix + "num_pairs"] = t2n(num_pairs)
+    out[prefix + "labels"] = t2n(labels)
+
+
+# ------------------------------------------------------------------------------------------
+# G1: sampler
+# ------------------------------------------------------------------------------------------
+def make_sampler():
+    for gname in ("A", "B", "C"):
+        n, edges, w, g = graph(gname)
+        out = {"edges": edges, "weights": w, "n_nodes": np.int64(n)}
+        for S in (6, 16, 32):
+            for seed in (0, 1, 2):
+                key = f"S{S}_seed{seed}_"
+                # raw contexts
+                np.random.seed(seed)
+                ctxs, nums = [], []
+                for t in range(2, 2 + 8):
+                    c, k = _sample_context_neigh(g, t, [16, 8, 4], S - 1)
+                    ctxs.append(c)
+                    nums.append(k)
+                out[key + "ctx"] = np.array(ctxs, dtype=np.int64)
+                out[key + "num_ctx"] = np.array(nums, dtype=np.int64)
+                idx = [0, 5, 7, n - 1, 3, 11]
+                node_ids = np.arange(2, n + 2)
+                # training items
+                np.random.seed(seed)
+                ds = PMGTDataset(g, node_ids, max_ctx_neigh=S - 1)
+                collated_to_np(key + "train_", pmgt_collate_fn([ds[i] for i in idx]), out)
+                # eval items
+                np.random.seed(seed)
+                ds = PMGTDataset(g, node_ids, max_ctx_neigh=S - 1, is_training=False)
+                collated_to_np(key + "eval_", pmgt_collate_fn([ds[i] for i in idx]), out)
+                # inference items
+                np.random.seed(seed)
+                ds = PMGTDataset(g, max_ctx_neigh=S - 1, is_training=False, is_inference=True)
+                inf = pmgt_collate_fn([ds[i] for i in idx])
+                out[key + "inf_ids"] = t2n(inf["node_ids"])
+                out[key + "inf_mask"] = t2n(inf["attention_mask"])
+        out["idx"] = np.array([0, 5, 7, n - 1, 3, 11], dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, f"sampler_{gname}.npz"), **out)
+        print("sampler", gname, "ok")
+
+    # G7: train_test_split partitions (pmgt/pmgt/trainer.py:45-52)
+    from sklearn.model_selection import train_test_split
+    out = {}
+    for n, vs, seed in ((301, 0.2, 0), (7252, 0.2, 0), (10834, 0.1, 3)):
+        tr, va = train_test_split(np.arange(2, n + 2), test_size=vs, random_state=seed)
+        k = f"n{n}_v{vs}_s{seed}_"
+        out[k + "train_head"] = tr[:64]
+        out[k + "valid_head"] = va[:64]
+        out[k + "train_sha"] = np.frombuffer(hashlib.sha256(tr.astype(np.int64).tobytes()).digest(), dtype=np.uint8)
+        out[k + "valid_sha"] = np.frombuffer(hashlib.sha256(va.astype(np.int64).tobytes()).digest(), dtype=np.uint8)
+        out[k + "sizes"] = np.array([len(tr), len(va)])
+    np.savez_compressed(os.path.join(HERE, "split.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
+# G2-G5: model
+# ------------------------------------------------------------------------------------------
+MODEL_CASES = {
+    # name: (graph, cfg kwargs, S, B, sampler seed, param seed)
+    "m1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5), 16, 4, 0, 11),
+    "m1_beta1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=1.0), 16, 4, 0, 11),
+    "m1_beta0": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.0), 16, 4, 0, 11),
+    "m1_pad": ("B", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5), 16, 4, 1, 12),
+    "m2": ("A", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, beta=0.5), 16, 3, 2, 13),
+    "m3": ("C", dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256, beta=0.5), 32, 2, 3, 14),
+    "m4": ("C", dict(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, intermediate_size=512, beta=0.3), 6, 5, 4, 15),
+}
+
+
+def ref_model(n, cfgkw, pseed, tseed=77):
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfgkw)
+    rcfg = PMGTConfig(**{k: v for k, v in cfg.items()})
+    tables = po.synth_tables(n, cfg["feat_hidden_sizes"], tseed)
+    model = PMGT(node_size=n, config=rcfg, feat_init_emb=[t.numpy() for t in tables])
+    params = po.synth_params(cfg, pseed)
+    sd = model.state_dict()
+    for k, v in params.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k].copy_(v)
+    names = [nme for nme, p in model.named_parameters() if p.requires_grad]
+    assert names == [nme for nme, _ in po.param_shapes(cfg)], "param order differs from reference"
+    return cfg, model, tables
+
+
+def store(out, key, arr):
+    a = np.ascontiguousarray(arr)
+    if a.size > BIG:
+        out[key + "@strided"] = a.ravel()[::STRIDE].copy()
+        out[key + "@norm"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    else:
+        out[key] = a
+
+
+def draw_nfr(seed, ids, n):
+    """Replay the three draws PMGT.forward makes (pmgt/pmgt/models.py:135-147) for torch seed."""
+    torch.manual_seed(seed)
+    B, S = ids.shape
+    r1 = torch.rand(B, S - 1)
+    m1 = (r1 < 0.02) * (ids[:, 1:] != 0)
+    repl = torch.randint(2, n + 2, (int(m1.sum()),))
+    r2 = torch.rand(B, S - 1)
+    return r1, repl, r2
+
+
+def make_model():
+    for name, (gname, cfgkw, S, B, sseed, pseed) in MODEL_CASES.items():
+        n, edges, w, g = graph(gname)
+        cfg, model, tables = ref_model(n, cfgkw, pseed)
+        out = {"S": np.int64(S), "B": np.int64(B), "graph": np.array(gname), "pseed": np.int64(pseed),
+               "tseed": np.int64(77)}
+        np.random.seed(sseed)
+        ds = PMGTDataset(g, np.arange(2, n + 2), max_ctx_neigh=S - 1)
+        idx = np.random.RandomState(sseed + 100).choice(n, B, replace=False)
+        out["idx"] = idx
+        batch = pmgt_collate_fn([ds[int(i)] for i in idx])
+        collated_to_np("b_", batch, out)
+
+        # ---- eval forward (G3) + module-level (G2)
+        model.eval()
+        with torch.no_grad():
+            o = model(*batch, output_attentions=True, output_hidden_states=True)
+        out["eval_loss"] = t2n(o.loss)
+        out["eval_logits"] = t2n(o.prediction_logits)
+        full = name == "m1"           # one case keeps every module output in full
+        keep = (lambda k, a: out.__setitem__(k, a)) if full else (lambda k, a: store(out, k, a))
+        keep("eval_last_hidden", t2n(o.last_hidden_state))
+        for i, hs in enumerate(o.hidden_states):
+            keep(f"eval_hidden_{i}", t2n(hs))
+        for i, at in enumerate(o.attentions):
+            keep(f"eval_attn_{i}", t2n(at))
+        with torch.no_grad():
+            inf = model(batch[0])                      # inference path: loss None → [0] is hidden
+        out["inf_cls"] = t2n(inf[0][:, 0])
+
+        # ---- train forward/backward with captured NFR draws (G4)
+        model.train()
+        model.zero_grad()
+        nseed = 1000 + pseed
+        torch.manual_seed(nseed)
+        o = model(*batch)
+        o.loss.backward()
+        r1, repl, r2 = draw_nfr(nseed, batch[0]["node_ids"], n)
+        out["nfr_r1"], out["nfr_repl"], out["nfr_r2"] = t2n(r1), t2n(repl), t2n(r2)
+        out["train_loss"] = t2n(o.loss)
+        out["train_logits"] = t2n(o.prediction_logits)
+        # gsr part = eval loss on same batch (dropout 0) → nfr = loss - gsr
+        for nme, p in model.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None, nme
+                store(out, "grad/" + nme, t2n(p.grad))
+
+        # ---- optimizer steps (G5): clip 5.0 + DenseSparseAdamW(lr 1e-3, wd 1e-2), same batch,
+        #      NFR draws re-seeded per step.
+        no_decay = ["bias", "LayerNorm.weight"]
+        groups = [
+            {"params": [p for nme, p in model.named_parameters() if p.requires_grad and not any(nd in nme for nd in no_decay)],
+             "weight_decay": 1e-2, "lr": 1e-3},
+            {"params": [p for nme, p in model.named_parameters() if p.requires_grad and any(nd in nme for nd in no_decay)],
+             "weight_decay": 0.0, "lr": 1e-3},
+        ]
+        opt = DenseSparseAdamW(groups)
+        nsteps = 6 if name != "m3" else 3
+        losses, norms = [], []
+        draws = []
+        for step in range(nsteps):
+            model.zero_grad()
+            torch.manual_seed(2000 + step)
+            o = model(*batch)
+            o.loss.backward()
+            r1, repl, r2 = draw_nfr(2000 + step, batch[0]["node_ids"], n)
+            draws.append((t2n(r1), t2n(repl), t2n(r2)))
+            tn = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 5.0)
+            opt.step()
+            losses.append(float(o.loss))
+            norms.append(float(tn))
+        out["opt_losses"] = np.array(losses, dtype=np.float64)
+        out["opt_gradnorms"] = np.array(norms, dtype=np.float64)
+        for s, (a, b, c) in enumerate(draws):
+            out[f"opt_r1_{s}"], out[f"opt_repl_{s}"], out[f"opt_r2_{s}"] = a, b, c
+        for nme, p in model.named_parameters():
+            if p.requires_grad:
+                store(out, "final/" + nme, t2n(p))
+        np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
+        print("model", name, "eval", float(out["eval_loss"]), "train", float(out["train_loss"]), losses)
+
+    # ---- G6: init statistics of a fresh reference model (pmgt/pmgt/modeling_pmgt.py:44-58)
+    torch.manual_seed(0)
+    cfg = po.default_cfg(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128)
+    tables = po.synth_tables(60, cfg["feat_hidden_sizes"], 77)
+    model = PMGT(node_size=60, config=PMGTConfig(**cfg), feat_init_emb=[t.numpy() for t in tables])
+    out = {}
+    for nme, p in model.named_parameters():
+        if p.requires_grad:
+            out["mean/" + nme] = np.float64(p.mean().item())
+            out["std/" + nme] = np.float64(p.std().item()) if p.numel() > 1 else np.float64(0)
+            out["absmax/" + nme] = np.float64(p.abs().max().item())
+    np.savez_compressed(os.path.join(HERE, "init_stats.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_sampler()
+    make_model()
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print("total fixture bytes", tot)

@@ -1,0 +1,71 @@
+"""Helpers shared by the parity tests: rebuild the deterministic inputs that the golden fixtures
+were generated from (tests/golden/make_golden.py) and unpack stored reference outputs."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import pmgt_oracle as po
+from oracle import sampler_oracle as so
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STRIDE = 37
+
+GRAPHS = {"A": dict(n=60, e=200, seed=1), "B": dict(n=40, e=44, seed=2), "C": dict(n=300, e=1500, seed=3)}
+
+MODEL_CASES = {
+    "m1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)),
+    "m1_beta1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=1.0)),
+    "m1_beta0": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.0)),
+    "m1_pad": ("B", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)),
+    "m2": ("A", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, beta=0.5)),
+    "m3": ("C", dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256, beta=0.5)),
+    "m4": ("C", dict(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, intermediate_size=512, beta=0.3)),
+}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def graph(gname):
+    spec = GRAPHS[gname]
+    edges, w = so.synth_graph(spec["n"], spec["e"], spec["seed"])
+    return spec["n"], edges, w
+
+
+def model_case(name, dtype=torch.float32):
+    """→ dict(cfg, params, tables, batch, n_nodes, gold)"""
+    gname, cfgkw = MODEL_CASES[name]
+    gold = load("model_" + name)
+    n = GRAPHS[gname]["n"]
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfgkw)
+    params = po.synth_params(cfg, int(gold["pseed"]), dtype)
+    tables = po.synth_tables(n, cfg["feat_hidden_sizes"], int(gold["tseed"]), dtype)
+    batch = batch_from(gold, "b_")
+    return dict(cfg=cfg, params=params, tables=tables, batch=batch, n_nodes=n, gold=gold, name=name)
+
+
+def batch_from(gold, prefix):
+    tgt = {"node_ids": torch.from_numpy(gold[prefix + "tgt_ids"]),
+           "attention_mask": torch.from_numpy(gold[prefix + "tgt_mask"])}
+    pair = {"node_ids": torch.from_numpy(gold[prefix + "pair_ids"]),
+            "attention_mask": torch.from_numpy(gold[prefix + "pair_mask"])}
+    return tgt, pair, torch.from_numpy(gold[prefix + "num_pairs"]), torch.from_numpy(gold[prefix + "labels"])
+
+
+def nfr_inject(gold, ids, n_nodes, prefix="nfr_", suffix=""):
+    r1 = torch.from_numpy(gold[prefix + "r1" + suffix])
+    repl = torch.from_numpy(gold[prefix + "repl" + suffix])
+    r2 = torch.from_numpy(gold[prefix + "r2" + suffix])
+    return po.nfr_masking(ids, n_nodes, r1, repl, r2)
+
+
+def check_stored(gold, key, arr, rtol, atol):
+    """Compare `arr` with a fixture entry stored either in full or strided (+L2 norm)."""
+    a = np.asarray(arr, dtype=np.float64)
+    if key in gold.files:
+        np.testing.assert_allclose(a, gold[key], rtol=rtol, atol=atol, err_msg=key)
+    else:
+        np.testing.assert_allclose(a.ravel()[::STRIDE], gold[key + "@strided"], rtol=rtol, atol=atol, err_msg=key)
+        np.testing.assert_allclose(np.sqrt((a ** 2).sum()), float(gold[key + "@norm"]), rtol=max(rtol, 1e-5), err_msg=key)
