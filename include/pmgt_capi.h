@@ -1,0 +1,195 @@
+/*
+ * pmgt_capi.h — C ABI of the MI355X-native PMGT pre-training engine (libpmgt_hip.so) and of the
+ * host MCNSampling library (libpmgt_sampler.so).
+ *
+ * The reference (uoo723/PMGT) is pure Python and has no FFI of its own; this ABI is what a
+ * maintainer binds (ctypes) behind the reference's Python surface.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes only (no torch types); all tensor memory is owned by the
+ * caller (device pointers unless stated); row-major contiguous; int64 ids, fp32 masks, nn.Linear
+ * weights as [out, in]; every call is asynchronous on the given hipStream_t (passed as void*), never
+ * synchronises, never throws; returns 0 or a negative code, message via pmgt_last_error().
+ */
+#ifndef PMGT_CAPI_H
+#define PMGT_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMGT_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define PMGT_DTYPE_BF16 1 /* perf mode: bf16 activations/weight copies, fp32 accumulate + master weights */
+
+/* Mirrors PMGTConfig (pmgt/pmgt/configuration_pmgt.py:11-41). */
+typedef struct pmgt_config {
+    int hidden_size;
+    int num_hidden_layers;
+    int num_attention_heads;
+    int intermediate_size;
+    int feat_size_v; /* feat_hidden_sizes[0] (visual, 1536) */
+    int feat_size_t; /* feat_hidden_sizes[1] (textual, 768) */
+    int max_position_embeddings;
+    float layer_norm_eps;
+    float beta;
+    float hidden_dropout_prob;
+    float attention_probs_dropout_prob;
+    int dtype; /* PMGT_DTYPE_* */
+} pmgt_config;
+
+typedef struct pmgt_engine pmgt_engine;
+
+const char* pmgt_last_error(void);
+int pmgt_abi_version(void);
+
+/* ---- engine lifetime & parameter layout ---------------------------------------------------------
+ * Replaces PMGT.__init__ / PMGTModel.__init__ module construction (pmgt/pmgt/models.py:22-54,
+ * pmgt/pmgt/modeling_pmgt.py:65-74,155-187,213-220,287-294,378-410,549-558): parameters live in ONE
+ * flat fp32 buffer; pmgt_param_entry() reports where each reference-named tensor sits in it. */
+pmgt_engine* pmgt_engine_create(const pmgt_config* cfg);
+void pmgt_engine_destroy(pmgt_engine* e);
+int64_t pmgt_param_count(const pmgt_engine* e);
+int pmgt_param_num_entries(const pmgt_engine* e);
+/* name: reference state_dict key (e.g. "bert.encoder.layer.0.attention.self.query.weight");
+ * offset/numel in floats; rows/cols (cols = 0 for vectors); decay = 1 if AdamW weight decay applies
+ * (pmgt/base_trainer.py:38-59). */
+int pmgt_param_entry(const pmgt_engine* e, int index, char* name, int name_cap, int64_t* offset, int64_t* numel,
+                     int* rows, int* cols, int* decay);
+/* bytes of scratch the calls below need for n_seq sequences of seq_len tokens (n_targets of them targets). */
+int64_t pmgt_workspace_bytes(const pmgt_engine* e, int n_seq, int seq_len, int n_targets, int training);
+
+/* persistent device tensors owned by the caller */
+typedef struct pmgt_tensors {
+    float* params;       /* [pmgt_param_count] fp32 master weights */
+    float* grads;        /* same shape; written (or accumulated) by pmgt_pretrain_step */
+    const void* table_v; /* [n_nodes + 2, feat_size_v] frozen features in the engine dtype (models.py:40-54) */
+    const void* table_t; /* [n_nodes + 2, feat_size_t] */
+    int64_t n_nodes;
+    uint64_t* rng_state; /* device [2]: {seed, step}; drives dropout + NFR masking */
+} pmgt_tensors;
+
+/* One collated batch, exactly what pmgt_collate_fn returns (pmgt/pmgt/datasets.py:186-208). */
+typedef struct pmgt_batch {
+    int n_targets;            /* B */
+    int n_pairs;              /* sum(num_pairs) */
+    int seq_len;              /* S = max_ctx_neigh + 1 */
+    const int64_t* tgt_ids;   /* [B, S] */
+    const float* tgt_mask;    /* [B, S] */
+    const int64_t* pair_ids;  /* [P, S] (NULL with n_pairs = 0: inference) */
+    const float* pair_mask;   /* [P, S] */
+    const int64_t* num_pairs; /* [B] */
+    const float* labels;      /* [P] */
+    /* optional injected NFR masking (parity tests): masked ids and, per position, the id to
+     * reconstruct (-1 = not masked).  NULL = draw on device (pmgt/pmgt/models.py:132-151). */
+    const int64_t* nfr_masked_ids; /* [B, S] */
+    const int64_t* nfr_targets;    /* [B, S] */
+    float random_node_ratio;
+    float mask_node_ratio;
+} pmgt_batch;
+
+typedef struct pmgt_outputs {
+    float* loss;       /* device [3]: loss, gsr, nfr */
+    float* logits;     /* device [P] prediction_logits */
+    void* last_hidden; /* device [B, S, d] in the engine dtype (target sequences), nullable */
+    int* nfr_count;    /* device [1], nullable: number of masked positions */
+} pmgt_outputs;
+
+#define PMGT_FLAG_TRAINING 1   /* dropout + NFR branch (module.training) */
+#define PMGT_FLAG_BACKWARD 2   /* also compute parameter gradients */
+#define PMGT_FLAG_ACCUMULATE 4 /* grads += instead of grads = */
+
+/* PMGT.forward + loss.backward() of one batch (pmgt/pmgt/models.py:56-176; trainer step
+ * pmgt/pmgt/trainer.py:156-160). */
+int pmgt_pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* b, const pmgt_outputs* o,
+                       void* workspace, int64_t workspace_bytes, int flags, void* stream);
+
+/* PMGTModel.forward on node ids (gather fused): inference/export path
+ * (pmgt/pmgt/modeling_pmgt.py:80-152, pmgt/pmgt/trainer.py:153-154).  hidden_states: optional
+ * [L+1, n_seq, S, d]; attn_probs: optional [L, n_seq, H, S, S] fp32 (output_attentions). */
+int pmgt_encode_ids(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const float* mask, int n_seq,
+                    int seq_len, void* last_hidden, void* hidden_states, float* attn_probs, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+/* PMGTModel.forward(*input_feat_embeds) on already-gathered features [n_seq, S, F_m] in the engine dtype. */
+int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t,
+                      const float* mask, int n_seq, int seq_len, void* last_hidden, void* hidden_states,
+                      float* attn_probs, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Global-norm clip + DenseSparseAdamW dense step over the flat buffers
+ * (pmgt/base_trainer.py:312-315, pmgt/optimizers.py:256-270). */
+typedef struct pmgt_adam {
+    float* exp_avg;       /* [count] */
+    float* exp_avg_sq;    /* [count] */
+    const uint8_t* decay; /* [count] 1 where weight decay applies */
+    float lr, weight_decay, beta1, beta2, eps;
+    float max_grad_norm; /* <= 0: no clipping */
+    int64_t* step;       /* device [1] */
+    float* scalars;      /* device [4] out: clip coef, lr/bc1, 1/sqrt(bc2), grad norm */
+    float* scratch;      /* device [1024] */
+} pmgt_adam;
+int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* a, void* stream);
+
+/* dtype plumbing */
+int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
+int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);
+
+/* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
+int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
+                    int64_t ldc, int M, int N, int K, const float* bias, int epilogue, void* aux, int64_t ldaux,
+                    const void* residual, int64_t ldr, float drop_p, uint32_t drop_site, const uint64_t* rng,
+                    const int* m_dev, void* stream);
+int64_t pmgt_op_gemm_tn_slab_elems(int dtype, int M, int N1, int N2);
+int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, const int64_t* q_rows, int M,
+                    int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream);
+int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream);
+int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const float* gamma, const float* beta,
+                          int M, int d, float eps, float drop_p, uint32_t drop_site, const uint64_t* rng, void* stream);
+int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                          void* dx_drop, float* part, float* dgamma_dbeta, int M, int d, float in_drop_p,
+                          uint32_t in_site, float out_drop_p, uint32_t out_site, const uint64_t* rng, void* stream);
+int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,
+                          int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                          const uint64_t* rng, void* stream);
+int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq,
+                          int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                          const uint64_t* rng, void* stream);
+
+/* ---- host MCNSampling (libpmgt_sampler.so; pure host code, no HIP) --------------------------------
+ * Replaces _sample_context_neigh / get_input_tensor / PMGTDataset.__getitem__ / pmgt_collate_fn
+ * (pmgt/pmgt/datasets.py:14-208).  The graph is an ordered adjacency in CSR form: node ids 2..N+1
+ * (0 = <pad>, 1 = <mask>), indptr has N+3 entries (rows 0 and 1 empty), neighbours in networkx
+ * insertion order, float64 edge weights. */
+typedef struct pmgt_sampler pmgt_sampler;
+pmgt_sampler* pmgt_sampler_create(int64_t n_nodes, const int64_t* indptr, const int64_t* indices,
+                                  const double* weights, const int* hop_sizes, int n_hops, int max_ctx_neigh,
+                                  int max_total_samples, int min_neg_samples);
+void pmgt_sampler_destroy(pmgt_sampler* s);
+const char* pmgt_sampler_last_error(void);
+/* np.random.seed(seed) of the reference's process-global legacy MT19937 stream (pmgt/utils/base.py:37). */
+void pmgt_sampler_seed(pmgt_sampler* s, uint32_t seed);
+/* One context: ids[S] (target first), mask[S]; returns num_ctx or <0 (datasets.py:64-79). */
+int pmgt_sampler_context(pmgt_sampler* s, int64_t target, int64_t* ids, float* mask);
+/* Collated batch in dataset order from ONE sequential stream (bit-exact with the reference run with
+ * num_workers=0).  mode: 0 train, 1 eval, 2 inference.  pair buffers sized n*max_pairs(mode) rows.
+ * Returns total pairs or <0. */
+int pmgt_sampler_batch(pmgt_sampler* s, const int64_t* targets, int n, int mode, int64_t* tgt_ids, float* tgt_mask,
+                       int64_t* pair_ids, float* pair_mask, int64_t* num_pairs, float* labels);
+/* Same batch layout, sampled by n_threads host threads; every target gets its own stream seeded from
+ * (base_seed, counter), so results do not depend on the thread count (statistical, not bit, parity
+ * with the reference — the reference's own worker streams depend on the torch version). */
+int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mode, uint64_t base_seed,
+                          uint64_t counter, int n_threads, int64_t* tgt_ids, float* tgt_mask, int64_t* pair_ids,
+                          float* pair_mask, int64_t* num_pairs, float* labels);
+int pmgt_sampler_max_pairs(const pmgt_sampler* s, int mode);
+/* legacy-stream primitives exposed for tests */
+double pmgt_sampler_random_sample(pmgt_sampler* s);
+int64_t pmgt_sampler_randint(pmgt_sampler* s, int64_t n);
+/* sklearn train_test_split(arange(2, N+2), test_size, random_state=seed) (pmgt/pmgt/trainer.py:45-52) */
+int pmgt_train_valid_split(int64_t n_nodes, double valid_size, uint32_t seed, int64_t* train_out, int64_t* valid_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMGT_CAPI_H */

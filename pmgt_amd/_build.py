@@ -1,0 +1,79 @@
+"""In-tree build of the native libraries (gfx950 only).
+
+  pmgt_amd/lib/libpmgt_hip.so      HIP kernels + engine + C ABI   (hipcc --offload-arch=gfx950)
+  pmgt_amd/lib/libpmgt_sampler.so  host MCNSampling               (g++)
+
+hipcc cross-compiles without a GPU, so this runs in the dev container; the built .so files travel
+to the GPU box with the repo snapshot (they are git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+HIP_SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "loss.hip", "optim.hip", "engine.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+
+
+def hip_lib_path():
+    return os.path.join(LIB, "libpmgt_hip.so")
+
+
+def sampler_lib_path():
+    return os.path.join(LIB, "libpmgt_sampler.so")
+
+
+def build_hip(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "pmgt_capi.h"))
+    jobs, objs = [], []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj])
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(_run, jobs))
+    out = hip_lib_path()
+    if force or jobs or _newer(out, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
+def build_sampler(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    src = os.path.join(CSRC, "sampler.cpp")
+    out = sampler_lib_path()
+    hdr = os.path.join(os.path.dirname(HERE), "include", "pmgt_capi.h")
+    if force or _newer(out, [src, hdr]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
+    return out
+
+
+def build_all(force=False):
+    return build_hip(force), build_sampler(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

@@ -1,0 +1,144 @@
+"""ctypes bindings of include/pmgt_capi.h.
+
+The HIP library is the ONLY compute path of this package: if it is missing or cannot be loaded the
+import of anything that needs it raises — there is no eager/PyTorch or CPU fallback.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.POINTER(C.c_float)
+
+
+class PMGTConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int), ("num_hidden_layers", C.c_int), ("num_attention_heads", C.c_int),
+                ("intermediate_size", C.c_int), ("feat_size_v", C.c_int), ("feat_size_t", C.c_int),
+                ("max_position_embeddings", C.c_int), ("layer_norm_eps", C.c_float), ("beta", C.c_float),
+                ("hidden_dropout_prob", C.c_float), ("attention_probs_dropout_prob", C.c_float), ("dtype", C.c_int)]
+
+
+class TensorsC(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("table_v", C.c_void_p), ("table_t", C.c_void_p),
+                ("n_nodes", C.c_int64), ("rng_state", C.c_void_p)]
+
+
+class BatchC(C.Structure):
+    _fields_ = [("n_targets", C.c_int), ("n_pairs", C.c_int), ("seq_len", C.c_int),
+                ("tgt_ids", C.c_void_p), ("tgt_mask", C.c_void_p), ("pair_ids", C.c_void_p), ("pair_mask", C.c_void_p),
+                ("num_pairs", C.c_void_p), ("labels", C.c_void_p), ("nfr_masked_ids", C.c_void_p),
+                ("nfr_targets", C.c_void_p), ("random_node_ratio", C.c_float), ("mask_node_ratio", C.c_float)]
+
+
+class OutputsC(C.Structure):
+    _fields_ = [("loss", C.c_void_p), ("logits", C.c_void_p), ("last_hidden", C.c_void_p), ("nfr_count", C.c_void_p)]
+
+
+class AdamC(C.Structure):
+    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("decay", C.c_void_p),
+                ("lr", C.c_float), ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("max_grad_norm", C.c_float), ("step", C.c_void_p), ("scalars", C.c_void_p),
+                ("scratch", C.c_void_p)]
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+FLAG_TRAINING, FLAG_BACKWARD, FLAG_ACCUMULATE = 1, 2, 4
+EPI_NONE, EPI_GELU, EPI_GELU_GRAD = 0, 1, 2
+
+# every symbol include/pmgt_capi.h declares for libpmgt_hip.so
+HIP_SYMBOLS = [
+    "pmgt_last_error", "pmgt_abi_version", "pmgt_engine_create", "pmgt_engine_destroy", "pmgt_param_count",
+    "pmgt_param_num_entries", "pmgt_param_entry", "pmgt_workspace_bytes", "pmgt_pretrain_step", "pmgt_encode_ids",
+    "pmgt_encode_feats", "pmgt_optimizer_step", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_op_gemm_nt",
+    "pmgt_op_gemm_tn_slab_elems", "pmgt_op_gemm_tn", "pmgt_op_colsum", "pmgt_op_layernorm_fwd",
+    "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd",
+]
+SAMPLER_SYMBOLS = [
+    "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
+    "pmgt_sampler_context", "pmgt_sampler_batch", "pmgt_sampler_batch_mt", "pmgt_sampler_max_pairs",
+    "pmgt_sampler_random_sample", "pmgt_sampler_randint", "pmgt_train_valid_split",
+]
+
+_hip = None
+_sampler = None
+
+
+def _load(path, what):
+    if not os.path.exists(path):
+        raise ImportError(f"{what} not built: {path} is missing. Run `python __graft_entry__.py` "
+                          f"(or pmgt_amd._build.build_all()); pmgt_amd has no fallback path.")
+    try:
+        return C.CDLL(path)
+    except OSError as e:   # fail loudly: no CPU/eager fallback exists
+        raise ImportError(f"cannot load {what} ({path}): {e}") from e
+
+
+def hip():
+    """libpmgt_hip.so with argtypes set."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    L = _load(_build.hip_lib_path(), "HIP engine library")
+    vp, i, i64, f, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+    L.pmgt_last_error.restype = C.c_char_p
+    L.pmgt_abi_version.restype = i
+    L.pmgt_engine_create.restype = vp
+    L.pmgt_engine_create.argtypes = [C.POINTER(PMGTConfigC)]
+    L.pmgt_engine_destroy.argtypes = [vp]
+    L.pmgt_engine_destroy.restype = None
+    L.pmgt_param_count.restype = i64
+    L.pmgt_param_count.argtypes = [vp]
+    L.pmgt_param_num_entries.argtypes = [vp]
+    L.pmgt_param_entry.argtypes = [vp, i, C.c_char_p, i, c_i64p, c_i64p, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.pmgt_workspace_bytes.restype = i64
+    L.pmgt_workspace_bytes.argtypes = [vp, i, i, i, i]
+    L.pmgt_pretrain_step.argtypes = [vp, C.POINTER(TensorsC), C.POINTER(BatchC), C.POINTER(OutputsC), vp, i64, i, vp]
+    L.pmgt_encode_ids.argtypes = [vp, C.POINTER(TensorsC), vp, vp, i, i, vp, vp, vp, vp, i64, vp]
+    L.pmgt_encode_feats.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, i, i, vp, vp, vp, vp, i64, vp]
+    L.pmgt_optimizer_step.argtypes = [vp, C.POINTER(TensorsC), C.POINTER(AdamC), vp]
+    L.pmgt_cast_from_f32.argtypes = [i, vp, vp, i64, vp]
+    L.pmgt_cast_to_f32.argtypes = [i, vp, vp, i64, vp]
+    L.pmgt_op_gemm_nt.argtypes = [i, vp, i64, vp, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, vp]
+    L.pmgt_op_gemm_tn_slab_elems.restype = i64
+    L.pmgt_op_gemm_tn_slab_elems.argtypes = [i, i, i, i]
+    L.pmgt_op_gemm_tn.argtypes = [i, vp, i64, vp, i64, vp, i, i, i, vp, vp, i, vp, vp]
+    L.pmgt_op_colsum.argtypes = [i, vp, i64, i, i, vp, vp, vp]
+    L.pmgt_op_layernorm_fwd.argtypes = [i, vp, vp, vp, vp, vp, i, i, f, f, u32, vp, vp]
+    L.pmgt_op_layernorm_bwd.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, i, i, f, u32, f, u32, vp, vp]
+    L.pmgt_op_attention_fwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
+    L.pmgt_op_attention_bwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
+    _hip = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"pmgt HIP engine error {rc}: {hip().pmgt_last_error().decode()}")
+
+
+def sampler():
+    """libpmgt_sampler.so (host only) with argtypes set."""
+    global _sampler
+    if _sampler is not None:
+        return _sampler
+    L = _load(_build.sampler_lib_path(), "host sampler library")
+    vp, i, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.pmgt_sampler_create.restype = vp
+    L.pmgt_sampler_create.argtypes = [i64, vp, vp, vp, vp, i, i, i, i]
+    L.pmgt_sampler_destroy.argtypes = [vp]
+    L.pmgt_sampler_destroy.restype = None
+    L.pmgt_sampler_last_error.restype = C.c_char_p
+    L.pmgt_sampler_seed.argtypes = [vp, C.c_uint32]
+    L.pmgt_sampler_seed.restype = None
+    L.pmgt_sampler_context.argtypes = [vp, i64, vp, vp]
+    L.pmgt_sampler_batch.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, vp]
+    L.pmgt_sampler_batch_mt.argtypes = [vp, vp, i, i, C.c_uint64, C.c_uint64, i, vp, vp, vp, vp, vp, vp]
+    L.pmgt_sampler_max_pairs.argtypes = [vp, i]
+    L.pmgt_sampler_random_sample.restype = C.c_double
+    L.pmgt_sampler_random_sample.argtypes = [vp]
+    L.pmgt_sampler_randint.restype = i64
+    L.pmgt_sampler_randint.argtypes = [vp, i64]
+    L.pmgt_train_valid_split.argtypes = [i64, C.c_double, C.c_uint32, vp, vp]
+    _sampler = L
+    return L

@@ -1,0 +1,21 @@
+// PMGT dual-softmax attention (declarations); see attention.hip.
+#pragma once
+#include "common.h"
+
+namespace pmgt {
+
+struct AttnArgs {
+    const void* qkvc = nullptr;   // [Tseq*S, 4d]: q | k | v | c (ctx_attention), head h at columns h*dh
+    const float* mask = nullptr;  // [Tseq, S] 1 = valid key, 0 = padded key (nullable = all valid)
+    void* ctx = nullptr;          // [Tseq*S, d] forward output
+    float* probs = nullptr;       // optional [Tseq, H, S, S] mixed probabilities (output_attentions)
+    int Tseq = 0, S = 0, H = 0, dh = 0;
+    float beta = 0.5f;
+    DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
+    const void* dctx = nullptr;   // backward: [Tseq*S, d]
+    void* dqkvc = nullptr;        // backward: [Tseq*S, 4d]
+};
+template <typename T> int attn_fwd(const AttnArgs& a, hipStream_t st);
+template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
+
+}  // namespace pmgt

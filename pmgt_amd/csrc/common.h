@@ -1,0 +1,143 @@
+// Shared device helpers for the PMGT gfx950 kernels: storage types (fp32 parity mode / bf16 perf
+// mode), wave64 reductions, the counter-based dropout RNG and launch/error plumbing.
+// Written for CDNA4 only (wavefront = 64, MFMA, 160 KiB LDS); no CUDA / multi-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmgt {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define PMGT_CHECK(cond, code, ...)                                                               \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            ::pmgt::set_error(__VA_ARGS__);                                                       \
+            return (code);                                                                        \
+        }                                                                                         \
+    } while (0)
+#define PMGT_HIP(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            ::pmgt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,   \
+                              __LINE__);                                                          \
+            return -100;                                                                          \
+        }                                                                                         \
+    } while (0)
+#define PMGT_LAUNCH_OK()                                                                          \
+    do {                                                                                          \
+        hipError_t e__ = hipGetLastError();                                                       \
+        if (e__ != hipSuccess) {                                                                  \
+            ::pmgt::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),         \
+                              __FILE__, __LINE__);                                                \
+            return -101;                                                                          \
+        }                                                                                         \
+    } while (0)
+
+// ---- scalar conversions -----------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }   // RNE, NaN-safe
+
+// Load / store 4 consecutive elements as fp32 (16 B for float, 8 B for bf16).
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
+    bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)p = r;
+}
+
+// ---- wave64 reductions ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reductions inside aligned lane groups of G lanes (G = 16, 32 or 64)
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- dropout RNG --------------------------------------------------------------------------------
+// Counter-based: keep(element) = hash(seed, step, site, element index) >= p * 2^32.  Nothing is
+// stored; backward kernels regenerate the same mask from the same (seed, step, site, index).
+// `rng` points at device memory {seed, step}: the step is advanced by the optimizer kernel, so a
+// captured hipGraph replays with fresh masks.
+struct DropCfg {
+    const uint64_t* rng;   // device: [0] = seed, [1] = step counter
+    float p;               // drop probability; 0 disables
+    uint32_t site;         // unique per dropout site (layer * 8 + kind)
+};
+struct DropKey {
+    uint32_t k0, k1, thr;
+    float scale;
+    bool on;
+};
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ DropKey make_drop_key(const DropCfg& c) {
+    DropKey k;
+    k.on = c.p > 0.f;
+    k.k0 = k.k1 = k.thr = 0; k.scale = 1.f;
+    if (k.on) {
+        uint64_t seed = c.rng[0], step = c.rng[1];
+        k.k0 = fmix32((uint32_t)seed ^ (c.site * 0x9E3779B1u));
+        k.k1 = fmix32((uint32_t)(seed >> 32) + (uint32_t)step * 0x7FEB352Du + (uint32_t)(step >> 32) + c.site);
+        double t = (double)c.p * 4294967296.0;
+        k.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+        k.scale = 1.f / (1.f - c.p);
+    }
+    return k;
+}
+__device__ __forceinline__ float drop_mul(const DropKey& k, uint64_t idx) {
+    uint32_t x = fmix32(((uint32_t)idx ^ k.k0) * 0x9E3779B1u + (uint32_t)(idx >> 32));
+    x = fmix32(x + k.k1);
+    return x >= k.thr ? k.scale : 0.f;
+}
+enum DropSite { SITE_EMB = 0, SITE_A1 = 1, SITE_A2 = 2, SITE_AO = 3, SITE_FO = 4, SITE_NFR1 = 5, SITE_NFR2 = 6 };
+__host__ __device__ inline uint32_t site_id(int layer, int kind) { return (uint32_t)(layer + 1) * 8u + (uint32_t)kind; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace pmgt

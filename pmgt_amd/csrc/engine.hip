@@ -1,0 +1,748 @@
+// Orchestration of one PMGT pre-training step on one MI355X and the C ABI (include/pmgt_capi.h).
+//
+// One call = one stream-ordered chain of kernel launches (no host sync, no allocation): the whole
+// step (mask -> mirror -> embeddings -> L layers -> GSR/NFR -> backward) can therefore be captured
+// in a hipGraph by the caller.  All B(1 + pairs + 1) sequences of a step go through ONE batched
+// encoder pass (the reference makes B+2 separate calls, pmgt/pmgt/models.py:93,113,153).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pmgt_capi.h"
+#include "attention.h"
+#include "gemm.h"
+#include "loss.h"
+#include "optim.h"
+#include "rowops.h"
+
+namespace pmgt {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct ParamEntry {
+    std::string name;
+    int64_t offset, numel;
+    int rows, cols, decay;
+};
+
+struct LayerOff {
+    int64_t Wqkvc, bqkvc, Wo, bo, ln1g, ln1b, W1, b1, W2, b2, ln2g, ln2b;
+    // mirror offsets (elements of T); -1 = not mirrored (fp32 reads the master copy)
+    int64_t mWqkvc, mWqkvcT, mWo, mWoT, mW1, mW1T, mW2, mW2T;
+};
+
+}  // namespace pmgt
+
+using namespace pmgt;
+
+struct pmgt_engine {
+    pmgt_config cfg;
+    int d, L, H, I, Fv, Ft, dh;
+    // flat parameter layout (floats)
+    int64_t pos, role, Wv, Wt, bvt, ln_g, ln_b, Wa, ba, Wn, bn, total;
+    std::vector<LayerOff> layers;
+    std::vector<ParamEntry> entries;
+    // mirror
+    int64_t mWv, mWt, mWn, mWnT, mirror_elems;
+    std::vector<MirrorDesc> desc;
+    MirrorDesc* desc_dev = nullptr;
+    int mirror_tiles = 0;
+};
+
+namespace pmgt {
+
+static int64_t take(int64_t& cur, int64_t n) {
+    int64_t o = cur;
+    cur += align_up(n, 4);     // keep every tensor 16-byte aligned
+    return o;
+}
+
+static void add_entry(pmgt_engine* e, const std::string& name, int64_t off, int rows, int cols) {
+    ParamEntry p;
+    p.name = name; p.offset = off; p.rows = rows; p.cols = cols;
+    p.numel = (int64_t)rows * (cols > 0 ? cols : 1);
+    p.decay = !(name.find("bias") != std::string::npos || name.find("LayerNorm.weight") != std::string::npos);
+    e->entries.push_back(p);
+}
+
+static void build_layout(pmgt_engine* e) {
+    const int d = e->d, I = e->I, Fv = e->Fv, Ft = e->Ft, P = e->cfg.max_position_embeddings;
+    int64_t cur = 0;
+    const std::string em = "bert.embeddings.";
+    e->pos = take(cur, (int64_t)P * d);   add_entry(e, em + "position_embeddings.weight", e->pos, P, d);
+    e->role = take(cur, 2 * d);           add_entry(e, em + "role_embeddings.weight", e->role, 2, d);
+    e->Wv = take(cur, (int64_t)d * Fv);   add_entry(e, em + "feat_linear.0.weight", e->Wv, d, Fv);
+    e->Wt = take(cur, (int64_t)d * Ft);   add_entry(e, em + "feat_linear.1.weight", e->Wt, d, Ft);
+    e->bvt = take(cur, 2 * d);
+    add_entry(e, em + "feat_linear.0.bias", e->bvt, d, 0);
+    add_entry(e, em + "feat_linear.1.bias", e->bvt + d, d, 0);
+    // ln_g | ln_b | Wa | ba are contiguous in exactly the order of embed_mix_bwd's partials (6d + 4)
+    e->ln_g = take(cur, d);               add_entry(e, em + "LayerNorm.weight", e->ln_g, d, 0);
+    e->ln_b = take(cur, d);               add_entry(e, em + "LayerNorm.bias", e->ln_b, d, 0);
+    e->Wa = take(cur, 4 * d);             add_entry(e, em + "attention.1.weight", e->Wa, 2, 2 * d);
+    e->ba = take(cur, 4);                 add_entry(e, em + "attention.1.bias", e->ba, 2, 0);
+    e->layers.resize(e->L);
+    for (int l = 0; l < e->L; ++l) {
+        LayerOff& o = e->layers[l];
+        const std::string p = "bert.encoder.layer." + std::to_string(l) + ".";
+        o.Wqkvc = take(cur, (int64_t)4 * d * d);
+        const char* nm[4] = {"query", "key", "value", "ctx_attention"};
+        for (int k = 0; k < 4; ++k) add_entry(e, p + "attention.self." + nm[k] + ".weight", o.Wqkvc + (int64_t)k * d * d, d, d);
+        o.bqkvc = take(cur, 4 * d);
+        for (int k = 0; k < 4; ++k) add_entry(e, p + "attention.self." + nm[k] + ".bias", o.bqkvc + (int64_t)k * d, d, 0);
+        o.Wo = take(cur, (int64_t)d * d);  add_entry(e, p + "attention.output.dense.weight", o.Wo, d, d);
+        o.bo = take(cur, d);               add_entry(e, p + "attention.output.dense.bias", o.bo, d, 0);
+        o.ln1g = take(cur, d);             add_entry(e, p + "attention.output.LayerNorm.weight", o.ln1g, d, 0);
+        o.ln1b = take(cur, d);             add_entry(e, p + "attention.output.LayerNorm.bias", o.ln1b, d, 0);
+        o.W1 = take(cur, (int64_t)I * d);  add_entry(e, p + "intermediate.dense.weight", o.W1, I, d);
+        o.b1 = take(cur, I);               add_entry(e, p + "intermediate.dense.bias", o.b1, I, 0);
+        o.W2 = take(cur, (int64_t)d * I);  add_entry(e, p + "output.dense.weight", o.W2, d, I);
+        o.b2 = take(cur, d);               add_entry(e, p + "output.dense.bias", o.b2, d, 0);
+        o.ln2g = take(cur, d);             add_entry(e, p + "output.LayerNorm.weight", o.ln2g, d, 0);
+        o.ln2b = take(cur, d);             add_entry(e, p + "output.LayerNorm.bias", o.ln2b, d, 0);
+    }
+    e->Wn = take(cur, (int64_t)(Fv + Ft) * d);
+    add_entry(e, "nfr_loss.projections.0.weight", e->Wn, Fv, d);
+    add_entry(e, "nfr_loss.projections.1.weight", e->Wn + (int64_t)Fv * d, Ft, d);
+    e->bn = take(cur, Fv + Ft);
+    add_entry(e, "nfr_loss.projections.0.bias", e->bn, Fv, 0);
+    add_entry(e, "nfr_loss.projections.1.bias", e->bn + Fv, Ft, 0);
+    e->total = cur;
+
+    // ---- mirror layout
+    const bool half = e->cfg.dtype == PMGT_DTYPE_BF16;
+    int64_t mc = 0;
+    int tiles = 0;
+    auto add_m = [&](int64_t src, int rows, int cols, bool copy, bool transpose, int64_t* dst, int64_t* dst_t) {
+        MirrorDesc m;
+        m.src = src; m.rows = rows; m.cols = cols;
+        m.dst = copy ? mc : -1;
+        if (copy) mc += align_up((int64_t)rows * cols, 8);
+        m.dst_t = transpose ? mc : -1;
+        if (transpose) mc += align_up((int64_t)rows * cols, 8);
+        m.tile_start = tiles;
+        tiles += cdiv(rows, 32) * cdiv(cols, 32);
+        if (dst) *dst = m.dst;
+        if (dst_t) *dst_t = m.dst_t;
+        if (copy || transpose) e->desc.push_back(m);
+        else tiles = m.tile_start;
+    };
+    add_m(e->Wv, d, Fv, half, false, &e->mWv, nullptr);
+    add_m(e->Wt, d, Ft, half, false, &e->mWt, nullptr);
+    for (int l = 0; l < e->L; ++l) {
+        LayerOff& o = e->layers[l];
+        add_m(o.Wqkvc, 4 * d, d, half, true, &o.mWqkvc, &o.mWqkvcT);
+        add_m(o.Wo, d, d, half, true, &o.mWo, &o.mWoT);
+        add_m(o.W1, I, d, half, true, &o.mW1, &o.mW1T);
+        add_m(o.W2, d, I, half, true, &o.mW2, &o.mW2T);
+    }
+    add_m(e->Wn, Fv + Ft, d, half, true, &e->mWn, &e->mWnT);
+    e->mirror_elems = mc;
+    e->mirror_tiles = tiles;
+}
+
+// ---- workspace carving ---------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    int64_t cur = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    void* raw(int64_t bytes) {
+        void* p = base ? base + cur : nullptr;
+        cur += align_up(std::max<int64_t>(bytes, 16), 256);
+        return p;
+    }
+    template <typename U> U* get(int64_t n) { return (U*)raw(n * (int64_t)sizeof(U)); }
+};
+
+template <typename T> struct LayerBufs {
+    T *qkvc, *ctx, *ao_pre, *u, *ff_pre, *g, *fo_pre, *hout;
+    float *stats1, *stats2;
+};
+
+template <typename T> struct Bufs {
+    int64_t* ids;      // [Tseq, S] concatenated node ids
+    float* mask;       // [Tseq, S]
+    T* mirror;
+    T *E, *emb_pre, *h0;
+    float *a, *emb_stats;
+    std::vector<LayerBufs<T>> layer;
+    // backward temporaries
+    T *bA, *bB, *bC, *bD, *big;
+    float *slab, *part;     // gemm_tn slabs; LN / embed / colsum partials
+    float* possum;
+    // losses
+    int* off;
+    float *gsr_part, *sse_part;
+    int64_t *nfr_masked, *nfr_tgt, *nfr_rows, *nfr_tids;
+    int* nfr_count;
+    T *pred, *dq;
+};
+
+static int64_t tn_slab_elems(int dtype, int M, int N1, int N2) {
+    const int bkm = dtype == PMGT_DTYPE_BF16 ? 64 : 32;
+    return (int64_t)gemm_tn_pick_splits(M, N1, N2, bkm) * N1 * N2;
+}
+
+template <typename T>
+static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, int B, bool training) {
+    const int d = e->d, I = e->I, L = e->L, F = e->Fv + e->Ft;
+    const int64_t M = (int64_t)Tseq * S;
+    b.ids = c.get<int64_t>(M);
+    b.mask = c.get<float>(M);
+    b.mirror = c.get<T>(e->mirror_elems);
+    b.E = c.get<T>(M * 2 * d);
+    b.a = c.get<float>(M * 2);
+    b.emb_pre = c.get<T>(M * d);
+    b.emb_stats = c.get<float>(M * 2);
+    b.h0 = c.get<T>(M * d);
+    const int nl = training ? L : std::min(L, 2);
+    b.layer.resize(L);
+    for (int l = 0; l < nl; ++l) {
+        LayerBufs<T>& lb = b.layer[l];
+        lb.qkvc = c.get<T>(M * 4 * d);
+        lb.ctx = c.get<T>(M * d);
+        lb.ao_pre = c.get<T>(M * d);
+        lb.stats1 = c.get<float>(M * 2);
+        lb.u = c.get<T>(M * d);
+        lb.ff_pre = c.get<T>(M * I);
+        lb.g = c.get<T>(M * I);
+        lb.fo_pre = c.get<T>(M * d);
+        lb.stats2 = c.get<float>(M * 2);
+        lb.hout = c.get<T>(M * d);
+    }
+    for (int l = nl; l < L; ++l) b.layer[l] = b.layer[l & 1];
+    // losses (eval needs GSR only)
+    b.off = c.get<int>(B + 1);
+    b.gsr_part = c.get<float>(std::max(B, 1));
+    b.nfr_count = c.get<int>(4);
+    if (!training) return;
+    const int cap = B * std::max(S - 1, 1);
+    b.bA = c.get<T>(M * d);
+    b.bB = c.get<T>(M * d);
+    b.bC = c.get<T>(M * d);
+    b.bD = c.get<T>(M * d);
+    b.big = c.get<T>(M * std::max(I, 4 * d));
+    int64_t slab = 0;
+    const int dt = e->cfg.dtype;
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, 4 * d, d));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, d));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, I, d));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, I));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Fv));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Ft));
+    slab = std::max(slab, tn_slab_elems(dt, std::max(256, cap / 5), F, d));
+    b.slab = c.get<float>(slab);
+    int64_t part = 0;
+    part = std::max(part, (int64_t)ln_bwd_parts((int)M) * 2 * d);
+    part = std::max(part, (int64_t)embed_bwd_parts((int)M) * (6 * d + 4));
+    part = std::max(part, colsum_slab_elems((int)M, std::max(std::max(I, 4 * d), 2 * d)));
+    part = std::max(part, colsum_slab_elems(Tseq, S * d));
+    part = std::max(part, colsum_slab_elems(cap, F));
+    b.part = c.get<float>(part);
+    b.possum = c.get<float>((int64_t)S * d);
+    b.sse_part = c.get<float>((int64_t)nfr_diff_parts(cap) * 2);
+    b.nfr_masked = c.get<int64_t>((int64_t)B * S);
+    b.nfr_tgt = c.get<int64_t>((int64_t)B * S);
+    b.nfr_rows = c.get<int64_t>(cap);
+    b.nfr_tids = c.get<int64_t>(cap);
+    b.pred = c.get<T>((int64_t)cap * F);
+    b.dq = c.get<T>((int64_t)cap * d);
+}
+
+template <typename T> static inline const T* wsel(const pmgt_engine* e, const pmgt_tensors* t, const Bufs<T>& b, int64_t master_off, int64_t mirror_off) {
+    if (mirror_off >= 0) return b.mirror + mirror_off;
+    return (const T*)(t->params + master_off);     // only reachable when T == float
+}
+
+static inline DropCfg dropcfg(const pmgt_tensors* t, bool on, float p, int layer, int kind) {
+    DropCfg c;
+    c.rng = t->rng_state;
+    c.p = on ? p : 0.f;
+    c.site = site_id(layer, kind);
+    return c;
+}
+
+#define RUN(x)                                                                                    \
+    do {                                                                                          \
+        int rc__ = (x);                                                                           \
+        if (rc__ != 0) return rc__;                                                               \
+    } while (0)
+
+// ---- encoder forward ---------------------------------------------------------------------------
+template <typename T>
+static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, const int64_t* ids,
+                           const T* feat_v, const T* feat_t, const float* mask, bool train, T* hidden_states,
+                           float* attn_probs, hipStream_t st) {
+    const int d = e->d, I = e->I, L = e->L, H = e->H;
+    const int M = Tseq * S;
+    const float* P = t->params;
+    PMGT_CHECK(S <= e->cfg.max_position_embeddings, -2, "sequence length %d exceeds max_position_embeddings %d", S,
+               e->cfg.max_position_embeddings);
+    const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
+    // feature projections (gather fused into the A-operand load)
+    for (int mod = 0; mod < 2; ++mod) {
+        GemmNT g;
+        const int F = mod == 0 ? e->Fv : e->Ft;
+        if (ids) { g.A = mod == 0 ? t->table_v : t->table_t; g.a_rows = ids; }
+        else g.A = mod == 0 ? (const void*)feat_v : (const void*)feat_t;
+        g.lda = F;
+        g.B = wsel<T>(e, t, b, mod == 0 ? e->Wv : e->Wt, mod == 0 ? e->mWv : e->mWt);
+        g.ldb = F;
+        g.C = b.E + mod * d; g.ldc = 2 * d;
+        g.M = M; g.N = d; g.K = F;
+        g.bias = P + e->bvt + mod * d;
+        RUN(gemm_nt<T>(g, st));
+    }
+    {
+        EmbedMix m;
+        m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
+        m.gamma = P + e->ln_g; m.beta = P + e->ln_b; m.eps = e->cfg.layer_norm_eps;
+        m.a = b.a; m.pre = b.emb_pre; m.stats = b.emb_stats; m.h0 = b.h0;
+        m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
+        RUN(embed_mix_fwd<T>(m, st));
+    }
+    if (hidden_states) PMGT_HIP(hipMemcpyAsync(hidden_states, b.h0, (size_t)M * d * sizeof(T), hipMemcpyDeviceToDevice, st));
+    const T* hin = b.h0;
+    for (int l = 0; l < L; ++l) {
+        const LayerOff& o = e->layers[l];
+        LayerBufs<T>& lb = b.layer[l];
+        {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
+            GemmNT g;
+            g.A = hin; g.lda = d; g.B = wsel<T>(e, t, b, o.Wqkvc, o.mWqkvc); g.ldb = d;
+            g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
+            RUN(gemm_nt<T>(g, st));
+        }
+        {
+            AttnArgs a;
+            a.qkvc = lb.qkvc; a.mask = mask; a.ctx = lb.ctx;
+            a.probs = attn_probs ? attn_probs + (int64_t)l * Tseq * H * S * S : nullptr;
+            a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
+            a.drop1 = dropcfg(t, train, pa, l, SITE_A1);
+            a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
+            RUN(attn_fwd<T>(a, st));
+        }
+        {   // BertSelfOutput: LN(dropout(dense(ctx)) + hin)
+            GemmNT g;
+            g.A = lb.ctx; g.lda = d; g.B = wsel<T>(e, t, b, o.Wo, o.mWo); g.ldb = d;
+            g.C = lb.ao_pre; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = P + o.bo;
+            g.drop = dropcfg(t, train, pd, l, SITE_AO);
+            g.res = hin; g.ldr = d;
+            RUN(gemm_nt<T>(g, st));
+            RUN(ln_fwd<T>(lb.ao_pre, lb.u, lb.stats1, P + o.ln1g, P + o.ln1b, M, d, e->cfg.layer_norm_eps,
+                          DropCfg{nullptr, 0.f, 0}, st));
+        }
+        {   // BertIntermediate: gelu(dense(u))
+            GemmNT g;
+            g.A = lb.u; g.lda = d; g.B = wsel<T>(e, t, b, o.W1, o.mW1); g.ldb = d;
+            g.C = lb.g; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = P + o.b1;
+            g.epi = EPI_GELU; g.aux = lb.ff_pre; g.ldaux = I;
+            RUN(gemm_nt<T>(g, st));
+        }
+        {   // BertOutput: LN(dropout(dense(g)) + u)
+            GemmNT g;
+            g.A = lb.g; g.lda = I; g.B = wsel<T>(e, t, b, o.W2, o.mW2); g.ldb = I;
+            g.C = lb.fo_pre; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = P + o.b2;
+            g.drop = dropcfg(t, train, pd, l, SITE_FO);
+            g.res = lb.u; g.ldr = d;
+            RUN(gemm_nt<T>(g, st));
+            RUN(ln_fwd<T>(lb.fo_pre, lb.hout, lb.stats2, P + o.ln2g, P + o.ln2b, M, d, e->cfg.layer_norm_eps,
+                          DropCfg{nullptr, 0.f, 0}, st));
+        }
+        if (hidden_states)
+            PMGT_HIP(hipMemcpyAsync(hidden_states + (int64_t)(l + 1) * M * d, lb.hout, (size_t)M * d * sizeof(T),
+                                    hipMemcpyDeviceToDevice, st));
+        hin = lb.hout;
+    }
+    return 0;
+}
+
+// wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs
+template <typename T>
+static int wgrad(const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
+                 int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t st) {
+    GemmTN g;
+    g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
+    g.slab = b.slab; g.m_dev = m_dev;
+    g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
+    RUN(gemm_tn<T>(g, st));
+    return slab_reduce(b.slab, g.splits, (int64_t)N1 * N2, dst, acc, st);
+}
+
+// ---- encoder backward: dcur (in b.bA) = d loss / d h_L; leaves parameter grads in t->grads ----------
+template <typename T>
+static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st) {
+    const int d = e->d, I = e->I, L = e->L, H = e->H;
+    const int M = Tseq * S;
+    const float* P = t->params;
+    float* G = t->grads;
+    const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
+    const bool dd = pd > 0.f;
+    const DropCfg nodrop = {nullptr, 0.f, 0};
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerOff& o = e->layers[l];
+        LayerBufs<T>& lb = b.layer[l];
+        const T* hin = l == 0 ? b.h0 : b.layer[l - 1].hout;
+        // LN2 backward: bA -> bB (residual branch), bC (masked: gradient of the FFN2 dense output)
+        RUN(ln_bwd<T>(b.bA, lb.fo_pre, lb.stats2, P + o.ln2g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
+                      dropcfg(t, true, pd, l, SITE_FO), st));
+        RUN(slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln2g, acc, st));
+        const T* dY2 = dd ? b.bC : b.bB;
+        RUN(wgrad<T>(e, b, dY2, d, lb.g, I, nullptr, M, M, d, I, G + o.W2, acc, nullptr, st));
+        RUN(colsum<T>(dY2, d, M, d, b.part, G + o.b2, acc, nullptr, st));
+        {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
+            GemmNT g;
+            g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = b.big; g.ldc = I;
+            g.M = M; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = lb.ff_pre; g.ldaux = I;
+            RUN(gemm_nt<T>(g, st));
+        }
+        RUN(wgrad<T>(e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st));
+        RUN(colsum<T>(b.big, I, M, I, b.part, G + o.b1, acc, nullptr, st));
+        {   // du = dff W1 + residual branch
+            GemmNT g;
+            g.A = b.big; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = b.bD; g.ldc = d;
+            g.M = M; g.N = d; g.K = I; g.res = b.bB; g.ldr = d;
+            RUN(gemm_nt<T>(g, st));
+        }
+        // LN1 backward
+        RUN(ln_bwd<T>(b.bD, lb.ao_pre, lb.stats1, P + o.ln1g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
+                      dropcfg(t, true, pd, l, SITE_AO), st));
+        RUN(slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln1g, acc, st));
+        const T* dYo = dd ? b.bC : b.bB;
+        RUN(wgrad<T>(e, b, dYo, d, lb.ctx, d, nullptr, M, M, d, d, G + o.Wo, acc, nullptr, st));
+        RUN(colsum<T>(dYo, d, M, d, b.part, G + o.bo, acc, nullptr, st));
+        {   // dctx = dYo Wo
+            GemmNT g;
+            g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = b.bD; g.ldc = d; g.M = M; g.N = d; g.K = d;
+            RUN(gemm_nt<T>(g, st));
+        }
+        {
+            AttnArgs a;
+            a.qkvc = lb.qkvc; a.mask = b.mask; a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
+            a.drop1 = dropcfg(t, true, pa, l, SITE_A1);
+            a.drop2 = dropcfg(t, true, pa, l, SITE_A2);
+            a.dctx = b.bD; a.dqkvc = b.big;
+            RUN(attn_bwd<T>(a, st));
+        }
+        RUN(wgrad<T>(e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st));
+        RUN(colsum<T>(b.big, 4 * d, M, 4 * d, b.part, G + o.bqkvc, acc, nullptr, st));
+        {   // d hin = dqkvc Wqkvc + residual branch
+            GemmNT g;
+            g.A = b.big; g.lda = 4 * d; g.B = b.mirror + o.mWqkvcT; g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
+            g.M = M; g.N = d; g.K = 4 * d; g.res = b.bB; g.ldr = d;
+            RUN(gemm_nt<T>(g, st));
+        }
+    }
+    // embeddings
+    {
+        EmbedMix m;
+        m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
+        m.stats = b.emb_stats; m.drop = dropcfg(t, true, pd, -1, SITE_EMB);
+        m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB; m.part = b.part;
+        RUN(embed_mix_bwd<T>(m, st));
+        RUN(slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
+        RUN(colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
+        RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
+        RUN(colsum<T>(b.big, 2 * d, M, 2 * d, b.part, G + e->bvt, acc, nullptr, st));
+        RUN(wgrad<T>(e, b, b.big, 2 * d, (const T*)t->table_v, e->Fv, b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st));
+        RUN(wgrad<T>(e, b, b.big + d, 2 * d, (const T*)t->table_t, e->Ft, b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st));
+    }
+    return 0;
+}
+
+template <typename T>
+static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* bt, const pmgt_outputs* o, void* ws,
+                         int64_t ws_bytes, int flags, hipStream_t st) {
+    const bool train = flags & PMGT_FLAG_TRAINING, bwd = flags & PMGT_FLAG_BACKWARD, acc = flags & PMGT_FLAG_ACCUMULATE;
+    const int B = bt->n_targets, Pn = bt->n_pairs, S = bt->seq_len, d = e->d, F = e->Fv + e->Ft;
+    PMGT_CHECK(B > 0 && S > 0, -2, "pretrain_step: empty batch");
+    PMGT_CHECK(!bwd || train, -2, "pretrain_step: BACKWARD requires TRAINING (the workspace keeps activations only then)");
+    PMGT_CHECK(Pn > 0 && bt->pair_ids && bt->labels && bt->num_pairs, -2,
+               "labels must be passed, when set pair_node_inputs (pmgt/pmgt/models.py:66-72)");
+    const int Tseq = B + Pn + (train ? B : 0);
+    Carver c(ws);
+    Bufs<T> b;
+    carve<T>(e, c, b, Tseq, S, B, train);
+    PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
+    const int64_t bs = (int64_t)B * S, ps = (int64_t)Pn * S;
+    PMGT_HIP(hipMemcpyAsync(b.ids, bt->tgt_ids, bs * 8, hipMemcpyDeviceToDevice, st));
+    PMGT_HIP(hipMemcpyAsync(b.mask, bt->tgt_mask, bs * 4, hipMemcpyDeviceToDevice, st));
+    PMGT_HIP(hipMemcpyAsync(b.ids + bs, bt->pair_ids, ps * 8, hipMemcpyDeviceToDevice, st));
+    PMGT_HIP(hipMemcpyAsync(b.mask + bs, bt->pair_mask, ps * 4, hipMemcpyDeviceToDevice, st));
+    if (train) {
+        if (bt->nfr_masked_ids) {
+            PMGT_CHECK(bt->nfr_targets, -2, "nfr_targets must accompany nfr_masked_ids");
+            PMGT_HIP(hipMemcpyAsync(b.ids + bs + ps, bt->nfr_masked_ids, bs * 8, hipMemcpyDeviceToDevice, st));
+            PMGT_HIP(hipMemcpyAsync(b.nfr_tgt, bt->nfr_targets, bs * 8, hipMemcpyDeviceToDevice, st));
+        } else {
+            RUN(nfr_generate(bt->tgt_ids, B, S, (int)t->n_nodes, bt->random_node_ratio, bt->mask_node_ratio, t->rng_state,
+                             b.ids + bs + ps, b.nfr_tgt, st));
+        }
+        PMGT_HIP(hipMemcpyAsync(b.mask + bs + ps, bt->tgt_mask, bs * 4, hipMemcpyDeviceToDevice, st));   // models.py:153-156
+        RUN(nfr_compact(b.nfr_tgt, B, S, B + Pn, b.nfr_rows, b.nfr_tids, b.nfr_count, st));
+    }
+    RUN(build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, (const T*)nullptr, (const T*)nullptr, b.mask, train, (T*)nullptr,
+                           (float*)nullptr, st));
+    T* hL = b.layer[e->L - 1].hout;
+    const int M = Tseq * S;
+    if (bwd) PMGT_HIP(hipMemsetAsync(b.bA, 0, (size_t)M * d * sizeof(T), st));
+    RUN(pair_offsets(bt->num_pairs, B, b.off, st));
+    {
+        GsrArgs g;
+        g.h = hL; g.dh = bwd ? b.bA : nullptr; g.B = B; g.S = S; g.d = d; g.off = b.off; g.labels = bt->labels;
+        g.logits = o->logits; g.loss_part = b.gsr_part;
+        RUN(gsr_fwd_bwd<T>(g, st));
+    }
+    const int cap = B * std::max(S - 1, 1);
+    if (train) {
+        GemmNT g;   // projections of the masked rows (row gather by token index)
+        g.A = hL; g.lda = d; g.a_rows = b.nfr_rows; g.B = wsel<T>(e, t, b, e->Wn, e->mWn); g.ldb = d;
+        g.C = b.pred; g.ldc = F; g.M = cap; g.N = F; g.K = d; g.bias = t->params + e->bn; g.m_dev = b.nfr_count;
+        RUN(gemm_nt<T>(g, st));
+        NfrDiffArgs a;
+        a.pred = b.pred; a.tids = b.nfr_tids; a.count = b.nfr_count; a.cap = cap; a.Fv = e->Fv; a.Ft = e->Ft;
+        a.table_v = t->table_v; a.table_t = t->table_t; a.sse_part = b.sse_part;
+        RUN(nfr_diff<T>(a, st));
+    }
+    RUN(loss_finish(b.gsr_part, B, train ? b.sse_part : nullptr, nfr_diff_parts(cap), b.nfr_count, e->Fv, e->Ft, train,
+                    o->loss, st));
+    if (o->last_hidden) PMGT_HIP(hipMemcpyAsync(o->last_hidden, hL, (size_t)bs * d * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (o->nfr_count && train) PMGT_HIP(hipMemcpyAsync(o->nfr_count, b.nfr_count, 4, hipMemcpyDeviceToDevice, st));
+    if (bwd) {
+        const int msp = std::max(256, cap / 5);
+        RUN(wgrad<T>(e, b, b.pred, F, hL, d, b.nfr_rows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st));
+        RUN(colsum<T>(b.pred, F, cap, F, b.part, t->grads + e->bn, acc, b.nfr_count, st));
+        GemmNT g;
+        g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.C = b.dq; g.ldc = d; g.M = cap; g.N = d; g.K = F;
+        g.m_dev = b.nfr_count;
+        RUN(gemm_nt<T>(g, st));
+        RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
+        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st));
+    }
+    if (train) RUN(advance_rng(t->rng_state, st));
+    return 0;
+}
+
+template <typename T>
+static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* fv, const void* ft,
+                  const float* mask, int Tseq, int S, void* last_hidden, void* hidden_states, float* attn_probs, void* ws,
+                  int64_t ws_bytes, hipStream_t st) {
+    PMGT_CHECK(Tseq > 0 && S > 0, -2, "encode: empty input");
+    Carver c(ws);
+    Bufs<T> b;
+    carve<T>(e, c, b, Tseq, S, 1, false);
+    PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
+    const float* m = mask;
+    if (!m) {   // attention_mask=None -> ones (pmgt/pmgt/modeling_pmgt.py:113-114)
+        m = nullptr;
+    }
+    RUN(build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUN(encoder_forward<T>(e, t, b, Tseq, S, ids, (const T*)fv, (const T*)ft, m, false, (T*)hidden_states, attn_probs, st));
+    if (last_hidden)
+        PMGT_HIP(hipMemcpyAsync(last_hidden, b.layer[e->L - 1].hout, (size_t)Tseq * S * e->d * sizeof(T),
+                                hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // namespace pmgt
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+const char* pmgt_last_error(void) { return g_err; }
+int pmgt_abi_version(void) { return 1; }
+
+pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
+    if (!cfg) { set_error("config is NULL"); return nullptr; }
+    if (cfg->hidden_size <= 0 || cfg->num_attention_heads <= 0 || cfg->hidden_size % cfg->num_attention_heads != 0) {
+        set_error("The hidden size (%d) is not a multiple of the number of attention heads (%d)", cfg->hidden_size,
+                  cfg->num_attention_heads);   // pmgt/pmgt/modeling_pmgt.py:381-387
+        return nullptr;
+    }
+    const int ali = cfg->dtype == PMGT_DTYPE_BF16 ? 8 : 4;
+    if (cfg->hidden_size % ali || cfg->intermediate_size % ali || cfg->feat_size_v % ali || cfg->feat_size_t % ali ||
+        cfg->hidden_size > 1024) {
+        set_error("HIP path needs hidden/intermediate/feature sizes that are multiples of %d and hidden_size <= 1024", ali);
+        return nullptr;
+    }
+    if (cfg->dtype != PMGT_DTYPE_F32 && cfg->dtype != PMGT_DTYPE_BF16) { set_error("unknown dtype %d", cfg->dtype); return nullptr; }
+    pmgt_engine* e = new pmgt_engine();
+    e->cfg = *cfg;
+    e->d = cfg->hidden_size; e->L = cfg->num_hidden_layers; e->H = cfg->num_attention_heads; e->I = cfg->intermediate_size;
+    e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
+    build_layout(e);
+    if (!e->desc.empty()) {
+        if (hipMalloc((void**)&e->desc_dev, e->desc.size() * sizeof(MirrorDesc)) != hipSuccess ||
+            hipMemcpy(e->desc_dev, e->desc.data(), e->desc.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("pmgt_engine_create: no usable HIP device (hipMalloc/hipMemcpy failed)");
+            delete e;
+            return nullptr;
+        }
+    }
+    return e;
+}
+
+void pmgt_engine_destroy(pmgt_engine* e) {
+    if (!e) return;
+    if (e->desc_dev) (void)hipFree(e->desc_dev);
+    delete e;
+}
+
+int64_t pmgt_param_count(const pmgt_engine* e) { return e->total; }
+int pmgt_param_num_entries(const pmgt_engine* e) { return (int)e->entries.size(); }
+int pmgt_param_entry(const pmgt_engine* e, int index, char* name, int name_cap, int64_t* offset, int64_t* numel, int* rows,
+                     int* cols, int* decay) {
+    PMGT_CHECK(index >= 0 && index < (int)e->entries.size(), -2, "param index %d out of range", index);
+    const ParamEntry& p = e->entries[index];
+    if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = p.offset;
+    if (numel) *numel = p.numel;
+    if (rows) *rows = p.rows;
+    if (cols) *cols = p.cols;
+    if (decay) *decay = p.decay;
+    return 0;
+}
+
+int64_t pmgt_workspace_bytes(const pmgt_engine* e, int n_seq, int seq_len, int n_targets, int training) {
+    Carver c(nullptr);
+    if (e->cfg.dtype == PMGT_DTYPE_BF16) { Bufs<bf16> b; carve<bf16>(e, c, b, n_seq, seq_len, std::max(n_targets, 1), training != 0); }
+    else { Bufs<float> b; carve<float>(e, c, b, n_seq, seq_len, std::max(n_targets, 1), training != 0); }
+    return c.cur;
+}
+
+int pmgt_pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* b, const pmgt_outputs* o, void* workspace,
+                       int64_t workspace_bytes, int flags, void* stream) {
+    PMGT_CHECK(e && t && b && o && workspace, -2, "pmgt_pretrain_step: NULL argument");
+    PMGT_CHECK(t->params && t->table_v && t->table_t && t->rng_state && o->loss && o->logits, -2, "pmgt_pretrain_step: NULL tensor");
+    PMGT_CHECK(!(flags & PMGT_FLAG_BACKWARD) || t->grads, -2, "pmgt_pretrain_step: grads buffer is NULL");
+    if (e->cfg.dtype == PMGT_DTYPE_BF16) return pretrain_step<bf16>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    return pretrain_step<float>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
+}
+
+int pmgt_encode_ids(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const float* mask, int n_seq, int seq_len,
+                    void* last_hidden, void* hidden_states, float* attn_probs, void* workspace, int64_t workspace_bytes,
+                    void* stream) {
+    PMGT_CHECK(e && t && ids && workspace && t->params && t->table_v && t->table_t, -2, "pmgt_encode_ids: NULL argument");
+    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+        return encode<bf16>(e, t, ids, nullptr, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+    return encode<float>(e, t, ids, nullptr, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t, const float* mask,
+                      int n_seq, int seq_len, void* last_hidden, void* hidden_states, float* attn_probs, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+    PMGT_CHECK(e && t && feat_v && feat_t && workspace && t->params, -2, "pmgt_encode_feats: NULL argument");
+    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+        return encode<bf16>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+    return encode<float>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* a, void* stream) {
+    PMGT_CHECK(e && t && a && t->params && t->grads && a->exp_avg && a->exp_avg_sq && a->decay && a->step && a->scalars && a->scratch,
+               -2, "pmgt_optimizer_step: NULL argument");
+    AdamArgs x;
+    x.p = t->params; x.g = t->grads; x.m = a->exp_avg; x.v = a->exp_avg_sq; x.decay = a->decay; x.n = e->total;
+    x.lr = a->lr; x.wd = a->weight_decay; x.b1 = a->beta1; x.b2 = a->beta2; x.eps = a->eps; x.max_norm = a->max_grad_norm;
+    x.step = a->step; x.scal = a->scalars; x.part = a->scratch;
+    return adamw_step(x, (hipStream_t)stream);
+}
+
+int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {
+    if (dtype == PMGT_DTYPE_BF16) return cast_f32<bf16>(src, (bf16*)dst, n, (hipStream_t)stream);
+    return cast_f32<float>(src, (float*)dst, n, (hipStream_t)stream);
+}
+int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream) {
+    if (dtype == PMGT_DTYPE_BF16) return cast_to_f32<bf16>((const bf16*)src, dst, n, (hipStream_t)stream);
+    return cast_to_f32<float>((const float*)src, dst, n, (hipStream_t)stream);
+}
+
+// ---- single-kernel entry points --------------------------------------------------------------------
+int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
+                    int64_t ldc, int M, int N, int K, const float* bias, int epilogue, void* aux, int64_t ldaux,
+                    const void* residual, int64_t ldr, float drop_p, uint32_t drop_site, const uint64_t* rng, const int* m_dev,
+                    void* stream) {
+    GemmNT g;
+    g.A = A; g.lda = lda; g.a_rows = a_rows; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux; g.res = residual; g.ldr = ldr;
+    g.drop = DropCfg{rng, rng ? drop_p : 0.f, drop_site}; g.m_dev = m_dev;
+    if (dtype == PMGT_DTYPE_BF16) return gemm_nt<bf16>(g, (hipStream_t)stream);
+    return gemm_nt<float>(g, (hipStream_t)stream);
+}
+
+int64_t pmgt_op_gemm_tn_slab_elems(int dtype, int M, int N1, int N2) { return tn_slab_elems(dtype, M, N1, N2); }
+
+int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, const int64_t* q_rows, int M, int N1,
+                    int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream) {
+    GemmTN g;
+    g.P = P; g.ldp = ldp; g.Q = Q; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2; g.slab = slab; g.m_dev = m_dev;
+    g.splits = gemm_tn_pick_splits(M, N1, N2, dtype == PMGT_DTYPE_BF16 ? 64 : 32);
+    int rc = dtype == PMGT_DTYPE_BF16 ? gemm_tn<bf16>(g, (hipStream_t)stream) : gemm_tn<float>(g, (hipStream_t)stream);
+    if (rc) return rc;
+    return slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, accumulate != 0, (hipStream_t)stream);
+}
+
+int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream) {
+    if (dtype == PMGT_DTYPE_BF16) return colsum<bf16>((const bf16*)Y, ldy, M, N, slab, out, false, nullptr, (hipStream_t)stream);
+    return colsum<float>((const float*)Y, ldy, M, N, slab, out, false, nullptr, (hipStream_t)stream);
+}
+
+int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const float* gamma, const float* beta, int M,
+                          int d, float eps, float drop_p, uint32_t drop_site, const uint64_t* rng, void* stream) {
+    DropCfg dc{rng, rng ? drop_p : 0.f, drop_site};
+    if (dtype == PMGT_DTYPE_BF16) return ln_fwd<bf16>((const bf16*)x, (bf16*)y, stats, gamma, beta, M, d, eps, dc, (hipStream_t)stream);
+    return ln_fwd<float>((const float*)x, (float*)y, stats, gamma, beta, M, d, eps, dc, (hipStream_t)stream);
+}
+
+int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                          void* dx_drop, float* part, float* dgamma_dbeta, int M, int d, float in_drop_p, uint32_t in_site,
+                          float out_drop_p, uint32_t out_site, const uint64_t* rng, void* stream) {
+    DropCfg di{rng, rng ? in_drop_p : 0.f, in_site}, dout{rng, rng ? out_drop_p : 0.f, out_site};
+    int rc;
+    if (dtype == PMGT_DTYPE_BF16)
+        rc = ln_bwd<bf16>((const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_drop, part, M, d, di, dout, (hipStream_t)stream);
+    else
+        rc = ln_bwd<float>((const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_drop, part, M, d, di, dout, (hipStream_t)stream);
+    if (rc) return rc;
+    return slab_reduce(part, ln_bwd_parts(M), 2 * d, dgamma_dbeta, false, (hipStream_t)stream);
+}
+
+static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, int H, int dh, float beta, float drop_p,
+                        uint32_t s1, uint32_t s2, const uint64_t* rng) {
+    AttnArgs a;
+    a.qkvc = qkvc; a.mask = mask; a.Tseq = n_seq; a.S = S; a.H = H; a.dh = dh; a.beta = beta;
+    a.drop1 = DropCfg{rng, rng ? drop_p : 0.f, s1};
+    a.drop2 = DropCfg{rng, rng ? drop_p : 0.f, s2};
+    return a;
+}
+
+int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S, int H,
+                          int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream) {
+    AttnArgs a = mk_attn(qkvc, mask, n_seq, S, H, dh, beta, drop_p, site1, site2, rng);
+    a.ctx = ctx; a.probs = probs;
+    if (dtype == PMGT_DTYPE_BF16) return attn_fwd<bf16>(a, (hipStream_t)stream);
+    return attn_fwd<float>(a, (hipStream_t)stream);
+}
+
+int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq, int S,
+                          int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng,
+                          void* stream) {
+    AttnArgs a = mk_attn(qkvc, mask, n_seq, S, H, dh, beta, drop_p, site1, site2, rng);
+    a.dctx = dctx; a.dqkvc = dqkvc;
+    if (dtype == PMGT_DTYPE_BF16) return attn_bwd<bf16>(a, (hipStream_t)stream);
+    return attn_bwd<float>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// MFMA GEMM kernels of the PMGT engine (declarations).  See gemm.hip for the tiling.
+#pragma once
+#include "common.h"
+
+namespace pmgt {
+
+enum GemmEpi { EPI_NONE = 0, EPI_GELU = 1, EPI_GELU_GRAD = 2 };
+
+// C[M,N] = epilogue( A[M,K] * B[N,K]^T ).  Both operands have the reduction index contiguous
+// ("NT"): forward linears use B = W[out,in]; data-gradients use B = W^T[in,out] copies.
+struct GemmNT {
+    const void* A = nullptr; int64_t lda = 0;
+    const int64_t* a_rows = nullptr;   // optional row gather: logical row m reads A + a_rows[m]*lda
+    const void* B = nullptr; int64_t ldb = 0;
+    void* C = nullptr; int64_t ldc = 0;
+    int M = 0, N = 0, K = 0;
+    const float* bias = nullptr;       // [N] fp32, added first
+    int epi = EPI_NONE;
+    void* aux = nullptr; int64_t ldaux = 0;   // EPI_GELU: pre-activation out; EPI_GELU_GRAD: pre-activation in
+    DropCfg drop = {nullptr, 0.f, 0};  // dropout on (acc+bias [+act]), element index m*N+n
+    const void* res = nullptr; int64_t ldr = 0;   // residual added last (same dtype as C)
+    const int* m_dev = nullptr;        // optional device-side row count (<= M)
+};
+template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
+
+// Partial weight gradients: slab[s][N1,N2] = sum over the s-th chunk of rows m of P[m,n1]*Q[m,n2]
+// ("TN": the reduction index is the row).  `slab_reduce` then sums the slabs in a fixed order.
+struct GemmTN {
+    const void* P = nullptr; int64_t ldp = 0;   // [M,N1]  (dY)
+    const void* Q = nullptr; int64_t ldq = 0;   // [M,N2]  (X)
+    const int64_t* q_rows = nullptr;            // optional row gather on Q
+    int M = 0, N1 = 0, N2 = 0;
+    float* slab = nullptr;                      // [splits][N1][N2] fp32 workspace
+    int splits = 1;
+    const int* m_dev = nullptr;
+};
+template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st);
+int gemm_tn_pick_splits(int M, int N1, int N2, int bkm);
+template <typename T> int gemm_tn_bkm();
+
+// dst[i] (+)= sum_s slab[s*n + i]
+int slab_reduce(const float* slab, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st);
+
+// Column sums of Y[M,N] (bias gradients): dst[n] (+)= sum_m Y[m,n]; needs slab of cdiv(M,256)*N floats.
+template <typename T>
+int colsum(const T* Y, int64_t ldy, int M, int N, float* slab, float* dst, bool accumulate,
+           const int* m_dev, hipStream_t st);
+inline int64_t colsum_slab_elems(int M, int N) { return (int64_t)cdiv(M, 256) * N; }
+
+}  // namespace pmgt

@@ -1,0 +1,415 @@
+// MFMA GEMMs for the PMGT engine on gfx950.
+//
+// gemm_nt : C[M,N] = epi(A[M,K] * B[N,K]^T)      forward linears and data-gradients
+// gemm_tn : slab[s] = P[rows_s,N1]^T * Q[rows_s,N2]   weight-gradients, split over row chunks
+//
+// Tiling (both): 256 threads = 4 waves in a 2x2 grid, 128x128 output tile, each wave 64x64 as
+// 4x4 MFMA 16x16 tiles (64 accumulator VGPRs).  Operands are staged global -> registers -> LDS in
+// 16-byte chunks (double-buffered LDS, one barrier per K-step, next tile's global loads issued
+// before the MFMAs of the current one).
+//   * bf16 mode: v_mfma_f32_16x16x32_bf16, K-step 64; fp32 parity mode: v_mfma_f32_16x16x4_f32
+//     (exact fp32 FMA chain), K-step 32.  Same kernel body, `T` selects the fragment path.
+//   * NT LDS image: [rows][128 B] with the 16-B chunk index XOR-swizzled by (row & 7) so the
+//     ds_read_b128 fragment reads of 16 rows x same k-chunk are bank-conflict free.
+//   * TN LDS image: the tiles as they sit in memory ([m][128 cols]); the bf16 path builds the
+//     k-strided MFMA fragments with ds_read_b64_tr_b16 (hardware transpose read) and an XOR
+//     swizzle chosen so the 32 lanes of a half-wave hit 32 distinct 8-byte slots.
+//   * blockIdx -> tile mapping keeps the N-tiles of one M-tile on one XCD (ids b, b+8 share an
+//     XCD's L2), so the A tile is fetched from HBM once.
+#include "gemm.h"
+
+namespace pmgt {
+
+// ------------------------------------------------------------------------------------------------
+// NT
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
+    constexpr int EPC = 16 / sizeof(T);   // elements per 16-byte chunk
+    constexpr int BK = 8 * EPC;           // 128-byte LDS rows
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int LA = BM / 32, LB = BN / 32;   // 16-B chunks per thread per tile
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
+    char* sA = smem;
+    char* sB = smem + 2 * BM * 128;
+
+    const int num_n = (g.N + BN - 1) / BN;
+    const int num_m = (g.M + BM - 1) / BM;
+    const int b = blockIdx.x;
+    const int grp = b / (8 * num_n), within = b % (8 * num_n);
+    const int m_tile = grp * 8 + (within & 7), n_tile = within >> 3;
+    if (m_tile >= num_m) return;
+    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (m0 >= Mlim) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    // per-thread staging assignment: chunk c of rows r0 + 32 i
+    const int c = tid & 7, r0 = tid >> 3;
+    const char* arow[LA];
+    const char* brow[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        int m = min(m0 + r0 + 32 * i, Mlim - 1);
+        int64_t row = g.a_rows ? g.a_rows[m] : (int64_t)m;
+        arow[i] = (const char*)g.A + row * g.lda * (int64_t)sizeof(T);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        int n = min(n0 + r0 + 32 * i, g.N - 1);
+        brow[i] = (const char*)g.B + (int64_t)n * g.ldb * (int64_t)sizeof(T);
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[LA], rb[LB];
+    auto gload = [&](int k0) {
+        const int k = k0 + c * EPC;
+        const bool ok = k < g.K;
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            ra[i] = ok ? *(const u32x4*)(arow[i] + (int64_t)k * sizeof(T)) : (u32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            rb[i] = ok ? *(const u32x4*)(brow[i] + (int64_t)k * sizeof(T)) : (u32x4){0, 0, 0, 0};
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *(u32x4*)(sA + buf * BM * 128 + nt_off(r0 + 32 * i, c)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *(u32x4*)(sB + buf * BN * 128 + nt_off(r0 + 32 * i, c)) = rb[i];
+    };
+
+    const int nk = (g.K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const char* a_base = sA + buf * BM * 128;
+        const char* b_base = sB + buf * BN * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *(const bf16x8*)(a_base + nt_off(wm * (BM / 2) + i * 16 + r, 4 * kk + q));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *(const bf16x8*)(b_base + nt_off(wn * (BN / 2) + j * 16 + r, 4 * kk + q));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            } else {
+                // lane (r,q) holds k = 16kk + 4q + e, e = 0..3; MFMA e pairs the e-th elements, so the
+                // hardware k-slot q of MFMA e is the same real k for A and B.
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *(const f32x4*)(a_base + nt_off(wm * (BM / 2) + i * 16 + r, 4 * kk + q));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *(const f32x4*)(b_base + nt_off(wn * (BN / 2) + j * 16 + r, 4 * kk + q));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+    const DropKey dk = make_drop_key(g.drop);
+    T* C = (T*)g.C;
+    const T* R = (const T*)g.res;
+    T* AUX = (T*)g.aux;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + r;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + 4 * q + e;
+                if (m >= Mlim) continue;
+                float v = acc[i][j][e] + bv;
+                if (g.epi == EPI_GELU) {
+                    T pre = from_f<T>(v);
+                    AUX[(int64_t)m * g.ldaux + n] = pre;
+                    v = gelu_erf(to_f<T>(pre));
+                } else if (g.epi == EPI_GELU_GRAD) {
+                    v *= gelu_erf_grad(to_f<T>(AUX[(int64_t)m * g.ldaux + n]));
+                }
+                if (dk.on) v *= drop_mul(dk, (uint64_t)m * (uint64_t)g.N + (uint64_t)n);
+                if (R) v += to_f<T>(R[(int64_t)m * g.ldr + n]);
+                C[(int64_t)m * g.ldc + n] = from_f<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
+    constexpr int EPC = 16 / sizeof(T);
+    if (g.M <= 0 || g.N <= 0) return 0;
+    PMGT_CHECK(g.K > 0 && g.K % EPC == 0, -2, "gemm_nt: K=%d must be a positive multiple of %d", g.K, EPC);
+    PMGT_CHECK(g.lda % EPC == 0 && g.ldb % EPC == 0, -2, "gemm_nt: lda=%lld ldb=%lld must be multiples of %d",
+               (long long)g.lda, (long long)g.ldb, EPC);
+    PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, -2, "gemm_nt: operands must be 16-byte aligned");
+    PMGT_CHECK(g.lda >= g.K && g.ldb >= g.K && g.ldc >= g.N, -2, "gemm_nt: leading dimensions too small");
+    PMGT_CHECK(g.epi == EPI_NONE || g.aux != nullptr, -2, "gemm_nt: epilogue %d needs aux", g.epi);
+    constexpr int BM = 128, BN = 128;
+    const int num_m = cdiv(g.M, BM), num_n = cdiv(g.N, BN);
+    const int grid = cdiv(num_m, 8) * 8 * num_n;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int gemm_nt<float>(const GemmNT&, hipStream_t);
+template int gemm_nt<bf16>(const GemmNT&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// TN (weight gradients)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T> int gemm_tn_bkm() { return sizeof(T) == 2 ? 64 : 32; }
+template int gemm_tn_bkm<float>();
+template int gemm_tn_bkm<bf16>();
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BKM = sizeof(T) == 2 ? 64 : 32;    // reduction rows per step
+    constexpr int ROWB = 128 * sizeof(T);            // LDS bytes per tile row (128 columns)
+    constexpr int CPR = ROWB / 16;                   // 16-B chunks per row
+    constexpr int TILEB = BKM * ROWB;                // 16 KiB either way
+    constexpr int LPT = BKM * CPR / 256;             // chunks per thread per tile (= 4)
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILEB];
+    char* sP = smem;
+    char* sQ = smem + 2 * TILEB;
+
+    const int n1_0 = blockIdx.x * 128, n2_0 = blockIdx.y * 128, split = blockIdx.z;
+    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 rp[LPT], rq[LPT];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR, ch = idx % CPR;
+            const int m = mb + row;
+            const int cp = n1_0 + ch * EPC, cq = n2_0 + ch * EPC;
+            const bool okm = m < mend;
+            rp[i] = (okm && cp < g.N1) ? *(const u32x4*)((const char*)g.P + ((int64_t)m * g.ldp + cp) * (int64_t)sizeof(T))
+                                       : (u32x4){0, 0, 0, 0};
+            if (okm && cq < g.N2) {
+                const int64_t qr = g.q_rows ? g.q_rows[m] : (int64_t)m;
+                rq[i] = *(const u32x4*)((const char*)g.Q + (qr * g.ldq + cq) * (int64_t)sizeof(T));
+            } else {
+                rq[i] = (u32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR, ch = idx % CPR;
+            int off;
+            if constexpr (sizeof(T) == 2) off = row * ROWB + ((ch ^ (tn_f(row) << 1)) << 4);
+            else off = row * ROWB + (ch << 4);
+            *(u32x4*)(sP + buf * TILEB + off) = rp[i];
+            *(u32x4*)(sQ + buf * TILEB + off) = rq[i];
+        }
+    };
+
+    const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
+    if (nk > 0) {
+        gload(mbeg);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(mbeg + (kt + 1) * BKM);
+        const char* p_base = sP + buf * TILEB;
+        const char* q_base = sQ + buf * TILEB;
+        if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // ds_read_b64_tr_b16: the 16 lanes of group q read a 4(row) x 16(col) block and each lane
+                // receives one column (4 rows).  Lane i of the group supplies row (i >> 2), cols 4*(i & 3).
+                const int row = 32 * kk + 8 * q + (r >> 2);
+                const int sw = tn_f(row) << 1;                 // same for row and row + 4
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = wm * 64 + i * 16 + 4 * (r & 3);
+                    const int off = row * ROWB + (((col >> 3) ^ sw) << 4) + ((col & 7) << 1);
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p_base + off));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p_base + off + 4 * ROWB));
+                    fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = wn * 64 + j * 16 + 4 * (r & 3);
+                    const int off = row * ROWB + (((col >> 3) ^ sw) << 4) + ((col & 7) << 1);
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q_base + off));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q_base + off + 4 * ROWB));
+                    fb[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < BKM / 4; ++s) {
+                const int row = 4 * s + q;
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = *(const float*)(p_base + row * ROWB + (wm * 64 + i * 16 + r) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *(const float*)(q_base + row * ROWB + (wn * 64 + j * 16 + r) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = g.slab + (int64_t)split * g.N1 * g.N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = n2_0 + wn * 64 + j * 16 + r;
+            if (n2 >= g.N2) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
+                if (n1 < g.N1) out[(int64_t)n1 * g.N2 + n2] = acc[i][j][e];
+            }
+        }
+}
+
+int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
+    const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
+    int splits = cdiv(512, tiles);                       // ~2 workgroups per CU
+    const int max_by_rows = std::max(1, M / (4 * bkm));  // at least 4 K-steps per split
+    splits = std::max(1, std::min(splits, max_by_rows));
+    return splits;
+}
+
+template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
+    constexpr int EPC = 16 / sizeof(T);
+    if (g.N1 <= 0 || g.N2 <= 0) return 0;
+    PMGT_CHECK(g.N1 % EPC == 0 && g.N2 % EPC == 0, -2, "gemm_tn: N1=%d N2=%d must be multiples of %d", g.N1, g.N2, EPC);
+    PMGT_CHECK(g.ldp % EPC == 0 && g.ldq % EPC == 0, -2, "gemm_tn: leading dims must be multiples of %d", EPC);
+    PMGT_CHECK(((uintptr_t)g.P % 16) == 0 && ((uintptr_t)g.Q % 16) == 0, -2, "gemm_tn: operands must be 16-byte aligned");
+    PMGT_CHECK(g.splits >= 1 && g.slab, -2, "gemm_tn: bad splits/slab");
+    const int bkm = gemm_tn_bkm<T>();
+    int chunk = cdiv(cdiv(std::max(g.M, 1), g.splits), bkm) * bkm;
+    dim3 grid(cdiv(g.N1, 128), cdiv(g.N2, 128), g.splits);
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), 0, st, g, chunk);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int gemm_tn<float>(const GemmTN&, hipStream_t);
+template int gemm_tn<bf16>(const GemmTN&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// slab reduce / column sums
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,
+                                                          float* __restrict__ dst, int accumulate) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n && (n % 4) == 0) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < splits; ++k) s += *(const f32x4*)(slab + (int64_t)k * n + i4);
+        if (accumulate) s += *(const f32x4*)(dst + i4);
+        *(f32x4*)(dst + i4) = s;
+    } else {
+        for (int64_t i = i4; i < n && i < i4 + 4; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * n + i];
+            dst[i] = accumulate ? dst[i] + s : s;
+        }
+    }
+}
+
+int slab_reduce(const float* slab, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st) {
+    if (n <= 0) return 0;
+    PMGT_CHECK(((uintptr_t)slab % 16) == 0 && ((uintptr_t)dst % 16 == 0 || n % 4 != 0), -2,
+               "slab_reduce: unaligned buffers");
+    const int64_t blocks = cdiv64(cdiv64(n, 4), 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, splits, n, dst, accumulate ? 1 : 0);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, int64_t ldy, int M, int N,
+                                                     float* __restrict__ slab, const int* m_dev) {
+    const int Mlim = m_dev ? min(M, *m_dev) : M;
+    const int c4 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c4 >= N) return;
+    const int mb = blockIdx.x * 256, me = min(Mlim, mb + 256);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int m = mb; m < me; ++m) s += load4<T>(Y + (int64_t)m * ldy + c4);
+    *(f32x4*)(slab + (int64_t)blockIdx.x * N + c4) = s;
+}
+
+template <typename T>
+int colsum(const T* Y, int64_t ldy, int M, int N, float* slab, float* dst, bool accumulate, const int* m_dev,
+           hipStream_t st) {
+    if (N <= 0) return 0;
+    PMGT_CHECK(N % 4 == 0 && ldy % 4 == 0, -2, "colsum: N=%d / ld must be multiples of 4", N);
+    const int rb = std::max(1, cdiv(M, 256));
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(rb, cdiv(N, 1024)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
+    PMGT_LAUNCH_OK();
+    return slab_reduce(slab, rb, N, dst, accumulate, st);
+}
+template int colsum<float>(const float*, int64_t, int, int, float*, float*, bool, const int*, hipStream_t);
+template int colsum<bf16>(const bf16*, int64_t, int, int, float*, float*, bool, const int*, hipStream_t);
+
+}  // namespace pmgt

@@ -1,0 +1,40 @@
+// Loss heads (declarations); see loss.hip.
+#pragma once
+#include "common.h"
+
+namespace pmgt {
+
+int pair_offsets(const int64_t* num_pairs, int B, int* off, hipStream_t st);
+int nfr_generate(const int64_t* ids, int B, int S, int n_nodes, float random_ratio, float mask_ratio,
+                 const uint64_t* rng, int64_t* masked_ids, int64_t* tgt_full, hipStream_t st);
+int nfr_compact(const int64_t* tgt_full, int B, int S, int seq_off, int64_t* rows, int64_t* tids, int* count,
+                hipStream_t st);
+
+struct GsrArgs {
+    const void* h = nullptr;        // [Tseq*S, d] encoder output; sequences 0..B-1 = targets, B.. = pairs
+    void* dh = nullptr;             // same shape, pre-zeroed; CLS rows receive the gradient (nullable: eval)
+    int B = 0, S = 0, d = 0;
+    const int* off = nullptr;       // [B+1] pair offsets
+    const float* labels = nullptr;  // [P]
+    float* logits = nullptr;        // [P] out
+    float* loss_part = nullptr;     // [B] out: loss_i / B
+};
+template <typename T> int gsr_fwd_bwd(const GsrArgs& g, hipStream_t st);
+
+struct NfrDiffArgs {
+    void* pred = nullptr;           // [cap, Fv+Ft] in: projections; out: d loss / d pred
+    const int64_t* tids = nullptr;  // [cap] ids to reconstruct
+    const int* count = nullptr;     // device row count
+    int cap = 0, Fv = 0, Ft = 0;
+    const void* table_v = nullptr;  // [N+2, Fv]
+    const void* table_t = nullptr;  // [N+2, Ft]
+    float* sse_part = nullptr;      // [nfr_diff_parts(cap)][2]
+};
+inline int nfr_diff_parts(int cap) { return cdiv(cap, 8); }
+template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st);
+template <typename T>
+int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st);
+int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
+                bool with_nfr, float* out, hipStream_t st);
+
+}  // namespace pmgt

@@ -1,0 +1,294 @@
+// Loss heads of PMGT pre-training and their gradients wrt the encoder output:
+//   GSR  (graph structure reconstruction): pmgt/pmgt/modeling_pmgt.py:537-546 + loop pmgt/pmgt/models.py:106-126
+//   NFR  (masked node feature reconstruction): pmgt/pmgt/models.py:129-162, pmgt/pmgt/modeling_pmgt.py:549-569
+// All row counts that depend on the random mask stay on the device (no host sync): kernels take a
+// device-side count and tiles beyond it exit.
+#include "loss.h"
+
+namespace pmgt {
+
+__device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// ------------------------------------------------------------------------------------------------
+// small single-block utilities
+// ------------------------------------------------------------------------------------------------
+// off[i] = sum_{k<i} num_pairs[k], off[B] = total
+__global__ __launch_bounds__(1024) void pair_offsets_kernel(const int64_t* __restrict__ num_pairs, int B, int* __restrict__ off) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(B, b0 + per);
+    int s = 0;
+    for (int i = b0; i < b1; ++i) s += (int)num_pairs[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid > 0 ? part[tid - 1] : 0;
+    for (int i = b0; i < b1; ++i) { off[i] = run; run += (int)num_pairs[i]; }
+    if (tid == 1023) off[B] = part[1023];
+}
+
+int pair_offsets(const int64_t* num_pairs, int B, int* off, hipStream_t st) {
+    hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), 0, st, num_pairs, B, off);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// NFR masking with the device RNG (pmgt/pmgt/models.py:132-151): writes masked ids and, per position,
+// the id to reconstruct (-1 where not masked).
+__global__ void nfr_generate_kernel(const int64_t* __restrict__ ids, int B, int S, int n_nodes, float random_ratio,
+                                    float mask_ratio, const uint64_t* rng, int64_t* __restrict__ masked_ids,
+                                    int64_t* __restrict__ tgt_full) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * S) return;
+    const int s = idx % S;
+    int64_t id = ids[idx];
+    int64_t tgt = -1;
+    if (s > 0 && id != 0) {
+        DropCfg c1 = {rng, 0.5f, SITE_NFR1}, c2 = {rng, 0.5f, SITE_NFR2};
+        const DropKey k1 = make_drop_key(c1), k2 = make_drop_key(c2);
+        auto u32 = [](const DropKey& k, uint64_t i) {
+            uint32_t x = fmix32(((uint32_t)i ^ k.k0) * 0x9E3779B1u + (uint32_t)(i >> 32));
+            return fmix32(x + k.k1);
+        };
+        const float r1 = (float)(u32(k1, 2 * (uint64_t)idx) >> 8) * (1.f / 16777216.f);
+        if (r1 < random_ratio) id = 2 + (int64_t)(u32(k1, 2 * (uint64_t)idx + 1) % (uint32_t)n_nodes);
+        const float r2 = (float)(u32(k2, (uint64_t)idx) >> 8) * (1.f / 16777216.f);
+        if (r2 < mask_ratio) { tgt = id; id = 1; }
+    }
+    masked_ids[idx] = id;
+    tgt_full[idx] = tgt;
+}
+
+int nfr_generate(const int64_t* ids, int B, int S, int n_nodes, float random_ratio, float mask_ratio,
+                 const uint64_t* rng, int64_t* masked_ids, int64_t* tgt_full, hipStream_t st) {
+    hipLaunchKernelGGL(nfr_generate_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, st, ids, B, S, n_nodes, random_ratio,
+                       mask_ratio, rng, masked_ids, tgt_full);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// Row-major compaction of the masked positions: rows[k] = token row (seq_off + b) * S + s,
+// tids[k] = id to reconstruct, *count = number of masked positions.
+__global__ __launch_bounds__(1024) void nfr_compact_kernel(const int64_t* __restrict__ tgt_full, int B, int S, int seq_off,
+                                                           int64_t* __restrict__ rows, int64_t* __restrict__ tids,
+                                                           int* __restrict__ count) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, n = B * S;
+    const int per = (n + 1023) / 1024;
+    const int e0 = min(n, tid * per), e1 = min(n, e0 + per);
+    int c = 0;
+    for (int i = e0; i < e1; ++i) c += tgt_full[i] >= 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int k = tid > 0 ? part[tid - 1] : 0;
+    for (int i = e0; i < e1; ++i) {
+        const int64_t t = tgt_full[i];
+        if (t >= 0) {
+            rows[k] = (int64_t)seq_off * S + i;
+            tids[k] = t;
+            ++k;
+        }
+    }
+    if (tid == 1023) *count = part[1023];
+}
+
+int nfr_compact(const int64_t* tgt_full, int B, int S, int seq_off, int64_t* rows, int64_t* tids, int* count,
+                hipStream_t st) {
+    hipLaunchKernelGGL(nfr_compact_kernel, dim3(1), dim3(1024), 0, st, tgt_full, B, S, seq_off, rows, tids, count);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GSR: one wave per target node
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void gsr_kernel(GsrArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= g.B) return;
+    const int d = g.d, nch = d >> 2;
+    const int64_t rs = (int64_t)g.S * d;                 // CLS row stride (one sequence)
+    const T* H = (const T*)g.h;
+    T* DH = (T*)g.dh;
+    f32x4 zt[NCH], dzt[NCH];
+    float n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        zt[c] = ch < nch ? load4<T>(H + (int64_t)i * rs + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dzt[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        n2 += sum4(zt[c] * zt[c]);
+    }
+    const float nt = fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) zt[c] = zt[c] / nt;     // z_hat_t
+    const int j0 = g.off[i], j1 = g.off[i + 1];
+    const float inv_cnt = 1.f / (float)(j1 - j0);
+    float loss = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        f32x4 zp[NCH];
+        float p2 = 0.f, dot = 0.f;
+        const T* row = H + (int64_t)(g.B + j) * rs;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            zp[c] = ch < nch ? load4<T>(row + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            p2 += sum4(zp[c] * zp[c]);
+        }
+        const float np = fmaxf(sqrtf(wave_sum(p2)), 1e-12f);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { zp[c] = zp[c] / np; dot += sum4(zp[c] * zt[c]); }
+        const float l = wave_sum(dot);
+        const float y = g.labels[j];
+        loss += fmaxf(l, 0.f) - l * y + log1pf(expf(-fabsf(l)));       // BCEWithLogits
+        if (lane == 0 && g.logits) g.logits[j] = l;
+        if (DH) {
+            const float dl = (1.f / (1.f + expf(-l)) - y) * inv_cnt / (float)g.B;
+            // d z_hat_p = dl * z_hat_t ; through the normalisation: (g - (g . z_hat) z_hat) / |z|
+            const float gz = dl * l;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch) store4<T>(DH + (int64_t)(g.B + j) * rs + 4 * ch, (zt[c] * dl - zp[c] * gz) / np);
+                dzt[c] += zp[c] * dl;
+            }
+        }
+    }
+    if (lane == 0) g.loss_part[i] = loss * inv_cnt / (float)g.B;
+    if (DH) {
+        float gz = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) gz += sum4(dzt[c] * zt[c]);
+        gz = wave_sum(gz);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) store4<T>(DH + (int64_t)i * rs + 4 * ch, (dzt[c] - zt[c] * gz) / nt);
+        }
+    }
+}
+
+template <typename T> int gsr_fwd_bwd(const GsrArgs& g, hipStream_t st) {
+    if (g.B <= 0) return 0;
+    PMGT_CHECK(g.d % 4 == 0 && g.d <= 1024, -2, "gsr: hidden size %d must be a multiple of 4 and <= 1024", g.d);
+    dim3 grid(cdiv(g.B, 4)), block(256);
+    if (g.d <= 256) hipLaunchKernelGGL((gsr_kernel<T, 1>), grid, block, 0, st, g);
+    else if (g.d <= 512) hipLaunchKernelGGL((gsr_kernel<T, 2>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gsr_kernel<T, 4>), grid, block, 0, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int gsr_fwd_bwd<float>(const GsrArgs&, hipStream_t);
+template int gsr_fwd_bwd<bf16>(const GsrArgs&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// NFR: pred (from the GEMM) -> dpred in place + squared-error partials per modality
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nfr_diff_kernel(NfrDiffArgs a) {
+    __shared__ float red[8];
+    const int n = *a.count;
+    const int r0 = blockIdx.x * 8;
+    float sv = 0.f, stx = 0.f;
+    if (r0 < n) {
+        const int F = a.Fv + a.Ft;
+        const float cv = 1.f / ((float)n * (float)a.Fv), ct = 1.f / ((float)n * (float)a.Ft);   // d(0.5*(mse_v+mse_t))/dpred
+        const int r1 = min(n, r0 + 8);
+        for (int r = r0; r < r1; ++r) {
+            const int64_t tid = a.tids[r];
+            T* p = (T*)a.pred + (int64_t)r * F;
+            const T* tv = (const T*)a.table_v + tid * a.Fv;
+            const T* tt = (const T*)a.table_t + tid * a.Ft;
+            for (int c4 = threadIdx.x * 4; c4 < F; c4 += 1024) {
+                const bool isv = c4 < a.Fv;
+                f32x4 diff = load4<T>(p + c4) - (isv ? load4<T>(tv + c4) : load4<T>(tt + (c4 - a.Fv)));
+                const float ss = sum4(diff * diff);
+                if (isv) sv += ss; else stx += ss;
+                store4<T>(p + c4, diff * (isv ? cv : ct));
+            }
+        }
+    }
+    sv = wave_sum(sv);
+    stx = wave_sum(stx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = sv; red[4 + wave] = stx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.sse_part[2 * (int64_t)blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        a.sse_part[2 * (int64_t)blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st) {
+    if (a.cap <= 0) return 0;
+    PMGT_CHECK(a.Fv % 4 == 0 && a.Ft % 4 == 0, -2, "nfr_diff: feature sizes must be multiples of 4");
+    hipLaunchKernelGGL((nfr_diff_kernel<T>), dim3(nfr_diff_parts(a.cap)), dim3(256), 0, st, a);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int nfr_diff<float>(const NfrDiffArgs&, hipStream_t);
+template int nfr_diff<bf16>(const NfrDiffArgs&, hipStream_t);
+
+// dst[rows[k], :] = src[k, :] for k < *count
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ rows,
+                                                           const int* __restrict__ count, int d, T* __restrict__ dst) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= *count) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = rows[k];
+    for (int c4 = lane * 4; c4 < d; c4 += 256) store4<T>(dst + r * d + c4, load4<T>(src + (int64_t)k * d + c4));
+}
+template <typename T>
+int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st) {
+    if (cap <= 0) return 0;
+    hipLaunchKernelGGL((scatter_rows_kernel<T>), dim3(cdiv(cap, 4)), dim3(256), 0, st, src, rows, count, d, dst);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int scatter_rows<float>(const float*, const int64_t*, const int*, int, int, float*, hipStream_t);
+template int scatter_rows<bf16>(const bf16*, const int64_t*, const int*, int, int, bf16*, hipStream_t);
+
+// out = {loss, gsr, nfr};  nfr = 0.5 * (sse_v / (n Fv) + sse_t / (n Ft)); n == 0 gives NaN like the reference
+__global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ gsr_part, int B,
+                                                         const float* __restrict__ sse_part, int nparts,
+                                                         const int* __restrict__ count, int Fv, int Ft, int with_nfr,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    float g = 0.f, sv = 0.f, stx = 0.f;
+    for (int i = lane; i < B; i += 64) g += gsr_part[i];
+    g = wave_sum(g);
+    float nfr = 0.f;
+    if (with_nfr) {
+        const int n = *count;
+        const int used = (n + 7) / 8;
+        for (int i = lane; i < used && i < nparts; i += 64) { sv += sse_part[2 * i]; stx += sse_part[2 * i + 1]; }
+        sv = wave_sum(sv);
+        stx = wave_sum(stx);
+        nfr = 0.5f * (sv / ((float)n * (float)Fv) + stx / ((float)n * (float)Ft));
+    }
+    if (lane == 0) { out[0] = g + nfr; out[1] = g; out[2] = nfr; }
+}
+
+int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
+                bool with_nfr, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, gsr_part, B, sse_part, nparts, count, Fv, Ft,
+                       with_nfr ? 1 : 0, out);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace pmgt

@@ -1,0 +1,49 @@
+// Row-wise kernels of the PMGT engine: LayerNorm fwd/bwd, the modality-attention embedding mix
+// (PMGTEmbeddings minus its two GEMMs), loss heads, optimizer.  Declarations.
+#pragma once
+#include "common.h"
+
+namespace pmgt {
+
+// ---- LayerNorm ------------------------------------------------------------------------------
+// y = dropout(LN(x)); stats[m] = {mean, rstd}.  d % 4 == 0, d <= 1024.  One wave per row.
+template <typename T>
+int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
+           DropCfg out_drop, hipStream_t st);
+// dx = LN'(dy * in_mask); optional second output dx_drop = dx * out_mask (gradient of the dropout
+// that fed the residual sum).  Partial dgamma/dbeta go to `part` ([ln_bwd_parts(M)][2][d] floats).
+template <typename T>
+int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
+           int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st);
+inline int ln_bwd_parts(int M) { return cdiv(M, 64); }
+
+// ---- embedding mix (pmgt/pmgt/modeling_pmgt.py:199-208) ----------------------------------------
+struct EmbedMix {
+    int M = 0, S = 0, d = 0;
+    const void* E = nullptr;       // [M, 2d]: e_v | e_t (bias already added by the GEMM epilogue)
+    const float* Wa = nullptr;     // [2, 2d]
+    const float* ba = nullptr;     // [2]
+    const float* pos = nullptr;    // [max_pos, d]
+    const float* role = nullptr;   // [2, d]
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float eps = 1e-12f;
+    float* a = nullptr;            // [M, 2] modality weights (saved for backward)
+    void* pre = nullptr;           // [M, d] LayerNorm input (saved)
+    float* stats = nullptr;        // [M, 2]
+    void* h0 = nullptr;            // [M, d] output
+    DropCfg drop = {nullptr, 0.f, 0};
+    // backward only
+    const void* dh0 = nullptr;     // [M, d]
+    void* dE = nullptr;            // [M, 2d]
+    void* dF = nullptr;            // [M, d] gradient wrt (mix + pos + role), feeds the pos/role sums
+    float* part = nullptr;         // [embed_bwd_parts(M)][6d + 4]: dgamma | dbeta | dWa (2 x 2d) | dba
+};
+template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st);
+template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st);
+inline int embed_bwd_parts(int M) { return cdiv(M, 64); }
+// dpos[s,:] = colsum over sequences (given as possum [S*d]); drole[0] = possum[0], drole[1] = sum_{s>=1}
+int pos_role_finish(const float* possum, int S, int d, int max_pos, float* dpos, float* drole, bool accumulate,
+                    hipStream_t st);
+
+}  // namespace pmgt

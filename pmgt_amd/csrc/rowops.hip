@@ -1,0 +1,418 @@
+// Row-wise fused kernels: LayerNorm fwd/bwd and the PMGTEmbeddings modality mix fwd/bwd.
+// One wave (64 lanes) owns one row; a lane holds 4-element chunks `lane + 64*i` of the row in
+// registers (d <= 1024), so every row is read once and reduced with wave shuffles.  These kernels
+// are HBM-bound: algorithmic bytes per row are listed in DESIGN.md.
+#include "rowops.h"
+
+namespace pmgt {
+
+template <int NCH> __device__ __forceinline__ bool ch_ok(int lane, int i, int nch) { return lane + 64 * i < nch; }
+
+__device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int M, int d, float eps, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const int nch = d >> 2;
+    const T* xr = x + (int64_t)m * d;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        v[i] = ch < nch ? load4<T>(xr + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        s += sum4(v[i]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < nch) {
+            f32x4 t = v[i] - mean;
+            ss += sum4(t * t);
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)d + eps);
+    if (lane == 0) { stats[2 * (int64_t)m] = mean; stats[2 * (int64_t)m + 1] = rstd; }
+    const DropKey dk = make_drop_key(drop);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            f32x4 g = *(const f32x4*)(gamma + 4 * ch), b = *(const f32x4*)(beta + 4 * ch);
+            f32x4 o = (v[i] - mean) * rstd * g + b;
+            if (dk.on) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= drop_mul(dk, (uint64_t)m * d + 4 * ch + e);
+            }
+            store4<T>(y + (int64_t)m * d + 4 * ch, o);
+        }
+    }
+}
+
+template <typename T>
+int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
+           DropCfg out_drop, hipStream_t st) {
+    if (M <= 0) return 0;
+    PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_fwd: hidden size %d must be a multiple of 4 and <= 1024", d);
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (d <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop);
+    else if (d <= 512) hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop);
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int ln_fwd<float>(const float*, float*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t);
+template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  64 rows per block (16 per wave); dgamma/dbeta partials per block.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
+                                                     int M, int d, DropCfg in_drop, DropCfg out_drop) {
+    __shared__ float red[2 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = d >> 2;
+    const DropKey ik = make_drop_key(in_drop), ok = make_drop_key(out_drop);
+    f32x4 gam[NCH], dgam[NCH], dbet[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        gam[i] = ch < nch ? *(const f32x4*)(gamma + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dgam[i] = dbet[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int it = 0; it < 16; ++it) {
+        const int m = blockIdx.x * 64 + it * 4 + wave;
+        if (m >= M) break;
+        const float mean = stats[2 * (int64_t)m], rstd = stats[2 * (int64_t)m + 1];
+        f32x4 g[NCH], xh[NCH];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 dyv = load4<T>(dy + (int64_t)m * d + 4 * ch);
+                if (ik.on) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dyv[e] *= drop_mul(ik, (uint64_t)m * d + 4 * ch + e);
+                }
+                xh[i] = (load4<T>(x + (int64_t)m * d + 4 * ch) - mean) * rstd;
+                g[i] = dyv * gam[i];
+                dgam[i] += dyv * xh[i];
+                dbet[i] += dyv;
+                sg += sum4(g[i]);
+                sgx += sum4(g[i] * xh[i]);
+            } else {
+                g[i] = xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        sg = wave_sum(sg) / (float)d;
+        sgx = wave_sum(sgx) / (float)d;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 o = (g[i] - sg - xh[i] * sgx) * rstd;
+                store4<T>(dx + (int64_t)m * d + 4 * ch, o);
+                if (dx_drop) {
+                    if (ok.on) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] *= drop_mul(ok, (uint64_t)m * d + 4 * ch + e);
+                    }
+                    store4<T>(dx_drop + (int64_t)m * d + 4 * ch, o);
+                }
+            }
+        }
+    }
+    // cross-wave reduction of the partials, one wave at a time into LDS
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    f32x4 a = dgam[i], b = dbet[i];
+                    if (w > 0) { a += *(f32x4*)(red + 4 * ch); b += *(f32x4*)(red + d + 4 * ch); }
+                    *(f32x4*)(red + 4 * ch) = a;
+                    *(f32x4*)(red + d + 4 * ch) = b;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (int64_t)blockIdx.x * 2 * d;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) out[i] = red[i];
+}
+
+template <typename T>
+int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part, int M,
+           int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st) {
+    if (M <= 0) return 0;
+    PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_bwd: hidden size %d must be a multiple of 4 and <= 1024", d);
+    dim3 grid(ln_bwd_parts(M)), block(256);
+    if (d <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop);
+    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop);
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int ln_bwd<float>(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, DropCfg, DropCfg, hipStream_t);
+template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, bf16*, bf16*, float*, int, int, DropCfg, DropCfg, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// Embedding mix forward: a = softmax(Wa tanh([e_v;e_t]) + ba); x = a0 e_v + a1 e_t + pos[s] + role[s>0];
+// h0 = dropout(LN(x)).   (pmgt/pmgt/modeling_pmgt.py:199-208)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= p.M) return;
+    const int d = p.d, nch = d >> 2;
+    const int s = m % p.S;
+    const T* E = (const T*)p.E + (int64_t)m * 2 * d;
+    f32x4 ev[NCH], et[NCH];
+    float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            ev[i] = load4<T>(E + 4 * ch);
+            et[i] = load4<T>(E + d + 4 * ch);
+            f32x4 tv, tt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tv[e] = tanhf(ev[i][e]); tt[e] = tanhf(et[i][e]); }
+            z0 += sum4(tv * *(const f32x4*)(p.Wa + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + d + 4 * ch));
+            z1 += sum4(tv * *(const f32x4*)(p.Wa + 2 * d + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + 3 * d + 4 * ch));
+        } else {
+            ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    z0 = wave_sum(z0) + p.ba[0];
+    z1 = wave_sum(z1) + p.ba[1];
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
+    if (lane == 0) { p.a[2 * (int64_t)m] = a0; p.a[2 * (int64_t)m + 1] = a1; }
+
+    f32x4 x[NCH];
+    float sum = 0.f;
+    const float* pos = p.pos + (int64_t)s * d;
+    const float* role = p.role + (s > 0 ? d : 0);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            f32x4 v = ev[i] * a0 + et[i] * a1 + *(const f32x4*)(pos + 4 * ch) + *(const f32x4*)(role + 4 * ch);
+            store4<T>((T*)p.pre + (int64_t)m * d + 4 * ch, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = to_f<T>(from_f<T>(v[e]));   // LN sees what backward will re-read
+            x[i] = v;
+            sum += sum4(v);
+        } else {
+            x[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < nch) { f32x4 t = x[i] - mean; ss += sum4(t * t); }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)d + p.eps);
+    if (lane == 0) { p.stats[2 * (int64_t)m] = mean; p.stats[2 * (int64_t)m + 1] = rstd; }
+    const DropKey dk = make_drop_key(p.drop);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            f32x4 o = (x[i] - mean) * rstd * *(const f32x4*)(p.gamma + 4 * ch) + *(const f32x4*)(p.beta + 4 * ch);
+            if (dk.on) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= drop_mul(dk, (uint64_t)m * d + 4 * ch + e);
+            }
+            store4<T>((T*)p.h0 + (int64_t)m * d + 4 * ch, o);
+        }
+    }
+}
+
+template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st) {
+    if (e.M <= 0) return 0;
+    PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_fwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
+    dim3 grid(cdiv(e.M, 4)), block(256);
+    if (e.d <= 256) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 1>), grid, block, 0, st, e);
+    else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 2>), grid, block, 0, st, e);
+    else hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 4>), grid, block, 0, st, e);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int embed_mix_fwd<float>(const EmbedMix&, hipStream_t);
+template int embed_mix_fwd<bf16>(const EmbedMix&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// Embedding mix backward.  Partials per block: dgamma[d] | dbeta[d] | dWa[2][2d] | dba[2] (+2 pad)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
+    __shared__ float red[6 * 1024 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = p.d, nch = d >> 2;
+    const DropKey ik = make_drop_key(p.drop);
+    f32x4 gam[NCH], dgam[NCH], dbet[NCH], dw0v[NCH], dw0t[NCH], dw1v[NCH], dw1t[NCH];
+    f32x4 w0v[NCH], w0t[NCH], w1v[NCH], w1t[NCH];
+    float dba0 = 0.f, dba1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + 64 * i;
+        const bool ok = ch < nch;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        gam[i] = ok ? *(const f32x4*)(p.gamma + 4 * ch) : z;
+        w0v[i] = ok ? *(const f32x4*)(p.Wa + 4 * ch) : z;
+        w0t[i] = ok ? *(const f32x4*)(p.Wa + d + 4 * ch) : z;
+        w1v[i] = ok ? *(const f32x4*)(p.Wa + 2 * d + 4 * ch) : z;
+        w1t[i] = ok ? *(const f32x4*)(p.Wa + 3 * d + 4 * ch) : z;
+        dgam[i] = dbet[i] = dw0v[i] = dw0t[i] = dw1v[i] = dw1t[i] = z;
+    }
+    for (int it = 0; it < 16; ++it) {
+        const int m = blockIdx.x * 64 + it * 4 + wave;
+        if (m >= p.M) break;
+        const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
+        const float a0 = p.a[2 * (int64_t)m], a1 = p.a[2 * (int64_t)m + 1];
+        f32x4 g[NCH], xh[NCH];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 dyv = load4<T>((const T*)p.dh0 + (int64_t)m * d + 4 * ch);
+                if (ik.on) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dyv[e] *= drop_mul(ik, (uint64_t)m * d + 4 * ch + e);
+                }
+                xh[i] = (load4<T>((const T*)p.pre + (int64_t)m * d + 4 * ch) - mean) * rstd;
+                g[i] = dyv * gam[i];
+                dgam[i] += dyv * xh[i];
+                dbet[i] += dyv;
+                sg += sum4(g[i]);
+                sgx += sum4(g[i] * xh[i]);
+            } else {
+                g[i] = xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        sg = wave_sum(sg) / (float)d;
+        sgx = wave_sum(sgx) / (float)d;
+        // df = gradient wrt the pre-LN sum; then through f = a0 e_v + a1 e_t
+        f32x4 df[NCH], ev[NCH], et[NCH];
+        float da0 = 0.f, da1 = 0.f;
+        const T* E = (const T*)p.E + (int64_t)m * 2 * d;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                df[i] = (g[i] - sg - xh[i] * sgx) * rstd;
+                store4<T>((T*)p.dF + (int64_t)m * d + 4 * ch, df[i]);
+                ev[i] = load4<T>(E + 4 * ch);
+                et[i] = load4<T>(E + d + 4 * ch);
+                da0 += sum4(df[i] * ev[i]);
+                da1 += sum4(df[i] * et[i]);
+            } else {
+                df[i] = ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        da0 = wave_sum(da0);
+        da1 = wave_sum(da1);
+        const float dot = a0 * da0 + a1 * da1;
+        const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
+        dba0 += dz0;
+        dba1 += dz1;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 tv, tt, dev, det;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tv[e] = tanhf(ev[i][e]); tt[e] = tanhf(et[i][e]); }
+                dw0v[i] += tv * dz0; dw0t[i] += tt * dz0;
+                dw1v[i] += tv * dz1; dw1t[i] += tt * dz1;
+                dev = df[i] * a0 + (1.f - tv * tv) * (w0v[i] * dz0 + w1v[i] * dz1);
+                det = df[i] * a1 + (1.f - tt * tt) * (w0t[i] * dz0 + w1t[i] * dz1);
+                store4<T>((T*)p.dE + (int64_t)m * 2 * d + 4 * ch, dev);
+                store4<T>((T*)p.dE + (int64_t)m * 2 * d + d + 4 * ch, det);
+            }
+        }
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    f32x4 v[6] = {dgam[i], dbet[i], dw0v[i], dw0t[i], dw1v[i], dw1t[i]};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        float* dst = red + k * d + 4 * ch;
+                        if (w > 0) v[k] += *(f32x4*)dst;
+                        *(f32x4*)dst = v[k];
+                    }
+                }
+            }
+            if (lane == 0) {   // dz is wave-uniform, so lane 0 carries the row sums
+                red[6 * d] = (w > 0 ? red[6 * d] : 0.f) + dba0;
+                red[6 * d + 1] = (w > 0 ? red[6 * d + 1] : 0.f) + dba1;
+                red[6 * d + 2] = 0.f;
+                red[6 * d + 3] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = p.part + (int64_t)blockIdx.x * (6 * d + 4);
+    for (int i = threadIdx.x; i < 6 * d + 4; i += 256) out[i] = red[i];
+}
+
+template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st) {
+    if (e.M <= 0) return 0;
+    PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_bwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
+    dim3 grid(embed_bwd_parts(e.M)), block(256);
+    if (e.d <= 256) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 1>), grid, block, 0, st, e);
+    else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 2>), grid, block, 0, st, e);
+    else hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 4>), grid, block, 0, st, e);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int embed_mix_bwd<float>(const EmbedMix&, hipStream_t);
+template int embed_mix_bwd<bf16>(const EmbedMix&, hipStream_t);
+
+__global__ void pos_role_finish_kernel(const float* __restrict__ possum, int S, int d, int max_pos,
+                                       float* __restrict__ dpos, float* __restrict__ drole, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float r1 = 0.f;
+    for (int s = 0; s < max_pos; ++s) {
+        const float v = s < S ? possum[(int64_t)s * d + c] : 0.f;
+        if (s >= 1) r1 += v;
+        float* o = dpos + (int64_t)s * d + c;
+        *o = accumulate ? *o + v : v;
+    }
+    const float r0 = possum[c];
+    drole[c] = accumulate ? drole[c] + r0 : r0;
+    drole[d + c] = accumulate ? drole[d + c] + r1 : r1;
+}
+
+int pos_role_finish(const float* possum, int S, int d, int max_pos, float* dpos, float* drole, bool accumulate,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(pos_role_finish_kernel, dim3(cdiv(d, 256)), dim3(256), 0, st, possum, S, d, max_pos, dpos,
+                       drole, accumulate ? 1 : 0);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace pmgt

@@ -1,0 +1,393 @@
+// Host MCNSampling for PMGT pre-training (libpmgt_sampler.so; pure C++17, no HIP).
+//
+// Re-implements pmgt/pmgt/datasets.py:14-208 of the reference on a CSR graph and reproduces the
+// reference's random streams bit for bit WITHOUT numpy: the reference draws from numpy's legacy
+// process-global MT19937 (np.random.seed / choice / randint), so this file carries
+//   * MT19937 with numpy's legacy integer seeding (init_genrand),
+//   * random_sample():  ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two 32-bit outputs,
+//   * choice(a, n, replace=True, p): cdf = cumsum(p) / cdf[-1]; searchsorted(cdf, u, 'right'),
+//   * randint(n) / permutation(): masked rejection of 32-bit draws (Fisher-Yates from the top),
+//   * scipy softmax in float64 with numpy's pairwise summation order,
+// as listed in SURVEY.md Appendix C.  Tested bit-exact against numpy, the oracle and the golden
+// vectors (tests/test_sampler.py).  Per-node CDFs are computed once at creation (the reference
+// recomputes softmax + cumsum on every visit), which does not change any draw.
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../include/pmgt_capi.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+void set_err(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- numpy legacy MT19937 --------------------------------------------------------------------------
+struct MT19937 {
+    uint32_t key[624];
+    int pos;
+    void seed(uint32_t s) {            // numpy _legacy_seeding(int) -> mt19937_seed (init_genrand)
+        for (int i = 0; i < 624; ++i) {
+            key[i] = s;
+            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+        }
+        pos = 624;
+    }
+    void gen() {
+        const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
+        int i;
+        uint32_t y;
+        for (i = 0; i < 624 - 397; ++i) {
+            y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+            key[i] = key[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+        }
+        for (; i < 623; ++i) {
+            y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+            key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+        }
+        y = (key[623] & UPPER) | (key[0] & LOWER);
+        key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+        pos = 0;
+    }
+    inline uint32_t next32() {
+        if (pos == 624) gen();
+        uint32_t y = key[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    inline double next_double() {
+        const uint32_t a = next32() >> 5, b = next32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    // legacy random_interval / masked bounded draw: uniform integer in [0, max]
+    inline uint64_t interval(uint64_t max) {
+        if (max == 0) return 0;
+        uint64_t mask = max;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        uint64_t v;
+        if (max <= 0xffffffffull) {
+            while ((v = (next32() & mask)) > max) {}
+        } else {
+            do {
+                const uint64_t hi = next32(), lo = next32();     // legacy next_uint64 = (hi << 32) | lo
+                v = ((hi << 32) | lo) & mask;
+            } while (v > max);
+        }
+        return v;
+    }
+};
+
+// numpy pairwise summation (DOUBLE_pairwise_sum) — the order np.sum uses on a contiguous 1-D array
+double pairwise_sum(const double* a, int64_t n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+
+struct Scratch {     // per-thread sampling state
+    MT19937 rng;
+    std::vector<int32_t> cnt, cnt_ver, sc_idx, sc_ver;   // dense per-node stamps
+    int32_t ver = 0;
+    std::vector<int64_t> cur, nxt, hop_order;
+    std::vector<std::pair<int64_t, int64_t>> scores;      // (node, score) in first-scored order
+    std::vector<int64_t> perm;
+    void ensure(int64_t n) {
+        if ((int64_t)cnt.size() < n) {
+            cnt.assign(n, 0); cnt_ver.assign(n, 0); sc_idx.assign(n, 0); sc_ver.assign(n, 0);
+            ver = 0;
+        }
+    }
+};
+
+}  // namespace
+
+struct pmgt_sampler {
+    int64_t n_nodes = 0;
+    std::vector<int64_t> indptr, indices;
+    std::vector<double> cdf;          // per-edge: normalised cumulative softmax of the row
+    std::vector<int> hops;
+    int max_ctx = 0, max_total = 10, min_neg = 5;
+    Scratch main;                      // the sequential (reference-order) stream
+    // sorted adjacency for the negative-sampling membership test
+    std::vector<int64_t> sorted_idx;
+
+    inline int64_t deg(int64_t v) const { return indptr[v + 1] - indptr[v]; }
+    bool is_neighbor(int64_t u, int64_t v) const {
+        const int64_t* b = sorted_idx.data() + indptr[u];
+        const int64_t* e = sorted_idx.data() + indptr[u + 1];
+        return std::binary_search(b, e, v);
+    }
+};
+
+namespace {
+
+// pmgt/pmgt/datasets.py:14-53
+int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* ids, float* mask) {
+    const int depth = (int)s->hops.size();
+    const int S = s->max_ctx + 1;
+    if (target < 2 || target >= s->n_nodes + 2) { set_err("target id %lld out of range", (long long)target); return -2; }
+    sc.ensure(s->n_nodes + 2);
+    sc.scores.clear();
+    sc.cur.assign(1, target);
+    if (++sc.ver == INT32_MAX) { std::fill(sc.sc_ver.begin(), sc.sc_ver.end(), 0); std::fill(sc.cnt_ver.begin(), sc.cnt_ver.end(), 0); sc.ver = 1; }
+    const int32_t score_ver = sc.ver;
+    for (int k = 1; k <= depth; ++k) {
+        const int size = s->hops[k - 1];
+        sc.nxt.clear();
+        for (int64_t node : sc.cur) {
+            const int64_t b = s->indptr[node], dg = s->indptr[node + 1] - b;
+            if (dg <= 0) { set_err("node %lld has no neighbours (the reference raises here)", (long long)node); return -3; }
+            const double* cdf = s->cdf.data() + b;
+            for (int r = 0; r < size; ++r) {
+                const double u = sc.rng.next_double();
+                // searchsorted(cdf, u, side='right') = first index with cdf[i] > u
+                const int64_t idx = std::upper_bound(cdf, cdf + dg, u) - cdf;
+                sc.nxt.push_back(s->indices[b + (idx < dg ? idx : dg - 1)]);
+            }
+        }
+        // Counter(sampled[k]) in first-appearance order
+        if (++sc.ver == INT32_MAX) { set_err("stamp overflow"); return -4; }
+        const int32_t cv = sc.ver;
+        sc.hop_order.clear();
+        for (int64_t v : sc.nxt) {
+            if (sc.cnt_ver[v] != cv) { sc.cnt_ver[v] = cv; sc.cnt[v] = 0; sc.hop_order.push_back(v); }
+            ++sc.cnt[v];
+        }
+        const int64_t w = depth - k + 1;
+        for (int64_t v : sc.hop_order) {
+            if (v == target) continue;
+            if (sc.sc_ver[v] != score_ver) {
+                sc.sc_ver[v] = score_ver;
+                sc.sc_idx[v] = (int32_t)sc.scores.size();
+                sc.scores.emplace_back(v, 0);
+            }
+            sc.scores[sc.sc_idx[v]].second += (int64_t)sc.cnt[v] * w;
+        }
+        sc.cur.swap(sc.nxt);
+    }
+    if (sc.scores.empty()) { set_err("target %lld has no scored neighbour (reference raises at datasets.py:42)", (long long)target); return -3; }
+    std::stable_sort(sc.scores.begin(), sc.scores.end(),
+                     [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) { return a.second > b.second; });
+    const int num = (int)std::min<int64_t>((int64_t)sc.scores.size(), s->max_ctx);
+    ids[0] = target;
+    for (int i = 0; i < s->max_ctx; ++i) ids[1 + i] = i < num ? sc.scores[i].first : 0;
+    for (int i = 0; i < S; ++i) mask[i] = i <= num ? 1.f : 0.f;
+    return num;
+}
+
+int max_pairs(const pmgt_sampler* s, int mode) { return mode == 0 ? s->max_total : (mode == 1 ? 2 : 0); }
+
+// PMGTDataset.__getitem__ (pmgt/pmgt/datasets.py:113-165); returns number of pairs or <0
+int sample_item(const pmgt_sampler* s, Scratch& sc, int64_t target, int mode, int64_t* tgt_ids, float* tgt_mask,
+                int64_t* pair_ids, float* pair_mask, float* labels) {
+    const int S = s->max_ctx + 1;
+    int rc = sample_context(s, sc, target, tgt_ids, tgt_mask);
+    if (rc < 0) return rc;
+    if (mode == 2) return 0;
+    const int k = mode == 0 ? (s->max_total - s->min_neg) : 1;
+    const int64_t b = s->indptr[target], dg = s->indptr[target + 1] - b;
+    const int npos = (int)std::min<int64_t>(k, dg);
+    // np.random.choice(neigh, npos, replace=False) = permutation(len)[:npos]: Fisher-Yates from the top
+    sc.perm.resize(dg);
+    for (int64_t i = 0; i < dg; ++i) sc.perm[i] = i;
+    for (int64_t i = dg - 1; i >= 1; --i) {
+        const int64_t j = (int64_t)sc.rng.interval((uint64_t)i);
+        std::swap(sc.perm[i], sc.perm[j]);
+    }
+    int64_t pos_nodes[64];
+    if (npos > 64) { set_err("too many positives"); return -5; }
+    for (int i = 0; i < npos; ++i) pos_nodes[i] = s->indices[b + sc.perm[i]];
+    int np_ = 0;
+    for (int i = 0; i < npos; ++i, ++np_) {
+        rc = sample_context(s, sc, pos_nodes[i], pair_ids + (int64_t)np_ * S, pair_mask + (int64_t)np_ * S);
+        if (rc < 0) return rc;
+        labels[np_] = 1.f;
+    }
+    const int nneg = mode == 0 ? std::max(s->min_neg, s->max_total - npos) : 1;
+    int64_t neg_nodes[64];
+    if (nneg > 64) { set_err("too many negatives"); return -5; }
+    for (int i = 0; i < nneg; ++i) {       // datasets.py:173-180 (all negatives are drawn before their contexts)
+        int64_t cand = (int64_t)sc.rng.interval((uint64_t)(s->n_nodes - 1)) + 2;
+        while (s->is_neighbor(target, cand)) cand = (int64_t)sc.rng.interval((uint64_t)(s->n_nodes - 1)) + 2;
+        neg_nodes[i] = cand;
+    }
+    for (int i = 0; i < nneg; ++i, ++np_) {
+        rc = sample_context(s, sc, neg_nodes[i], pair_ids + (int64_t)np_ * S, pair_mask + (int64_t)np_ * S);
+        if (rc < 0) return rc;
+        labels[np_] = 0.f;
+    }
+    return np_;
+}
+
+inline uint32_t mix_seed(uint64_t base, uint64_t ctr) {   // splitmix64 -> 32-bit MT seed
+    uint64_t z = base + 0x9E3779B97F4A7C15ull * (ctr + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z ^ (z >> 32));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pmgt_sampler_last_error(void) { return g_err; }
+
+pmgt_sampler* pmgt_sampler_create(int64_t n_nodes, const int64_t* indptr, const int64_t* indices, const double* weights,
+                                  const int* hop_sizes, int n_hops, int max_ctx_neigh, int max_total_samples,
+                                  int min_neg_samples) {
+    if (n_nodes <= 0 || !indptr || !indices || !weights || !hop_sizes || n_hops <= 0 || max_ctx_neigh <= 0) {
+        set_err("pmgt_sampler_create: bad arguments");
+        return nullptr;
+    }
+    pmgt_sampler* s = new pmgt_sampler();
+    s->n_nodes = n_nodes;
+    s->indptr.assign(indptr, indptr + n_nodes + 3);
+    const int64_t nnz = indptr[n_nodes + 2];
+    s->indices.assign(indices, indices + nnz);
+    s->hops.assign(hop_sizes, hop_sizes + n_hops);
+    s->max_ctx = max_ctx_neigh;
+    s->max_total = max_total_samples;
+    s->min_neg = min_neg_samples;
+    s->cdf.resize(nnz);
+    s->sorted_idx = s->indices;
+    std::vector<double> ex;
+    for (int64_t v = 0; v < n_nodes + 2; ++v) {
+        const int64_t b = indptr[v], dg = indptr[v + 1] - b;
+        if (dg <= 0) continue;
+        for (int64_t i = 0; i < dg; ++i) {
+            const int64_t u = indices[b + i];
+            if (u < 2 || u >= n_nodes + 2) { set_err("neighbour id %lld out of range", (long long)u); delete s; return nullptr; }
+        }
+        // scipy.special.softmax (float64): exp(x - max) / sum, np.sum = pairwise
+        double mx = weights[b];
+        for (int64_t i = 1; i < dg; ++i) mx = weights[b + i] > mx ? weights[b + i] : mx;
+        ex.resize(dg);
+        for (int64_t i = 0; i < dg; ++i) ex[i] = exp(weights[b + i] - mx);
+        const double tot = pairwise_sum(ex.data(), dg);
+        // choice(): cdf = p.cumsum(); cdf /= cdf[-1]
+        double run = 0.;
+        for (int64_t i = 0; i < dg; ++i) { run += ex[i] / tot; s->cdf[b + i] = run; }
+        const double last = s->cdf[b + dg - 1];
+        for (int64_t i = 0; i < dg; ++i) s->cdf[b + i] /= last;
+        std::sort(s->sorted_idx.begin() + b, s->sorted_idx.begin() + b + dg);
+    }
+    s->main.rng.seed(0);
+    return s;
+}
+
+void pmgt_sampler_destroy(pmgt_sampler* s) { delete s; }
+void pmgt_sampler_seed(pmgt_sampler* s, uint32_t seed) { s->main.rng.seed(seed); }
+int pmgt_sampler_max_pairs(const pmgt_sampler* s, int mode) { return max_pairs(s, mode); }
+double pmgt_sampler_random_sample(pmgt_sampler* s) { return s->main.rng.next_double(); }
+int64_t pmgt_sampler_randint(pmgt_sampler* s, int64_t n) { return (int64_t)s->main.rng.interval((uint64_t)(n - 1)); }
+
+int pmgt_sampler_context(pmgt_sampler* s, int64_t target, int64_t* ids, float* mask) {
+    return sample_context(s, s->main, target, ids, mask);
+}
+
+int pmgt_sampler_batch(pmgt_sampler* s, const int64_t* targets, int n, int mode, int64_t* tgt_ids, float* tgt_mask,
+                       int64_t* pair_ids, float* pair_mask, int64_t* num_pairs, float* labels) {
+    const int S = s->max_ctx + 1;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = sample_item(s, s->main, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
+                                   pair_ids ? pair_ids + tot * S : nullptr, pair_mask ? pair_mask + tot * S : nullptr,
+                                   labels ? labels + tot : nullptr);
+        if (rc < 0) return rc;
+        if (num_pairs) num_pairs[i] = rc;
+        tot += rc;
+    }
+    return (int)tot;
+}
+
+int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mode, uint64_t base_seed, uint64_t counter,
+                          int n_threads, int64_t* tgt_ids, float* tgt_mask, int64_t* pair_ids, float* pair_mask,
+                          int64_t* num_pairs, float* labels) {
+    const int S = s->max_ctx + 1, mp = max_pairs(s, mode);
+    if (n <= 0) return 0;
+    n_threads = std::max(1, std::min(n_threads, n));
+    // every target samples into a private slot of max_pairs rows, then the rows are compacted in order
+    std::vector<int64_t> pid((size_t)n * mp * S);
+    std::vector<float> pmk((size_t)n * mp * S), lab((size_t)n * mp);
+    std::vector<int> cnt(n, 0);
+    std::atomic<int> next(0), fail(0);
+    std::vector<std::string> errs(n_threads);
+    auto work = [&](int tid) {
+        Scratch sc;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n || fail.load()) break;
+            sc.rng.seed(mix_seed(base_seed, counter + (uint64_t)i));
+            const int rc = sample_item(s, sc, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
+                                       pid.data() + (size_t)i * mp * S, pmk.data() + (size_t)i * mp * S, lab.data() + (size_t)i * mp);
+            if (rc < 0) { errs[tid] = g_err; fail.store(rc); break; }
+            cnt[i] = rc;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    if (fail.load()) {
+        for (auto& e : errs) if (!e.empty()) { set_err("%s", e.c_str()); break; }
+        return fail.load();
+    }
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (cnt[i] > 0) {
+            memcpy(pair_ids + tot * S, pid.data() + (size_t)i * mp * S, sizeof(int64_t) * cnt[i] * S);
+            memcpy(pair_mask + tot * S, pmk.data() + (size_t)i * mp * S, sizeof(float) * cnt[i] * S);
+            memcpy(labels + tot, lab.data() + (size_t)i * mp, sizeof(float) * cnt[i]);
+        }
+        if (num_pairs) num_pairs[i] = cnt[i];
+        tot += cnt[i];
+    }
+    return (int)tot;
+}
+
+int pmgt_train_valid_split(int64_t n_nodes, double valid_size, uint32_t seed, int64_t* train_out, int64_t* valid_out) {
+    if (n_nodes <= 0) return -1;
+    MT19937 rng;
+    rng.seed(seed);
+    std::vector<int64_t> perm(n_nodes);
+    for (int64_t i = 0; i < n_nodes; ++i) perm[i] = i;
+    for (int64_t i = n_nodes - 1; i >= 1; --i) std::swap(perm[i], perm[(int64_t)rng.interval((uint64_t)i)]);
+    const int64_t n_test = (int64_t)ceil(valid_size * (double)n_nodes);
+    for (int64_t i = 0; i < n_test; ++i) valid_out[i] = perm[i] + 2;
+    for (int64_t i = n_test; i < n_nodes; ++i) train_out[i - n_test] = perm[i] + 2;
+    return (int)n_test;
+}
+
+}  // extern "C"

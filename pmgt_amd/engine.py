@@ -1,0 +1,198 @@
+"""Device-side state of one PMGT replica and thin wrappers over the C ABI (include/pmgt_capi.h).
+
+PyTorch is used here only as plumbing: device memory (torch tensors own every buffer handed to the
+library), the current HIP stream, and torch.distributed for the data-parallel gradient all-reduce.
+All math runs in libpmgt_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """Flat fp32 parameters/gradients, frozen feature tables, RNG state and scratch for one GPU."""
+
+    def __init__(self, config, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pmgt_amd.Engine needs a HIP device; there is no CPU fallback")
+        self.lib = _lib.hip()
+        self.config = config
+        self.dtype_name = dtype
+        self.dtype_code = {"fp32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16}[dtype]
+        self.torch_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[dtype]
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        feats = list(config.feat_hidden_sizes)
+        if len(feats) != 2:
+            raise ValueError("the HIP path implements the reference's two modalities (visual, textual)")
+        self.cfg_c = _lib.PMGTConfigC(
+            config.hidden_size, config.num_hidden_layers, config.num_attention_heads, config.intermediate_size,
+            feats[0], feats[1], config.max_position_embeddings, config.layer_norm_eps, config.beta,
+            config.hidden_dropout_prob, config.attention_probs_dropout_prob, self.dtype_code)
+        self.h = self.lib.pmgt_engine_create(C.byref(self.cfg_c))
+        if not self.h:
+            raise ValueError(self.lib.pmgt_last_error().decode())
+        self.n_params = int(self.lib.pmgt_param_count(self.h))
+        self.entries: List[dict] = []
+        name = C.create_string_buffer(256)
+        off, numel = C.c_int64(), C.c_int64()
+        rows, cols, decay = C.c_int(), C.c_int(), C.c_int()
+        for i in range(self.lib.pmgt_param_num_entries(self.h)):
+            _lib.check(self.lib.pmgt_param_entry(self.h, i, name, 256, C.byref(off), C.byref(numel), C.byref(rows),
+                                                 C.byref(cols), C.byref(decay)))
+            shape = (rows.value, cols.value) if cols.value > 0 else (rows.value,)
+            self.entries.append(dict(name=name.value.decode(), offset=off.value, numel=numel.value, shape=shape,
+                                     decay=bool(decay.value)))
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        dm = torch.zeros(self.n_params, dtype=torch.uint8)
+        for e in self.entries:
+            if e["decay"]:
+                dm[e["offset"]: e["offset"] + e["numel"]] = 1
+        self.decay_mask = dm.to(self.device)
+        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+        self.table_v = self.table_t = None
+        self.n_nodes = 0
+        self._ws: Optional[torch.Tensor] = None
+        # optimizer state (created lazily)
+        self.exp_avg = self.exp_avg_sq = None
+        self.opt_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.opt_scalars = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.opt_scratch = torch.zeros(1024, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.pmgt_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------
+    def view(self, name: str, grad: bool = False) -> torch.Tensor:
+        e = next(x for x in self.entries if x["name"] == name)
+        buf = self.grads if grad else self.params
+        return buf[e["offset"]: e["offset"] + e["numel"]].view(*e["shape"])
+
+    def named_views(self, grad: bool = False) -> Dict[str, torch.Tensor]:
+        return {e["name"]: self.view(e["name"], grad) for e in self.entries}
+
+    def load_params(self, params: Dict[str, torch.Tensor]):
+        for e in self.entries:
+            self.view(e["name"]).copy_(params[e["name"]].to(torch.float32))
+
+    def set_tables(self, visual, textual):
+        """Frozen feature tables [N+2, F_m] (pmgt/pmgt/models.py:40-54), cast once to the engine dtype."""
+        tabs = []
+        for a in (visual, textual):
+            t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+            tabs.append(t.to(self.device, dtype=self.torch_dtype).contiguous())
+        self.table_v, self.table_t = tabs
+        self.n_nodes = int(self.table_v.shape[0] - 2)
+
+    def cast(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 device tensor -> engine dtype through the library's own cast kernel."""
+        x = x.to(self.device, torch.float32).contiguous()
+        out = torch.empty(x.shape, dtype=self.torch_dtype, device=self.device)
+        _lib.check(self.lib.pmgt_cast_from_f32(self.dtype_code, _ptr(x), _ptr(out), x.numel(), _stream()))
+        return out
+
+    def _tensors(self):
+        return _lib.TensorsC(self.params.data_ptr(), self.grads.data_ptr(),
+                             0 if self.table_v is None else self.table_v.data_ptr(),
+                             0 if self.table_t is None else self.table_t.data_ptr(), self.n_nodes,
+                             self.rng_state.data_ptr())
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- PMGT.forward (+ backward) ---------------------------------------------------------------
+    def pretrain_step(self, batch, training: bool, backward: bool = False, accumulate: bool = False,
+                      nfr_inject=None, random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16,
+                      want_hidden: bool = True):
+        """batch = (target_dict, pair_dict, num_pairs, labels) of device tensors (pmgt_collate_fn layout).
+        nfr_inject = (masked_ids [B,S] int64, nfr_targets [B,S] int64 with -1 = not masked)."""
+        tgt, pair, num_pairs, labels = batch
+        ids = tgt["node_ids"].contiguous()
+        B, S = ids.shape
+        P = int(pair["node_ids"].shape[0])
+        n_seq = B + P + (B if training else 0)
+        ws = self._workspace(self.lib.pmgt_workspace_bytes(self.h, n_seq, S, B, 1 if training else 0))
+        loss = torch.empty(3, dtype=torch.float32, device=self.device)
+        logits = torch.empty(P, dtype=torch.float32, device=self.device)
+        hidden = torch.empty(B, S, self.config.hidden_size, dtype=self.torch_dtype, device=self.device) if want_hidden else None
+        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        keep = [ids, tgt["attention_mask"].contiguous(), pair["node_ids"].contiguous(),
+                pair["attention_mask"].contiguous(), num_pairs.contiguous(), labels.to(torch.float32).contiguous()]
+        bc = _lib.BatchC(B, P, S, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
+                         keep[4].data_ptr(), keep[5].data_ptr(), 0, 0, random_node_ratio, mask_node_ratio)
+        if nfr_inject is not None:
+            mi, mt = nfr_inject[0].contiguous(), nfr_inject[1].contiguous()
+            keep += [mi, mt]
+            bc.nfr_masked_ids, bc.nfr_targets = mi.data_ptr(), mt.data_ptr()
+        oc = _lib.OutputsC(loss.data_ptr(), logits.data_ptr(), 0 if hidden is None else hidden.data_ptr(), count.data_ptr())
+        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_BACKWARD if backward else 0) | \
+                (_lib.FLAG_ACCUMULATE if accumulate else 0)
+        tc = self._tensors()
+        _lib.check(self.lib.pmgt_pretrain_step(self.h, C.byref(tc), C.byref(bc), C.byref(oc), _ptr(ws), ws.numel(),
+                                               flags, _stream()))
+        return dict(loss=loss[0], gsr=loss[1], nfr=loss[2], losses=loss, logits=logits, last_hidden_state=hidden,
+                    nfr_count=count)
+
+    # ---- PMGTModel.forward ---------------------------------------------------------------------------
+    def encode(self, ids: Optional[torch.Tensor] = None, feats=None, attention_mask: Optional[torch.Tensor] = None,
+               output_hidden_states: bool = False, output_attentions: bool = False):
+        cfg = self.config
+        if ids is not None:
+            n_seq, S = ids.shape
+        else:
+            n_seq, S = feats[0].shape[:2]
+        d, L, H = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads
+        ws = self._workspace(self.lib.pmgt_workspace_bytes(self.h, n_seq, S, 1, 0))
+        last = torch.empty(n_seq, S, d, dtype=self.torch_dtype, device=self.device)
+        hs = torch.empty(L + 1, n_seq, S, d, dtype=self.torch_dtype, device=self.device) if output_hidden_states else None
+        pr = torch.empty(L, n_seq, H, S, S, dtype=torch.float32, device=self.device) if output_attentions else None
+        m = None if attention_mask is None else attention_mask.to(self.device, torch.float32).contiguous()
+        tc = self._tensors()
+        if ids is not None:
+            ids = ids.to(self.device).contiguous()
+            _lib.check(self.lib.pmgt_encode_ids(self.h, C.byref(tc), _ptr(ids), _ptr(m), n_seq, S, _ptr(last), _ptr(hs),
+                                                _ptr(pr), _ptr(ws), ws.numel(), _stream()))
+        else:
+            fv = feats[0].to(self.device, self.torch_dtype).contiguous()
+            ft = feats[1].to(self.device, self.torch_dtype).contiguous()
+            _lib.check(self.lib.pmgt_encode_feats(self.h, C.byref(tc), _ptr(fv), _ptr(ft), _ptr(m), n_seq, S, _ptr(last),
+                                                  _ptr(hs), _ptr(pr), _ptr(ws), ws.numel(), _stream()))
+        return last, hs, pr
+
+    # ---- clip + AdamW ----------------------------------------------------------------------------------
+    def optimizer_step(self, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)
+        ac = _lib.AdamC(self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.decay_mask.data_ptr(), lr, weight_decay,
+                        betas[0], betas[1], eps, float(max_grad_norm) if max_grad_norm else 0.0,
+                        self.opt_step.data_ptr(), self.opt_scalars.data_ptr(), self.opt_scratch.data_ptr())
+        tc = self._tensors()
+        _lib.check(self.lib.pmgt_optimizer_step(self.h, C.byref(tc), C.byref(ac), _stream()))
+
+    def grad_norm(self) -> torch.Tensor:
+        """Pre-clip global gradient norm of the last optimizer_step (device scalar)."""
+        return self.opt_scalars[3]

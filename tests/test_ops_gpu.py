@@ -1,0 +1,285 @@
+"""Per-kernel parity tests: every HIP kernel is called through the C ABI (pmgt_op_*) and compared
+with a plain torch fp32/fp64 CPU computation of the same op (for attention: the oracle's
+restatement of pmgt/pmgt/modeling_pmgt.py:420-534 with autograd for the backward)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"fp32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+
+
+def _setup():
+    from pmgt_amd import _lib
+    return _lib, _lib.hip()
+
+
+def P(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(x, tdt):
+    return x.to("cuda", tdt).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def tol(dt):
+    return 2e-5 if dt == "fp32" else 2e-2
+
+
+def rounded(x, tdt):
+    return x.to(tdt).to(torch.float64)
+
+
+# ------------------------------------------------------------------------------------------- gemm_nt
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (77, 40, 24), (1000, 256, 1536), (513, 264, 256)])
+def test_gemm_nt_plain(dt, M, N, K):
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) * 0.3
+    bias = torch.randn(N, generator=g)
+    Ad, Bd, bd = to_dev(A, tdt), to_dev(B, tdt), to_dev(bias, torch.float32)
+    Cd = torch.full((M, N), float("nan"), device="cuda", dtype=tdt)
+    _lib.check(L.pmgt_op_gemm_nt(code, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, P(bd), 0, None, 0, None, 0, 0.0, 0,
+                                 None, None, stream()))
+    ref = rounded(A, tdt) @ rounded(B, tdt).T + bias.double()
+    assert rel_err(Cd, ref) < tol(dt), rel_err(Cd, ref)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_gemm_nt_epilogues_and_gather(dt):
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(5)
+    M, N, K, R = 333, 136, 72, 50
+    table = torch.randn(R, K, generator=g)
+    rows = torch.randint(0, R, (M,), generator=g)
+    B = torch.randn(N, K, generator=g) * 0.3
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    td, Bd, bd, rd, rowd = to_dev(table, tdt), to_dev(B, tdt), to_dev(bias, torch.float32), to_dev(res, tdt), rows.cuda()
+    Cd = torch.zeros(M, N, device="cuda", dtype=tdt)
+    aux = torch.zeros(M, N, device="cuda", dtype=tdt)
+    # gather + bias + gelu (stores pre-activation) + residual
+    _lib.check(L.pmgt_op_gemm_nt(code, P(td), K, P(rowd), P(Bd), K, P(Cd), N, M, N, K, P(bd), 1, P(aux), N, P(rd), N, 0.0, 0,
+                                 None, None, stream()))
+    pre = rounded(table, tdt)[rows] @ rounded(B, tdt).T + bias.double()
+    pre_r = rounded(pre.float(), tdt)
+    ref = torch.nn.functional.gelu(pre_r) + rounded(res, tdt)
+    assert rel_err(aux, pre) < tol(dt)
+    assert rel_err(Cd, ref) < tol(dt)
+    # gelu-grad epilogue: C = (A B^T) * gelu'(aux)
+    A = torch.randn(M, K, generator=g)
+    Ad = to_dev(A, tdt)
+    _lib.check(L.pmgt_op_gemm_nt(code, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, None, 2, P(aux), N, None, 0, 0.0, 0, None,
+                                 None, stream()))
+    x = aux.double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref2 = (rounded(A, tdt) @ rounded(B, tdt).T) * x.grad
+    assert rel_err(Cd, ref2) < tol(dt)
+    # device-side row count: rows >= m_dev untouched
+    Cd.fill_(7.0)
+    cnt = torch.tensor([100], dtype=torch.int32, device="cuda")
+    _lib.check(L.pmgt_op_gemm_nt(code, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, None, 0, None, 0, None, 0, 0.0, 0, None,
+                                 P(cnt), stream()))
+    ref3 = rounded(A, tdt) @ rounded(B, tdt).T
+    assert rel_err(Cd[:100], ref3[:100]) < tol(dt)
+    assert bool((Cd[100:].float() == 7.0).all())
+
+
+# ------------------------------------------------------------------------------------------- gemm_tn
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N1,N2", [(500, 64, 96), (4096, 256, 256), (130, 24, 1536), (3000, 1024, 256)])
+def test_gemm_tn(dt, M, N1, N2):
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M + N1)
+    Pm = torch.randn(M, N1, generator=g)
+    Q = torch.randn(M, N2, generator=g)
+    Pd, Qd = to_dev(Pm, tdt), to_dev(Q, tdt)
+    slab = torch.empty(L.pmgt_op_gemm_tn_slab_elems(code, M, N1, N2), device="cuda")
+    out = torch.full((N1, N2), float("nan"), device="cuda")
+    _lib.check(L.pmgt_op_gemm_tn(code, P(Pd), N1, P(Qd), N2, None, M, N1, N2, P(slab), P(out), 0, None, stream()))
+    ref = rounded(Pm, tdt).T @ rounded(Q, tdt)
+    assert rel_err(out, ref) < (1e-5 if dt == "fp32" else 2e-3)
+    # accumulate + gather on Q + device row count
+    R = 40
+    table = torch.randn(R, N2, generator=g)
+    rows = torch.randint(0, R, (M,), generator=g)
+    td, rowd = to_dev(table, tdt), rows.cuda()
+    cnt = torch.tensor([M - 37], dtype=torch.int32, device="cuda")
+    _lib.check(L.pmgt_op_gemm_tn(code, P(Pd), N1, P(td), N2, P(rowd), M, N1, N2, P(slab), P(out), 1, P(cnt), stream()))
+    ref2 = ref + rounded(Pm, tdt)[: M - 37].T @ rounded(table, tdt)[rows[: M - 37]]
+    assert rel_err(out, ref2) < (1e-5 if dt == "fp32" else 2e-3)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_colsum(dt):
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    M, N = 1000, 1032
+    Y = torch.randn(M, N)
+    Yd = to_dev(Y, tdt)
+    slab = torch.empty(((M + 255) // 256) * N, device="cuda")
+    out = torch.empty(N, device="cuda")
+    _lib.check(L.pmgt_op_colsum(code, P(Yd), N, M, N, P(slab), P(out), stream()))
+    assert rel_err(out, rounded(Y, tdt).sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- layernorm
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,d", [(100, 64), (257, 256), (64, 512), (33, 1024), (10, 128)])
+def test_layernorm_fwd_bwd(dt, M, d):
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(M, d, generator=g) * 2 + 0.5
+    gam = 1 + 0.1 * torch.randn(d, generator=g)
+    bet = 0.1 * torch.randn(d, generator=g)
+    dy = torch.randn(M, d, generator=g)
+    xd, gd, bd, dyd = to_dev(x, tdt), to_dev(gam, torch.float32), to_dev(bet, torch.float32), to_dev(dy, tdt)
+    y = torch.empty(M, d, device="cuda", dtype=tdt)
+    stats = torch.empty(M, 2, device="cuda")
+    _lib.check(L.pmgt_op_layernorm_fwd(code, P(xd), P(y), P(stats), P(gd), P(bd), M, d, 1e-12, 0.0, 0, None, stream()))
+    xr = rounded(x, tdt).requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-12)
+    assert rel_err(y, ref.detach()) < tol(dt)
+    ref.backward(rounded(dy, tdt))
+    dx = torch.empty(M, d, device="cuda", dtype=tdt)
+    part = torch.empty(((M + 63) // 64) * 2 * d, device="cuda")
+    dgb = torch.empty(2 * d, device="cuda")
+    _lib.check(L.pmgt_op_layernorm_bwd(code, P(dyd), P(xd), P(stats), P(gd), P(dx), None, P(part), P(dgb), M, d, 0.0, 0, 0.0, 0,
+                                       None, stream()))
+    assert rel_err(dx, xr.grad) < tol(dt)
+    assert rel_err(dgb[:d], gr.grad) < 1e-4
+    assert rel_err(dgb[d:], br.grad) < 1e-4
+
+
+def test_dropout_masks_consistent_and_calibrated():
+    """The GEMM epilogue, LayerNorm-backward output mask and LayerNorm-forward mask of the same
+    (seed, step, site) must coincide; the keep rate must be 1-p with scale 1/(1-p)."""
+    _lib, L = _setup()
+    M, d, K = 640, 256, 32
+    p = 0.1
+    rng = torch.tensor([1234, 5], dtype=torch.int64, device="cuda")
+    A = torch.ones(M, K, device="cuda")
+    B = torch.ones(d, K, device="cuda") / K
+    out = torch.empty(M, d, device="cuda")
+    _lib.check(L.pmgt_op_gemm_nt(0, P(A), K, None, P(B), K, P(out), d, M, d, K, None, 0, None, 0, None, 0, p, 77, P(rng), None,
+                                 stream()))
+    keep = out != 0
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    assert torch.allclose(out[keep], torch.full_like(out[keep], 1 / (1 - p)), rtol=1e-5)
+    # LN backward second output uses the same mask
+    x = torch.randn(M, d, device="cuda")
+    dy = torch.randn(M, d, device="cuda")
+    gam = torch.ones(d, device="cuda")
+    bet = torch.zeros(d, device="cuda")
+    y = torch.empty_like(x)
+    stats = torch.empty(M, 2, device="cuda")
+    _lib.check(L.pmgt_op_layernorm_fwd(0, P(x), P(y), P(stats), P(gam), P(bet), M, d, 1e-12, p, 77, P(rng), stream()))
+    assert bool(((y != 0) == keep).all())
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    part = torch.empty(((M + 63) // 64) * 2 * d, device="cuda")
+    dgb = torch.empty(2 * d, device="cuda")
+    _lib.check(L.pmgt_op_layernorm_bwd(0, P(dy), P(x), P(stats), P(gam), P(dx), P(dxd), P(part), P(dgb), M, d, 0.0, 0, p, 77,
+                                       P(rng), stream()))
+    assert torch.allclose(dxd, dx * keep / (1 - p), rtol=1e-5, atol=1e-7)
+    # a different step gives a different mask
+    rng2 = torch.tensor([1234, 6], dtype=torch.int64, device="cuda")
+    out2 = torch.empty_like(out)
+    _lib.check(L.pmgt_op_gemm_nt(0, P(A), K, None, P(B), K, P(out2), d, M, d, K, None, 0, None, 0, None, 0, p, 77, P(rng2), None,
+                                 stream()))
+    assert float(((out2 != 0) != keep).float().mean()) > 0.05
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkvc, mask, H, beta):
+    """Oracle restatement on a packed [T,S,4d] tensor (fp64)."""
+    T, S, d4 = qkvc.shape
+    d = d4 // 4
+    dh = d // H
+
+    def heads(x):
+        return x.view(T, S, H, dh).permute(0, 2, 1, 3)
+
+    q, k, v, c = (heads(qkvc[..., i * d:(i + 1) * d]) for i in range(4))
+    add = (1.0 - mask)[:, None, None, :] * -10000.0
+    rho = torch.linalg.norm(c, dim=-1, keepdim=True)
+    s1 = 1.0 - (c @ c.transpose(-1, -2)) / (rho @ rho.transpose(-1, -2)) + torch.eye(S, dtype=qkvc.dtype) + add
+    s2 = (q @ k.transpose(-1, -2)) / math.sqrt(dh) + add
+    w = beta * torch.softmax(s1, -1) + (1 - beta) * torch.softmax(s2, -1)
+    return (w @ v).permute(0, 2, 1, 3).reshape(T, S, d), w
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("T,S,H,dh,beta", [(5, 16, 4, 16, 0.5), (7, 32, 8, 32, 0.5), (3, 6, 2, 64, 0.3), (2, 64, 2, 64, 0.5),
+                                           (4, 32, 1, 128, 1.0), (6, 20, 4, 32, 0.0), (9, 33, 2, 32, 0.7)])
+def test_attention_fwd_bwd(dt, T, S, H, dh, beta):
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    d = H * dh
+    g = torch.Generator().manual_seed(S * 100 + dh)
+    x = torch.randn(T, S, 4 * d, generator=g)
+    mask = torch.ones(T, S)
+    for t in range(T):            # ragged valid lengths, position 0 always valid
+        n = 1 + (t * 5) % S
+        mask[t, n:] = 0
+    mask[0] = 1
+    dctx = torch.randn(T, S, d, generator=g)
+    xd, md, dod = to_dev(x, tdt), mask.cuda(), to_dev(dctx, tdt)
+    ctx = torch.empty(T, S, d, device="cuda", dtype=tdt)
+    probs = torch.empty(T, H, S, S, device="cuda")
+    _lib.check(L.pmgt_op_attention_fwd(code, P(xd), P(md), P(ctx), P(probs), T, S, H, dh, beta, 0.0, 0, 0, None, stream()))
+    xr = rounded(x, tdt).requires_grad_(True)
+    ref, w = _attn_ref(xr, mask.double(), H, beta)
+    assert rel_err(probs, w.detach()) < (1e-5 if dt == "fp32" else 2e-2)
+    assert rel_err(ctx, ref.detach()) < tol(dt)
+    ref.backward(rounded(dctx, tdt))
+    dx = torch.empty(T, S, 4 * d, device="cuda", dtype=tdt)
+    _lib.check(L.pmgt_op_attention_bwd(code, P(xd), P(md), P(dod), P(dx), T, S, H, dh, beta, 0.0, 0, 0, None, stream()))
+    e = rel_err(dx, xr.grad)
+    assert e < (2e-4 if dt == "fp32" else 3e-2), e
+    # without a mask pointer == all ones
+    _lib.check(L.pmgt_op_attention_fwd(code, P(xd), None, P(ctx), None, T, S, H, dh, beta, 0.0, 0, 0, None, stream()))
+    ref1, _ = _attn_ref(rounded(x, tdt), torch.ones(T, S, dtype=torch.float64), H, beta)
+    assert rel_err(ctx, ref1) < tol(dt)
+
+
+def test_attention_dropout_forward_backward_consistent():
+    """With dropout on, the backward must regenerate the forward masks: check dV against
+    P_dropped^T dO using the probabilities the forward reports."""
+    _lib, L = _setup()
+    T, S, H, dh, beta, p = 4, 32, 4, 32, 0.5, 0.2
+    d = H * dh
+    x = torch.randn(T, S, 4 * d).cuda()
+    dctx = torch.randn(T, S, d).cuda()
+    rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+    ctx = torch.empty(T, S, d, device="cuda")
+    probs = torch.empty(T, H, S, S, device="cuda")
+    _lib.check(L.pmgt_op_attention_fwd(0, P(x), None, P(ctx), P(probs), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+    dx = torch.empty(T, S, 4 * d, device="cuda")
+    _lib.check(L.pmgt_op_attention_bwd(0, P(x), None, P(dctx), P(dx), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+    v = x[..., 2 * d:3 * d].view(T, S, H, dh).permute(0, 2, 1, 3)
+    do = dctx.view(T, S, H, dh).permute(0, 2, 1, 3)
+    assert rel_err(ctx, (probs @ v).permute(0, 2, 1, 3).reshape(T, S, d)) < 1e-5
+    dv_ref = (probs.transpose(-1, -2) @ do).permute(0, 2, 1, 3).reshape(T, S, d)
+    assert rel_err(dx[..., 2 * d:3 * d], dv_ref) < 1e-5
+    zero_frac = float((probs == 0).float().mean())
+    assert 0.01 < zero_frac < 0.1        # both branches dropped together: ~p^2
