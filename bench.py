@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""PMGT pre-training throughput on MI355X (BASELINE.json metric: target nodes/sec).
+
+One "step" = one full pre-training step of the hot path on one batch of B target nodes per GPU
+(12 sequences of S tokens per target: target + 10 pairs + masked copy): device NFR masking, batched
+encoder forward, GSR + NFR losses, backward, [RCCL gradient all-reduce when N > 1], global-norm clip +
+AdamW.  Inputs (sampled node-context batches, feature tables) are resident in HBM before the timed
+region.  Workload at N=1: BASELINE.json configs[1] — VG-sized synthetic item graph (7 252 nodes /
+88 606 edges), L=4 H=8 d=256 I=256 S=32, bf16, dropout 0.1, lr 1e-4, wd 1e-2, clip 5.0.
+
+Prints ONE JSON line (rank 0).  Launch N > 1 with torch.distributed.run (one process per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 (never the 2:1-sparse figure)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: (nodes, edges, L, H, d, I, S)
+    "c1": (7252, 88606, 2, 4, 128, 128, 16),
+    "c2": (7252, 88606, 4, 8, 256, 256, 32),
+    "c3": (10834, 38252, 4, 8, 256, 256, 32),
+    "c4": (1000000, 20000000, 6, 8, 512, 512, 64),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=256, help="target nodes per GPU per step (reference CLI default 256)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--intermediate", type=int, default=0, help="override intermediate size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phase-profile", action="store_true")
+    ap.add_argument("--sampler-threads", type=int, default=0)
+    ap.add_argument("--end-to-end", action="store_true", help="also time steps fed by the live host sampler")
+    return ap.parse_args()
+
+
+def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
+    """Algorithmic (flops, bytes) of ONE launch group of a phase, for the roofline object.
+    M = tokens in the step, esz = bytes per activation element."""
+    F = Fv + Ft
+    g = lambda m, n, k: 2.0 * m * n * k
+    table = {
+        "fwd.gemm_featproj": (g(M, d, F) / 2, M * F / 2 * esz + M * d * esz),   # two launches: avg of (Fv, Ft)
+        "fwd.gemm_qkvc": (g(M, 4 * d, d), M * 5 * d * esz),
+        "fwd.gemm_attn_out": (g(M, d, d), M * 3 * d * esz),
+        "fwd.gemm_ffn1": (g(M, I, d), M * (d + 2 * I) * esz),
+        "fwd.gemm_ffn2": (g(M, d, I), M * (I + 2 * d) * esz),
+        "fwd.attention": (6.0 * M * S * d, M * 5 * d * esz),
+        "bwd.attention": (16.0 * M * S * d, M * 9 * d * esz),
+        "bwd.dgrad_ffn2": (g(M, I, d), M * (d + 2 * I) * esz),
+        "bwd.dgrad_ffn1": (g(M, d, I), M * (I + 2 * d) * esz),
+        "bwd.dgrad_attn_out": (g(M, d, d), M * 2 * d * esz),
+        "bwd.dgrad_qkvc": (g(M, d, 4 * d), M * 6 * d * esz),
+        "bwd.wgrad_ffn2": (g(M, d, I), M * (d + I) * esz),
+        "bwd.wgrad_ffn1": (g(M, I, d), M * (d + I) * esz),
+        "bwd.wgrad_attn_out": (g(M, d, d), M * 2 * d * esz),
+        "bwd.wgrad_qkvc": (g(M, 4 * d, d), M * 5 * d * esz),
+        "bwd.wgrad_featproj": (g(M, d, F) / 2, M * (d + F / 2) * esz),
+        "fwd.layernorm": (0.0, M * 2 * d * esz),
+        "bwd.layernorm": (0.0, M * 4 * d * esz),
+        "fwd.embed_mix": (0.0, M * 4 * d * esz),
+        "bwd.embed_mix": (0.0, M * 7 * d * esz),
+    }
+    return table.get(name)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = f"cuda:{local}"
+
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    from pmgt_amd.engine import Engine
+    from pmgt_amd.graph import synthetic_graph
+    from pmgt_amd.models import reference_init, synthetic_features, train_flops_per_node
+    from pmgt_amd.trainer import Trainer
+
+    nodes, edges, L, H, d, I, S = WORKLOADS[args.workload]
+    if args.intermediate:
+        I = args.intermediate
+    B = args.batch
+    cfg = PMGTConfig(hidden_size=d, num_hidden_layers=L, num_attention_heads=H, intermediate_size=I,
+                     hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout, beta=0.5)
+    graph = synthetic_graph(nodes, edges, seed=0)
+    vis, txt = synthetic_features(nodes, seed=0)
+    eng = Engine(cfg, dtype=args.dtype, device=dev, seed=1234)
+    reference_init(eng, seed=0)
+    eng.set_tables(vis, txt)
+    del vis, txt
+    trainer = Trainer(eng, lr=1e-4, weight_decay=1e-2, max_grad_norm=5.0, world_size=world)
+    trainer.broadcast_parameters()
+
+    # ---- pre-stage node-context batches in HBM (host MCNSampling, C++ threads)
+    threads = args.sampler_threads or min(os.cpu_count() or 1, 32)
+    sampler = MCNSampler(graph, max_ctx_neigh=S - 1)
+    perm = np.random.RandomState(0).permutation(nodes) + 2
+    shard = perm[rank::world]
+    n_stage = min(args.steps + args.warmup, 8)
+    staged = []
+    t0 = time.time()
+    for i in range(n_stage):
+        tg = np.resize(shard[(i * B) % max(len(shard) - B, 1):], B) if len(shard) >= B else np.resize(shard, B)
+        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, threads=threads, base_seed=rank, counter=i * B)
+        cu = lambda dct: {k: v.to(dev) for k, v in dct.items()}
+        staged.append((cu(tgt), cu(pair), num_pairs.to(dev), labels.to(dev)))
+    sampler_nodes_per_s = n_stage * B / max(time.time() - t0, 1e-9)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        trainer.train_step(staged[i % n_stage])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.train_step(staged[(args.warmup + i) % n_stage])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    loss_last = trainer.last_loss.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    out = {
+        "metric": "PMGT pre-train nodes/sec",
+        "value": round(value, 2),
+        "unit": "target nodes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic (seeded G(n,m)+ring item graph, N(0,1) visual/textual features, random-init weights)",
+        "config": {"workload": f"{args.workload}: {nodes} nodes / {edges} edges, L={L} H={H} d={d} I={I} S={S} "
+                               f"(context=S tokens incl. target), B={B} targets/GPU/step, 12 sequences/target, "
+                               f"dropout {args.dropout}, clip 5.0, AdamW lr 1e-4 wd 1e-2",
+                   "parallelism": f"dp{world}", "global_batch": world * B, "seq_len": S},
+        "loss_last": round(loss_last, 5),
+        "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count()},
+    }
+
+    flops_node = train_flops_per_node(d, I, L, S)
+    out["train_gflop_per_node"] = round(flops_node / 1e9, 3)
+    out["mfma_util_vs_bf16_dense_peak"] = round(value / world * flops_node / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
+
+    # ---- per-phase HIP-event timers (separate pass, not part of `value`)
+    if rank == 0 and not args.no_phase_profile:
+        nprof = 5
+        eng.profile_begin()
+        for i in range(nprof):
+            trainer.train_step(staged[i % n_stage])
+        prof = eng.profile_end()
+        torch.cuda.synchronize()
+        tot = sum(ms for _, ms in prof.values())
+        phases = {k: {"launches_per_step": c // nprof, "ms_per_step": round(ms / nprof, 4), "share": round(ms / tot, 4)}
+                  for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        out["phases"] = phases
+        esz = 2 if args.dtype == "bf16" else 4
+        M = 12 * B * S
+        dom = next(iter(phases))
+        w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz)
+        cnt, ms = prof[dom]
+        avg_s = ms / cnt / 1e3
+        if w is not None:
+            flops, byts = w
+            peak_t = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            if flops > 0 and flops / (peak_t * 1e12) >= byts / (HBM_PEAK_GBS * 1e9):
+                ach = flops / avg_s / 1e12
+                out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": peak_t,
+                                   "unit": "TFLOP/s", "frac": round(ach / peak_t, 5), "traffic": None,
+                                   "avg_launch_ms": round(avg_s * 1e3, 5), "algorithmic_gflop_per_launch": round(flops / 1e9, 3)}
+            else:
+                ach = byts / avg_s / 1e9
+                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                                   "avg_launch_ms": round(avg_s * 1e3, 5), "algorithmic_mb_per_launch": round(byts / 1e6, 3)}
+
+    # ---- end-to-end with the live host sampler (optional, reported separately)
+    if args.end_to_end and rank == 0:
+        out["end_to_end"] = trainer.run_live(sampler, shard, B, steps=min(args.steps, 10), threads=threads)
+
+    # ---- CPU baseline: the oracle (CPU restatement pinned to the reference) on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, graph, S, args.dropout)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, graph, S, dropout):
+    """Times the CPU oracle (oracle/pmgt_oracle.py, checked against the reference's golden vectors) on the
+    host cores: fp32, all threads, same shapes, B=16 targets per step (192 sequences), fwd+bwd+clip+AdamW."""
+    from oracle import pmgt_oracle as po
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = po.default_cfg(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                          num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                          hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout, beta=cfg.beta)
+    n = graph.n_nodes
+    params = po.synth_params(ocfg, 0)
+    tables = po.synth_tables(n, ocfg["feat_hidden_sizes"], 0)
+    Bc = 16
+    smp = MCNSampler(graph, S - 1)
+    batch = smp.batch(np.arange(2, 2 + Bc), MODE_TRAIN, threads=4, base_seed=1, counter=0)
+    drop = (lambda x, site: torch.nn.functional.dropout(x, dropout, True)) if dropout > 0 else None
+    state = {}
+    times = []
+    t_all = time.time()
+    for it in range(12):
+        t0 = time.perf_counter()
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        ids = batch[0]["node_ids"]
+        r1, r2 = torch.rand(Bc, S - 1), torch.rand(Bc, S - 1)
+        repl = torch.randint(2, n + 2, (Bc * (S - 1),))
+        inj = po.nfr_masking(ids, n, r1, repl, r2)
+        out = po.pretrain_forward(p, ocfg, tables, batch, training=True, nfr_inject=inj, drop=drop)
+        out["loss"].backward()
+        grads = {k: v.grad for k, v in p.items()}
+        po.clip_grad_norm(grads, 5.0)
+        po.adamw_step(params, grads, state, lr=1e-4, wd=1e-2)
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+        if time.time() - t_all > 25 and len(times) >= 2:
+            break
+    per = float(np.mean(times))
+    return {"value": round(Bc / per, 2), "unit": "target nodes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed steps of B={Bc} targets ({12 * Bc} sequences x S={S}) after 1 warm-up, "
+                      f"fp32 torch CPU oracle, fwd+bwd+clip+AdamW, {per * 1e3:.0f} ms/step"}
+
+
+if __name__ == "__main__":
+    main()

@@ -131,6 +131,12 @@ typedef struct pmgt_adam {
 } pmgt_adam;
 int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* a, void* stream);
 
+/* Per-phase timers (what the reference lacks entirely): between begin and end every group of
+ * kernel launches is bracketed by HIP events on its stream; end() waits for them and writes one
+ * "name count total_ms" line per phase into buf.  Off by default. */
+int pmgt_profile_begin(pmgt_engine* e);
+int pmgt_profile_end(pmgt_engine* e, char* buf, int cap);
+
 /* dtype plumbing */
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
 int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);

@@ -30,6 +30,25 @@ void set_error(const char* fmt, ...) {
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Optional per-phase timers: HIP events recorded on the launch stream around each group of kernels.
+// Off by default (zero overhead); bench.py turns them on for a separate, untimed pass.
+struct Profiler {
+    bool on = false;
+    struct Rec { const char* name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void clear() {
+        for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear();
+    }
+};
+
 struct ParamEntry {
     std::string name;
     int64_t offset, numel;
@@ -58,6 +77,7 @@ struct pmgt_engine {
     std::vector<MirrorDesc> desc;
     MirrorDesc* desc_dev = nullptr;
     int mirror_tiles = 0;
+    pmgt::Profiler prof;
 };
 
 namespace pmgt {
@@ -278,6 +298,16 @@ static inline DropCfg dropcfg(const pmgt_tensors* t, bool on, float p, int layer
         int rc__ = (x);                                                                           \
         if (rc__ != 0) return rc__;                                                               \
     } while (0)
+// RUN with an optional event bracket (phase timers)
+#define RUNP(name, x)                                                                             \
+    do {                                                                                          \
+        Profiler& pf__ = const_cast<pmgt_engine*>(e)->prof;                                       \
+        hipEvent_t ea__ = nullptr, eb__ = nullptr;                                                \
+        if (pf__.on) { ea__ = pf__.get(); eb__ = pf__.get(); (void)hipEventRecord(ea__, st); }     \
+        int rc__ = (x);                                                                           \
+        if (pf__.on) { (void)hipEventRecord(eb__, st); pf__.recs.push_back({name, ea__, eb__}); }  \
+        if (rc__ != 0) return rc__;                                                               \
+    } while (0)
 
 // ---- encoder forward ---------------------------------------------------------------------------
 template <typename T>
@@ -302,7 +332,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         g.C = b.E + mod * d; g.ldc = 2 * d;
         g.M = M; g.N = d; g.K = F;
         g.bias = P + e->bvt + mod * d;
-        RUN(gemm_nt<T>(g, st));
+        RUNP("fwd.gemm_featproj", gemm_nt<T>(g, st));
     }
     {
         EmbedMix m;
@@ -310,7 +340,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         m.gamma = P + e->ln_g; m.beta = P + e->ln_b; m.eps = e->cfg.layer_norm_eps;
         m.a = b.a; m.pre = b.emb_pre; m.stats = b.emb_stats; m.h0 = b.h0;
         m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
-        RUN(embed_mix_fwd<T>(m, st));
+        RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
     }
     if (hidden_states) PMGT_HIP(hipMemcpyAsync(hidden_states, b.h0, (size_t)M * d * sizeof(T), hipMemcpyDeviceToDevice, st));
     const T* hin = b.h0;
@@ -321,7 +351,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             GemmNT g;
             g.A = hin; g.lda = d; g.B = wsel<T>(e, t, b, o.Wqkvc, o.mWqkvc); g.ldb = d;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
-            RUN(gemm_nt<T>(g, st));
+            RUNP("fwd.gemm_qkvc", gemm_nt<T>(g, st));
         }
         {
             AttnArgs a;
@@ -330,7 +360,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
             a.drop1 = dropcfg(t, train, pa, l, SITE_A1);
             a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
-            RUN(attn_fwd<T>(a, st));
+            RUNP("fwd.attention", attn_fwd<T>(a, st));
         }
         {   // BertSelfOutput: LN(dropout(dense(ctx)) + hin)
             GemmNT g;
@@ -338,8 +368,8 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.C = lb.ao_pre; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = P + o.bo;
             g.drop = dropcfg(t, train, pd, l, SITE_AO);
             g.res = hin; g.ldr = d;
-            RUN(gemm_nt<T>(g, st));
-            RUN(ln_fwd<T>(lb.ao_pre, lb.u, lb.stats1, P + o.ln1g, P + o.ln1b, M, d, e->cfg.layer_norm_eps,
+            RUNP("fwd.gemm_attn_out", gemm_nt<T>(g, st));
+            RUNP("fwd.layernorm", ln_fwd<T>(lb.ao_pre, lb.u, lb.stats1, P + o.ln1g, P + o.ln1b, M, d, e->cfg.layer_norm_eps,
                           DropCfg{nullptr, 0.f, 0}, st));
         }
         {   // BertIntermediate: gelu(dense(u))
@@ -347,7 +377,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.A = lb.u; g.lda = d; g.B = wsel<T>(e, t, b, o.W1, o.mW1); g.ldb = d;
             g.C = lb.g; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = P + o.b1;
             g.epi = EPI_GELU; g.aux = lb.ff_pre; g.ldaux = I;
-            RUN(gemm_nt<T>(g, st));
+            RUNP("fwd.gemm_ffn1", gemm_nt<T>(g, st));
         }
         {   // BertOutput: LN(dropout(dense(g)) + u)
             GemmNT g;
@@ -355,8 +385,8 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.C = lb.fo_pre; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = P + o.b2;
             g.drop = dropcfg(t, train, pd, l, SITE_FO);
             g.res = lb.u; g.ldr = d;
-            RUN(gemm_nt<T>(g, st));
-            RUN(ln_fwd<T>(lb.fo_pre, lb.hout, lb.stats2, P + o.ln2g, P + o.ln2b, M, d, e->cfg.layer_norm_eps,
+            RUNP("fwd.gemm_ffn2", gemm_nt<T>(g, st));
+            RUNP("fwd.layernorm", ln_fwd<T>(lb.fo_pre, lb.hout, lb.stats2, P + o.ln2g, P + o.ln2b, M, d, e->cfg.layer_norm_eps,
                           DropCfg{nullptr, 0.f, 0}, st));
         }
         if (hidden_states)
@@ -369,14 +399,15 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
 
 // wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs
 template <typename T>
-static int wgrad(const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
+static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
                  int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t st) {
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
     g.slab = b.slab; g.m_dev = m_dev;
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
-    RUN(gemm_tn<T>(g, st));
-    return slab_reduce(b.slab, g.splits, (int64_t)N1 * N2, dst, acc, st);
+    RUNP(name, gemm_tn<T>(g, st));
+    RUNP("bwd.slab_reduce", slab_reduce(b.slab, g.splits, (int64_t)N1 * N2, dst, acc, st));
+    return 0;
 }
 
 // ---- encoder backward: dcur (in b.bA) = d loss / d h_L; leaves parameter grads in t->grads ----------
@@ -394,37 +425,37 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         LayerBufs<T>& lb = b.layer[l];
         const T* hin = l == 0 ? b.h0 : b.layer[l - 1].hout;
         // LN2 backward: bA -> bB (residual branch), bC (masked: gradient of the FFN2 dense output)
-        RUN(ln_bwd<T>(b.bA, lb.fo_pre, lb.stats2, P + o.ln2g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
+        RUNP("bwd.layernorm", ln_bwd<T>(b.bA, lb.fo_pre, lb.stats2, P + o.ln2g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
                       dropcfg(t, true, pd, l, SITE_FO), st));
-        RUN(slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln2g, acc, st));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln2g, acc, st));
         const T* dY2 = dd ? b.bC : b.bB;
-        RUN(wgrad<T>(e, b, dY2, d, lb.g, I, nullptr, M, M, d, I, G + o.W2, acc, nullptr, st));
-        RUN(colsum<T>(dY2, d, M, d, b.part, G + o.b2, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, lb.g, I, nullptr, M, M, d, I, G + o.W2, acc, nullptr, st));
+        RUNP("bwd.colsum", colsum<T>(dY2, d, M, d, b.part, G + o.b2, acc, nullptr, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
             GemmNT g;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = b.big; g.ldc = I;
             g.M = M; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = lb.ff_pre; g.ldaux = I;
-            RUN(gemm_nt<T>(g, st));
+            RUNP("bwd.dgrad_ffn2", gemm_nt<T>(g, st));
         }
-        RUN(wgrad<T>(e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st));
-        RUN(colsum<T>(b.big, I, M, I, b.part, G + o.b1, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st));
+        RUNP("bwd.colsum", colsum<T>(b.big, I, M, I, b.part, G + o.b1, acc, nullptr, st));
         {   // du = dff W1 + residual branch
             GemmNT g;
             g.A = b.big; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = b.bD; g.ldc = d;
             g.M = M; g.N = d; g.K = I; g.res = b.bB; g.ldr = d;
-            RUN(gemm_nt<T>(g, st));
+            RUNP("bwd.dgrad_ffn1", gemm_nt<T>(g, st));
         }
         // LN1 backward
-        RUN(ln_bwd<T>(b.bD, lb.ao_pre, lb.stats1, P + o.ln1g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
+        RUNP("bwd.layernorm", ln_bwd<T>(b.bD, lb.ao_pre, lb.stats1, P + o.ln1g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
                       dropcfg(t, true, pd, l, SITE_AO), st));
-        RUN(slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln1g, acc, st));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln1g, acc, st));
         const T* dYo = dd ? b.bC : b.bB;
-        RUN(wgrad<T>(e, b, dYo, d, lb.ctx, d, nullptr, M, M, d, d, G + o.Wo, acc, nullptr, st));
-        RUN(colsum<T>(dYo, d, M, d, b.part, G + o.bo, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, nullptr, M, M, d, d, G + o.Wo, acc, nullptr, st));
+        RUNP("bwd.colsum", colsum<T>(dYo, d, M, d, b.part, G + o.bo, acc, nullptr, st));
         {   // dctx = dYo Wo
             GemmNT g;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = b.bD; g.ldc = d; g.M = M; g.N = d; g.K = d;
-            RUN(gemm_nt<T>(g, st));
+            RUNP("bwd.dgrad_attn_out", gemm_nt<T>(g, st));
         }
         {
             AttnArgs a;
@@ -432,15 +463,15 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.drop1 = dropcfg(t, true, pa, l, SITE_A1);
             a.drop2 = dropcfg(t, true, pa, l, SITE_A2);
             a.dctx = b.bD; a.dqkvc = b.big;
-            RUN(attn_bwd<T>(a, st));
+            RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
-        RUN(wgrad<T>(e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st));
-        RUN(colsum<T>(b.big, 4 * d, M, 4 * d, b.part, G + o.bqkvc, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st));
+        RUNP("bwd.colsum", colsum<T>(b.big, 4 * d, M, 4 * d, b.part, G + o.bqkvc, acc, nullptr, st));
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + o.mWqkvcT; g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
             g.M = M; g.N = d; g.K = 4 * d; g.res = b.bB; g.ldr = d;
-            RUN(gemm_nt<T>(g, st));
+            RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
         }
     }
     // embeddings
@@ -449,13 +480,13 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
         m.stats = b.emb_stats; m.drop = dropcfg(t, true, pd, -1, SITE_EMB);
         m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB; m.part = b.part;
-        RUN(embed_mix_bwd<T>(m, st));
-        RUN(slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
-        RUN(colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
+        RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
+        RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
         RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-        RUN(colsum<T>(b.big, 2 * d, M, 2 * d, b.part, G + e->bvt, acc, nullptr, st));
-        RUN(wgrad<T>(e, b, b.big, 2 * d, (const T*)t->table_v, e->Fv, b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st));
-        RUN(wgrad<T>(e, b, b.big + d, 2 * d, (const T*)t->table_t, e->Ft, b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st));
+        RUNP("bwd.colsum", colsum<T>(b.big, 2 * d, M, 2 * d, b.part, G + e->bvt, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, (const T*)t->table_v, e->Fv, b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, (const T*)t->table_t, e->Ft, b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st));
     }
     return 0;
 }
@@ -491,7 +522,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         PMGT_HIP(hipMemcpyAsync(b.mask + bs + ps, bt->tgt_mask, bs * 4, hipMemcpyDeviceToDevice, st));   // models.py:153-156
         RUN(nfr_compact(b.nfr_tgt, B, S, B + Pn, b.nfr_rows, b.nfr_tids, b.nfr_count, st));
     }
-    RUN(build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUNP("mirror", build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, (const T*)nullptr, (const T*)nullptr, b.mask, train, (T*)nullptr,
                            (float*)nullptr, st));
     T* hL = b.layer[e->L - 1].hout;
@@ -502,18 +533,18 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         GsrArgs g;
         g.h = hL; g.dh = bwd ? b.bA : nullptr; g.B = B; g.S = S; g.d = d; g.off = b.off; g.labels = bt->labels;
         g.logits = o->logits; g.loss_part = b.gsr_part;
-        RUN(gsr_fwd_bwd<T>(g, st));
+        RUNP("loss.gsr", gsr_fwd_bwd<T>(g, st));
     }
     const int cap = B * std::max(S - 1, 1);
     if (train) {
         GemmNT g;   // projections of the masked rows (row gather by token index)
         g.A = hL; g.lda = d; g.a_rows = b.nfr_rows; g.B = wsel<T>(e, t, b, e->Wn, e->mWn); g.ldb = d;
         g.C = b.pred; g.ldc = F; g.M = cap; g.N = F; g.K = d; g.bias = t->params + e->bn; g.m_dev = b.nfr_count;
-        RUN(gemm_nt<T>(g, st));
+        RUNP("loss.gemm_nfr", gemm_nt<T>(g, st));
         NfrDiffArgs a;
         a.pred = b.pred; a.tids = b.nfr_tids; a.count = b.nfr_count; a.cap = cap; a.Fv = e->Fv; a.Ft = e->Ft;
         a.table_v = t->table_v; a.table_t = t->table_t; a.sse_part = b.sse_part;
-        RUN(nfr_diff<T>(a, st));
+        RUNP("loss.nfr_diff", nfr_diff<T>(a, st));
     }
     RUN(loss_finish(b.gsr_part, B, train ? b.sse_part : nullptr, nfr_diff_parts(cap), b.nfr_count, e->Fv, e->Ft, train,
                     o->loss, st));
@@ -521,12 +552,12 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     if (o->nfr_count && train) PMGT_HIP(hipMemcpyAsync(o->nfr_count, b.nfr_count, 4, hipMemcpyDeviceToDevice, st));
     if (bwd) {
         const int msp = std::max(256, cap / 5);
-        RUN(wgrad<T>(e, b, b.pred, F, hL, d, b.nfr_rows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st));
-        RUN(colsum<T>(b.pred, F, cap, F, b.part, t->grads + e->bn, acc, b.nfr_count, st));
+        RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hL, d, b.nfr_rows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st));
+        RUNP("bwd.colsum", colsum<T>(b.pred, F, cap, F, b.part, t->grads + e->bn, acc, b.nfr_count, st));
         GemmNT g;
         g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.C = b.dq; g.ldc = d; g.M = cap; g.N = d; g.K = F;
         g.m_dev = b.nfr_count;
-        RUN(gemm_nt<T>(g, st));
+        RUNP("bwd.dgrad_nfr", gemm_nt<T>(g, st));
         RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
         RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st));
     }
@@ -657,7 +688,41 @@ int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* 
     x.p = t->params; x.g = t->grads; x.m = a->exp_avg; x.v = a->exp_avg_sq; x.decay = a->decay; x.n = e->total;
     x.lr = a->lr; x.wd = a->weight_decay; x.b1 = a->beta1; x.b2 = a->beta2; x.eps = a->eps; x.max_norm = a->max_grad_norm;
     x.step = a->step; x.scal = a->scalars; x.part = a->scratch;
-    return adamw_step(x, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    RUNP("optimizer.clip_adamw", adamw_step(x, st));
+    return 0;
+}
+
+int pmgt_profile_begin(pmgt_engine* e) {
+    e->prof.clear();
+    e->prof.on = true;
+    return 0;
+}
+
+// Stops collection, waits for the recorded events and writes one "name count total_ms" line per phase.
+int pmgt_profile_end(pmgt_engine* e, char* buf, int cap) {
+    e->prof.on = false;
+    std::vector<std::string> names;
+    std::vector<double> ms;
+    std::vector<int> cnt;
+    for (auto& r : e->prof.recs) {
+        PMGT_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        PMGT_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        size_t k = 0;
+        for (; k < names.size(); ++k) if (names[k] == r.name) break;
+        if (k == names.size()) { names.push_back(r.name); ms.push_back(0.); cnt.push_back(0); }
+        ms[k] += t; cnt[k] += 1;
+    }
+    e->prof.clear();
+    std::string out;
+    for (size_t k = 0; k < names.size(); ++k) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s %d %.6f\n", names[k].c_str(), cnt[k], ms[k]);
+        out += line;
+    }
+    if (buf && cap > 0) { strncpy(buf, out.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return 0;
 }
 
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {

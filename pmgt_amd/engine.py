@@ -193,6 +193,20 @@ class Engine:
         tc = self._tensors()
         _lib.check(self.lib.pmgt_optimizer_step(self.h, C.byref(tc), C.byref(ac), _stream()))
 
+    # ---- phase timers -------------------------------------------------------------------------------------
+    def profile_begin(self):
+        _lib.check(self.lib.pmgt_profile_begin(self.h))
+
+    def profile_end(self) -> Dict[str, tuple]:
+        """{phase: (launch groups, total ms)} measured with HIP events on the launch stream."""
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self.lib.pmgt_profile_end(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
     def grad_norm(self) -> torch.Tensor:
         """Pre-clip global gradient norm of the last optimizer_step (device scalar)."""
         return self.opt_scalars[3]

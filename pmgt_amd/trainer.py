@@ -1,0 +1,113 @@
+"""Trainer step of the PMGT pre-training hot path (reference: `PMGTTrainerModel.training_step`,
+pmgt/pmgt/trainer.py:156-160, driven by PL's loop with `gradient_clip_val`, `DenseSparseAdamW` from
+`get_optimizer`, and DDP when gpus > 1 — pmgt/base_trainer.py:35-68,309-322).
+
+Data parallelism: one process per GPU, every rank holds a full replica (graph on the
+host, feature tables + weights on the device); the ONLY exchange is one all-reduce(AVG) of the flat
+fp32 gradient buffer per optimizer step over RCCL/xGMI (12 MB at L4/d256: far below one link's
+bandwidth-delay product, so a single un-bucketed collective is the right shape); the clip uses the
+post-reduce global norm, identical on all ranks.  Each rank takes indices rank::world of one seeded
+permutation (DistributedSampler semantics).
+"""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .datasets import MODE_TRAIN
+
+
+class Trainer:
+    def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
+                 random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16):
+        self.engine = engine
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.max_grad_norm = max_grad_norm
+        self.world_size = world_size
+        self.accum = max(1, accumulate_grad_batches)
+        self.random_node_ratio, self.mask_node_ratio = random_node_ratio, mask_node_ratio
+        self.last_loss = None
+        self._micro = 0
+
+    def broadcast_parameters(self, src: int = 0):
+        """DDP constructor semantics: every replica starts from rank `src`'s parameters."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.engine.params, src=src)
+
+    def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
+        """loss = net(*batch)[0] with gradients left in engine.grads (pmgt/pmgt/trainer.py:156-160)."""
+        out = self.engine.pretrain_step(batch, training=True, backward=True, accumulate=self._micro > 0,
+                                        random_node_ratio=self.random_node_ratio, mask_node_ratio=self.mask_node_ratio,
+                                        want_hidden=False)
+        self.last_loss = out["loss"]
+        return out["loss"]
+
+    def optimizer_step(self):
+        eng = self.engine
+        if self.accum > 1:
+            eng.grads.div_(self.accum)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.AVG)
+        eng.optimizer_step(lr=self.lr, weight_decay=self.weight_decay, betas=self.betas, eps=self.eps,
+                           max_grad_norm=self.max_grad_norm)
+
+    def train_step(self, batch) -> torch.Tensor:
+        """One micro-batch; steps the optimizer every `accumulate_grad_batches` calls."""
+        loss = self.training_step(batch)
+        self._micro += 1
+        if self._micro == self.accum:
+            self.optimizer_step()
+            self._micro = 0
+        return loss
+
+    # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
+    def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3):
+        eng = self.engine
+        dev = eng.device
+        copy_stream = torch.cuda.Stream(device=dev)
+        slots = [sampler.alloc(batch_size, MODE_TRAIN, pinned=True) for _ in range(depth)]
+        free_q: "queue.Queue[int]" = queue.Queue()
+        ready_q: "queue.Queue" = queue.Queue()
+        for i in range(depth):
+            free_q.put(i)
+        n = len(node_ids)
+
+        def producer():
+            for step in range(steps):
+                slot = free_q.get()
+                lo = (step * batch_size) % max(n - batch_size, 1)
+                tg = np.resize(node_ids[lo:], batch_size)
+                tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, out=slots[slot], threads=threads,
+                                                            base_seed=7, counter=step * batch_size)
+                with torch.cuda.stream(copy_stream):
+                    cu = lambda dct: {k: v.to(dev, non_blocking=True) for k, v in dct.items()}
+                    b = (cu(tgt), cu(pair), num_pairs.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                ready_q.put((slot, b, ev))
+
+        th = threading.Thread(target=producer, daemon=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th.start()
+        for _ in range(steps):
+            slot, b, ev = ready_q.get()
+            torch.cuda.current_stream().wait_event(ev)
+            self.train_step(b)
+            ev2 = torch.cuda.Event()
+            ev2.record()
+            ev2.synchronize()          # the pinned slot may be refilled once its copies and step are done
+            free_q.put(slot)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        th.join()
+        return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+                "sampler_threads": threads, "steps": steps}
