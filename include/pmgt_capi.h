@@ -152,9 +152,12 @@ int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_
 int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream);
 int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const float* gamma, const float* beta,
                           int M, int d, float eps, float drop_p, uint32_t drop_site, const uint64_t* rng, void* stream);
+/* part: [ceil(M/64)][3][d] scratch; dgamma_dbeta: [3*d] out = dgamma | dbeta | column sum of dx_drop (or dx) */
 int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                           void* dx_drop, float* part, float* dgamma_dbeta, int M, int d, float in_drop_p,
                           uint32_t in_site, float out_drop_p, uint32_t out_site, const uint64_t* rng, void* stream);
+/* A/B switch: 1 routes bf16 attention through the generic fp32-VALU kernel instead of the MFMA one */
+void pmgt_debug_force_valu_attention(int on);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,
                           int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
                           const uint64_t* rng, void* stream);

@@ -15,6 +15,10 @@ struct AttnArgs {
     const void* dctx = nullptr;   // backward: [Tseq*S, d]
     void* dqkvc = nullptr;        // backward: [Tseq*S, 4d]
 };
+// bf16 MFMA path (attention_mfma.hip): S <= 64, head size 32 or 64
+bool attn_mfma_supported(const AttnArgs& a);
+int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st);
+void attn_force_valu(int on);   // debugging / A-B: route bf16 through the generic VALU kernel
 template <typename T> int attn_fwd(const AttnArgs& a, hipStream_t st);
 template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
 

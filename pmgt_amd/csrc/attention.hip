@@ -358,8 +358,14 @@ template <typename T, int DH> static int launch_gs(const AttnArgs& a, bool bwd, 
     return launch<T, DH, 64>(a, bwd, st);
 }
 
+static int g_force_valu = 0;
+void attn_force_valu(int on) { g_force_valu = on; }
+
 template <typename T> static int dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
     if (a.Tseq <= 0) return 0;
+    if constexpr (sizeof(T) == 2) {
+        if (!g_force_valu && attn_mfma_supported(a)) return attn_mfma(a, bwd, st);   // bf16 perf path
+    }
     PMGT_CHECK(a.S >= 1 && a.S <= 64, -3,
                "attention: sequence length %d not supported by the HIP path yet (1..64; the reference allows <= 100)", a.S);
     switch (a.dh) {

@@ -1,0 +1,481 @@
+// bf16 MFMA version of the PMGT dual-softmax attention (forward and backward), S <= 64, head size 32/64.
+//
+// One wave owns one (sequence, head); a workgroup is 4 independent waves.  Everything S x S stays in
+// registers / wave-private LDS.  All score-shaped matrices are held TRANSPOSED in the MFMA C/D layout
+// ("key j on (lane>>4, reg), query i on lane&15"): X^T[j][i] = sum_c K[j][c] Q[i][c] is an NT product
+// whose fragments load straight from global rows, the softmax over j is a register + 2-shuffle
+// reduction, and an accumulator tile is directly the B operand of every product that sums over its
+// ROW index j (O^T = V^T P^T, dQ^T = K^T dS2^T, first half of dC) — with the k-slot permutation
+// j(q, e) = 32 ks + 16 (e >> 2) + 4 q + (e & 3) applied to the A operand, which is fetched with
+// ds_read_b64_tr_b16 from a row-major LDS tile.  Products that sum over the COLUMN index i (dV, dK,
+// second half of dC) read the bf16 image of the matrix back from LDS row-wise (one transpose through
+// LDS, as cdna_hip_programming.md section 3 prescribes).
+#include "attention.h"
+
+namespace pmgt {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16* row_ptr, bool ok) {
+    if (ok) return *(const bf16x8*)row_ptr;
+    return (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+}
+// A operand (16 "c" rows x 32 k) of a product whose k index is a ROW of the row-major LDS tile
+// `tile` ([rows][DH] bf16): element e of lane (r, q) is tile[krow(q, e)][c0 + r].
+// PERM = true: krow = k0 + 16 (e >> 2) + 4 q + (e & 3)  (matches an accumulator tile used as B);
+// PERM = false: krow = k0 + 8 q + e                      (natural order, matches row-read B fragments).
+template <int DH, bool PERM>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int c0, int r, int q) {
+    const int row_lo = PERM ? (k0 + 4 * q + (r >> 2)) : (k0 + 8 * q + (r >> 2));
+    const int row_hi = PERM ? (row_lo + 16) : (row_lo + 4);
+    const int colb = (c0 + 4 * (r & 3)) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + row_lo * (DH * 2) + colb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + row_hi * (DH * 2) + colb));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) {
+    // combine the 4 lanes (q = 0..3) that share a query column
+    float o = __shfl_xor(v, 16, 64);
+    v = is_max ? fmaxf(v, o) : v + o;
+    o = __shfl_xor(v, 32, 64);
+    return is_max ? fmaxf(v, o) : v + o;
+}
+
+// Recompute both normalised probability matrices (transposed, fp32, in registers).
+// fq/fk/fc: NT-form fragments of Q, K, C rows.  On return a1/a2[jt][it][e] = A[i = 16 it + r][j = 16 jt + 4 q + e]
+// (0 where i or j is padding).
+template <int NT, int KD>
+__device__ __forceinline__ void probs_T(const bf16x8 (&fq)[NT][KD], const bf16x8 (&fk)[NT][KD], const bf16x8 (&fc)[NT][KD],
+                                        const float* rho, const float* madd, int S, int r, int q, float sq,
+                                        f32x4 (&a1)[NT][NT], f32x4 (&a2)[NT][NT]) {
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1;
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) {
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt][ks], fc[it][ks], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt][ks], fq[it][ks], x2, 0, 0, 0);
+            }
+            a1[jt][it] = x1;
+            a2[jt][it] = x2;
+        }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const int i = 16 * it + r;
+        const bool iv = i < S;
+        const float rho_i = rho[i];
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const bool ok = iv && j < S;
+                const float v1 = ok ? (1.f - a1[jt][it][e] / (rho_i * rho[j]) + (i == j ? 1.f : 0.f) + madd[j]) : -INFINITY;
+                const float v2 = ok ? (a2[jt][it][e] / sq + madd[j]) : -INFINITY;
+                a1[jt][it][e] = v1;
+                a2[jt][it][e] = v2;
+                m1 = fmaxf(m1, v1);
+                m2 = fmaxf(m2, v2);
+            }
+        m1 = red_q<NT>(m1, true);
+        m2 = red_q<NT>(m2, true);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e1 = iv ? __expf(a1[jt][it][e] - m1) : 0.f;
+                const float e2 = iv ? __expf(a2[jt][it][e] - m2) : 0.f;
+                a1[jt][it][e] = e1;
+                a2[jt][it][e] = e2;
+                s1 += e1;
+                s2 += e2;
+            }
+        s1 = red_q<NT>(s1, false);
+        s2 = red_q<NT>(s2, false);
+        const float i1 = iv ? 1.f / s1 : 0.f, i2 = iv ? 1.f / s2 : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            a1[jt][it] *= i1;
+            a2[jt][it] *= i2;
+        }
+    }
+}
+
+// pack an accumulator-layout matrix column block `it` into B fragments (k-step ks covers key tiles 2ks, 2ks+1)
+template <int NT>
+__device__ __forceinline__ bf16x8 pack_b(const f32x4 (&x)[NT][NT], int it, int ks) {
+    bf16x8 b;
+    const f32x4 lo = x[2 * ks][it];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = (bf16)lo[e];
+    if (2 * ks + 1 < NT) {
+        const f32x4 hi = x[(2 * ks + 1 < NT) ? 2 * ks + 1 : 0][it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[4 + e] = (bf16)hi[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[4 + e] = (bf16)0.f;
+    }
+    return b;
+}
+
+// Cooperative (one wave) load of a [rows][DH] bf16 tile from global rows (stride ld elements) into LDS,
+// rows >= S zero-filled; optional per-row scale (used to normalise C rows).
+template <int DH>
+__device__ __forceinline__ void load_tile(char* tile, const bf16* src, int64_t ld, int rows, int S, int lane,
+                                          const float* row_scale) {
+    constexpr int CPR = DH / 8;
+    for (int idx = lane; idx < rows * CPR; idx += 64) {
+        const int s = idx / CPR, c = idx % CPR;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (s < S) {
+            v = *(const bf16x8*)(src + (int64_t)s * ld + c * 8);
+            if (row_scale) {
+                const float sc = row_scale[s];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * sc);
+            }
+        }
+        *(bf16x8*)(tile + s * (DH * 2) + c * 16) = v;
+    }
+}
+
+template <int DH, int NT> struct FwdSmem {
+    static constexpr int SP = NT * 16, SP2 = (SP + 31) / 32 * 32;
+    static constexpr int TILE = SP2 * DH * 2;
+    static constexpr int BYTES = TILE + 2 * 64 * 4;
+};
+
+template <int DH, int NT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
+    using SM = FwdSmem<DH, NT>;
+    constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int gidx = blockIdx.x * 4 + wave;
+    const int S = a.S, H = a.H, d = H * DH;
+    const bool act = gidx < a.Tseq * H;
+    const int t = act ? gidx / H : 0, h = act ? gidx % H : 0;
+    char* base = smem + wave * SM::BYTES;
+    char* tV = base;
+    float* rho = (float*)(base + SM::TILE);
+    float* madd = rho + 64;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    const int64_t ld = 4 * d;
+    const int Sv = act ? S : 0;
+
+    load_tile<DH>(tV, X + 2 * d, ld, SM::SP2, Sv, lane, nullptr);
+    bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int row = 16 * tt + r;
+        const bool ok = row < Sv;
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const bf16* p = X + (int64_t)row * ld + 32 * ks + 8 * q;
+            fq[tt][ks] = ld_frag(p, ok);
+            fk[tt][ks] = ld_frag(p + d, ok);
+            fc[tt][ks] = ld_frag(p + 3 * d, ok);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
+        }
+        ss = red_q<NT>(ss, false);
+        if (q == 0) rho[row] = sqrtf(ss);
+    }
+    madd[lane] = (lane < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : 0.f;
+    __syncthreads();
+
+    f32x4 a1[NT][NT], a2[NT][NT];
+    probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, sqrtf((float)DH), a1, a2);
+
+    // mix + dropout -> P^T in a1
+    const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
+    const float beta = a.beta, omb = 1.f - a.beta;
+    const uint64_t hbase = ((uint64_t)t * H + h) * S;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const int i = 16 * it + r;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                float p1 = beta * a1[jt][it][e], p2 = omb * a2[jt][it][e];
+                if (k1.on) {
+                    const uint64_t idx = (hbase + i) * S + j;
+                    p1 *= drop_mul(k1, idx);
+                    p2 *= drop_mul(k2, idx);
+                }
+                const float p = p1 + p2;
+                a1[jt][it][e] = p;
+                if (a.probs && i < Sv && j < Sv) a.probs[(hbase + i) * S + j] = p;
+            }
+    }
+    // O^T[c][i] = sum_j V[j][c] P[i][j]
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        bf16x8 pb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pb[ks] = pack_b<NT>(a1, it, ks);
+        const int i = 16 * it + r;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q), pb[ks], o, 0, 0, 0);
+            if (i < Sv) store4<bf16>((bf16*)a.ctx + ((int64_t)t * S + i) * d + h * DH + 16 * ct + 4 * q, o);
+        }
+    }
+}
+
+template <int DH, int NT> struct BwdSmem {
+    static constexpr int SP = NT * 16, SP2 = (SP + 31) / 32 * 32;
+    static constexpr int TILE = SP2 * DH * 2;         // Q, K, dO, C-hat
+    static constexpr int IMG = SP * SP2 * 2;          // P^T, dS1^T, dS2^T as [j][i] bf16
+    static constexpr int BYTES = 4 * TILE + 3 * IMG + 2 * 64 * 4;
+};
+
+template <int DH, int NT>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
+    using SM = BwdSmem<DH, NT>;
+    constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nw = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int gidx = blockIdx.x * nw + wave;
+    const int S = a.S, H = a.H, d = H * DH;
+    const bool act = gidx < a.Tseq * H;
+    const int t = act ? gidx / H : 0, h = act ? gidx % H : 0;
+    char* base = smem + wave * SM::BYTES;
+    char* tQ = base;
+    char* tK = tQ + SM::TILE;
+    char* tO = tK + SM::TILE;
+    char* tC = tO + SM::TILE;
+    char* iP = tC + SM::TILE;
+    char* iS1 = iP + SM::IMG;
+    char* iS2 = iS1 + SM::IMG;
+    float* rho = (float*)(iS2 + SM::IMG);
+    float* madd = rho + 64;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
+    bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
+    const int64_t ld = 4 * d;
+    const int Sv = act ? S : 0;
+    const float sq = sqrtf((float)DH);
+
+    load_tile<DH>(tQ, X, ld, SP2, Sv, lane, nullptr);
+    load_tile<DH>(tK, X + d, ld, SP2, Sv, lane, nullptr);
+    load_tile<DH>(tO, DO, d, SP2, Sv, lane, nullptr);
+    f32x4 a1[NT][NT], a2[NT][NT];
+    {
+        bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int row = 16 * tt + r;
+            const bool ok = row < Sv;
+            float ss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) {
+                const bf16* p = X + (int64_t)row * ld + 32 * ks + 8 * q;
+                fq[tt][ks] = ld_frag(p, ok);
+                fk[tt][ks] = ld_frag(p + d, ok);
+                fc[tt][ks] = ld_frag(p + 3 * d, ok);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
+            }
+            ss = red_q<NT>(ss, false);
+            if (q == 0) rho[row] = sqrtf(ss);
+        }
+        madd[lane] = (lane < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : 0.f;
+        __syncthreads();
+        probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, sq, a1, a2);
+    }
+    // C-hat tile (rows scaled by 1 / |c|); madd is no longer needed: reuse it for the inverse norms
+    madd[lane] = (lane < Sv) ? 1.f / rho[lane] : 0.f;
+    __syncthreads();
+    load_tile<DH>(tC, X + 3 * d, ld, SP2, Sv, lane, madd);
+
+    // dP^T[j][i] = sum_c V[j][c] dO[i][c]
+    f32x4 dp[NT][NT];
+    {
+        bf16x8 fv[NT][KD], fo[NT][KD];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int row = 16 * tt + r;
+            const bool ok = row < Sv;
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) {
+                fv[tt][ks] = ld_frag(X + (int64_t)row * ld + 2 * d + 32 * ks + 8 * q, ok);
+                fo[tt][ks] = ld_frag(DO + (int64_t)row * d + 32 * ks + 8 * q, ok);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KD; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt][ks], fo[it][ks], x, 0, 0, 0);
+                dp[jt][it] = x;
+            }
+    }
+    // softmax backward (both branches) in registers; images of P^T, dS1^T, dS2^T to LDS
+    const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
+    const float beta = a.beta, omb = 1.f - a.beta;
+    const uint64_t hbase = ((uint64_t)t * H + h) * S;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const int i = 16 * it + r;
+        float rd1 = 0.f, rd2 = 0.f;
+        f32x4 g1[NT], g2[NT], pm[NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                float m1 = beta, m2 = omb;
+                if (k1.on) {
+                    const uint64_t idx = (hbase + i) * S + j;
+                    m1 *= drop_mul(k1, idx);
+                    m2 *= drop_mul(k2, idx);
+                }
+                const float x1 = m1 * dp[jt][it][e], x2 = m2 * dp[jt][it][e];
+                g1[jt][e] = x1;
+                g2[jt][e] = x2;
+                pm[jt][e] = m1 * a1[jt][it][e] + m2 * a2[jt][it][e];
+                rd1 = fmaf(a1[jt][it][e], x1, rd1);
+                rd2 = fmaf(a2[jt][it][e], x2, rd2);
+            }
+        rd1 = red_q<NT>(rd1, false);
+        rd2 = red_q<NT>(rd2, false);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const float ds1 = a1[jt][it][e] * (g1[jt][e] - rd1);     // a == 0 on padding -> ds == 0
+                const float ds2 = a2[jt][it][e] * (g2[jt][e] - rd2);
+                a1[jt][it][e] = ds1;
+                a2[jt][it][e] = ds2;
+                *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)pm[jt][e];
+                *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)ds1;
+                *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)ds2;
+            }
+    }
+    if (SP2 > SP) {     // zero the padding columns i in [SP, SP2) of the images
+        for (int idx = lane; idx < SP * (SP2 - SP); idx += 64) {
+            const int j = idx / (SP2 - SP), i = SP + idx % (SP2 - SP);
+            *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
+            *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
+            *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- products with the query / "x" index on the lane
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        bf16x8 b2[KS], b1[KS], bt[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            b2[ks] = pack_b<NT>(a2, it, ks);
+            b1[ks] = pack_b<NT>(a1, it, ks);
+            // dS1 with the roles swapped: B[k = y][n = x] = dS1^T[x][y]  (image row x, 8 consecutive y)
+            bt[ks] = *(const bf16x8*)(iS1 + ((16 * it + r) * SP2 + 32 * ks + 8 * q) * 2);
+        }
+        const int x = 16 * it + r;
+        f32x4 dch[CT];
+        float dt = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
+                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
+            }
+            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq / sq);
+            dch[ct] = -dc;       // dN = -dS1
+            const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+            dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
+        }
+        dt = red_q<NT>(dt, false);
+        const float inv = madd[x < 64 ? x : 0];     // 1 / |c_x|
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 3 * d + 16 * ct + 4 * q, (dch[ct] - ch * dt) * inv);
+        }
+    }
+    // ---- products with the key index on the lane: dV^T[c][j] = sum_i dO[i][c] P[i][j], dK^T[c][j] = sum_i Q[i][c] dS2[i][j]
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        bf16x8 bp[KS], bs[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bp[ks] = *(const bf16x8*)(iP + ((16 * jt + r) * SP2 + 32 * ks + 8 * q) * 2);
+            bs[ks] = *(const bf16x8*)(iS2 + ((16 * jt + r) * SP2 + 32 * ks + 8 * q) * 2);
+        }
+        const int j = 16 * jt + r;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
+            }
+            if (j < Sv) {
+                store4<bf16>(DX + (int64_t)j * ld + 2 * d + 16 * ct + 4 * q, dv);
+                store4<bf16>(DX + (int64_t)j * ld + d + 16 * ct + 4 * q, dk / sq);
+            }
+        }
+    }
+}
+
+template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
+    const int groups = a.Tseq * a.H;
+    if (!bwd) {
+        const size_t shmem = (size_t)FwdSmem<DH, NT>::BYTES * 4;
+        auto kern = attn_fwd_mfma_kernel<DH, NT>;
+        if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(kern, dim3(cdiv(groups, 4)), dim3(256), shmem, st, a);
+    } else {
+        const size_t per = BwdSmem<DH, NT>::BYTES;
+        const int nw = per * 4 <= 150 * 1024 ? 4 : (per * 2 <= 150 * 1024 ? 2 : 1);
+        const size_t shmem = per * nw;
+        auto kern = attn_bwd_mfma_kernel<DH, NT>;
+        if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(kern, dim3(cdiv(groups, nw)), dim3(64 * nw), shmem, st, a);
+    }
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+template <int DH> static int launch_nt(const AttnArgs& a, bool bwd, hipStream_t st) {
+    const int nt = cdiv(a.S, 16);
+    switch (nt) {
+        case 1: return launch_mfma<DH, 1>(a, bwd, st);
+        case 2: return launch_mfma<DH, 2>(a, bwd, st);
+        case 3: return launch_mfma<DH, 3>(a, bwd, st);
+        default: return launch_mfma<DH, 4>(a, bwd, st);
+    }
+}
+
+bool attn_mfma_supported(const AttnArgs& a) { return a.S >= 1 && a.S <= 64 && (a.dh == 32 || a.dh == 64); }
+
+int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
+    if (a.Tseq <= 0) return 0;
+    if (a.dh == 32) return launch_nt<32>(a, bwd, st);
+    return launch_nt<64>(a, bwd, st);
+}
+
+}  // namespace pmgt

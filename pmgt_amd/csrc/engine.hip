@@ -121,16 +121,17 @@ static void build_layout(pmgt_engine* e) {
         for (int k = 0; k < 4; ++k) add_entry(e, p + "attention.self." + nm[k] + ".weight", o.Wqkvc + (int64_t)k * d * d, d, d);
         o.bqkvc = take(cur, 4 * d);
         for (int k = 0; k < 4; ++k) add_entry(e, p + "attention.self." + nm[k] + ".bias", o.bqkvc + (int64_t)k * d, d, 0);
+        // ln_g | ln_b | dense bias contiguous = the order of ln_bwd's three partials
         o.Wo = take(cur, (int64_t)d * d);  add_entry(e, p + "attention.output.dense.weight", o.Wo, d, d);
-        o.bo = take(cur, d);               add_entry(e, p + "attention.output.dense.bias", o.bo, d, 0);
         o.ln1g = take(cur, d);             add_entry(e, p + "attention.output.LayerNorm.weight", o.ln1g, d, 0);
         o.ln1b = take(cur, d);             add_entry(e, p + "attention.output.LayerNorm.bias", o.ln1b, d, 0);
+        o.bo = take(cur, d);               add_entry(e, p + "attention.output.dense.bias", o.bo, d, 0);
         o.W1 = take(cur, (int64_t)I * d);  add_entry(e, p + "intermediate.dense.weight", o.W1, I, d);
         o.b1 = take(cur, I);               add_entry(e, p + "intermediate.dense.bias", o.b1, I, 0);
         o.W2 = take(cur, (int64_t)d * I);  add_entry(e, p + "output.dense.weight", o.W2, d, I);
-        o.b2 = take(cur, d);               add_entry(e, p + "output.dense.bias", o.b2, d, 0);
         o.ln2g = take(cur, d);             add_entry(e, p + "output.LayerNorm.weight", o.ln2g, d, 0);
         o.ln2b = take(cur, d);             add_entry(e, p + "output.LayerNorm.bias", o.ln2b, d, 0);
+        o.b2 = take(cur, d);               add_entry(e, p + "output.dense.bias", o.b2, d, 0);
     }
     e->Wn = take(cur, (int64_t)(Fv + Ft) * d);
     add_entry(e, "nfr_loss.projections.0.weight", e->Wn, Fv, d);
@@ -264,7 +265,7 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     slab = std::max(slab, tn_slab_elems(dt, std::max(256, cap / 5), F, d));
     b.slab = c.get<float>(slab);
     int64_t part = 0;
-    part = std::max(part, (int64_t)ln_bwd_parts((int)M) * 2 * d);
+    part = std::max(part, (int64_t)ln_bwd_parts((int)M) * 3 * d);
     part = std::max(part, (int64_t)embed_bwd_parts((int)M) * (6 * d + 4));
     part = std::max(part, colsum_slab_elems((int)M, std::max(std::max(I, 4 * d), 2 * d)));
     part = std::max(part, colsum_slab_elems(Tseq, S * d));
@@ -427,10 +428,9 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         // LN2 backward: bA -> bB (residual branch), bC (masked: gradient of the FFN2 dense output)
         RUNP("bwd.layernorm", ln_bwd<T>(b.bA, lb.fo_pre, lb.stats2, P + o.ln2g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
                       dropcfg(t, true, pd, l, SITE_FO), st));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln2g, acc, st));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 3 * d, G + o.ln2g, acc, st));   // dgamma | dbeta | db2
         const T* dY2 = dd ? b.bC : b.bB;
         RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, lb.g, I, nullptr, M, M, d, I, G + o.W2, acc, nullptr, st));
-        RUNP("bwd.colsum", colsum<T>(dY2, d, M, d, b.part, G + o.b2, acc, nullptr, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
             GemmNT g;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = b.big; g.ldc = I;
@@ -448,10 +448,9 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         // LN1 backward
         RUNP("bwd.layernorm", ln_bwd<T>(b.bD, lb.ao_pre, lb.stats1, P + o.ln1g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
                       dropcfg(t, true, pd, l, SITE_AO), st));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 2 * d, G + o.ln1g, acc, st));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 3 * d, G + o.ln1g, acc, st));   // dgamma | dbeta | dbo
         const T* dYo = dd ? b.bC : b.bB;
         RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, nullptr, M, M, d, d, G + o.Wo, acc, nullptr, st));
-        RUNP("bwd.colsum", colsum<T>(dYo, d, M, d, b.part, G + o.bo, acc, nullptr, st));
         {   // dctx = dYo Wo
             GemmNT g;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = b.bD; g.ldc = d; g.M = M; g.N = d; g.K = d;
@@ -781,7 +780,7 @@ int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float*
     else
         rc = ln_bwd<float>((const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_drop, part, M, d, di, dout, (hipStream_t)stream);
     if (rc) return rc;
-    return slab_reduce(part, ln_bwd_parts(M), 2 * d, dgamma_dbeta, false, (hipStream_t)stream);
+    return slab_reduce(part, ln_bwd_parts(M), 3 * d, dgamma_dbeta, false, (hipStream_t)stream);
 }
 
 static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, int H, int dh, float beta, float drop_p,
@@ -792,6 +791,8 @@ static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, i
     a.drop2 = DropCfg{rng, rng ? drop_p : 0.f, s2};
     return a;
 }
+
+void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
 
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S, int H,
                           int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream) {

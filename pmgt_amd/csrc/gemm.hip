@@ -136,35 +136,64 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+    // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.
+    // The accumulators go through LDS (two passes of 64 rows, fp32, row stride 132 words: the
+    // ds_write_b32 pattern is 2-way = free) so that bias / GELU / dropout / residual run on
+    // row-contiguous 8-element chunks and every global access is a full 16-byte vector.
     const DropKey dk = make_drop_key(g.drop);
     T* C = (T*)g.C;
     const T* R = (const T*)g.res;
     T* AUX = (T*)g.aux;
+    constexpr int ES = BN + 4;                      // staged row stride in floats
+    float* stage = (float*)smem;                    // 64 x ES floats = 33 KiB (BN = 128)
+    static_assert(64 * ES * 4 <= 2 * (BM + BN) * 128, "epilogue staging does not fit");
+    const int er = tid >> 4, ec = (tid & 15) * (BN / 16);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        if (wm == pass) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + r;
-            if (n >= g.N) continue;
-            const float bv = g.bias ? g.bias[n] : 0.f;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + 4 * q + e;
-                if (m >= Mlim) continue;
-                float v = acc[i][j][e] + bv;
-                if (g.epi == EPI_GELU) {
-                    T pre = from_f<T>(v);
-                    AUX[(int64_t)m * g.ldaux + n] = pre;
-                    v = gelu_erf(to_f<T>(pre));
-                } else if (g.epi == EPI_GELU_GRAD) {
-                    v *= gelu_erf_grad(to_f<T>(AUX[(int64_t)m * g.ldaux + n]));
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(i * 16 + 4 * q + e) * ES + wn * (BN / 2) + j * 16 + r] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = er + 16 * it;
+            const int m = m0 + pass * 64 + row;
+            if (m < Mlim) {
+#pragma unroll
+                for (int h = 0; h < BN / 64; ++h) {            // 4-element pieces of this thread's chunk
+                    const int n = n0 + ec + 4 * h;
+                    if (n < g.N) {                              // N % 4 == 0 is checked on the host
+                        f32x4 v = *(const f32x4*)(stage + row * ES + ec + 4 * h);
+                        if (g.bias) v += *(const f32x4*)(g.bias + n);
+                        if (g.epi == EPI_GELU) {
+                            f32x4 pre;                              // rounded to T: what backward re-reads
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pre[e] = to_f<T>(from_f<T>(v[e]));
+                            store4<T>(AUX + (int64_t)m * g.ldaux + n, pre);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(pre[e]);
+                        } else if (g.epi == EPI_GELU_GRAD) {
+                            f32x4 pre = load4<T>(AUX + (int64_t)m * g.ldaux + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(pre[e]);
+                        }
+                        if (dk.on) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= drop_mul(dk, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n + e));
+                        }
+                        if (R) v += load4<T>(R + (int64_t)m * g.ldr + n);
+                        store4<T>(C + (int64_t)m * g.ldc + n, v);
+                    }
                 }
-                if (dk.on) v *= drop_mul(dk, (uint64_t)m * (uint64_t)g.N + (uint64_t)n);
-                if (R) v += to_f<T>(R[(int64_t)m * g.ldr + n]);
-                C[(int64_t)m * g.ldc + n] = from_f<T>(v);
             }
         }
+        __syncthreads();
     }
 }
 
@@ -177,6 +206,8 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, -2, "gemm_nt: operands must be 16-byte aligned");
     PMGT_CHECK(g.lda >= g.K && g.ldb >= g.K && g.ldc >= g.N, -2, "gemm_nt: leading dimensions too small");
     PMGT_CHECK(g.epi == EPI_NONE || g.aux != nullptr, -2, "gemm_nt: epilogue %d needs aux", g.epi);
+    PMGT_CHECK(g.N % 4 == 0 && g.ldc % 4 == 0 && (g.res == nullptr || g.ldr % 4 == 0) && (g.aux == nullptr || g.ldaux % 4 == 0),
+               -2, "gemm_nt: N and the output leading dimensions must be multiples of 4 (N=%d ldc=%lld)", g.N, (long long)g.ldc);
     constexpr int BM = 128, BN = 128;
     const int num_m = cdiv(g.M, BM), num_n = cdiv(g.N, BN);
     const int grid = cdiv(num_m, 8) * 8 * num_n;
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
-    int splits = cdiv(512, tiles);                       // ~2 workgroups per CU
+    int splits = cdiv(256, tiles);                       // ~1 workgroup per CU: slab traffic = splits * N1 * N2 * 4 B
     const int max_by_rows = std::max(1, M / (4 * bkm));  // at least 4 K-steps per split
     splits = std::max(1, std::min(splits, max_by_rows));
     return splits;
@@ -359,53 +390,112 @@ template int gemm_tn<bf16>(const GemmTN&, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // slab reduce / column sums
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,
-                                                          float* __restrict__ dst, int accumulate) {
-    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    if (i4 + 4 <= n && (n % 4) == 0) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < splits; ++k) s += *(const f32x4*)(slab + (int64_t)k * n + i4);
-        if (accumulate) s += *(const f32x4*)(dst + i4);
-        *(f32x4*)(dst + i4) = s;
-    } else {
-        for (int64_t i = i4; i < n && i < i4 + 4; ++i) {
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * n + i];
-            dst[i] = accumulate ? dst[i] + s : s;
+// Deterministic tree: rows of `src` (stride `rs` floats) are summed in a fixed order.  A block is
+// 64 float4-columns x 4 row-lanes; blockIdx.y selects a group of `group` consecutive rows.  Level 1
+// (final == 0) writes each group's sum over the group's first row (only that block touches those
+// columns of those rows); level 2 sums the group heads into dst.
+__global__ __launch_bounds__(256) void rows_reduce_kernel(float* __restrict__ src, int64_t rs, int nrows, int group,
+                                                          int64_t row_step, int64_t n, float* __restrict__ dst,
+                                                          int accumulate, int final) {
+    __shared__ f32x4 red[256];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i4 = ((int64_t)blockIdx.x * 64 + c) * 4;
+    const int r0 = blockIdx.y * group, r1 = min(nrows, r0 + group);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (i4 < n) {
+        int r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            s0 += *(const f32x4*)(src + (int64_t)r * row_step * rs + i4);
+            s1 += *(const f32x4*)(src + (int64_t)(r + 4) * row_step * rs + i4);
+        }
+        if (r < r1) s0 += *(const f32x4*)(src + (int64_t)r * row_step * rs + i4);
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && i4 < n) {
+        f32x4 t = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+        if (final) {
+            if (accumulate) t += *(const f32x4*)(dst + i4);
+            *(f32x4*)(dst + i4) = t;
+        } else {
+            *(f32x4*)(src + (int64_t)r0 * row_step * rs + i4) = t;
         }
     }
 }
 
-int slab_reduce(const float* slab, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st) {
+// dst[i] (+)= sum_s slab[s*n + i]; n must be a multiple of 4 (callers pad); the slab is clobbered.
+int slab_reduce(const float* slab_c, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st) {
     if (n <= 0) return 0;
-    PMGT_CHECK(((uintptr_t)slab % 16) == 0 && ((uintptr_t)dst % 16 == 0 || n % 4 != 0), -2,
-               "slab_reduce: unaligned buffers");
-    const int64_t blocks = cdiv64(cdiv64(n, 4), 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, splits, n, dst, accumulate ? 1 : 0);
+    float* slab = const_cast<float*>(slab_c);
+    PMGT_CHECK(n % 4 == 0, -2, "slab_reduce: n=%lld must be a multiple of 4", (long long)n);
+    PMGT_CHECK(((uintptr_t)slab % 16) == 0 && ((uintptr_t)dst % 16) == 0, -2, "slab_reduce: unaligned buffers");
+    const unsigned cb = (unsigned)cdiv64(n / 4, 64);
+    const int G = 32;
+    if (splits <= G) {
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3(cb, 1), dim3(256), 0, st, slab, n, splits, splits, (int64_t)1, n, dst,
+                           accumulate ? 1 : 0, 1);
+    } else {
+        const int groups = cdiv(splits, G);
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3(cb, groups), dim3(256), 0, st, slab, n, splits, G, (int64_t)1, n, dst, 0, 0);
+        PMGT_LAUNCH_OK();
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3(cb, 1), dim3(256), 0, st, slab, n, groups, groups, (int64_t)G, n, dst,
+                           accumulate ? 1 : 0, 1);
+    }
     PMGT_LAUNCH_OK();
     return 0;
 }
 
-template <typename T>
+// Column sums: a block owns 256 rows x (CC chunk-columns of 16 bytes); thread = (chunk, row lane).
+template <typename T, int CC>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, int64_t ldy, int M, int N,
                                                      float* __restrict__ slab, const int* m_dev) {
+    constexpr int EPC = 16 / sizeof(T), RL = 256 / CC;
+    __shared__ float red[256 * EPC];
     const int Mlim = m_dev ? min(M, *m_dev) : M;
-    const int c4 = (blockIdx.y * 256 + threadIdx.x) * 4;
-    if (c4 >= N) return;
+    const int cc = threadIdx.x % CC, rl = threadIdx.x / CC;
+    const int col = (blockIdx.y * CC + cc) * EPC;
     const int mb = blockIdx.x * 256, me = min(Mlim, mb + 256);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int m = mb; m < me; ++m) s += load4<T>(Y + (int64_t)m * ldy + c4);
-    *(f32x4*)(slab + (int64_t)blockIdx.x * N + c4) = s;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    if (col < N) {
+        for (int m = mb + rl; m < me; m += RL) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 v = *(const bf16x8*)(Y + (int64_t)m * ldy + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            } else {
+                f32x4 v = *(const f32x4*)(Y + (int64_t)m * ldy + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[threadIdx.x * EPC + e] = acc[e];
+    __syncthreads();
+    if (rl == 0 && col < N) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float t = 0.f;
+            for (int k = 0; k < RL; ++k) t += red[(k * CC + cc) * EPC + e];
+            slab[(int64_t)blockIdx.x * N + col + e] = t;
+        }
+    }
 }
 
 template <typename T>
 int colsum(const T* Y, int64_t ldy, int M, int N, float* slab, float* dst, bool accumulate, const int* m_dev,
            hipStream_t st) {
     if (N <= 0) return 0;
-    PMGT_CHECK(N % 4 == 0 && ldy % 4 == 0, -2, "colsum: N=%d / ld must be multiples of 4", N);
+    constexpr int EPC = 16 / sizeof(T);
+    PMGT_CHECK(N % EPC == 0 && ldy % EPC == 0 && ((uintptr_t)Y % 16) == 0, -2,
+               "colsum: N=%d / ld must be multiples of %d and Y 16-byte aligned", N, EPC);
     const int rb = std::max(1, cdiv(M, 256));
-    hipLaunchKernelGGL((colsum_kernel<T>), dim3(rb, cdiv(N, 1024)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
+    const int chunks = N / EPC;
+    if (chunks <= 32) hipLaunchKernelGGL((colsum_kernel<T, 32>), dim3(rb, cdiv(chunks, 32)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
+    else if (chunks <= 64) hipLaunchKernelGGL((colsum_kernel<T, 64>), dim3(rb, cdiv(chunks, 64)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
+    else hipLaunchKernelGGL((colsum_kernel<T, 128>), dim3(rb, cdiv(chunks, 128)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
     PMGT_LAUNCH_OK();
     return slab_reduce(slab, rb, N, dst, accumulate, st);
 }

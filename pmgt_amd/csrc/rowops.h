@@ -11,7 +11,8 @@ template <typename T>
 int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
            DropCfg out_drop, hipStream_t st);
 // dx = LN'(dy * in_mask); optional second output dx_drop = dx * out_mask (gradient of the dropout
-// that fed the residual sum).  Partial dgamma/dbeta go to `part` ([ln_bwd_parts(M)][2][d] floats).
+// that fed the residual sum).  Partials go to `part` ([ln_bwd_parts(M)][3][d] floats): dgamma, dbeta and
+// dbias = column sum of dx_drop (or dx): the bias gradient of the dense layer in front of the LayerNorm.
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
            int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st);

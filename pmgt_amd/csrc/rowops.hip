@@ -80,16 +80,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
                                                      int M, int d, DropCfg in_drop, DropCfg out_drop) {
-    __shared__ float red[2 * 1024];
+    __shared__ float red[3 * 1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = d >> 2;
     const DropKey ik = make_drop_key(in_drop), ok = make_drop_key(out_drop);
-    f32x4 gam[NCH], dgam[NCH], dbet[NCH];
+    f32x4 gam[NCH], dgam[NCH], dbet[NCH], dbia[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         gam[i] = ch < nch ? *(const f32x4*)(gamma + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        dgam[i] = dbet[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dgam[i] = dbet[i] = dbia[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int it = 0; it < 16; ++it) {
         const int m = blockIdx.x * 64 + it * 4 + wave;
@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     }
                     store4<T>(dx_drop + (int64_t)m * d + 4 * ch, o);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dbia[i][e] += to_f<T>(from_f<T>(o[e]));   // column sum of what the GEMMs will read
             }
         }
     }
@@ -141,17 +143,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + 64 * i;
                 if (ch < nch) {
-                    f32x4 a = dgam[i], b = dbet[i];
-                    if (w > 0) { a += *(f32x4*)(red + 4 * ch); b += *(f32x4*)(red + d + 4 * ch); }
+                    f32x4 a = dgam[i], b = dbet[i], c = dbia[i];
+                    if (w > 0) { a += *(f32x4*)(red + 4 * ch); b += *(f32x4*)(red + d + 4 * ch); c += *(f32x4*)(red + 2 * d + 4 * ch); }
                     *(f32x4*)(red + 4 * ch) = a;
                     *(f32x4*)(red + d + 4 * ch) = b;
+                    *(f32x4*)(red + 2 * d + 4 * ch) = c;
                 }
             }
         }
         __syncthreads();
     }
-    float* out = part + (int64_t)blockIdx.x * 2 * d;
-    for (int i = threadIdx.x; i < 2 * d; i += 256) out[i] = red[i];
+    float* out = part + (int64_t)blockIdx.x * 3 * d;
+    for (int i = threadIdx.x; i < 3 * d; i += 256) out[i] = red[i];
 }
 
 template <typename T>

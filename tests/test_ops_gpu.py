@@ -162,13 +162,14 @@ def test_layernorm_fwd_bwd(dt, M, d):
     assert rel_err(y, ref.detach()) < tol(dt)
     ref.backward(rounded(dy, tdt))
     dx = torch.empty(M, d, device="cuda", dtype=tdt)
-    part = torch.empty(((M + 63) // 64) * 2 * d, device="cuda")
-    dgb = torch.empty(2 * d, device="cuda")
+    part = torch.empty(((M + 63) // 64) * 3 * d, device="cuda")
+    dgb = torch.empty(3 * d, device="cuda")
     _lib.check(L.pmgt_op_layernorm_bwd(code, P(dyd), P(xd), P(stats), P(gd), P(dx), None, P(part), P(dgb), M, d, 0.0, 0, 0.0, 0,
                                        None, stream()))
     assert rel_err(dx, xr.grad) < tol(dt)
     assert rel_err(dgb[:d], gr.grad) < 1e-4
-    assert rel_err(dgb[d:], br.grad) < 1e-4
+    assert rel_err(dgb[d:2 * d], br.grad) < 1e-4
+    assert rel_err(dgb[2 * d:], dx.double().sum(0)) < 1e-4       # bias gradient of the dense layer in front
 
 
 def test_dropout_masks_consistent_and_calibrated():
@@ -196,11 +197,12 @@ def test_dropout_masks_consistent_and_calibrated():
     _lib.check(L.pmgt_op_layernorm_fwd(0, P(x), P(y), P(stats), P(gam), P(bet), M, d, 1e-12, p, 77, P(rng), stream()))
     assert bool(((y != 0) == keep).all())
     dx, dxd = torch.empty_like(x), torch.empty_like(x)
-    part = torch.empty(((M + 63) // 64) * 2 * d, device="cuda")
-    dgb = torch.empty(2 * d, device="cuda")
+    part = torch.empty(((M + 63) // 64) * 3 * d, device="cuda")
+    dgb = torch.empty(3 * d, device="cuda")
     _lib.check(L.pmgt_op_layernorm_bwd(0, P(dy), P(x), P(stats), P(gam), P(dx), P(dxd), P(part), P(dgb), M, d, 0.0, 0, p, 77,
                                        P(rng), stream()))
     assert torch.allclose(dxd, dx * keep / (1 - p), rtol=1e-5, atol=1e-7)
+    assert rel_err(dgb[2 * d:], dxd.double().sum(0)) < 1e-4
     # a different step gives a different mask
     rng2 = torch.tensor([1234, 6], dtype=torch.int64, device="cuda")
     out2 = torch.empty_like(out)
@@ -283,3 +285,39 @@ def test_attention_dropout_forward_backward_consistent():
     assert rel_err(dx[..., 2 * d:3 * d], dv_ref) < 1e-5
     zero_frac = float((probs == 0).float().mean())
     assert 0.01 < zero_frac < 0.1        # both branches dropped together: ~p^2
+
+
+@pytest.mark.parametrize("S,H,dh", [(32, 4, 32), (48, 2, 64), (64, 2, 32)])
+def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
+    """bf16 MFMA attention: (a) with dropout on, forward output and dV are consistent with the reported
+    (dropped) probabilities, i.e. backward regenerates the forward masks; (b) it agrees with the generic
+    VALU kernel on the same bf16 inputs."""
+    _lib, L = _setup()
+    T, beta, p = 5, 0.5, 0.2
+    d = H * dh
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(T, S, 4 * d, generator=g).cuda().bfloat16()
+    dctx = torch.randn(T, S, d, generator=g).cuda().bfloat16()
+    mask = torch.ones(T, S)
+    mask[1, S // 2:] = 0
+    mask = mask.cuda()
+    rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+    outs = {}
+    for force in (0, 1):
+        L.pmgt_debug_force_valu_attention(force)
+        ctx = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
+        probs = torch.empty(T, H, S, S, device="cuda")
+        dx = torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pmgt_op_attention_fwd(1, P(x), P(mask), P(ctx), P(probs), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+        _lib.check(L.pmgt_op_attention_bwd(1, P(x), P(mask), P(dctx), P(dx), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+        outs[force] = (ctx.float(), probs, dx.float())
+    L.pmgt_debug_force_valu_attention(0)
+    ctx, probs, dx = outs[0]
+    v = x.float()[..., 2 * d:3 * d].view(T, S, H, dh).permute(0, 2, 1, 3)
+    do = dctx.float().view(T, S, H, dh).permute(0, 2, 1, 3)
+    assert rel_err(ctx, (probs @ v).permute(0, 2, 1, 3).reshape(T, S, d)) < 2e-2
+    assert rel_err(dx[..., 2 * d:3 * d], (probs.transpose(-1, -2) @ do).permute(0, 2, 1, 3).reshape(T, S, d)) < 2e-2
+    assert rel_err(probs, outs[1][1]) < 2e-2          # same masks, same probabilities
+    assert ((probs == 0) == (outs[1][1] == 0)).float().mean() > 0.999
+    assert rel_err(ctx, outs[1][0]) < 3e-2
+    assert rel_err(dx, outs[1][2]) < 4e-2
