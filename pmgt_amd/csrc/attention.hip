@@ -157,9 +157,10 @@ __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
 #pragma unroll
         for (int e = 0; e < DH; ++e) o[e] = 0.f;
         const uint64_t pbase = (((uint64_t)t * H + h) * S + li) * S;
+        const uint32_t prow = (uint32_t)(((uint64_t)t * H + h) * S + li);
         for (int j = 0; j < S; ++j) {
             float p1 = sc1[j * (GS + 1) + li] * w1, p2 = sc2[j * (GS + 1) + li] * w2;
-            if (k1.on) { p1 *= drop_mul(k1, pbase + j); p2 *= drop_mul(k2, pbase + j); }
+            if (k1.on) { p1 *= drop_mul1(k1, prow, (uint32_t)j); p2 *= drop_mul1(k2, prow, (uint32_t)j); }
             const float p = p1 + p2;
             if (a.probs) a.probs[pbase + j] = p;
             axpy_row<T, DH>(o, p, sV + j * RS);
@@ -267,7 +268,7 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
         for (int e = 0; e < DH; ++e) dv[e] = 0.f;
         for (int i = 0; i < S; ++i) {
             float p1 = beta * A1[j * (GS + 1) + i], p2 = omb * A2[j * (GS + 1) + i];
-            if (k1.on) { p1 *= drop_mul(k1, (hbase + i) * S + j); p2 *= drop_mul(k2, (hbase + i) * S + j); }
+            if (k1.on) { p1 *= drop_mul1(k1, (uint32_t)(hbase + i), (uint32_t)j); p2 *= drop_mul1(k2, (uint32_t)(hbase + i), (uint32_t)j); }
             axpy_row<T, DH>(dv, p1 + p2, sO + i * RS);
         }
         store_row<T, DH>(DX + (int64_t)j * 4 * d + 2 * d, dv);
@@ -286,7 +287,7 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
         for (int j = 0; j < S; ++j) {
             const float dp = dot_row<T, DH>(doi, sV + j * RS);
             float g1 = beta * dp, g2 = omb * dp;
-            if (k1.on) { g1 *= drop_mul(k1, (hbase + i) * S + j); g2 *= drop_mul(k2, (hbase + i) * S + j); }
+            if (k1.on) { g1 *= drop_mul1(k1, (uint32_t)(hbase + i), (uint32_t)j); g2 *= drop_mul1(k2, (uint32_t)(hbase + i), (uint32_t)j); }
             rd1 = fmaf(A1[j * (GS + 1) + i], g1, rd1);
             rd2 = fmaf(A2[j * (GS + 1) + i], g2, rd2);
         }
@@ -296,7 +297,7 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
         for (int j = 0; j < S; ++j) {
             const float dp = dot_row<T, DH>(doi, sV + j * RS);
             float g1 = beta * dp, g2 = omb * dp;
-            if (k1.on) { g1 *= drop_mul(k1, (hbase + i) * S + j); g2 *= drop_mul(k2, (hbase + i) * S + j); }
+            if (k1.on) { g1 *= drop_mul1(k1, (uint32_t)(hbase + i), (uint32_t)j); g2 *= drop_mul1(k2, (uint32_t)(hbase + i), (uint32_t)j); }
             const float ds1 = A1[j * (GS + 1) + i] * (g1 - rd1);
             const float ds2 = A2[j * (GS + 1) + i] * (g2 - rd2);
             A1[j * (GS + 1) + i] = ds1;

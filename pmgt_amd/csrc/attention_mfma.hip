@@ -202,20 +202,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     for (int it = 0; it < NT; ++it) {
         const int i = 16 * it + r;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            if (k1.on) {
+                drop_mul4(k1, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d1);
+                drop_mul4(k2, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d2);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 16 * jt + 4 * q + e;
-                float p1 = beta * a1[jt][it][e], p2 = omb * a2[jt][it][e];
-                if (k1.on) {
-                    const uint64_t idx = (hbase + i) * S + j;
-                    p1 *= drop_mul(k1, idx);
-                    p2 *= drop_mul(k2, idx);
-                }
-                const float p = p1 + p2;
+                const float p = beta * d1[e] * a1[jt][it][e] + omb * d2[e] * a2[jt][it][e];
                 a1[jt][it][e] = p;
                 if (a.probs && i < Sv && j < Sv) a.probs[(hbase + i) * S + j] = p;
             }
+        }
     }
     // O^T[c][i] = sum_j V[j][c] P[i][j]
 #pragma unroll
@@ -336,16 +336,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         float rd1 = 0.f, rd2 = 0.f;
         f32x4 g1[NT], g2[NT], pm[NT];
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            if (k1.on) {
+                drop_mul4(k1, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d1);
+                drop_mul4(k2, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d2);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int j = 16 * jt + 4 * q + e;
-                float m1 = beta, m2 = omb;
-                if (k1.on) {
-                    const uint64_t idx = (hbase + i) * S + j;
-                    m1 *= drop_mul(k1, idx);
-                    m2 *= drop_mul(k2, idx);
-                }
+                const float m1 = beta * d1[e], m2 = omb * d2[e];
                 const float x1 = m1 * dp[jt][it][e], x2 = m2 * dp[jt][it][e];
                 g1[jt][e] = x1;
                 g2[jt][e] = x2;
@@ -353,6 +352,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 rd1 = fmaf(a1[jt][it][e], x1, rd1);
                 rd2 = fmaf(a2[jt][it][e], x2, rd2);
             }
+        }
         rd1 = red_q<NT>(rd1, false);
         rd2 = red_q<NT>(rd2, false);
 #pragma unroll

@@ -123,10 +123,23 @@ __device__ __forceinline__ DropKey make_drop_key(const DropCfg& c) {
     }
     return k;
 }
-__device__ __forceinline__ float drop_mul(const DropKey& k, uint64_t idx) {
-    uint32_t x = fmix32(((uint32_t)idx ^ k.k0) * 0x9E3779B1u + (uint32_t)(idx >> 32));
-    x = fmix32(x + k.k1);
-    return x >= k.thr ? k.scale : 0.f;
+// One hash pair decides 4 neighbouring elements (row, columns 4*cg .. 4*cg+3) with 16 bits each, so a
+// kept/dropped decision costs ~4 integer ops per element instead of ~14.  Every kernel that touches a
+// dropout site (forward epilogue, backward regeneration) indexes it by the same (row, column).
+__device__ __forceinline__ void drop_mul4(const DropKey& k, uint32_t row, uint32_t cg, float (&m)[4]) {
+    const uint32_t x = fmix32((row * 0x9E3779B1u) ^ (cg * 0x85EBCA77u) ^ k.k0);
+    const uint32_t y = fmix32(x + k.k1);
+    const uint32_t t = k.thr >> 16;
+    m[0] = (x & 0xFFFFu) >= t ? k.scale : 0.f;
+    m[1] = (x >> 16) >= t ? k.scale : 0.f;
+    m[2] = (y & 0xFFFFu) >= t ? k.scale : 0.f;
+    m[3] = (y >> 16) >= t ? k.scale : 0.f;
+}
+__device__ __forceinline__ float drop_mul1(const DropKey& k, uint32_t row, uint32_t col) {
+    float m[4];
+    drop_mul4(k, row, col >> 2, m);
+    const uint32_t e = col & 3u;
+    return e == 0 ? m[0] : (e == 1 ? m[1] : (e == 2 ? m[2] : m[3]));
 }
 enum DropSite { SITE_EMB = 0, SITE_A1 = 1, SITE_A2 = 2, SITE_AO = 3, SITE_FO = 4, SITE_NFR1 = 5, SITE_NFR2 = 6 };
 __host__ __device__ inline uint32_t site_id(int layer, int kind) { return (uint32_t)(layer + 1) * 8u + (uint32_t)kind; }

@@ -270,6 +270,7 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     part = std::max(part, colsum_slab_elems((int)M, std::max(std::max(I, 4 * d), 2 * d)));
     part = std::max(part, colsum_slab_elems(Tseq, S * d));
     part = std::max(part, colsum_slab_elems(cap, F));
+    part = std::max(part, (int64_t)512 * std::max(std::max(I, 4 * d), F));     // wgrad bias slabs [splits <= 512][N1]
     b.part = c.get<float>(part);
     b.possum = c.get<float>((int64_t)S * d);
     b.sse_part = c.get<float>((int64_t)nfr_diff_parts(cap) * 2);
@@ -401,13 +402,16 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
 // wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs
 template <typename T>
 static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
-                 int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t st) {
+                 int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t st,
+                 float* bias_dst = nullptr) {
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
     g.slab = b.slab; g.m_dev = m_dev;
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
+    g.bias_slab = bias_dst ? b.part : nullptr;          // [splits][N1] (fits: part >= 64 * max N1)
     RUNP(name, gemm_tn<T>(g, st));
     RUNP("bwd.slab_reduce", slab_reduce(b.slab, g.splits, (int64_t)N1 * N2, dst, acc, st));
+    if (bias_dst) RUNP("bwd.slab_reduce", slab_reduce(b.part, g.splits, N1, bias_dst, acc, st));
     return 0;
 }
 
@@ -437,8 +441,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             g.M = M; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = lb.ff_pre; g.ldaux = I;
             RUNP("bwd.dgrad_ffn2", gemm_nt<T>(g, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st));
-        RUNP("bwd.colsum", colsum<T>(b.big, I, M, I, b.part, G + o.b1, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st, G + o.b1));
         {   // du = dff W1 + residual branch
             GemmNT g;
             g.A = b.big; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = b.bD; g.ldc = d;
@@ -464,8 +467,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.dctx = b.bD; a.dqkvc = b.big;
             RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st));
-        RUNP("bwd.colsum", colsum<T>(b.big, 4 * d, M, 4 * d, b.part, G + o.bqkvc, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc));
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + o.mWqkvcT; g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
@@ -483,9 +485,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
         RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
         RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-        RUNP("bwd.colsum", colsum<T>(b.big, 2 * d, M, 2 * d, b.part, G + e->bvt, acc, nullptr, st));
-        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, (const T*)t->table_v, e->Fv, b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st));
-        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, (const T*)t->table_t, e->Ft, b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st));
+        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, (const T*)t->table_v, e->Fv, b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
+        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, (const T*)t->table_t, e->Ft, b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
     }
     return 0;
 }
@@ -551,8 +552,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     if (o->nfr_count && train) PMGT_HIP(hipMemcpyAsync(o->nfr_count, b.nfr_count, 4, hipMemcpyDeviceToDevice, st));
     if (bwd) {
         const int msp = std::max(256, cap / 5);
-        RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hL, d, b.nfr_rows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st));
-        RUNP("bwd.colsum", colsum<T>(b.pred, F, cap, F, b.part, t->grads + e->bn, acc, b.nfr_count, st));
+        RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hL, d, b.nfr_rows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st, t->grads + e->bn));
         GemmNT g;
         g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.C = b.dq; g.ldc = d; g.M = cap; g.N = d; g.K = F;
         g.m_dev = b.nfr_count;

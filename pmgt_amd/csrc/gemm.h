@@ -31,6 +31,7 @@ struct GemmTN {
     const int64_t* q_rows = nullptr;            // optional row gather on Q
     int M = 0, N1 = 0, N2 = 0;
     float* slab = nullptr;                      // [splits][N1][N2] fp32 workspace
+    float* bias_slab = nullptr;                 // optional [splits][N1]: column sums of P (bias gradient)
     int splits = 1;
     const int* m_dev = nullptr;
 };
@@ -38,7 +39,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st);
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm);
 template <typename T> int gemm_tn_bkm();
 
-// dst[i] (+)= sum_s slab[s*n + i]
+// dst[i] (+)= sum_s slab[s*n + i]   (n % 4 == 0; the slab is used as scratch and clobbered)
 int slab_reduce(const float* slab, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st);
 
 // Column sums of Y[M,N] (bias gradients): dst[n] (+)= sum_m Y[m,n]; needs slab of cdiv(M,256)*N floats.

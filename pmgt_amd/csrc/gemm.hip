@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
                             for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(pre[e]);
                         }
                         if (dk.on) {
+                            float dm[4];
+                            drop_mul4(dk, (uint32_t)m, (uint32_t)n >> 2, dm);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= drop_mul(dk, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n + e));
+                            for (int e = 0; e < 4; ++e) v[e] *= dm[e];
                         }
                         if (R) v += load4<T>(R + (int64_t)m * g.ldr + n);
                         store4<T>(C + (int64_t)m * g.ldc + n, v);
@@ -239,7 +241,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
     char* sP = smem;
     char* sQ = smem + 2 * TILEB;
 
-    const int n1_0 = blockIdx.x * 128, n2_0 = blockIdx.y * 128, split = blockIdx.z;
+    // 1-D grid: ids b and b + 8 share an XCD (and its L2).  All tiles of one row-chunk ("split") are
+    // placed on one XCD so the chunk's P and Q rows are fetched from HBM once and re-read from L2.
+    const int tn1 = (g.N1 + 127) / 128, tn2 = (g.N2 + 127) / 128, tiles = tn1 * tn2;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = idx % tiles, split = xcd + 8 * (idx / tiles);
+    if (split >= g.splits) return;
+    const int n1_0 = (tile / tn2) * 128, n2_0 = (tile % tn2) * 128;
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
 
@@ -252,6 +260,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // column sums of P (= bias gradient of the layer) ride along as one extra MFMA per tile against an
+    // all-ones B operand, in the blocks of the first N2 tile
+    const bool do_bias = g.bias_slab != nullptr && n2_0 == 0 && wn == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     u32x4 rp[LPT], rq[LPT];
     auto gload = [&](int mb) {
@@ -326,6 +341,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+                    const bf16 one = (bf16)1.f;
+                    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -341,12 +362,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], 1.f, accb[i], 0, 0, 0);
+                }
             }
         }
         if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
 
+    if (do_bias && r == 0) {        // every column of accb holds the same sums; lane column 0 writes
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
+                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + n1] = accb[i][e];
+            }
+    }
     float* out = g.slab + (int64_t)split * g.N1 * g.N2;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -364,9 +398,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
-    int splits = cdiv(256, tiles);                       // ~1 workgroup per CU: slab traffic = splits * N1 * N2 * 4 B
+    int splits = cdiv(512, tiles);                       // ~2 workgroups per CU; slab traffic = splits * N1 * N2 * 4 B
     const int max_by_rows = std::max(1, M / (4 * bkm));  // at least 4 K-steps per split
     splits = std::max(1, std::min(splits, max_by_rows));
+    if (splits > 8) splits = splits / 8 * 8;             // whole XCD groups (see the block mapping in the kernel)
     return splits;
 }
 
@@ -379,7 +414,8 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     PMGT_CHECK(g.splits >= 1 && g.slab, -2, "gemm_tn: bad splits/slab");
     const int bkm = gemm_tn_bkm<T>();
     int chunk = cdiv(cdiv(std::max(g.M, 1), g.splits), bkm) * bkm;
-    dim3 grid(cdiv(g.N1, 128), cdiv(g.N2, 128), g.splits);
+    const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);
+    dim3 grid(8 * tiles * cdiv(g.splits, 8));
     hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), 0, st, g, chunk);
     PMGT_LAUNCH_OK();
     return 0;

@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
             f32x4 g = *(const f32x4*)(gamma + 4 * ch), b = *(const f32x4*)(beta + 4 * ch);
             f32x4 o = (v[i] - mean) * rstd * g + b;
             if (dk.on) {
+{ float dm[4]; drop_mul4(dk, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] *= drop_mul(dk, (uint64_t)m * d + 4 * ch + e);
+                    for (int e = 0; e < 4; ++e) o[e] *= dm[e]; }
             }
             store4<T>(y + (int64_t)m * d + 4 * ch, o);
         }
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (ch < nch) {
                 f32x4 dyv = load4<T>(dy + (int64_t)m * d + 4 * ch);
                 if (ik.on) {
+{ float dm[4]; drop_mul4(ik, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dyv[e] *= drop_mul(ik, (uint64_t)m * d + 4 * ch + e);
+                    for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
                 }
                 xh[i] = (load4<T>(x + (int64_t)m * d + 4 * ch) - mean) * rstd;
                 g[i] = dyv * gam[i];
@@ -126,8 +128,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 store4<T>(dx + (int64_t)m * d + 4 * ch, o);
                 if (dx_drop) {
                     if (ok.on) {
+{ float dm[4]; drop_mul4(ok, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] *= drop_mul(ok, (uint64_t)m * d + 4 * ch + e);
+                    for (int e = 0; e < 4; ++e) o[e] *= dm[e]; }
                     }
                     store4<T>(dx_drop + (int64_t)m * d + 4 * ch, o);
                 }
@@ -240,8 +243,9 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
         if (ch < nch) {
             f32x4 o = (x[i] - mean) * rstd * *(const f32x4*)(p.gamma + 4 * ch) + *(const f32x4*)(p.beta + 4 * ch);
             if (dk.on) {
+{ float dm[4]; drop_mul4(dk, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] *= drop_mul(dk, (uint64_t)m * d + 4 * ch + e);
+                    for (int e = 0; e < 4; ++e) o[e] *= dm[e]; }
             }
             store4<T>((T*)p.h0 + (int64_t)m * d + 4 * ch, o);
         }
@@ -298,8 +302,9 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
             if (ch < nch) {
                 f32x4 dyv = load4<T>((const T*)p.dh0 + (int64_t)m * d + 4 * ch);
                 if (ik.on) {
+{ float dm[4]; drop_mul4(ik, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dyv[e] *= drop_mul(ik, (uint64_t)m * d + 4 * ch + e);
+                    for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
                 }
                 xh[i] = (load4<T>((const T*)p.pre + (int64_t)m * d + 4 * ch) - mean) * rstd;
                 g[i] = dyv * gam[i];
