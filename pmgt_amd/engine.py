@@ -83,8 +83,13 @@ class Engine:
             pass
 
     # ---- parameters -------------------------------------------------------------------------
+    def entry(self, name: str) -> dict:
+        if not hasattr(self, "_by_name"):
+            self._by_name = {e["name"]: e for e in self.entries}
+        return self._by_name[name]
+
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
-        e = next(x for x in self.entries if x["name"] == name)
+        e = self.entry(name)
         buf = self.grads if grad else self.params
         return buf[e["offset"]: e["offset"] + e["numel"]].view(*e["shape"])
 
@@ -111,8 +116,9 @@ class Engine:
         _lib.check(self.lib.pmgt_cast_from_f32(self.dtype_code, _ptr(x), _ptr(out), x.numel(), _stream()))
         return out
 
-    def _tensors(self):
-        return _lib.TensorsC(self.params.data_ptr(), self.grads.data_ptr(),
+    def _tensors(self, grad_buffer: Optional[torch.Tensor] = None):
+        g = self.grads if grad_buffer is None else grad_buffer
+        return _lib.TensorsC(self.params.data_ptr(), g.data_ptr(),
                              0 if self.table_v is None else self.table_v.data_ptr(),
                              0 if self.table_t is None else self.table_t.data_ptr(), self.n_nodes,
                              self.rng_state.data_ptr())
@@ -126,7 +132,7 @@ class Engine:
     # ---- PMGT.forward (+ backward) ---------------------------------------------------------------
     def pretrain_step(self, batch, training: bool, backward: bool = False, accumulate: bool = False,
                       nfr_inject=None, random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16,
-                      want_hidden: bool = True):
+                      want_hidden: bool = True, grad_buffer: Optional[torch.Tensor] = None):
         """batch = (target_dict, pair_dict, num_pairs, labels) of device tensors (pmgt_collate_fn layout).
         nfr_inject = (masked_ids [B,S] int64, nfr_targets [B,S] int64 with -1 = not masked)."""
         tgt, pair, num_pairs, labels = batch
@@ -150,7 +156,7 @@ class Engine:
         oc = _lib.OutputsC(loss.data_ptr(), logits.data_ptr(), 0 if hidden is None else hidden.data_ptr(), count.data_ptr())
         flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_BACKWARD if backward else 0) | \
                 (_lib.FLAG_ACCUMULATE if accumulate else 0)
-        tc = self._tensors()
+        tc = self._tensors(grad_buffer)
         _lib.check(self.lib.pmgt_pretrain_step(self.h, C.byref(tc), C.byref(bc), C.byref(oc), _ptr(ws), ws.numel(),
                                                flags, _stream()))
         return dict(loss=loss[0], gsr=loss[1], nfr=loss[2], losses=loss, logits=logits, last_hidden_state=hidden,

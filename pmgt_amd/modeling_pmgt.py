@@ -1,0 +1,140 @@
+"""`PMGTModel` and the output containers with the reference's Python surface
+(pmgt/pmgt/modeling_pmgt.py:65-152,572-579), backed by the HIP engine instead of torch.nn ops.
+
+Parameters keep the reference's state_dict names (`embeddings.feat_linear.0.weight`,
+`encoder.layer.3.attention.self.ctx_attention.bias`, ...): every nn.Parameter is a VIEW into the
+engine's flat fp32 buffer, so checkpoints load/save with the reference keys while the kernels see one
+contiguous buffer.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .configuration_pmgt import PMGTConfig
+from .engine import Engine
+
+
+class ModelOutput(OrderedDict):
+    """Minimal restatement of transformers' ModelOutput: attribute + key access, and integer indexing /
+    `to_tuple()` over the fields that are not None (so `out[0]` is `loss` when there is one and
+    `last_hidden_state` otherwise — the behaviour pmgt/pmgt/trainer.py:154,157,166-167 relies on)."""
+
+    _fields: Tuple[str, ...] = ()
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        for f in self._fields:
+            v = kwargs.get(f)
+            object.__setattr__(self, f, v)
+            if v is not None:
+                super().__setitem__(f, v)
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return super().__getitem__(k)
+        return self.to_tuple()[k]
+
+    def to_tuple(self):
+        return tuple(self[k] for k in self.keys())
+
+
+class BaseModelOutputWithPooling(ModelOutput):
+    _fields = ("last_hidden_state", "pooler_output", "hidden_states", "attentions")
+
+
+class PMGTForPreTrainingOutput(ModelOutput):
+    """pmgt/pmgt/modeling_pmgt.py:572-579."""
+    _fields = ("loss", "prediction_logits", "last_hidden_state", "pooler_output", "hidden_states", "attentions")
+
+
+def _attach_params(root: nn.Module, engine: Engine, prefix: str):
+    """Create the nested module tree + Parameter views for every engine entry under `prefix`."""
+    for e in engine.entries:
+        name = e["name"]
+        if not name.startswith(prefix):
+            continue
+        parts = name[len(prefix):].split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        param = nn.Parameter(engine.view(name), requires_grad=True)
+        mod.register_parameter(parts[-1], param)
+
+
+class PMGTPretrainedModel(nn.Module):
+    """Init rule of the reference (pmgt/pmgt/modeling_pmgt.py:44-58): Linear/Embedding weights
+    N(0, initializer_range), biases 0, LayerNorm (1, 0)."""
+    config_class = PMGTConfig
+    base_model_prefix = "pmgt"
+
+    def _init_weights(self):
+        std = self.config.initializer_range
+        with torch.no_grad():
+            for n, p in self.named_parameters():
+                if n.endswith("LayerNorm.weight"):
+                    p.fill_(1.0)
+                elif n.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(mean=0.0, std=std)
+
+
+class PMGTModel(PMGTPretrainedModel):
+    """Encoder with the reference call signature.  `forward(*input_feat_embeds, attention_mask=...)` takes
+    already-gathered features [T, S, F_m] (the compatible, materialised-input entry); the fused
+    gather + projection path is entered through `PMGT.forward` / `encode_ids`, which see node ids."""
+
+    def __init__(self, config: PMGTConfig, add_pooling_layer: bool = False, engine: Optional[Engine] = None,
+                 dtype: str = "bf16", device: str = "cuda:0"):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError(
+                f"The hidden size ({config.hidden_size}) is not a multiple of the number of attention "
+                f"heads ({config.num_attention_heads})")
+        if add_pooling_layer:
+            raise NotImplementedError("the reference never enables the pooler on this path (modeling_pmgt.py:66,72)")
+        self.config = config
+        self.engine = engine if engine is not None else Engine(config, dtype=dtype, device=device)
+        _attach_params(self, self.engine, "bert.")      # engine names carry PMGT's `bert.` prefix
+        emb = self._modules["embeddings"]
+        emb.register_buffer("position_ids", torch.arange(config.max_position_embeddings).unsqueeze(0))
+        emb.register_buffer("role_ids", torch.LongTensor([0] + [1] * (config.max_position_embeddings - 1)).unsqueeze(0))
+        self.pooler = None
+        if engine is None:
+            self._init_weights()
+
+    def forward(self, *input_feat_embeds, attention_mask=None, head_mask=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        first = input_feat_embeds[0]
+        assert all(first.size()[:-1] == f.size()[:-1] for f in input_feat_embeds[1:]), \
+            "All features are same dim except last one"
+        assert head_mask is None, "head masks are not supported by the HIP path (the reference passes None)"
+        cfg = self.config
+        output_attentions = output_attentions if output_attentions is not None else cfg.output_attentions
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else cfg.output_hidden_states
+        return_dict = return_dict if return_dict is not None else cfg.use_return_dict
+        last, hs, pr = self.engine.encode(feats=list(input_feat_embeds), attention_mask=attention_mask,
+                                          output_hidden_states=output_hidden_states, output_attentions=output_attentions)
+        return self._wrap(last, hs, pr, return_dict)
+
+    def encode_ids(self, node_ids, attention_mask=None, output_attentions=False, output_hidden_states=False,
+                   return_dict=True):
+        """Same as forward() but on node ids: the feature gather is fused into the projection GEMM."""
+        last, hs, pr = self.engine.encode(ids=node_ids, attention_mask=attention_mask,
+                                          output_hidden_states=output_hidden_states, output_attentions=output_attentions)
+        return self._wrap(last, hs, pr, return_dict)
+
+    @staticmethod
+    def _wrap(last, hs, pr, return_dict):
+        last = last.float()
+        hidden = tuple(h.float() for h in hs) if hs is not None else None
+        attn = tuple(p for p in pr) if pr is not None else None
+        if not return_dict:      # (sequence_output, pooled_output) + encoder_outputs[1:]  (modeling_pmgt.py:144-145)
+            return (last, None) + tuple(v for v in (hidden, attn) if v is not None)
+        return BaseModelOutputWithPooling(last_hidden_state=last, pooler_output=None, hidden_states=hidden, attentions=attn)

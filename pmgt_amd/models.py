@@ -54,3 +54,130 @@ def train_flops_per_node(d, I, L, S, Fv=1536, Ft=768, pairs=10):
     proj = 2 * F * d
     nfr = 3 * 0.16 * (S - 1) * 2 * d * F
     return tok * (3 * enc + 2 * proj) + nfr
+
+
+# ================================================================================================
+# PMGT: the reference's pre-training module surface (pmgt/pmgt/models.py:22-176)
+# ================================================================================================
+import torch.nn as nn  # noqa: E402
+
+from .configuration_pmgt import PMGTConfig  # noqa: E402
+from .engine import Engine  # noqa: E402
+from .modeling_pmgt import PMGTForPreTrainingOutput, PMGTModel, PMGTPretrainedModel, _attach_params  # noqa: E402
+
+
+class _PretrainLoss(torch.autograd.Function):
+    """Connects the engine's fused forward+backward to autograd: the step already left d loss / d params
+    in a flat scratch buffer; backward() hands the per-parameter views (scaled by the incoming gradient)
+    to autograd so `.grad` accumulation, `loss / accum` scaling and optimizers behave as usual."""
+
+    @staticmethod
+    def forward(ctx, loss, scratch, names, engine, *params):
+        ctx.scratch, ctx.names, ctx.engine = scratch, names, engine
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.scratch.mul_(grad_out)
+        eng = ctx.engine
+        views = []
+        for n in ctx.names:
+            e = eng.entry(n)
+            views.append(ctx.scratch[e["offset"]: e["offset"] + e["numel"]].view(*e["shape"]).clone())
+        return (None, None, None, None, *views)
+
+
+class PMGT(PMGTPretrainedModel):
+    """Same constructor / forward as the reference's `PMGT`.  One call runs all B(1 + pairs + 1) sequences
+    through the HIP engine as a single batched encoder pass; in training mode the same call also runs
+    the backward (device work is fused; autograd only distributes the resulting gradients)."""
+
+    def __init__(self, node_size: int, random_node_ratio: float = 0.2 * 0.1, mask_node_ratio: float = 0.2 * 0.8,
+                 config: PMGTConfig = None, feat_init_emb=None, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0):
+        super().__init__()
+        config = config if config is not None else PMGTConfig()
+        self.node_size = node_size
+        self.random_node_ratio = random_node_ratio
+        self.mask_node_ratio = mask_node_ratio
+        self.config = config
+        self.engine = Engine(config, dtype=dtype, device=device, seed=seed)
+        self.bert = PMGTModel(config, engine=self.engine)
+        _attach_params(self, self.engine, "nfr_loss.")          # creates self.projections.{0,1}.{weight,bias}
+        self._reroot("projections", "nfr_loss")                 # -> nfr_loss.projections.* like the reference
+        self.feat_embeddings = nn.Module()
+        for i, f in enumerate(config.feat_hidden_sizes):
+            holder = nn.Module()
+            holder.register_parameter("weight", nn.Parameter(torch.zeros(node_size + 2, f), requires_grad=False))
+            self.feat_embeddings.add_module(str(i), holder)
+        self.bert._init_weights()                               # PMGTModel.__init__ -> init_weights() (modeling_pmgt.py:74)
+        self._init_nfr_default()
+        if feat_init_emb is not None:
+            assert len(feat_init_emb) == len(config.feat_hidden_sizes)
+            self.set_features(feat_init_emb)
+
+    def _reroot(self, child: str, under: str):
+        sub = self._modules.pop(child)
+        holder = nn.Module()
+        holder.add_module(child, sub)
+        self.add_module(under, holder)
+
+    def _init_nfr_default(self):
+        """PMGT never runs _init_weights on itself: the NFR projections keep nn.Linear's default init
+        (pmgt/pmgt/models.py:31-54)."""
+        with torch.no_grad():
+            for n, p in self.nfr_loss.named_parameters():
+                bound = 1.0 / math.sqrt(self.config.hidden_size)
+                p.uniform_(-bound, bound)
+
+    def set_features(self, feat_init_emb):
+        with torch.no_grad():
+            for i, w in enumerate(feat_init_emb):
+                self.feat_embeddings._modules[str(i)].weight.copy_(torch.as_tensor(w))
+        self.engine.set_tables(self.feat_embeddings._modules["0"].weight, self.feat_embeddings._modules["1"].weight)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self.engine.set_tables(self.feat_embeddings._modules["0"].weight, self.feat_embeddings._modules["1"].weight)
+        return out
+
+    def forward(self, target_node_inputs, pair_node_inputs=None, num_pairs=None, labels=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, nfr_inject=None):
+        if pair_node_inputs is not None:
+            assert labels is not None, "labels must be passed, when set pair_node_inputs"
+            assert num_pairs is not None, "num_pairs must be passed, when set pair_node_inputs"
+        cfg = self.config
+        output_attentions = output_attentions if output_attentions is not None else cfg.output_attentions
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else cfg.output_hidden_states
+        return_dict = return_dict if return_dict is not None else cfg.use_return_dict
+        eng = self.engine
+        dev = eng.device
+        to = lambda d: {k: v.to(dev) for k, v in d.items()}
+        tgt = to(target_node_inputs)
+        hidden = attn = None
+        if output_attentions or output_hidden_states or pair_node_inputs is None:
+            enc = self.bert.encode_ids(tgt["node_ids"], tgt["attention_mask"], output_attentions, output_hidden_states)
+            hidden, attn = enc.hidden_states, enc.attentions
+            if pair_node_inputs is None:        # inference: loss is None, so out[0] is last_hidden_state
+                if not return_dict:
+                    return (None, None) + enc.to_tuple()
+                return PMGTForPreTrainingOutput(last_hidden_state=enc.last_hidden_state, hidden_states=hidden, attentions=attn)
+        batch = (tgt, to(pair_node_inputs), num_pairs.to(dev), labels.to(dev))
+        want_grad = self.training and torch.is_grad_enabled()
+        scratch = torch.empty_like(eng.params) if want_grad else None
+        out = eng.pretrain_step(batch, training=self.training, backward=want_grad, nfr_inject=nfr_inject,
+                                random_node_ratio=self.random_node_ratio, mask_node_ratio=self.mask_node_ratio,
+                                grad_buffer=scratch)
+        loss = out["loss"]
+        if want_grad:
+            names = [n for n, p in self.named_parameters() if p.requires_grad]
+            params = [p for _, p in self.named_parameters() if p.requires_grad]
+            loss = _PretrainLoss.apply(loss, scratch, [self._engine_name(n) for n in names], eng, *params)
+        last = out["last_hidden_state"].float()
+        if not return_dict:
+            return (loss, out["logits"], last, None) + tuple(v for v in (hidden, attn) if v is not None)
+        return PMGTForPreTrainingOutput(loss=loss, prediction_logits=out["logits"], last_hidden_state=last,
+                                        pooler_output=None, hidden_states=hidden, attentions=attn)
+
+    @staticmethod
+    def _engine_name(module_name: str) -> str:
+        return module_name            # module tree == engine entry names (bert.*, nfr_loss.*)

@@ -19,7 +19,8 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .datasets import MODE_TRAIN
+from .datasets import MODE_EVAL, MODE_INFERENCE, MODE_TRAIN
+from .parallel import allreduce_mean_, broadcast_
 
 
 class Trainer:
@@ -38,8 +39,7 @@ class Trainer:
     def broadcast_parameters(self, src: int = 0):
         """DDP constructor semantics: every replica starts from rank `src`'s parameters."""
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.broadcast(self.engine.params, src=src)
+            broadcast_(self.engine.params, src=src)
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         """loss = net(*batch)[0] with gradients left in engine.grads (pmgt/pmgt/trainer.py:156-160)."""
@@ -54,8 +54,7 @@ class Trainer:
         if self.accum > 1:
             eng.grads.div_(self.accum)
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(eng.grads, op=dist.ReduceOp.AVG)
+            allreduce_mean_(eng.grads)
         eng.optimizer_step(lr=self.lr, weight_decay=self.weight_decay, betas=self.betas, eps=self.eps,
                            max_grad_norm=self.max_grad_norm)
 
@@ -111,3 +110,58 @@ class Trainer:
         th.join()
         return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
                 "sampler_threads": threads, "steps": steps}
+
+
+def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:
+    """sklearn.metrics.roc_auc_score for binary labels (what `_valid_and_test_epoch_end` logs as val/auc,
+    pmgt/pmgt/trainer.py:182-195): Mann-Whitney U with midranks for ties."""
+    labels = np.asarray(labels).astype(bool)
+    scores = np.asarray(scores, dtype=np.float64)
+    n_pos, n_neg = int(labels.sum()), int((~labels).sum())
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    order = np.argsort(scores, kind="mergesort")
+    s = scores[order]
+    ranks = np.empty(len(s), dtype=np.float64)
+    i = 0
+    while i < len(s):
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[i:j + 1] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    r = np.empty_like(ranks)
+    r[order] = ranks
+    return float((r[labels].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+
+
+@torch.no_grad()
+def evaluate(engine, sampler, node_ids: np.ndarray, batch_size: int = 256, threads: int = 8, seed: int = 0):
+    """Validation pass (pmgt/pmgt/trainer.py:162-195): eval-mode forward with 1 positive + 1 negative
+    per target, sigmoid(logits) vs labels -> {'loss/val', 'val/auc'}."""
+    preds, labs, losses = [], [], []
+    for lo in range(0, len(node_ids), batch_size):
+        tg = node_ids[lo: lo + batch_size]
+        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_EVAL, threads=threads, base_seed=seed, counter=lo)
+        cu = lambda d: {k: v.to(engine.device) for k, v in d.items()}
+        out = engine.pretrain_step((cu(tgt), cu(pair), num_pairs.to(engine.device), labels.to(engine.device)),
+                                   training=False, want_hidden=False)
+        preds.append(torch.sigmoid(out["logits"]).cpu().numpy())
+        labs.append(labels.numpy())
+        losses.append(out["loss"].item() * len(tg))
+    preds, labs = np.concatenate(preds), np.concatenate(labs)
+    return {"loss/val": float(np.sum(losses) / len(node_ids)), "val/auc": roc_auc_score(labs, preds)}
+
+
+@torch.no_grad()
+def export_embeddings(engine, sampler, n_nodes: int, batch_size: int = 1024, threads: int = 8, seed: int = 0) -> np.ndarray:
+    """Inference / export (pmgt/pmgt/trainer.py:153-154,259-275; pmgt/base_trainer.py:400-407): CLS hidden
+    state of every node in id order as fp32 [N, d] (contexts are still randomly sampled, as in the reference)."""
+    out = np.empty((n_nodes, engine.config.hidden_size), dtype=np.float32)
+    ids = np.arange(2, n_nodes + 2)
+    for lo in range(0, n_nodes, batch_size):
+        tg = ids[lo: lo + batch_size]
+        tgt = sampler.batch(tg, MODE_INFERENCE, threads=threads, base_seed=seed, counter=lo)
+        last, _, _ = engine.encode(ids=tgt["node_ids"].to(engine.device), attention_mask=tgt["attention_mask"].to(engine.device))
+        out[lo: lo + len(tg)] = last[:, 0].float().cpu().numpy()
+    return out

@@ -1,0 +1,127 @@
+"""The reference's Python surface on top of the HIP engine: PMGTConfig / PMGTModel / PMGT /
+PMGTForPreTrainingOutput / get_optimizer + DenseSparseAdamW / trainer step, written the way the
+reference's own callers use them (pmgt/pmgt/trainer.py:118-160, pmgt/base_trainer.py:35-68), checked
+against the golden vectors."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pmgt_oracle as po
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def build(case, dtype="fp32"):
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.models import PMGT
+    cfg = PMGTConfig(**case["cfg"])
+    model = PMGT(node_size=case["n_nodes"], config=cfg, feat_init_emb=[t.numpy() for t in case["tables"]], dtype=dtype)
+    sd = model.state_dict()
+    for k, v in case["params"].items():
+        sd[k] = v
+    model.load_state_dict(sd)
+    return model
+
+
+def test_state_dict_keys_are_the_reference_keys():
+    case = gu.model_case("m1")
+    model = build(case)
+    want = {n for n, _ in po.param_shapes(case["cfg"])} | {"feat_embeddings.0.weight", "feat_embeddings.1.weight",
+                                                          "bert.embeddings.position_ids", "bert.embeddings.role_ids"}
+    assert set(model.state_dict().keys()) == want
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert set(trainable) == {n for n, _ in po.param_shapes(case["cfg"])}
+    assert not model.feat_embeddings._modules["0"].weight.requires_grad
+    # parameters are views of ONE flat buffer
+    lo = model.engine.params.data_ptr()
+    assert all(lo <= p.data_ptr() < lo + 4 * model.engine.n_params for n, p in model.named_parameters() if p.requires_grad)
+
+
+def test_forward_outputs_index_like_the_reference():
+    case = gu.model_case("m1")
+    gold = case["gold"]
+    model = build(case).eval()
+    batch = case["batch"]
+    out = model(*batch)                                         # eval: loss, logits, hidden
+    np.testing.assert_allclose(out[0].item(), gold["eval_loss"], rtol=1e-4)
+    np.testing.assert_allclose(out[1].cpu().numpy(), gold["eval_logits"], rtol=1e-4, atol=1e-5)
+    assert out.loss is out["loss"] and out.pooler_output is None and out.hidden_states is None
+    tup = model(*batch, return_dict=False)
+    assert tup[3] is None and torch.equal(tup[2], out.last_hidden_state)
+    inf = model(batch[0])                                       # inference: loss None -> [0] is last_hidden_state
+    assert inf.loss is None
+    np.testing.assert_allclose(inf[0][:, 0].cpu().numpy(), gold["inf_cls"], rtol=1e-4, atol=1e-4)
+    full = model(*batch, output_attentions=True, output_hidden_states=True)
+    assert len(full.hidden_states) == 3 and len(full.attentions) == 2
+    np.testing.assert_allclose(full.attentions[1].cpu().numpy(), gold["eval_attn_1"], rtol=1e-4, atol=1e-6)
+    with pytest.raises(AssertionError, match="labels must be passed"):
+        model(batch[0], batch[1])
+    # PMGTModel.forward(*input_feat_embeds): the materialised-input entry of the reference
+    feats = po.gather_feats(batch[0]["node_ids"], case["tables"])
+    enc = model.bert(*feats, attention_mask=batch[0]["attention_mask"])
+    np.testing.assert_allclose(enc[0].cpu().numpy(), gold["eval_last_hidden"], rtol=1e-4, atol=1e-4)
+    assert model.bert(*feats, return_dict=False)[1] is None
+
+
+def test_autograd_step_with_reference_optimizer_surface():
+    """loss = net(*batch)[0]; loss.backward(); clip; optimizer.step()  — the reference's training step."""
+    from pmgt_amd.optimizers import get_optimizer
+    case = gu.model_case("m1")
+    gold = case["gold"]
+    model = build(case).train()
+    args = types.SimpleNamespace(model=model, decay=1e-2, lr=1e-3, optim="adamw", gradient_max_norm=5.0)
+    opt = get_optimizer(args)
+    assert len(opt.param_groups) == 2 and opt.param_groups[1]["weight_decay"] == 0.0
+    ids = case["batch"][0]["node_ids"]
+    for s in range(len(gold["opt_losses"])):
+        masked, m2, tidx = gu.nfr_inject(gold, ids, case["n_nodes"], "opt_", f"_{s}")
+        full = torch.full_like(ids, -1)
+        full[:, 1:][m2] = tidx
+        opt.zero_grad()
+        loss = model(*case["batch"], nfr_inject=(masked.cuda(), full.cuda()))[0]
+        loss.backward()
+        assert model.bert.encoder.layer._modules["0"].attention.self.query.weight.grad is not None
+        opt.step()
+        np.testing.assert_allclose(loss.item(), gold["opt_losses"][s], rtol=2e-4)
+    for k, v in model.named_parameters():
+        if v.requires_grad:
+            gu.check_stored(gold, "final/" + k, v.detach().cpu().numpy(), 2e-3, 2e-5)
+
+
+def test_gradient_accumulation_scales_like_autograd():
+    case = gu.model_case("m4")
+    model = build(case).train()
+    ids = case["batch"][0]["node_ids"]
+    masked, m2, tidx = gu.nfr_inject(case["gold"], ids, case["n_nodes"])
+    full = torch.full_like(ids, -1)
+    full[:, 1:][m2] = tidx
+    inj = (masked.cuda(), full.cuda())
+    (model(*case["batch"], nfr_inject=inj)[0] / 2).backward()
+    (model(*case["batch"], nfr_inject=inj)[0] / 2).backward()
+    w = model.bert.embeddings.feat_linear._modules["0"].weight
+    gu.check_stored(case["gold"], "grad/bert.embeddings.feat_linear.0.weight", w.grad.cpu().numpy(), 2e-3, 1e-6)
+
+
+def test_trainer_eval_export_and_live_pipeline():
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.datasets import MCNSampler
+    from pmgt_amd.engine import Engine
+    from pmgt_amd.graph import synthetic_graph
+    from pmgt_amd.models import reference_init, synthetic_features
+    from pmgt_amd.trainer import Trainer, evaluate, export_embeddings
+    n, S = 500, 16
+    graph = synthetic_graph(n, 4000, seed=1)
+    eng = Engine(PMGTConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64), dtype="bf16")
+    reference_init(eng, 0)
+    eng.set_tables(*synthetic_features(n, seed=1))
+    smp = MCNSampler(graph, S - 1)
+    tr = Trainer(eng, lr=1e-3, max_grad_norm=5.0)
+    live = tr.run_live(smp, np.arange(2, n + 2), batch_size=32, steps=6, threads=4)
+    assert live["nodes_per_s"] > 0 and np.isfinite(tr.last_loss.item())
+    ev = evaluate(eng, smp, np.arange(2, 130), batch_size=64, threads=4)
+    assert 0.0 <= ev["val/auc"] <= 1.0 and np.isfinite(ev["loss/val"])
+    emb = export_embeddings(eng, smp, n, batch_size=256, threads=4)
+    assert emb.shape == (n, 64) and emb.dtype == np.float32 and np.isfinite(emb).all()
