@@ -156,6 +156,14 @@ int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const
 int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                           void* dx_drop, float* part, float* dgamma_dbeta, int M, int d, float in_drop_p,
                           uint32_t in_site, float out_drop_p, uint32_t out_site, const uint64_t* rng, void* stream);
+/* One linear layer through the engine's dispatcher: bf16 with K <= 256 runs the weight-stationary streaming
+ * kernel (gemm_ws.hip), everything else the tiled one; ln_out != NULL adds LayerNorm(C) (fused when N == 256). */
+int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                   const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
+                   uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
+                   const float* ln_beta, float ln_eps, void* stream);
+/* A/B switch: 1 forces the tiled GEMM kernel everywhere */
+void pmgt_debug_force_tile_gemm(int on);
 /* A/B switch: 1 routes bf16 attention through the generic fp32-VALU kernel instead of the MFMA one */
 void pmgt_debug_force_valu_attention(int on);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,

@@ -311,6 +311,28 @@ static inline DropCfg dropcfg(const pmgt_tensors* t, bool on, float p, int layer
         if (rc__ != 0) return rc__;                                                               \
     } while (0)
 
+// ---- linear layer dispatcher: weight-stationary streaming kernel when it applies (bf16, K <= 256), else the
+// tiled kernel (+ a separate LayerNorm launch when the caller asked for the fused one) -------------------
+static int g_force_tile = 0;
+
+template <typename T>
+static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (!g_force_tile && gemm_ws_supported(g)) {
+            RUNP(name, gemm_ws(g, st));
+            if (g.ln_out && !gemm_ws_fuses_ln(g))
+                RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
+                                                DropCfg{nullptr, 0.f, 0}, st));
+            return 0;
+        }
+    }
+    RUNP(name, gemm_nt<T>(g, st));
+    if (g.ln_out)
+        RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
+                                        DropCfg{nullptr, 0.f, 0}, st));
+    return 0;
+}
+
 // ---- encoder forward ---------------------------------------------------------------------------
 template <typename T>
 static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, const int64_t* ids,
@@ -350,10 +372,10 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         const LayerOff& o = e->layers[l];
         LayerBufs<T>& lb = b.layer[l];
         {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
-            GemmNT g;
+            GemmWS g;
             g.A = hin; g.lda = d; g.B = wsel<T>(e, t, b, o.Wqkvc, o.mWqkvc); g.ldb = d;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
-            RUNP("fwd.gemm_qkvc", gemm_nt<T>(g, st));
+            RUN(linear<T>(e, "fwd.gemm_qkvc", g, st));
         }
         {
             AttnArgs a;
@@ -365,31 +387,29 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             RUNP("fwd.attention", attn_fwd<T>(a, st));
         }
         {   // BertSelfOutput: LN(dropout(dense(ctx)) + hin)
-            GemmNT g;
+            GemmWS g;
             g.A = lb.ctx; g.lda = d; g.B = wsel<T>(e, t, b, o.Wo, o.mWo); g.ldb = d;
             g.C = lb.ao_pre; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = P + o.bo;
             g.drop = dropcfg(t, train, pd, l, SITE_AO);
             g.res = hin; g.ldr = d;
-            RUNP("fwd.gemm_attn_out", gemm_nt<T>(g, st));
-            RUNP("fwd.layernorm", ln_fwd<T>(lb.ao_pre, lb.u, lb.stats1, P + o.ln1g, P + o.ln1b, M, d, e->cfg.layer_norm_eps,
-                          DropCfg{nullptr, 0.f, 0}, st));
+            g.ln_out = lb.u; g.ln_stats = lb.stats1; g.ln_gamma = P + o.ln1g; g.ln_beta = P + o.ln1b; g.ln_eps = e->cfg.layer_norm_eps;
+            RUN(linear<T>(e, "fwd.gemm_attn_out", g, st));
         }
         {   // BertIntermediate: gelu(dense(u))
-            GemmNT g;
+            GemmWS g;
             g.A = lb.u; g.lda = d; g.B = wsel<T>(e, t, b, o.W1, o.mW1); g.ldb = d;
             g.C = lb.g; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = P + o.b1;
             g.epi = EPI_GELU; g.aux = lb.ff_pre; g.ldaux = I;
-            RUNP("fwd.gemm_ffn1", gemm_nt<T>(g, st));
+            RUN(linear<T>(e, "fwd.gemm_ffn1", g, st));
         }
         {   // BertOutput: LN(dropout(dense(g)) + u)
-            GemmNT g;
+            GemmWS g;
             g.A = lb.g; g.lda = I; g.B = wsel<T>(e, t, b, o.W2, o.mW2); g.ldb = I;
             g.C = lb.fo_pre; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = P + o.b2;
             g.drop = dropcfg(t, train, pd, l, SITE_FO);
             g.res = lb.u; g.ldr = d;
-            RUNP("fwd.gemm_ffn2", gemm_nt<T>(g, st));
-            RUNP("fwd.layernorm", ln_fwd<T>(lb.fo_pre, lb.hout, lb.stats2, P + o.ln2g, P + o.ln2b, M, d, e->cfg.layer_norm_eps,
-                          DropCfg{nullptr, 0.f, 0}, st));
+            g.ln_out = lb.hout; g.ln_stats = lb.stats2; g.ln_gamma = P + o.ln2g; g.ln_beta = P + o.ln2b; g.ln_eps = e->cfg.layer_norm_eps;
+            RUN(linear<T>(e, "fwd.gemm_ffn2", g, st));
         }
         if (hidden_states)
             PMGT_HIP(hipMemcpyAsync(hidden_states + (int64_t)(l + 1) * M * d, lb.hout, (size_t)M * d * sizeof(T),
@@ -436,17 +456,17 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         const T* dY2 = dd ? b.bC : b.bB;
         RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, lb.g, I, nullptr, M, M, d, I, G + o.W2, acc, nullptr, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
-            GemmNT g;
+            GemmWS g;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = b.big; g.ldc = I;
             g.M = M; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = lb.ff_pre; g.ldaux = I;
-            RUNP("bwd.dgrad_ffn2", gemm_nt<T>(g, st));
+            RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
         RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st, G + o.b1));
         {   // du = dff W1 + residual branch
-            GemmNT g;
+            GemmWS g;
             g.A = b.big; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = b.bD; g.ldc = d;
             g.M = M; g.N = d; g.K = I; g.res = b.bB; g.ldr = d;
-            RUNP("bwd.dgrad_ffn1", gemm_nt<T>(g, st));
+            RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
         }
         // LN1 backward
         RUNP("bwd.layernorm", ln_bwd<T>(b.bD, lb.ao_pre, lb.stats1, P + o.ln1g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
@@ -455,9 +475,9 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         const T* dYo = dd ? b.bC : b.bB;
         RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, nullptr, M, M, d, d, G + o.Wo, acc, nullptr, st));
         {   // dctx = dYo Wo
-            GemmNT g;
+            GemmWS g;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = b.bD; g.ldc = d; g.M = M; g.N = d; g.K = d;
-            RUNP("bwd.dgrad_attn_out", gemm_nt<T>(g, st));
+            RUN(linear<T>(e, "bwd.dgrad_attn_out", g, st));
         }
         {
             AttnArgs a;
@@ -793,6 +813,23 @@ static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, i
 }
 
 void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
+void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; }
+
+int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                   const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
+                   uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
+                   const float* ln_beta, float ln_eps, void* stream) {
+    GemmWS g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux; g.res = residual; g.ldr = ldr;
+    g.drop = DropCfg{rng, rng ? drop_p : 0.f, drop_site};
+    g.ln_out = ln_out; g.ln_stats = ln_stats; g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps;
+    pmgt_engine dummy;
+    const pmgt_engine* e = &dummy;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PMGT_DTYPE_BF16) return linear<bf16>(e, "op.linear", g, st);
+    return linear<float>(e, "op.linear", g, st);
+}
 
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S, int H,
                           int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream) {

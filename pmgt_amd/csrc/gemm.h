@@ -23,6 +23,19 @@ struct GemmNT {
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
 
+// Weight-stationary streaming variant for K <= 256 in bf16 (gemm_ws.hip); optional fused LayerNorm of the
+// output row when N == 256: ln_out = LN(C) with C the (bf16-rounded) epilogue result, stats = {mean, rstd}.
+struct GemmWS : GemmNT {
+    void* ln_out = nullptr;
+    float* ln_stats = nullptr;
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    float ln_eps = 1e-12f;
+};
+bool gemm_ws_supported(const GemmWS& g);
+bool gemm_ws_fuses_ln(const GemmWS& g);     // false: the caller runs LayerNorm as its own launch
+int gemm_ws(const GemmWS& g, hipStream_t st);
+
 // Partial weight gradients: slab[s][N1,N2] = sum over the s-th chunk of rows m of P[m,n1]*Q[m,n2]
 // ("TN": the reduction index is the row).  `slab_reduce` then sums the slabs in a fixed order.
 struct GemmTN {

@@ -1,0 +1,294 @@
+// Weight-stationary streaming GEMM for the d x d layers (bf16, K <= 256, K % 32 == 0).
+//
+//   C[M, N] = epi(A[M, K] * W[N, K]^T)   with optional fused LayerNorm over the full row (N == 256)
+//
+// At K = N = 256 these GEMMs have ~130 flop/byte: far below the MFMA/HBM ridge of MI355X, so the
+// right structure is a STREAM of A, not a tiled matmul.  One 512-thread workgroup per CU keeps a
+// 256-column slab of W in registers for its whole life (wave w owns output columns 32w..32w+31 as
+// 2 x KS MFMA B-fragments = 64 VGPRs at K = 256) and loops over 64-row tiles of A:
+//   global -> registers (two tiles in flight) -> XOR-swizzled LDS tile -> ds_read_b128 A fragments
+//   shared by the 8 waves -> 64 MFMAs per wave -> fp32 staging in LDS -> row-contiguous epilogue
+//   where 32 lanes own one output row: bias, GELU / GELU', dropout, residual and (optionally) the
+//   LayerNorm of the row, all with 16-byte global accesses.
+// A is read from HBM exactly once, W once per workgroup; column slabs of one row range (N > 256) are
+// placed on the same XCD so their A re-reads hit that XCD's L2.
+#include <type_traits>
+
+#include "gemm.h"
+
+namespace pmgt {
+
+template <int KS> struct WsCfg {
+    static constexpr int K = 32 * KS;
+    static constexpr int ROWB = K * 2;                 // A tile row bytes
+    static constexpr int CPR = K / 8;                  // 16-byte chunks per row
+    static constexpr int TILEB = 64 * ROWB;
+    static constexpr int LPT = 64 * CPR / 512;         // chunks per thread per tile (K >= 64)
+    static_assert(LPT * 512 == 64 * CPR, "tile must be a whole number of chunks per thread");
+    static constexpr int ES = 256 + 4;                 // staging row stride (floats)
+    static constexpr int SMEM = 2 * TILEB + 64 * ES * 4 + 3 * 256 * 4;   // A ring + staging + bias/gamma/beta
+    static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
+};
+
+// MODE (compile time, so every load in the loop is unconditional and the compiler can count vmcnt):
+//   0 bias only | 1 bias + GELU, stores the pre-activation | 2 GELU' of a loaded pre-activation
+//   3 bias + dropout + residual | 4 = 3 + fused LayerNorm of the row
+enum { WS_PLAIN = 0, WS_GELU = 1, WS_GELU_GRAD = 2, WS_RES = 3, WS_RES_LN = 4 };
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
+    constexpr bool HAS_PF = MODE == WS_GELU_GRAD || MODE == WS_RES || MODE == WS_RES_LN;
+    using C = WsCfg<KS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    float* stage = (float*)(smem + 2 * C::TILEB);
+    float* cvec = stage + 64 * C::ES;       // [3][256]: bias, LN gamma, LN beta of this column slab (LDS, so the
+                                            // epilogue never waits on vmcnt for them)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+
+    // block -> (row-range slot x, column slab y); slabs of one x sit on one XCD (ids b, b + 8, ...)
+    const int ny = (g.N + 255) / 256;
+    const int b = blockIdx.x;
+    const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
+    const int gx = gridDim.x / ny;
+    const int nb = y * 256;
+    const int num_mt = (g.M + 63) / 64;
+
+    // ---- resident W fragments: rows n = nb + 32 wave + 16 j + r, k = 32 ks + 8 q
+    bf16x8 wf[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nb + 32 * wave + 16 * j + r;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (n < g.N) wf[j][ks] = *(const bf16x8*)((const bf16*)g.B + (int64_t)n * g.ldb + 32 * ks + 8 * q);
+            else wf[j][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    if (tid < 256) {
+        const int n = nb + tid;
+        cvec[tid] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+        cvec[256 + tid] = (g.ln_out && n < g.N) ? g.ln_gamma[n] : 0.f;
+        cvec[512 + tid] = (g.ln_out && n < g.N) ? g.ln_beta[n] : 0.f;
+    }
+
+    u32x4 ra[2][C::LPT];
+    auto gload = [&](int mt, int set) {
+#pragma unroll
+        for (int i = 0; i < C::LPT; ++i) {
+            const int idx = tid + 512 * i;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            const int m = min(mt * 64 + row, g.M - 1);
+            ra[set][i] = *(const u32x4*)((const char*)g.A + ((int64_t)m * g.lda) * 2 + ch * 16);
+        }
+    };
+    auto sstore = [&](int buf, int set) {
+#pragma unroll
+        for (int i = 0; i < C::LPT; ++i) {
+            const int idx = tid + 512 * i;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
+        }
+    };
+
+    const DropKey dk = make_drop_key(g.drop);
+    bf16* Cp = (bf16*)g.C;
+    const bf16* R = (const bf16*)g.res;
+    bf16* AUX = (bf16*)g.aux;
+    bf16* LNO = (bf16*)g.ln_out;
+    // epilogue ownership: 32 consecutive lanes = one row, 8 consecutive columns per lane
+    const int erow = tid >> 5, ecol = (tid & 31) * 8;
+    const bf16* PF = (MODE == WS_GELU_GRAD) ? (const bf16*)AUX : R;      // prefetched epilogue operand
+    const int64_t ldpf = (MODE == WS_GELU_GRAD) ? g.ldaux : g.ldr;
+
+    // One tile: register set / LDS buffer index P is a compile-time constant (the loop below is unrolled by
+    // two), so the two prefetch register sets never get copied into each other and the compiler can leave the
+    // younger tile's loads in flight (counted vmcnt) while this tile is consumed.
+    auto tile_step = [&](auto Pc, int mt) {
+        constexpr int P = decltype(Pc)::value;
+        // epilogue operand (residual, or the saved pre-activation for GELU') of this tile: issued first so it
+        // is OLDER than the A prefetch below; the epilogue can then wait for it with a counted vmcnt and leave
+        // the prefetch in flight.
+        bf16x8 pf[4];
+        if constexpr (HAS_PF) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {      // clamped, unconditional loads (values of padding rows are unused)
+                const int m = min(mt * 64 + erow + 16 * ps, g.M - 1), n = min(nb + ecol, g.N - 8);
+                pf[ps] = *(const bf16x8*)(PF + (int64_t)m * ldpf + n);
+            }
+        }
+        sstore(P, P);
+        if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
+        __syncthreads();
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+        const char* a_base = sA + P * C::TILEB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * i + r;
+                fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], wf[0][ks], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], wf[1][ks], acc[i][1], 0, 0, 0);
+            }
+        }
+        // ---- stage the 64 x 256 fp32 tile (row = 16 i + 4 q + e, col = 32 wave + 16 j + r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    stage[(16 * i + 4 * q + e) * C::ES + 32 * wave + 16 * j + r] = acc[i][j][e];
+        __syncthreads();
+        // ---- row-contiguous epilogue: 16 rows per pass, 4 passes
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = erow + 16 * ps;
+            const int m = mt * 64 + row;
+            const int n = nb + ecol;
+            const bool ok = m < g.M && n < g.N;
+            float v[8];
+            if (ok) {
+                const f32x4 s0 = *(const f32x4*)(stage + row * C::ES + ecol), s1 = *(const f32x4*)(stage + row * C::ES + ecol + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
+                {
+                    const f32x4 b0 = *(const f32x4*)(cvec + ecol), b1 = *(const f32x4*)(cvec + ecol + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if constexpr (MODE == WS_GELU) {
+                    bf16x8 pre;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_erf((float)pre[e]); }
+                    *(bf16x8*)(AUX + (int64_t)m * g.ldaux + n) = pre;
+                } else if constexpr (MODE == WS_GELU_GRAD) {
+                    const bf16x8 pre = pf[ps];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)pre[e]);
+                }
+                if ((MODE == WS_RES || MODE == WS_RES_LN) && dk.on) {
+                    float d0[4], d1[4];
+                    drop_mul4(dk, (uint32_t)m, (uint32_t)n >> 2, d0);
+                    drop_mul4(dk, (uint32_t)m, ((uint32_t)n >> 2) + 1, d1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+                }
+                if constexpr (MODE == WS_RES || MODE == WS_RES_LN) {
+                    const bf16x8 rv = pf[ps];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
+                *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            if constexpr (MODE == WS_RES_LN) {      // fused LayerNorm over the row (host guarantees N == 256: 32 lanes x 8 columns)
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+                for (int o2 = 16; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2, 64);
+                const float mean = s * (1.f / 256.f);
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
+#pragma unroll
+                for (int o2 = 16; o2 > 0; o2 >>= 1) ss += __shfl_xor(ss, o2, 64);
+                const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + g.ln_eps);
+                if (ok) {
+                    if ((tid & 31) == 0) { g.ln_stats[2 * (int64_t)m] = mean; g.ln_stats[2 * (int64_t)m + 1] = rstd; }
+                    const f32x4 g0 = *(const f32x4*)(cvec + 256 + ecol), g1 = *(const f32x4*)(cvec + 256 + ecol + 4);
+                    const f32x4 b0 = *(const f32x4*)(cvec + 512 + ecol), b1 = *(const f32x4*)(cvec + 512 + ecol + 4);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (bf16)((v[e] - mean) * rstd * g0[e] + b0[e]);
+                        o[4 + e] = (bf16)((v[4 + e] - mean) * rstd * g1[e] + b1[e]);
+                    }
+                    *(bf16x8*)(LNO + (int64_t)m * g.ldc + n) = o;
+                }
+            }
+        }
+        // the next tile's staging writes happen after its first barrier, which every wave reaches only after
+        // finishing this epilogue; its A-tile write targets the other LDS buffer.
+    };
+
+    int mt = x;
+    if (mt < num_mt) gload(mt, 0);
+    if (mt + gx < num_mt) gload(mt + gx, 1);
+    while (mt < num_mt) {
+        tile_step(std::integral_constant<int, 0>{}, mt);
+        mt += gx;
+        if (mt >= num_mt) break;
+        tile_step(std::integral_constant<int, 1>{}, mt);
+        mt += gx;
+    }
+}
+
+static int ws_mode(const GemmWS& g) {
+    const bool drop = g.drop.p > 0.f;
+    if (g.epi == EPI_NONE && !g.res && !drop) return WS_PLAIN;
+    if (g.epi == EPI_GELU && !g.res && !drop) return WS_GELU;
+    if (g.epi == EPI_GELU_GRAD && !g.res && !drop) return WS_GELU_GRAD;
+    if (g.epi == EPI_NONE && g.res) return (g.ln_out && g.N == 256) ? WS_RES_LN : WS_RES;
+    return -1;
+}
+
+bool gemm_ws_supported(const GemmWS& g) {
+    return ws_mode(g) >= 0 && g.K % 32 == 0 && g.K >= 64 && g.K <= 256 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
+           g.M >= 64 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
+           (g.aux == nullptr || g.ldaux % 8 == 0);
+}
+bool gemm_ws_fuses_ln(const GemmWS& g) { return gemm_ws_supported(g) && ws_mode(g) == WS_RES_LN; }
+
+template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st) {
+    using C = WsCfg<KS>;
+    auto kern = gemm_ws_kernel<KS, MODE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+        attr_done = true;
+    }
+    const int ny = cdiv(g.N, 256), num_mt = cdiv(g.M, 64);
+    int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, ~one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(512), C::SMEM, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+template <int KS> static int launch_mode(const GemmWS& g, hipStream_t st) {
+    switch (ws_mode(g)) {
+        case WS_PLAIN: return launch_ws<KS, WS_PLAIN>(g, st);
+        case WS_GELU: return launch_ws<KS, WS_GELU>(g, st);
+        case WS_GELU_GRAD: return launch_ws<KS, WS_GELU_GRAD>(g, st);
+        case WS_RES: return launch_ws<KS, WS_RES>(g, st);
+        default: return launch_ws<KS, WS_RES_LN>(g, st);
+    }
+}
+
+int gemm_ws(const GemmWS& g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return 0;
+    PMGT_CHECK(gemm_ws_supported(g), -2, "gemm_ws: unsupported shape/epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
+    PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0, -2, "gemm_ws: unaligned operands");
+    switch (g.K) {
+        case 64: return launch_mode<2>(g, st);
+        case 128: return launch_mode<4>(g, st);
+        default: return launch_mode<8>(g, st);
+    }
+}
+
+}  // namespace pmgt

@@ -321,3 +321,63 @@ def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
     assert ((probs == 0) == (outs[1][1] == 0)).float().mean() > 0.999
     assert rel_err(ctx, outs[1][0]) < 3e-2
     assert rel_err(dx, outs[1][2]) < 4e-2
+
+
+@pytest.mark.parametrize("M,N,K,epi,res,drop,ln", [
+    (4096, 256, 256, 0, True, 0.1, True),      # attn-out / FFN2 shape: dropout + residual + fused LayerNorm
+    (1000, 256, 256, 1, False, 0.0, False),    # FFN1: GELU + pre-activation store, ragged M
+    (777, 256, 256, 2, True, 0.0, False),      # dgrad with GELU' and residual
+    (3000, 1024, 256, 0, False, 0.0, False),   # QKVC: four column slabs
+    (640, 128, 128, 0, True, 0.0, True),       # d = 128: streaming kernel, LayerNorm unfused
+    (500, 64, 64, 1, False, 0.0, False),
+    (100, 264, 256, 0, False, 0.0, False),     # N not a multiple of the slab
+])
+def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, drop, ln):
+    """bf16 weight-stationary streaming GEMM (gemm_ws.hip) == tiled kernel (same dropout masks) == torch."""
+    _lib, L = _setup()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.2).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda().bfloat16() if res else None
+    gam = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    bet = (0.1 * torch.randn(N, generator=g)).cuda()
+    aux_in = torch.randn(M, N, generator=g).cuda().bfloat16()
+    rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
+    outs = []
+    for force in (0, 1):
+        L.pmgt_debug_force_tile_gemm(force)
+        Cd = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        aux = aux_in.clone() if epi == 2 else torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        lno = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if ln else None
+        stats = torch.zeros(M, 2, device="cuda") if ln else None
+        _lib.check(L.pmgt_op_linear(1, P(A), K, P(W), K, P(Cd), N, M, N, K, P(bias), epi, P(aux) if epi else None, N,
+                                    P(R), N, drop, 33, P(rng), P(lno), P(stats), P(gam) if ln else None, P(bet) if ln else None,
+                                    1e-12, stream()))
+        outs.append((Cd.float(), aux.float(), None if lno is None else lno.float(), stats))
+    L.pmgt_debug_force_tile_gemm(0)
+    ws, tile = outs
+    assert rel_err(ws[0], tile[0]) < 1e-2
+    if epi == 1:
+        assert rel_err(ws[1], tile[1]) < 1e-2
+    if ln:
+        assert rel_err(ws[2], tile[2]) < 2e-2
+        assert rel_err(ws[3], tile[3]) < 1e-3
+    if drop > 0:
+        assert bool(((ws[0] == 0) == (tile[0] == 0)).float().mean() > 0.999)     # identical masks
+    if drop == 0:
+        pre = A.double() @ W.double().T + bias.double()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(pre.float().bfloat16().double())
+        elif epi == 2:
+            x = aux_in.double().requires_grad_(True)
+            torch.nn.functional.gelu(x).sum().backward()
+            ref = pre * x.grad
+        else:
+            ref = pre
+        if res:
+            ref = ref + R.double()
+        assert rel_err(ws[0], ref) < 2e-2
+        if ln:
+            lref = torch.nn.functional.layer_norm(ws[0].double(), (N,), gam.double(), bet.double(), 1e-12)
+            assert rel_err(ws[2], lref) < 2e-2
