@@ -16,9 +16,14 @@ namespace pmgt {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-__device__ __forceinline__ bf16x8 ld_frag(const bf16* row_ptr, bool ok) {
-    if (ok) return *(const bf16x8*)row_ptr;
-    return (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+// Row `row` of a [S][ld] matrix, 8 elements at column `col`; rows >= S read as zero.  The load itself is
+// UNCONDITIONAL on a clamped row (a branch around a load makes the compiler wait for it at the join, which
+// turns N independent loads into N serial memory round trips); the select happens on the loaded value.
+__device__ __forceinline__ bf16x8 ld_rows(const bf16* base, int64_t ld, int row, int S, int col) {
+    const int rc = max(min(row, S - 1), 0);
+    const bf16x8 v = *(const bf16x8*)(base + (int64_t)rc * ld + col);
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return row < S ? v : z;
 }
 // A operand (16 "c" rows x 32 k) of a product whose k index is a ROW of the row-major LDS tile
 // `tile` ([rows][DH] bf16): element e of lane (r, q) is tile[krow(q, e)][c0 + r].
@@ -43,11 +48,11 @@ template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) {
 }
 
 // Recompute both normalised probability matrices (transposed, fp32, in registers).
-// fq/fk/fc: NT-form fragments of Q, K, C rows.  On return a1/a2[jt][it][e] = A[i = 16 it + r][j = 16 jt + 4 q + e]
+// fq/fk/fc: NT-form fragments of Q, K, C rows; rho[] holds the INVERSE norms 1/|c_row|, isq = 1/sqrt(dh).  On return a1/a2[jt][it][e] = A[i = 16 it + r][j = 16 jt + 4 q + e]
 // (0 where i or j is padding).
 template <int NT, int KD>
 __device__ __forceinline__ void probs_T(const bf16x8 (&fq)[NT][KD], const bf16x8 (&fk)[NT][KD], const bf16x8 (&fc)[NT][KD],
-                                        const float* rho, const float* madd, int S, int r, int q, float sq,
+                                        const float* rho, const float* madd, int S, int r, int q, float isq,
                                         f32x4 (&a1)[NT][NT], f32x4 (&a2)[NT][NT]) {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -74,8 +79,8 @@ __device__ __forceinline__ void probs_T(const bf16x8 (&fq)[NT][KD], const bf16x8
             for (int e = 0; e < 4; ++e) {
                 const int j = 16 * jt + 4 * q + e;
                 const bool ok = iv && j < S;
-                const float v1 = ok ? (1.f - a1[jt][it][e] / (rho_i * rho[j]) + (i == j ? 1.f : 0.f) + madd[j]) : -INFINITY;
-                const float v2 = ok ? (a2[jt][it][e] / sq + madd[j]) : -INFINITY;
+                const float v1 = ok ? (1.f - a1[jt][it][e] * (rho_i * rho[j]) + (i == j ? 1.f : 0.f) + madd[j]) : -INFINITY;
+                const float v2 = ok ? (a2[jt][it][e] * isq + madd[j]) : -INFINITY;
                 a1[jt][it][e] = v1;
                 a2[jt][it][e] = v2;
                 m1 = fmaxf(m1, v1);
@@ -97,7 +102,7 @@ __device__ __forceinline__ void probs_T(const bf16x8 (&fq)[NT][KD], const bf16x8
             }
         s1 = red_q<NT>(s1, false);
         s2 = red_q<NT>(s2, false);
-        const float i1 = iv ? 1.f / s1 : 0.f, i2 = iv ? 1.f / s2 : 0.f;
+        const float i1 = iv ? __frcp_rn(s1) : 0.f, i2 = iv ? __frcp_rn(s2) : 0.f;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
             a1[jt][it] *= i1;
@@ -132,18 +137,43 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16* src, int64_t l
     constexpr int CPR = DH / 8;
     for (int idx = lane; idx < rows * CPR; idx += 64) {
         const int s = idx / CPR, c = idx % CPR;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (s < S) {
-            v = *(const bf16x8*)(src + (int64_t)s * ld + c * 8);
-            if (row_scale) {
-                const float sc = row_scale[s];
+        bf16x8 v = ld_rows(src, ld, s, S, c * 8);
+        if (row_scale) {
+            const float sc = row_scale[s];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * sc);
-            }
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * sc);
         }
         *(bf16x8*)(tile + s * (DH * 2) + c * 16) = v;
     }
 }
+
+// Split form of load_tile: issue all global loads of a tile into registers first (so every load of the kernel
+// is in flight at once: ONE memory round trip per wave instead of one per tile), commit to LDS later.
+template <int DH, int ROWS> struct TileRegs {
+    static constexpr int CPR = DH / 8, N = ROWS * CPR / 64;
+    static_assert(N * 64 == ROWS * CPR, "tile must be a whole number of chunks per lane");
+    bf16x8 v[N];
+    __device__ __forceinline__ void issue(const bf16* src, int64_t ld, int S, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = lane + 64 * i, s = idx / CPR, c = idx % CPR;
+            v[i] = ld_rows(src, ld, s, S, c * 8);
+        }
+    }
+    __device__ __forceinline__ void commit(char* tile, int lane, const float* row_scale) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = lane + 64 * i, s = idx / CPR, c = idx % CPR;
+            bf16x8 x = v[i];
+            if (row_scale) {
+                const float sc = row_scale[s];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = (bf16)((float)x[e] * sc);
+            }
+            *(bf16x8*)(tile + s * (DH * 2) + c * 16) = x;
+        }
+    }
+};
 
 template <int DH, int NT> struct FwdSmem {
     static constexpr int SP = NT * 16, SP2 = (SP + 31) / 32 * 32;
@@ -169,7 +199,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     const int64_t ld = 4 * d;
     const int Sv = act ? S : 0;
 
-    load_tile<DH>(tV, X + 2 * d, ld, SM::SP2, Sv, lane, nullptr);
+    TileRegs<DH, SM::SP2> rV;
+    rV.issue(X + 2 * d, ld, Sv, lane);
     bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
@@ -178,21 +209,21 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
         float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks) {
-            const bf16* p = X + (int64_t)row * ld + 32 * ks + 8 * q;
-            fq[tt][ks] = ld_frag(p, ok);
-            fk[tt][ks] = ld_frag(p + d, ok);
-            fc[tt][ks] = ld_frag(p + 3 * d, ok);
+            fq[tt][ks] = ld_rows(X, ld, row, Sv, 32 * ks + 8 * q);
+            fk[tt][ks] = ld_rows(X + d, ld, row, Sv, 32 * ks + 8 * q);
+            fc[tt][ks] = ld_rows(X + 3 * d, ld, row, Sv, 32 * ks + 8 * q);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
         }
         ss = red_q<NT>(ss, false);
-        if (q == 0) rho[row] = sqrtf(ss);
+        if (q == 0) rho[row] = ok ? rsqrtf(ss) : 0.f;        // 1 / |c_row|
     }
     madd[lane] = (lane < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : 0.f;
+    rV.commit(tV, lane, nullptr);
     __syncthreads();
 
     f32x4 a1[NT][NT], a2[NT][NT];
-    probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, sqrtf((float)DH), a1, a2);
+    probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, rsqrtf((float)DH), a1, a2);
 
     // mix + dropout -> P^T in a1
     const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
@@ -268,11 +299,31 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
     const int64_t ld = 4 * d;
     const int Sv = act ? S : 0;
-    const float sq = sqrtf((float)DH);
+    const float isq = rsqrtf((float)DH);
 
-    load_tile<DH>(tQ, X, ld, SP2, Sv, lane, nullptr);
-    load_tile<DH>(tK, X + d, ld, SP2, Sv, lane, nullptr);
-    load_tile<DH>(tO, DO, d, SP2, Sv, lane, nullptr);
+    // NT <= 2: every global load of the kernel is issued here, before anything is consumed
+    constexpr bool PRE = NT <= 2;
+    TileRegs<DH, PRE ? SP2 : 64 / (DH / 8)> rQ, rK, rO, rC;
+    bf16x8 fv[NT][KD], fo[NT][KD];
+    if constexpr (PRE) {
+        rQ.issue(X, ld, Sv, lane);
+        rK.issue(X + d, ld, Sv, lane);
+        rO.issue(DO, d, Sv, lane);
+        rC.issue(X + 3 * d, ld, Sv, lane);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int row = 16 * tt + r;
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) {
+                fv[tt][ks] = ld_rows(X + 2 * d, ld, row, Sv, 32 * ks + 8 * q);
+                fo[tt][ks] = ld_rows(DO, d, row, Sv, 32 * ks + 8 * q);
+            }
+        }
+    } else {
+        load_tile<DH>(tQ, X, ld, SP2, Sv, lane, nullptr);
+        load_tile<DH>(tK, X + d, ld, SP2, Sv, lane, nullptr);
+        load_tile<DH>(tO, DO, d, SP2, Sv, lane, nullptr);
+    }
     f32x4 a1[NT][NT], a2[NT][NT];
     {
         bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
@@ -283,37 +334,41 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             float ss = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KD; ++ks) {
-                const bf16* p = X + (int64_t)row * ld + 32 * ks + 8 * q;
-                fq[tt][ks] = ld_frag(p, ok);
-                fk[tt][ks] = ld_frag(p + d, ok);
-                fc[tt][ks] = ld_frag(p + 3 * d, ok);
+                fq[tt][ks] = ld_rows(X, ld, row, Sv, 32 * ks + 8 * q);
+                fk[tt][ks] = ld_rows(X + d, ld, row, Sv, 32 * ks + 8 * q);
+                fc[tt][ks] = ld_rows(X + 3 * d, ld, row, Sv, 32 * ks + 8 * q);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
             }
             ss = red_q<NT>(ss, false);
-            if (q == 0) rho[row] = sqrtf(ss);
+            if (q == 0) rho[row] = ok ? rsqrtf(ss) : 0.f;    // 1 / |c_row|
         }
         madd[lane] = (lane < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : 0.f;
+        if constexpr (PRE) {
+            rQ.commit(tQ, lane, nullptr);
+            rK.commit(tK, lane, nullptr);
+            rO.commit(tO, lane, nullptr);
+        }
         __syncthreads();
-        probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, sq, a1, a2);
+        probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, isq, a1, a2);
     }
-    // C-hat tile (rows scaled by 1 / |c|); madd is no longer needed: reuse it for the inverse norms
-    madd[lane] = (lane < Sv) ? 1.f / rho[lane] : 0.f;
-    __syncthreads();
-    load_tile<DH>(tC, X + 3 * d, ld, SP2, Sv, lane, madd);
+    // C-hat tile (rows scaled by the inverse norms)
+    if constexpr (PRE) rC.commit(tC, lane, rho);
+    else load_tile<DH>(tC, X + 3 * d, ld, SP2, Sv, lane, rho);
 
     // dP^T[j][i] = sum_c V[j][c] dO[i][c]
     f32x4 dp[NT][NT];
     {
-        bf16x8 fv[NT][KD], fo[NT][KD];
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const int row = 16 * tt + r;
-            const bool ok = row < Sv;
+            for (int tt = 0; tt < NT; ++tt) {
+                const int row = 16 * tt + r;
+                const bool ok = row < Sv;
 #pragma unroll
-            for (int ks = 0; ks < KD; ++ks) {
-                fv[tt][ks] = ld_frag(X + (int64_t)row * ld + 2 * d + 32 * ks + 8 * q, ok);
-                fo[tt][ks] = ld_frag(DO + (int64_t)row * d + 32 * ks + 8 * q, ok);
+                for (int ks = 0; ks < KD; ++ks) {
+                    fv[tt][ks] = ld_rows(X + 2 * d, ld, row, Sv, 32 * ks + 8 * q);
+                    fo[tt][ks] = ld_rows(DO, d, row, Sv, 32 * ks + 8 * q);
+                }
             }
         }
 #pragma unroll
@@ -402,13 +457,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
                 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
             }
-            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq / sq);
+            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);
             dch[ct] = -dc;       // dN = -dS1
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
             dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
         }
         dt = red_q<NT>(dt, false);
-        const float inv = madd[x < 64 ? x : 0];     // 1 / |c_x|
+        const float inv = rho[x < 64 ? x : 0];      // 1 / |c_x|
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
@@ -435,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             }
             if (j < Sv) {
                 store4<bf16>(DX + (int64_t)j * ld + 2 * d + 16 * ct + 4 * q, dv);
-                store4<bf16>(DX + (int64_t)j * ld + d + 16 * ct + 4 * q, dk / sq);
+                store4<bf16>(DX + (int64_t)j * ld + d + 16 * ct + 4 * q, dk * isq);
             }
         }
     }

@@ -268,7 +268,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Staging loads are UNCONDITIONAL on clamped addresses (zero-selected afterwards): a branch around a load
+    // makes the compiler wait at the join and serialises the memory round trips.  With a row gather on Q the
+    // indices of the NEXT K-step are fetched one step ahead, so the Q loads never wait on an index load.
     u32x4 rp[LPT], rq[LPT];
+    int64_t qidx[LPT];
+    auto iload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int row = (tid + 256 * i) / CPR;
+            const int mc = max(min(mb + row, mend - 1), 0);
+            qidx[i] = g.q_rows ? g.q_rows[mc] : (int64_t)mc;
+        }
+    };
     auto gload = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -277,17 +289,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
             const int m = mb + row;
             const int cp = n1_0 + ch * EPC, cq = n2_0 + ch * EPC;
             const bool okm = m < mend;
-            rp[i] = (okm && cp < g.N1) ? *(const u32x4*)((const char*)g.P + ((int64_t)m * g.ldp + cp) * (int64_t)sizeof(T))
-                                       : (u32x4){0, 0, 0, 0};
-            if (okm && cq < g.N2) {
-                const int64_t qr = g.q_rows ? g.q_rows[m] : (int64_t)m;
-                rq[i] = *(const u32x4*)((const char*)g.Q + (qr * g.ldq + cq) * (int64_t)sizeof(T));
-            } else {
-                rq[i] = (u32x4){0, 0, 0, 0};
-            }
+            const int mc = max(min(m, mend - 1), 0);
+            const int cpc = min(cp, g.N1 - EPC), cqc = min(cq, g.N2 - EPC);
+            (void)okm;      // the zero-select for padding rows/columns happens at LDS-store time (sstore), so the
+                            // loads stay in flight across the MFMA phase instead of being waited for here
+            rp[i] = *(const u32x4*)((const char*)g.P + ((int64_t)mc * g.ldp + cpc) * (int64_t)sizeof(T));
+            rq[i] = *(const u32x4*)((const char*)g.Q + (qidx[i] * g.ldq + cqc) * (int64_t)sizeof(T));
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int mb) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int idx = tid + 256 * i;
@@ -295,20 +305,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
             int off;
             if constexpr (sizeof(T) == 2) off = row * ROWB + ((ch ^ (tn_f(row) << 1)) << 4);
             else off = row * ROWB + (ch << 4);
-            *(u32x4*)(sP + buf * TILEB + off) = rp[i];
-            *(u32x4*)(sQ + buf * TILEB + off) = rq[i];
+            const bool okm = mb + row < mend;
+            const u32x4 z = {0, 0, 0, 0};
+            *(u32x4*)(sP + buf * TILEB + off) = (okm && n1_0 + ch * EPC < g.N1) ? rp[i] : z;
+            *(u32x4*)(sQ + buf * TILEB + off) = (okm && n2_0 + ch * EPC < g.N2) ? rq[i] : z;
         }
     };
 
     const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
     if (nk > 0) {
+        iload(mbeg);
         gload(mbeg);
-        sstore(0);
+        if (nk > 1) iload(mbeg + BKM);
+        sstore(0, mbeg);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(mbeg + (kt + 1) * BKM);
+        if (kt + 1 < nk) {
+            gload(mbeg + (kt + 1) * BKM);                       // uses the indices fetched one step ago
+            if (kt + 2 < nk) iload(mbeg + (kt + 2) * BKM);
+        }
         const char* p_base = sP + buf * TILEB;
         const char* q_base = sQ + buf * TILEB;
         if constexpr (sizeof(T) == 2) {
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
                 }
             }
         }
-        if (kt + 1 < nk) sstore(buf ^ 1);
+        if (kt + 1 < nk) sstore(buf ^ 1, mbeg + (kt + 1) * BKM);
         __syncthreads();
     }
 
