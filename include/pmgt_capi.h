@@ -162,6 +162,8 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
                    uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
                    const float* ln_beta, float ln_eps, void* stream);
+/* A/B switch: 1 runs the last layer on every token even when last_hidden is not requested */
+void pmgt_debug_disable_last_layer_shortcut(int on);
 /* A/B switch: 1 forces the tiled GEMM kernel everywhere */
 void pmgt_debug_force_tile_gemm(int on);
 /* A/B switch: 1 routes bf16 attention through the generic fp32-VALU kernel instead of the MFMA one */

@@ -208,6 +208,13 @@ template <typename T> struct Bufs {
     int64_t *nfr_masked, *nfr_tgt, *nfr_rows, *nfr_tids;
     int* nfr_count;
     T *pred, *dq;
+    // last-layer shortcut (training fast path): only the rows the loss reads go through the last layer's
+    // attn-out / FFN blocks.  Compact row order: target CLS (B), pair CLS (P), masked rows (count).
+    int rcap = 0;
+    int64_t* need_rows = nullptr;
+    int* need_cnt = nullptr;
+    LayerBufs<T> ctail;
+    T *c_dh = nullptr, *c_bB = nullptr, *c_bC = nullptr, *c_bD = nullptr, *c_big = nullptr;
 };
 
 static int64_t tn_slab_elems(int dtype, int M, int N1, int N2) {
@@ -280,6 +287,24 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     b.nfr_tids = c.get<int64_t>(cap);
     b.pred = c.get<T>((int64_t)cap * F);
     b.dq = c.get<T>((int64_t)cap * d);
+    const int64_t R = (int64_t)B + (Tseq - 2 * B) + cap;      // B targets + P pairs + masked rows (upper bound)
+    b.rcap = (int)R;
+    b.need_rows = c.get<int64_t>(R);
+    b.need_cnt = c.get<int>(4);
+    b.ctail.qkvc = nullptr; b.ctail.ctx = nullptr;
+    b.ctail.ao_pre = c.get<T>(R * d);
+    b.ctail.stats1 = c.get<float>(R * 2);
+    b.ctail.u = c.get<T>(R * d);
+    b.ctail.ff_pre = c.get<T>(R * I);
+    b.ctail.g = c.get<T>(R * I);
+    b.ctail.fo_pre = c.get<T>(R * d);
+    b.ctail.stats2 = c.get<float>(R * 2);
+    b.ctail.hout = c.get<T>(R * d);
+    b.c_dh = c.get<T>(R * d);
+    b.c_bB = c.get<T>(R * d);
+    b.c_bC = c.get<T>(R * d);
+    b.c_bD = c.get<T>(R * d);
+    b.c_big = c.get<T>(R * std::max(I, d));
 }
 
 template <typename T> static inline const T* wsel(const pmgt_engine* e, const pmgt_tensors* t, const Bufs<T>& b, int64_t master_off, int64_t mirror_off) {
@@ -314,6 +339,7 @@ static inline DropCfg dropcfg(const pmgt_tensors* t, bool on, float p, int layer
 // ---- linear layer dispatcher: weight-stationary streaming kernel when it applies (bf16, K <= 256), else the
 // tiled kernel (+ a separate LayerNorm launch when the caller asked for the fused one) -------------------
 static int g_force_tile = 0;
+static int g_no_shortcut = 0;
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -322,14 +348,14 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
             RUNP(name, gemm_ws(g, st));
             if (g.ln_out && !gemm_ws_fuses_ln(g))
                 RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
-                                                DropCfg{nullptr, 0.f, 0}, st));
+                                                DropCfg{nullptr, 0.f, 0}, st, g.m_dev));
             return 0;
         }
     }
     RUNP(name, gemm_nt<T>(g, st));
     if (g.ln_out)
         RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
-                                        DropCfg{nullptr, 0.f, 0}, st));
+                                        DropCfg{nullptr, 0.f, 0}, st, g.m_dev));
     return 0;
 }
 
@@ -337,7 +363,7 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
 template <typename T>
 static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, const int64_t* ids,
                            const T* feat_v, const T* feat_t, const float* mask, bool train, T* hidden_states,
-                           float* attn_probs, hipStream_t st) {
+                           float* attn_probs, hipStream_t st, bool shortcut = false) {
     const int d = e->d, I = e->I, L = e->L, H = e->H;
     const int M = Tseq * S;
     const float* P = t->params;
@@ -386,29 +412,36 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             RUNP("fwd.attention", attn_fwd<T>(a, st));
         }
+        // Tail of the layer (attn-out, FFN): on every token, or — last layer of the training fast path — only on
+        // the rows the loss reads (padded and unread positions never influence them: SURVEY Q6).
+        const bool sc = shortcut && l == L - 1;
+        LayerBufs<T>& tb = sc ? b.ctail : lb;
+        const int Mt = sc ? b.rcap : M;
+        const int64_t* rows = sc ? b.need_rows : nullptr;
+        const int* mdev = sc ? b.need_cnt : nullptr;
         {   // BertSelfOutput: LN(dropout(dense(ctx)) + hin)
             GemmWS g;
-            g.A = lb.ctx; g.lda = d; g.B = wsel<T>(e, t, b, o.Wo, o.mWo); g.ldb = d;
-            g.C = lb.ao_pre; g.ldc = d; g.M = M; g.N = d; g.K = d; g.bias = P + o.bo;
+            g.A = lb.ctx; g.lda = d; g.a_rows = rows; g.B = wsel<T>(e, t, b, o.Wo, o.mWo); g.ldb = d;
+            g.C = tb.ao_pre; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.bias = P + o.bo; g.m_dev = mdev;
             g.drop = dropcfg(t, train, pd, l, SITE_AO);
-            g.res = hin; g.ldr = d;
-            g.ln_out = lb.u; g.ln_stats = lb.stats1; g.ln_gamma = P + o.ln1g; g.ln_beta = P + o.ln1b; g.ln_eps = e->cfg.layer_norm_eps;
+            g.res = hin; g.ldr = d; g.res_gather = sc;
+            g.ln_out = tb.u; g.ln_stats = tb.stats1; g.ln_gamma = P + o.ln1g; g.ln_beta = P + o.ln1b; g.ln_eps = e->cfg.layer_norm_eps;
             RUN(linear<T>(e, "fwd.gemm_attn_out", g, st));
         }
         {   // BertIntermediate: gelu(dense(u))
             GemmWS g;
-            g.A = lb.u; g.lda = d; g.B = wsel<T>(e, t, b, o.W1, o.mW1); g.ldb = d;
-            g.C = lb.g; g.ldc = I; g.M = M; g.N = I; g.K = d; g.bias = P + o.b1;
-            g.epi = EPI_GELU; g.aux = lb.ff_pre; g.ldaux = I;
+            g.A = tb.u; g.lda = d; g.B = wsel<T>(e, t, b, o.W1, o.mW1); g.ldb = d;
+            g.C = tb.g; g.ldc = I; g.M = Mt; g.N = I; g.K = d; g.bias = P + o.b1; g.m_dev = mdev;
+            g.epi = EPI_GELU; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "fwd.gemm_ffn1", g, st));
         }
         {   // BertOutput: LN(dropout(dense(g)) + u)
             GemmWS g;
-            g.A = lb.g; g.lda = I; g.B = wsel<T>(e, t, b, o.W2, o.mW2); g.ldb = I;
-            g.C = lb.fo_pre; g.ldc = d; g.M = M; g.N = d; g.K = I; g.bias = P + o.b2;
+            g.A = tb.g; g.lda = I; g.B = wsel<T>(e, t, b, o.W2, o.mW2); g.ldb = I;
+            g.C = tb.fo_pre; g.ldc = d; g.M = Mt; g.N = d; g.K = I; g.bias = P + o.b2; g.m_dev = mdev;
             g.drop = dropcfg(t, train, pd, l, SITE_FO);
-            g.res = lb.u; g.ldr = d;
-            g.ln_out = lb.hout; g.ln_stats = lb.stats2; g.ln_gamma = P + o.ln2g; g.ln_beta = P + o.ln2b; g.ln_eps = e->cfg.layer_norm_eps;
+            g.res = tb.u; g.ldr = d;
+            g.ln_out = tb.hout; g.ln_stats = tb.stats2; g.ln_gamma = P + o.ln2g; g.ln_beta = P + o.ln2b; g.ln_eps = e->cfg.layer_norm_eps;
             RUN(linear<T>(e, "fwd.gemm_ffn2", g, st));
         }
         if (hidden_states)
@@ -437,7 +470,8 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
 
 // ---- encoder backward: dcur (in b.bA) = d loss / d h_L; leaves parameter grads in t->grads ----------
 template <typename T>
-static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st) {
+static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st,
+                            bool shortcut = false) {
     const int d = e->d, I = e->I, L = e->L, H = e->H;
     const int M = Tseq * S;
     const float* P = t->params;
@@ -449,35 +483,53 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         const LayerOff& o = e->layers[l];
         LayerBufs<T>& lb = b.layer[l];
         const T* hin = l == 0 ? b.h0 : b.layer[l - 1].hout;
-        // LN2 backward: bA -> bB (residual branch), bC (masked: gradient of the FFN2 dense output)
-        RUNP("bwd.layernorm", ln_bwd<T>(b.bA, lb.fo_pre, lb.stats2, P + o.ln2g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
-                      dropcfg(t, true, pd, l, SITE_FO), st));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 3 * d, G + o.ln2g, acc, st));   // dgamma | dbeta | db2
-        const T* dY2 = dd ? b.bC : b.bB;
-        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, lb.g, I, nullptr, M, M, d, I, G + o.W2, acc, nullptr, st));
+        // tail of the layer on all tokens, or (last layer, fast path) on the compacted rows the loss read
+        const bool sc = shortcut && l == L - 1;
+        LayerBufs<T>& tb = sc ? b.ctail : lb;
+        const int Mt = sc ? b.rcap : M;
+        const int msp = sc ? std::max(256, Mt / 3) : M;               // row count used to size the wgrad splits
+        const int64_t* rows = sc ? b.need_rows : nullptr;
+        const int* mdev = sc ? b.need_cnt : nullptr;
+        T* gA = sc ? b.c_dh : b.bA;
+        T* gB = sc ? b.c_bB : b.bB;
+        T* gC = sc ? b.c_bC : b.bC;
+        T* gD = sc ? b.c_bD : b.bD;
+        T* gbig = sc ? b.c_big : b.big;
+        // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
+        RUNP("bwd.layernorm", ln_bwd<T>(gA, tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
+                      dropcfg(t, true, pd, l, SITE_FO), st, mdev));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln2g, acc, st));   // dgamma | dbeta | db2
+        const T* dY2 = dd ? gC : gB;
+        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
             GemmWS g;
-            g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = b.big; g.ldc = I;
-            g.M = M; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = lb.ff_pre; g.ldaux = I;
+            g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = gbig; g.ldc = I; g.m_dev = mdev;
+            g.M = Mt; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, b.big, I, lb.u, d, nullptr, M, M, I, d, G + o.W1, acc, nullptr, st, G + o.b1));
+        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1));
         {   // du = dff W1 + residual branch
             GemmWS g;
-            g.A = b.big; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = b.bD; g.ldc = d;
-            g.M = M; g.N = d; g.K = I; g.res = b.bB; g.ldr = d;
+            g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gD; g.ldc = d; g.m_dev = mdev;
+            g.M = Mt; g.N = d; g.K = I; g.res = gB; g.ldr = d;
             RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
         }
         // LN1 backward
-        RUNP("bwd.layernorm", ln_bwd<T>(b.bD, lb.ao_pre, lb.stats1, P + o.ln1g, b.bB, dd ? b.bC : nullptr, b.part, M, d, nodrop,
-                      dropcfg(t, true, pd, l, SITE_AO), st));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(M), 3 * d, G + o.ln1g, acc, st));   // dgamma | dbeta | dbo
-        const T* dYo = dd ? b.bC : b.bB;
-        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, nullptr, M, M, d, d, G + o.Wo, acc, nullptr, st));
+        RUNP("bwd.layernorm", ln_bwd<T>(gD, tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
+                      dropcfg(t, true, pd, l, SITE_AO), st, mdev));
+        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln1g, acc, st));   // dgamma | dbeta | dbo
+        const T* dYo = dd ? gC : gB;
+        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
         {   // dctx = dYo Wo
             GemmWS g;
-            g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = b.bD; g.ldc = d; g.M = M; g.N = d; g.K = d;
+            g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = gD; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.m_dev = mdev;
             RUN(linear<T>(e, "bwd.dgrad_attn_out", g, st));
+        }
+        if (sc) {   // back to the full token layout: zero everywhere except the compacted rows
+            PMGT_HIP(hipMemsetAsync(b.bD, 0, (size_t)M * d * sizeof(T), st));
+            PMGT_HIP(hipMemsetAsync(b.bB, 0, (size_t)M * d * sizeof(T), st));
+            RUN(scatter_rows<T>(gD, b.need_rows, b.need_cnt, Mt, d, b.bD, st));
+            RUN(scatter_rows<T>(gB, b.need_rows, b.need_cnt, Mt, d, b.bB, st));
         }
         {
             AttnArgs a;
@@ -543,22 +595,31 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         RUN(nfr_compact(b.nfr_tgt, B, S, B + Pn, b.nfr_rows, b.nfr_tids, b.nfr_count, st));
     }
     RUNP("mirror", build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    // Training fast path: the caller does not ask for last_hidden_state, so the last layer's attn-out/FFN blocks
+    // only run on the rows the loss reads (compact order: B target CLS, P pair CLS, masked rows).
+    const bool sc = train && !g_no_shortcut && o->last_hidden == nullptr;
+    if (sc) RUN(build_need_rows(B, Pn, S, b.nfr_rows, b.nfr_count, b.need_rows, b.need_cnt, st));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, (const T*)nullptr, (const T*)nullptr, b.mask, train, (T*)nullptr,
-                           (float*)nullptr, st));
-    T* hL = b.layer[e->L - 1].hout;
+                           (float*)nullptr, st, sc));
+    T* hL = sc ? b.ctail.hout : b.layer[e->L - 1].hout;
+    T* dhL = sc ? b.c_dh : b.bA;
     const int M = Tseq * S;
-    if (bwd) PMGT_HIP(hipMemsetAsync(b.bA, 0, (size_t)M * d * sizeof(T), st));
+    if (bwd) PMGT_HIP(hipMemsetAsync(dhL, 0, (size_t)(sc ? b.rcap : M) * d * sizeof(T), st));
     RUN(pair_offsets(bt->num_pairs, B, b.off, st));
     {
         GsrArgs g;
-        g.h = hL; g.dh = bwd ? b.bA : nullptr; g.B = B; g.S = S; g.d = d; g.off = b.off; g.labels = bt->labels;
+        g.h = hL; g.dh = bwd ? dhL : nullptr; g.B = B; g.S = S; g.d = d; g.off = b.off; g.labels = bt->labels;
+        g.cls_stride = sc ? d : (int64_t)S * d;
         g.logits = o->logits; g.loss_part = b.gsr_part;
         RUNP("loss.gsr", gsr_fwd_bwd<T>(g, st));
     }
     const int cap = B * std::max(S - 1, 1);
+    // rows of the masked positions inside hL: gathered by token index, or contiguous after the CLS rows when compacted
+    const T* hN = sc ? hL + (int64_t)(B + Pn) * d : hL;
+    const int64_t* nrows = sc ? nullptr : b.nfr_rows;
     if (train) {
-        GemmNT g;   // projections of the masked rows (row gather by token index)
-        g.A = hL; g.lda = d; g.a_rows = b.nfr_rows; g.B = wsel<T>(e, t, b, e->Wn, e->mWn); g.ldb = d;
+        GemmNT g;   // projections of the masked rows
+        g.A = hN; g.lda = d; g.a_rows = nrows; g.B = wsel<T>(e, t, b, e->Wn, e->mWn); g.ldb = d;
         g.C = b.pred; g.ldc = F; g.M = cap; g.N = F; g.K = d; g.bias = t->params + e->bn; g.m_dev = b.nfr_count;
         RUNP("loss.gemm_nfr", gemm_nt<T>(g, st));
         NfrDiffArgs a;
@@ -572,13 +633,13 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     if (o->nfr_count && train) PMGT_HIP(hipMemcpyAsync(o->nfr_count, b.nfr_count, 4, hipMemcpyDeviceToDevice, st));
     if (bwd) {
         const int msp = std::max(256, cap / 5);
-        RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hL, d, b.nfr_rows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st, t->grads + e->bn));
+        RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hN, d, nrows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st, t->grads + e->bn));
         GemmNT g;
-        g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.C = b.dq; g.ldc = d; g.M = cap; g.N = d; g.K = F;
-        g.m_dev = b.nfr_count;
+        g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.M = cap; g.N = d; g.K = F; g.m_dev = b.nfr_count;
+        g.C = sc ? dhL + (int64_t)(B + Pn) * d : b.dq; g.ldc = d;      // compacted: the masked rows ARE rows B+P.. of dhL
         RUNP("bwd.dgrad_nfr", gemm_nt<T>(g, st));
-        RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
-        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st));
+        if (!sc) RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
+        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc));
     }
     if (train) RUN(advance_rng(t->rng_state, st));
     return 0;
@@ -814,6 +875,7 @@ static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, i
 
 void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
 void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; }
+void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,

@@ -19,6 +19,7 @@ struct GemmNT {
     void* aux = nullptr; int64_t ldaux = 0;   // EPI_GELU: pre-activation out; EPI_GELU_GRAD: pre-activation in
     DropCfg drop = {nullptr, 0.f, 0};  // dropout on (acc+bias [+act]), element index m*N+n
     const void* res = nullptr; int64_t ldr = 0;   // residual added last (same dtype as C)
+    bool res_gather = false;           // residual row = a_rows[m] (compacted-row GEMMs)
     const int* m_dev = nullptr;        // optional device-side row count (<= M)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] *= dm[e];
                         }
-                        if (R) v += load4<T>(R + (int64_t)m * g.ldr + n);
+                        if (R) v += load4<T>(R + (g.res_gather ? g.a_rows[m] : (int64_t)m) * g.ldr + n);
                         store4<T>(C + (int64_t)m * g.ldc + n, v);
                     }
                 }

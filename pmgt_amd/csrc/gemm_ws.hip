@@ -249,7 +249,7 @@ static int ws_mode(const GemmWS& g) {
 }
 
 bool gemm_ws_supported(const GemmWS& g) {
-    return ws_mode(g) >= 0 && g.K % 32 == 0 && g.K >= 64 && g.K <= 256 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
+    return ws_mode(g) >= 0 && g.a_rows == nullptr && g.m_dev == nullptr && g.K % 32 == 0 && g.K >= 64 && g.K <= 256 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
            g.M >= 64 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
            (g.aux == nullptr || g.ldaux % 8 == 0);
 }

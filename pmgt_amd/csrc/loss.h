@@ -14,6 +14,7 @@ struct GsrArgs {
     const void* h = nullptr;        // [Tseq*S, d] encoder output; sequences 0..B-1 = targets, B.. = pairs
     void* dh = nullptr;             // same shape, pre-zeroed; CLS rows receive the gradient (nullable: eval)
     int B = 0, S = 0, d = 0;
+    int64_t cls_stride = 0;         // elements between consecutive CLS rows (S*d in the full layout, d when compacted)
     const int* off = nullptr;       // [B+1] pair offsets
     const float* labels = nullptr;  // [P]
     float* logits = nullptr;        // [P] out
@@ -34,6 +35,9 @@ inline int nfr_diff_parts(int cap) { return cdiv(cap, 8); }
 template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st);
 template <typename T>
 int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st);
+// rows the loss reads from the last layer: CLS of the B targets, CLS of the P pairs, then the masked rows
+int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
+                    hipStream_t st);
 int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
                 bool with_nfr, float* out, hipStream_t st);
 

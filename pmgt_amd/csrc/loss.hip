@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gsr_kernel(GsrArgs g) {
     const int i = blockIdx.x * 4 + wave;
     if (i >= g.B) return;
     const int d = g.d, nch = d >> 2;
-    const int64_t rs = (int64_t)g.S * d;                 // CLS row stride (one sequence)
+    const int64_t rs = g.cls_stride ? g.cls_stride : (int64_t)g.S * d;   // CLS row stride
     const T* H = (const T*)g.h;
     T* DH = (T*)g.dh;
     f32x4 zt[NCH], dzt[NCH];
@@ -261,6 +261,22 @@ int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, i
 }
 template int scatter_rows<float>(const float*, const int64_t*, const int*, int, int, float*, hipStream_t);
 template int scatter_rows<bf16>(const bf16*, const int64_t*, const int*, int, int, bf16*, hipStream_t);
+
+__global__ void build_need_rows_kernel(int B, int P, int S, const int64_t* __restrict__ nfr_rows,
+                                       const int* __restrict__ nfr_count, int64_t* __restrict__ rows, int* __restrict__ count) {
+    const int n = *nfr_count;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B + P) rows[i] = (int64_t)i * S;              // CLS token of sequence i (targets, then pairs)
+    else if (i < B + P + n) rows[i] = nfr_rows[i - B - P];
+    if (i == 0) *count = B + P + n;
+}
+int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
+                    hipStream_t st) {
+    const int cap = B + P + B * (S - 1 > 0 ? S - 1 : 1);
+    hipLaunchKernelGGL(build_need_rows_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, st, B, P, S, nfr_rows, nfr_count, rows, count);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
 
 // out = {loss, gsr, nfr};  nfr = 0.5 * (sse_v / (n Fv) + sse_t / (n Ft)); n == 0 gives NaN like the reference
 __global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ gsr_part, int B,

@@ -9,13 +9,13 @@ namespace pmgt {
 // y = dropout(LN(x)); stats[m] = {mean, rstd}.  d % 4 == 0, d <= 1024.  One wave per row.
 template <typename T>
 int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
-           DropCfg out_drop, hipStream_t st);
+           DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr);
 // dx = LN'(dy * in_mask); optional second output dx_drop = dx * out_mask (gradient of the dropout
 // that fed the residual sum).  Partials go to `part` ([ln_bwd_parts(M)][3][d] floats): dgamma, dbeta and
 // dbias = column sum of dx_drop (or dx): the bias gradient of the dense layer in front of the LayerNorm.
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
-           int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st);
+           int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr);
 inline int ln_bwd_parts(int M) { return cdiv(M, 64); }
 
 // ---- embedding mix (pmgt/pmgt/modeling_pmgt.py:199-208) ----------------------------------------

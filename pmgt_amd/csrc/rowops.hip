@@ -16,9 +16,10 @@ __device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + 
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int M, int d, float eps, DropCfg drop) {
+                                                     int M, int d, float eps, DropCfg drop, const int* m_dev) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
+    if (m_dev) M = min(M, *m_dev);
     if (m >= M) return;
     const int nch = d >> 2;
     const T* xr = x + (int64_t)m * d;
@@ -60,18 +61,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
 
 template <typename T>
 int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
-           DropCfg out_drop, hipStream_t st) {
+           DropCfg out_drop, hipStream_t st, const int* m_dev) {
     if (M <= 0) return 0;
     PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_fwd: hidden size %d must be a multiple of 4 and <= 1024", d);
     dim3 grid(cdiv(M, 4)), block(256);
-    if (d <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop);
-    else if (d <= 512) hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop);
-    else hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop);
+    if (d <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev);
+    else if (d <= 512) hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev);
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev);
     PMGT_LAUNCH_OK();
     return 0;
 }
-template int ln_fwd<float>(const float*, float*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t);
-template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t);
+template int ln_fwd<float>(const float*, float*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*);
+template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*);
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  64 rows per block (16 per wave); dgamma/dbeta partials per block.
@@ -80,8 +81,9 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
-                                                     int M, int d, DropCfg in_drop, DropCfg out_drop) {
+                                                     int M, int d, DropCfg in_drop, DropCfg out_drop, const int* m_dev) {
     __shared__ float red[3 * 1024];
+    if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = d >> 2;
     const DropKey ik = make_drop_key(in_drop), ok = make_drop_key(out_drop);
@@ -162,18 +164,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part, int M,
-           int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st) {
+           int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev) {
     if (M <= 0) return 0;
     PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_bwd: hidden size %d must be a multiple of 4 and <= 1024", d);
     dim3 grid(ln_bwd_parts(M)), block(256);
-    if (d <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop);
-    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop);
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop);
+    if (d <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev);
+    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev);
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev);
     PMGT_LAUNCH_OK();
     return 0;
 }
-template int ln_bwd<float>(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, DropCfg, DropCfg, hipStream_t);
-template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, bf16*, bf16*, float*, int, int, DropCfg, DropCfg, hipStream_t);
+template int ln_bwd<float>(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*);
+template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, bf16*, bf16*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*);
 
 // ------------------------------------------------------------------------------------------------
 // Embedding mix forward: a = softmax(Wa tanh([e_v;e_t]) + ba); x = a0 e_v + a1 e_t + pos[s] + role[s>0];

@@ -140,3 +140,26 @@ def test_device_nfr_masking_statistics_and_dropout_training():
         eng.optimizer_step(lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
         losses.append(out["loss"].item())
     assert np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+@pytest.mark.parametrize("name,dtype", [("m1", "fp32"), ("m1_pad", "fp32"), ("m3", "fp32"), ("m4", "fp32"), ("m3", "bf16")])
+def test_last_layer_shortcut_matches_full_path(name, dtype):
+    """Training fast path (no last_hidden_state requested): the last layer's attn-out/FFN blocks run only on the
+    rows the loss reads.  Losses and every gradient must equal the full path (and hence the reference)."""
+    case = gu.model_case(name)
+    gold = case["gold"]
+    inj, _ = inject_for(case)
+    batch = dev_batch(case["batch"])
+    res = {}
+    for label, want_hidden in (("full", True), ("fast", False)):
+        eng = make_engine(case, dtype=dtype)
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=want_hidden)
+        res[label] = (out["loss"].item(), out["logits"].cpu(), eng.grads.clone())
+    tol = 1e-5 if dtype == "fp32" else 2e-2
+    np.testing.assert_allclose(res["fast"][0], res["full"][0], rtol=tol)
+    if dtype == "fp32":
+        np.testing.assert_allclose(res["fast"][0], gold["train_loss"], rtol=1e-4)
+    torch.testing.assert_close(res["fast"][1], res["full"][1], rtol=tol, atol=tol)
+    g0, g1 = res["full"][2], res["fast"][2]
+    rel = ((g0 - g1).norm() / g0.norm()).item()
+    assert rel < (1e-5 if dtype == "fp32" else 3e-2), rel
