@@ -6,7 +6,7 @@ One "step" = one full pre-training step of the hot path on one batch of B target
 encoder forward, GSR + NFR losses, backward, [RCCL gradient all-reduce when N > 1], global-norm clip +
 AdamW.  Inputs (sampled node-context batches, feature tables) are resident in HBM before the timed
 region.  Workload at N=1: BASELINE.json configs[1] — VG-sized synthetic item graph (7 252 nodes /
-88 606 edges), L=4 H=8 d=256 I=256 S=32, bf16, dropout 0.1, lr 1e-4, wd 1e-2, clip 5.0.
+88 606 edges), L=4 H=8 d=256 I=256 S=32, bf16, B=1024 targets/GPU/step, dropout 0.1, lr 1e-4, wd 1e-2, clip 5.0.
 
 Prints ONE JSON line (rank 0).  Launch N > 1 with torch.distributed.run (one process per GPU).
 """
@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=256, help="target nodes per GPU per step (reference CLI default 256)")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="target nodes per GPU per step; SURVEY 8(d) lists 32 (author's script), 256 (CLI default), 1024")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--intermediate", type=int, default=0, help="override intermediate size")

@@ -77,6 +77,7 @@ struct pmgt_engine {
     std::vector<MirrorDesc> desc;
     MirrorDesc* desc_dev = nullptr;
     int mirror_tiles = 0;
+    const void* zeros = nullptr;      // device zero page (padding source of the LDS-DMA kernels)
     pmgt::Profiler prof;
 };
 
@@ -338,6 +339,13 @@ static inline DropCfg dropcfg(const pmgt_tensors* t, bool on, float p, int layer
 
 // ---- linear layer dispatcher: weight-stationary streaming kernel when it applies (bf16, K <= 256), else the
 // tiled kernel (+ a separate LayerNorm launch when the caller asked for the fused one) -------------------
+static void* g_zero_page = nullptr;
+static const void* zero_page() {
+    if (!g_zero_page) {
+        if (hipMalloc(&g_zero_page, 4096) != hipSuccess || hipMemset(g_zero_page, 0, 4096) != hipSuccess) g_zero_page = nullptr;
+    }
+    return g_zero_page;
+}
 static int g_force_tile = 0;
 static int g_no_shortcut = 0;
 
@@ -459,7 +467,7 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
                  float* bias_dst = nullptr) {
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
-    g.slab = b.slab; g.m_dev = m_dev;
+    g.slab = b.slab; g.m_dev = m_dev; g.zeros = e->zeros;
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
     g.bias_slab = bias_dst ? b.part : nullptr;          // [splits][N1] (fits: part >= 64 * max N1)
     RUNP(name, gemm_tn<T>(g, st));
@@ -695,6 +703,7 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     e->d = cfg->hidden_size; e->L = cfg->num_hidden_layers; e->H = cfg->num_attention_heads; e->I = cfg->intermediate_size;
     e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
     build_layout(e);
+    e->zeros = zero_page();
     if (!e->desc.empty()) {
         if (hipMalloc((void**)&e->desc_dev, e->desc.size() * sizeof(MirrorDesc)) != hipSuccess ||
             hipMemcpy(e->desc_dev, e->desc.data(), e->desc.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice) != hipSuccess) {
@@ -833,6 +842,7 @@ int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_
                     int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream) {
     GemmTN g;
     g.P = P; g.ldp = ldp; g.Q = Q; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2; g.slab = slab; g.m_dev = m_dev;
+    g.zeros = zero_page();
     g.splits = gemm_tn_pick_splits(M, N1, N2, dtype == PMGT_DTYPE_BF16 ? 64 : 32);
     int rc = dtype == PMGT_DTYPE_BF16 ? gemm_tn<bf16>(g, (hipStream_t)stream) : gemm_tn<float>(g, (hipStream_t)stream);
     if (rc) return rc;
@@ -874,7 +884,7 @@ static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, i
 }
 
 void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
-void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; }
+void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

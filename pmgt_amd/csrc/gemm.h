@@ -48,7 +48,9 @@ struct GemmTN {
     float* bias_slab = nullptr;                 // optional [splits][N1]: column sums of P (bias gradient)
     int splits = 1;
     const int* m_dev = nullptr;
+    const void* zeros = nullptr;                // >= 16 B of device zeros: enables the LDS-DMA kernel (bf16, no gather)
 };
+void gemm_tn_disable_dma(int on);
 template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st);
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm);
 template <typename T> int gemm_tn_bkm();

@@ -413,6 +413,164 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN, bf16, LDS-DMA pipeline.  Same tiling and fragment code as gemm_tn_kernel, but the operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers, no
+// ds_write), four 32-row stages in a ring, THREE stages in flight.  The register-staged kernel has at most
+// one K-step of loads in flight per workgroup and spends most of its time waiting for them; this one keeps
+// 48 KiB per workgroup in flight behind counted s_waitcnt vmcnt(N) and a raw s_barrier per stage:
+//     wait own DMAs of stage kt  ->  s_barrier (everyone's landed; everyone finished reading stage kt-1)
+//     ->  issue stage kt+3 into the ring slot stage kt-1 used  ->  tr-reads + MFMAs of stage kt.
+// An LDS-DMA destination is lane-linear (wave base + 16 * lane), so the bank-conflict swizzle of the
+// ds_read_b64_tr_b16 image is applied to the per-lane SOURCE address (chunk ^ swz(row)); rows / columns
+// outside the matrix read from a zero page.  No row gather (the gather variant stays register-staged).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_rows) {
+    constexpr int BKM = 32, ROWB = 256, STAGE = 2 * BKM * ROWB, NST = 4;     // 16 KiB per stage (P + Q)
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    const int tn1 = (g.N1 + 127) / 128, tn2 = (g.N2 + 127) / 128, tiles = tn1 * tn2;
+    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+    const int tile = bidx % tiles, split = xcd + 8 * (bidx / tiles);
+    if (split >= g.splits) return;
+    const int n1_0 = (tile / tn2) * 128, n2_0 = (tile % tn2) * 128;
+    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = g.bias_slab != nullptr && n2_0 == 0 && wn == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane's part of a stage: rows 8 wave + 4 j + (lane >> 4), j = 0, 1; LDS chunk slot lane & 15 holds
+    // global chunk (lane & 15) ^ swz(row)
+    const char* zero = (const char*)g.zeros;
+    auto issue = [&](int kt) {
+        const int mb = mbeg + kt * BKM;
+        char* st = smem + (kt & (NST - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * wave + 4 * j + (lane >> 4);
+            const int ch = (lane & 15) ^ (tn_f(row) << 1);
+            const int m = mb + row;
+            const int cp = n1_0 + ch * 8, cq = n2_0 + ch * 8;
+            const char* sp = (m < mend && cp < g.N1) ? (const char*)g.P + ((int64_t)m * g.ldp + cp) * 2 : zero;
+            const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + ((int64_t)m * g.ldq + cq) * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (8 * wave + 4 * j) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (8 * wave + 4 * j) * ROWB), 16, 0, 0);
+        }
+    };
+
+    const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    // per-lane byte offsets of the 4 + 4 fragment reads inside a stage (row = 8 q + (r >> 2); +4 rows = +1024 B)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    uint32_t offa[4], offb[4];
+    {
+        const int row = 8 * q + (r >> 2);
+        const int sw = tn_f(row) << 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ca = wm * 64 + i * 16 + 4 * (r & 3), cb = wn * 64 + i * 16 + 4 * (r & 3);
+            offa[i] = (uint32_t)(row * ROWB + (((ca >> 3) ^ sw) << 4) + ((ca & 7) << 1));
+            offb[i] = (uint32_t)(row * ROWB + (((cb >> 3) ^ sw) << 4) + ((cb & 7) << 1));
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        // 4 DMA instructions per wave per stage; leave the younger stages in flight
+        const int younger = min(2, nk - 1 - kt);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3);
+        // The fragment reads are inline asm on purpose: the compiler treats an in-flight LDS-DMA as a pending
+        // store to LDS and would put s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring.
+        // Ordering is ours: the counted vmcnt + s_barrier above retire stage kt; reads and their lgkmcnt(0) wait
+        // sit in ONE statement with early-clobber outputs (cdna_hip_programming.md section 5.7, form (i)).
+        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
+        u32x2 t[16];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\t"
+            "ds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\t"
+            "ds_read_b64_tr_b16 %3, %17 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\t"
+            "ds_read_b64_tr_b16 %5, %18 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\t"
+            "ds_read_b64_tr_b16 %7, %19 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %8, %20 offset:8192\n\t"
+            "ds_read_b64_tr_b16 %9, %20 offset:9216\n\t"
+            "ds_read_b64_tr_b16 %10, %21 offset:8192\n\t"
+            "ds_read_b64_tr_b16 %11, %21 offset:9216\n\t"
+            "ds_read_b64_tr_b16 %12, %22 offset:8192\n\t"
+            "ds_read_b64_tr_b16 %13, %22 offset:9216\n\t"
+            "ds_read_b64_tr_b16 %14, %23 offset:8192\n\t"
+            "ds_read_b64_tr_b16 %15, %23 offset:9216\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+              "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15])
+            : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
+              "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
+            : "memory");
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = __builtin_bit_cast(bf16x8, (u32x4){t[2 * i][0], t[2 * i][1], t[2 * i + 1][0], t[2 * i + 1][1]});
+            fb[i] = __builtin_bit_cast(bf16x8, (u32x4){t[8 + 2 * i][0], t[8 + 2 * i][1], t[9 + 2 * i][0], t[9 + 2 * i][1]});
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+            const bf16 one = (bf16)1.f;
+            const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        }
+    }
+
+    if (do_bias && r == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
+                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + n1] = accb[i][e];
+            }
+    }
+    float* out = g.slab + (int64_t)split * g.N1 * g.N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = n2_0 + wn * 64 + j * 16 + r;
+            if (n2 >= g.N2) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
+                if (n1 < g.N1) out[(int64_t)n1 * g.N2 + n2] = acc[i][j][e];
+            }
+        }
+}
+
+static int g_tn_no_dma = 0;
+void gemm_tn_disable_dma(int on) { g_tn_no_dma = on; }
+
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
     int splits = cdiv(512, tiles);                       // ~2 workgroups per CU; slab traffic = splits * N1 * N2 * 4 B
@@ -433,6 +591,13 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     int chunk = cdiv(cdiv(std::max(g.M, 1), g.splits), bkm) * bkm;
     const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);
     dim3 grid(8 * tiles * cdiv(g.splits, 8));
+    if constexpr (sizeof(T) == 2) {
+        if (!g_tn_no_dma && g.q_rows == nullptr && g.zeros != nullptr) {
+            hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(256), 0, st, g, chunk);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), 0, st, g, chunk);
     PMGT_LAUNCH_OK();
     return 0;
@@ -483,7 +648,7 @@ int slab_reduce(const float* slab_c, int splits, int64_t n, float* dst, bool acc
     PMGT_CHECK(n % 4 == 0, -2, "slab_reduce: n=%lld must be a multiple of 4", (long long)n);
     PMGT_CHECK(((uintptr_t)slab % 16) == 0 && ((uintptr_t)dst % 16) == 0, -2, "slab_reduce: unaligned buffers");
     const unsigned cb = (unsigned)cdiv64(n / 4, 64);
-    const int G = 32;
+    const int G = 128;          // up to 128 slabs in one launch (4 row lanes x 32 loads each); beyond that two levels
     if (splits <= G) {
         hipLaunchKernelGGL(rows_reduce_kernel, dim3(cb, 1), dim3(256), 0, st, slab, n, splits, splits, (int64_t)1, n, dst,
                            accumulate ? 1 : 0, 1);
