@@ -164,7 +164,9 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
                    const float* ln_beta, float ln_eps, void* stream);
 /* A/B switch: 1 runs the last layer on every token even when last_hidden is not requested */
 void pmgt_debug_disable_last_layer_shortcut(int on);
-/* A/B switch: 1 forces the tiled GEMM kernel everywhere */
+/* A/B switch: 1 selects the LDS-DMA variant of the tiled NT kernel (default: register-staged; same speed) */
+void pmgt_debug_enable_nt_dma(int on);
+/* A/B switch: 1 forces the register-staged tiled GEMM kernels everywhere (no streaming, no LDS-DMA) */
 void pmgt_debug_force_tile_gemm(int on);
 /* A/B switch: 1 routes bf16 attention through the generic fp32-VALU kernel instead of the MFMA one */
 void pmgt_debug_force_valu_attention(int on);

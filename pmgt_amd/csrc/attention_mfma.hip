@@ -10,6 +10,8 @@
 // ds_read_b64_tr_b16 from a row-major LDS tile.  Products that sum over the COLUMN index i (dV, dK,
 // second half of dC) read the bf16 image of the matrix back from LDS row-wise (one transpose through
 // LDS, as cdna_hip_programming.md section 3 prescribes).
+#include <stdlib.h>
+
 #include "attention.h"
 
 namespace pmgt {
@@ -505,7 +507,13 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
         hipLaunchKernelGGL(kern, dim3(cdiv(groups, 4)), dim3(256), shmem, st, a);
     } else {
         const size_t per = BwdSmem<DH, NT>::BYTES;
-        const int nw = per * 4 <= 150 * 1024 ? 4 : (per * 2 <= 150 * 1024 ? 2 : 1);
+        static int env_nw = -1;
+        if (env_nw < 0) { const char* ev = getenv("PMGT_ATTN_BWD_NW"); env_nw = ev ? atoi(ev) : 0; }
+        // waves per workgroup: 2 when that raises the LDS-limited wave count per CU (S=32/dh=32: 14.5 KiB per wave ->
+        // 5 x 2 waves instead of 2 x 4; measured 476 vs 500 us at 98k (sequence, head) pairs), never 1 (slower)
+        int nw = per * 2 <= 150 * 1024 ? 2 : 1;
+        if ((160 * 1024 / (per * 4)) * 4 >= (160 * 1024 / (per * 2)) * 2) nw = 4;
+        if (env_nw == 1 || env_nw == 2 || env_nw == 4) nw = (per * env_nw <= 150 * 1024) ? env_nw : nw;
         const size_t shmem = per * nw;
         auto kern = attn_bwd_mfma_kernel<DH, NT>;
         if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

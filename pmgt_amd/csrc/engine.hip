@@ -885,6 +885,7 @@ static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, i
 
 void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
 void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); }
+void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

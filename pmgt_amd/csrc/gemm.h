@@ -23,6 +23,7 @@ struct GemmNT {
     const int* m_dev = nullptr;        // optional device-side row count (<= M)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
+void gemm_nt_disable_dma(int on);     // A/B: force the register-staged tile kernel
 
 // Weight-stationary streaming variant for K <= 256 in bf16 (gemm_ws.hip); optional fused LayerNorm of the
 // output row when N == 256: ln_out = LN(C) with C the (bf16-rounded) epilogue result, stats = {mean, rstd}.

@@ -16,14 +16,86 @@
 //     swizzle chosen so the 32 lanes of a half-wave hit 32 distinct 8-byte slots.
 //   * blockIdx -> tile mapping keeps the N-tiles of one M-tile on one XCD (ids b, b+8 share an
 //     XCD's L2), so the A tile is fetched from HBM once.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace pmgt {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // ------------------------------------------------------------------------------------------------
 // NT
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// Shared epilogue of the NT kernels: accumulators -> LDS -> row-contiguous bias / GELU / dropout / residual.
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& g, f32x4 (&acc)[BM / 32][BN / 32], char* smem, int m0, int n0, int Mlim,
+                                            int tid, int wm, int wn, int r, int q) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.
+    // The accumulators go through LDS (two passes of 64 rows, fp32, row stride 132 words: the
+    // ds_write_b32 pattern is 2-way = free) so that bias / GELU / dropout / residual run on
+    // row-contiguous 8-element chunks and every global access is a full 16-byte vector.
+    const DropKey dk = make_drop_key(g.drop);
+    T* C = (T*)g.C;
+    const T* R = (const T*)g.res;
+    T* AUX = (T*)g.aux;
+    constexpr int ES = BN + 4;                      // staged row stride in floats
+    float* stage = (float*)smem;                    // 64 x ES floats = 33 KiB (BN = 128)
+    const int er = tid >> 4, ec = (tid & 15) * (BN / 16);
+#pragma unroll
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(i * 16 + 4 * q + e) * ES + wn * (BN / 2) + j * 16 + r] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = er + 16 * it;
+            const int m = m0 + pass * 64 + row;
+            if (m < Mlim) {
+#pragma unroll
+                for (int h = 0; h < BN / 64; ++h) {            // 4-element pieces of this thread's chunk
+                    const int n = n0 + ec + 4 * h;
+                    if (n < g.N) {                              // N % 4 == 0 is checked on the host
+                        f32x4 v = *(const f32x4*)(stage + row * ES + ec + 4 * h);
+                        if (g.bias) v += *(const f32x4*)(g.bias + n);
+                        if (g.epi == EPI_GELU) {
+                            f32x4 pre;                              // rounded to T: what backward re-reads
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pre[e] = to_f<T>(from_f<T>(v[e]));
+                            store4<T>(AUX + (int64_t)m * g.ldaux + n, pre);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(pre[e]);
+                        } else if (g.epi == EPI_GELU_GRAD) {
+                            f32x4 pre = load4<T>(AUX + (int64_t)m * g.ldaux + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(pre[e]);
+                        }
+                        if (dk.on) {
+                            float dm[4];
+                            drop_mul4(dk, (uint32_t)m, (uint32_t)n >> 2, dm);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= dm[e];
+                        }
+                        if (R) v += load4<T>(R + (g.res_gather ? g.a_rows[m] : (int64_t)m) * g.ldr + n);
+                        store4<T>(C + (int64_t)m * g.ldc + n, v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
@@ -136,68 +208,115 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.
-    // The accumulators go through LDS (two passes of 64 rows, fp32, row stride 132 words: the
-    // ds_write_b32 pattern is 2-way = free) so that bias / GELU / dropout / residual run on
-    // row-contiguous 8-element chunks and every global access is a full 16-byte vector.
-    const DropKey dk = make_drop_key(g.drop);
-    T* C = (T*)g.C;
-    const T* R = (const T*)g.res;
-    T* AUX = (T*)g.aux;
-    constexpr int ES = BN + 4;                      // staged row stride in floats
-    float* stage = (float*)smem;                    // 64 x ES floats = 33 KiB (BN = 128)
-    static_assert(64 * ES * 4 <= 2 * (BM + BN) * 128, "epilogue staging does not fit");
-    const int er = tid >> 4, ec = (tid & 15) * (BN / 16);
-#pragma unroll
-    for (int pass = 0; pass < BM / 64; ++pass) {
-        if (wm == pass) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        stage[(i * 16 + 4 * q + e) * ES + wn * (BN / 2) + j * 16 + r] = acc[i][j][e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = er + 16 * it;
-            const int m = m0 + pass * 64 + row;
-            if (m < Mlim) {
-#pragma unroll
-                for (int h = 0; h < BN / 64; ++h) {            // 4-element pieces of this thread's chunk
-                    const int n = n0 + ec + 4 * h;
-                    if (n < g.N) {                              // N % 4 == 0 is checked on the host
-                        f32x4 v = *(const f32x4*)(stage + row * ES + ec + 4 * h);
-                        if (g.bias) v += *(const f32x4*)(g.bias + n);
-                        if (g.epi == EPI_GELU) {
-                            f32x4 pre;                              // rounded to T: what backward re-reads
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pre[e] = to_f<T>(from_f<T>(v[e]));
-                            store4<T>(AUX + (int64_t)m * g.ldaux + n, pre);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(pre[e]);
-                        } else if (g.epi == EPI_GELU_GRAD) {
-                            f32x4 pre = load4<T>(AUX + (int64_t)m * g.ldaux + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(pre[e]);
-                        }
-                        if (dk.on) {
-                            float dm[4];
-                            drop_mul4(dk, (uint32_t)m, (uint32_t)n >> 2, dm);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= dm[e];
-                        }
-                        if (R) v += load4<T>(R + (g.res_gather ? g.a_rows[m] : (int64_t)m) * g.ldr + n);
-                        store4<T>(C + (int64_t)m * g.ldc + n, v);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    nt_epilogue<T, BM, BN>(g, acc, smem, m0, n0, Mlim, tid, wm, wn, r, q);
 }
+
+// ------------------------------------------------------------------------------------------------
+// NT, bf16, LDS-DMA pipeline (same idea as gemm_tn_dma_kernel): 128x128 tile, K-step 32 (64-byte LDS rows),
+// 4-stage ring with three stages in flight, fragments by inline-asm ds_read_b128.  A DMA instruction moves
+// 16 rows x 64 B; the 16-byte chunk index is XOR-swizzled by (row >> 2) & 3 on the SOURCE side so the
+// fragment reads of 16 rows x same k-chunk are bank-conflict free.  Row gather on A comes for free (the
+// source address is per lane; the tile's rows are fixed, so the indices are read once before the loop).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT g) {
+    typedef bf16 T;
+    constexpr int BM = 128, BN = 128, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = 4;     // 16 KiB per stage
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    const int num_n = (g.N + BN - 1) / BN;
+    const int num_m = (g.M + BM - 1) / BM;
+    const int b = blockIdx.x;
+    const int grp = b / (8 * num_n), within = b % (8 * num_n);
+    const int m_tile = grp * 8 + (within & 7), n_tile = within >> 3;
+    if (m_tile >= num_m) return;
+    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (m0 >= Mlim) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    // DMA ownership: wave w moves rows 32 w + 16 j + (lane >> 2), j = 0, 1, of both operand tiles;
+    // LDS slot (lane & 3) of a row receives global chunk (lane & 3) ^ ((row >> 2) & 3)
+    const char* asrc[2];
+    const char* bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * wave + 16 * j + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = min(m0 + row, Mlim - 1);
+        const int64_t arow = g.a_rows ? g.a_rows[m] : (int64_t)m;
+        const int n = min(n0 + row, g.N - 1);
+        asrc[j] = (const char*)g.A + arow * g.lda * 2 + ch * 16;
+        bsrc[j] = (const char*)g.B + (int64_t)n * g.ldb * 2 + ch * 16;
+    }
+    if (g.a_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // index loads retired before DMA counting starts
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & (NST - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + (int64_t)kt * ROWB),
+                                             (lds_void_t*)(st + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + (int64_t)kt * ROWB),
+                                             (lds_void_t*)(st + BM * ROWB + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    uint32_t offa[4], offb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + r, rb = wn * 64 + i * 16 + r;
+        offa[i] = (uint32_t)(ra * ROWB + ((q ^ ((ra >> 2) & 3)) << 4));
+        offb[i] = (uint32_t)(BM * ROWB + rb * ROWB + ((q ^ ((rb >> 2) & 3)) << 4));
+    }
+    const int nk = g.K / 32;
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = min(2, nk - 1 - kt);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3);
+        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
+        u32x4 t[8];
+        asm volatile(
+            "ds_read_b128 %0, %8\n\t"
+            "ds_read_b128 %1, %9\n\t"
+            "ds_read_b128 %2, %10\n\t"
+            "ds_read_b128 %3, %11\n\t"
+            "ds_read_b128 %4, %12\n\t"
+            "ds_read_b128 %5, %13\n\t"
+            "ds_read_b128 %6, %14\n\t"
+            "ds_read_b128 %7, %15\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+            : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
+              "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
+            : "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i]), __builtin_bit_cast(bf16x8, t[4 + j]),
+                                                                    acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();       // every wave is done reading the ring before it becomes the staging buffer
+    nt_epilogue<T, BM, BN>(g, acc, smem, m0, n0, Mlim, tid, wm, wn, r, q);
+}
+
+// The LDS-DMA NT kernel measures the same as the register-staged tile kernel on this model's shapes (both are
+// bound by re-reading A for the second N tile), so the simpler kernel stays the default; PMGT_NT_DMA=1 or
+// gemm_nt_disable_dma(0) selects it (tests run both).
+static int g_nt_no_dma = -1;
+void gemm_nt_disable_dma(int on) { g_nt_no_dma = on; }
 
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
@@ -213,6 +332,14 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     constexpr int BM = 128, BN = 128;
     const int num_m = cdiv(g.M, BM), num_n = cdiv(g.N, BN);
     const int grid = cdiv(num_m, 8) * 8 * num_n;
+    if constexpr (sizeof(T) == 2) {
+        if (g_nt_no_dma < 0) { const char* ev = getenv("PMGT_NT_DMA"); g_nt_no_dma = (ev && atoi(ev) == 1) ? 0 : 1; }
+        if (!g_nt_no_dma && g.K % 32 == 0 && g.K >= 64) {
+            hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(grid), dim3(256), 0, st, g);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, st, g);
     PMGT_LAUNCH_OK();
     return 0;
@@ -425,8 +552,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 // ds_read_b64_tr_b16 image is applied to the per-lane SOURCE address (chunk ^ swz(row)); rows / columns
 // outside the matrix read from a zero page.  No row gather (the gather variant stays register-staged).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_rows) {
     constexpr int BKM = 32, ROWB = 256, STAGE = 2 * BKM * ROWB, NST = 4;     // 16 KiB per stage (P + Q)

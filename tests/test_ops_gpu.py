@@ -61,12 +61,15 @@ def test_gemm_nt_plain(dt, M, N, K):
     assert rel_err(Cd, ref) < tol(dt), rel_err(Cd, ref)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_gemm_nt_epilogues_and_gather(dt):
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "bf16-dma"])
+@pytest.mark.parametrize("K", [72, 96, 256])      # bf16-dma: the LDS-DMA variant of the tile kernel (K % 32 == 0)
+def test_gemm_nt_epilogues_and_gather(dt, K):
     _lib, L = _setup()
+    L.pmgt_debug_enable_nt_dma(1 if dt == "bf16-dma" else 0)
+    dt = dt.split("-")[0]
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(5)
-    M, N, K, R = 333, 136, 72, 50
+    M, N, R = 333, 136, 50
     table = torch.randn(R, K, generator=g)
     rows = torch.randint(0, R, (M,), generator=g)
     B = torch.randn(N, K, generator=g) * 0.3
@@ -100,6 +103,7 @@ def test_gemm_nt_epilogues_and_gather(dt):
     ref3 = rounded(A, tdt) @ rounded(B, tdt).T
     assert rel_err(Cd[:100], ref3[:100]) < tol(dt)
     assert bool((Cd[100:].float() == 7.0).all())
+    L.pmgt_debug_enable_nt_dma(0)
 
 
 # ------------------------------------------------------------------------------------------- gemm_tn
