@@ -117,6 +117,22 @@ int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v,
                       const float* mask, int n_seq, int seq_len, void* last_hidden, void* hidden_states,
                       float* attn_probs, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* PMGTModel.forward + backward for a caller that owns the head (second caller of the boundary: PMGT_NCF,
+ * pmgt/pmgt_ncf/models.py:77-105 -- `self.bert(*input_feat_embeds, attention_mask=...)[0][:, 0]` followed by
+ * autograd).  pmgt_encode_train runs the encoder on node ids (ids != NULL, gather fused) or on gathered features
+ * (feat_v/feat_t [n_seq, S, F_m], engine dtype), keeps every activation in `workspace`
+ * (pmgt_workspace_bytes(e, n_seq, S, 1, 1) bytes, untouched until the backward call) and snapshots the dropout
+ * counter; PMGT_FLAG_TRAINING turns dropout on and advances the counter.  pmgt_encode_backward takes
+ * d loss / d last_hidden_state [n_seq, S, d] (engine dtype) and leaves the gradients of every `bert.*` entry in
+ * t->grads (= or += with PMGT_FLAG_ACCUMULATE; pass the same TRAINING flag); the frozen tables get none
+ * (pmgt/pmgt_ncf/models.py:45-47).  feat_v/feat_t are needed again only when the forward used them. */
+int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* feat_v, const void* feat_t,
+                      const float* mask, int n_seq, int seq_len, void* last_hidden, void* workspace,
+                      int64_t workspace_bytes, int flags, void* stream);
+int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t,
+                         const void* d_last_hidden, int n_seq, int seq_len, void* workspace, int64_t workspace_bytes,
+                         int flags, void* stream);
+
 /* Global-norm clip + DenseSparseAdamW dense step over the flat buffers
  * (pmgt/base_trainer.py:312-315, pmgt/optimizers.py:256-270). */
 typedef struct pmgt_adam {

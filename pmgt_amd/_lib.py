@@ -50,7 +50,7 @@ EPI_NONE, EPI_GELU, EPI_GELU_GRAD = 0, 1, 2
 HIP_SYMBOLS = [
     "pmgt_last_error", "pmgt_abi_version", "pmgt_engine_create", "pmgt_engine_destroy", "pmgt_param_count",
     "pmgt_param_num_entries", "pmgt_param_entry", "pmgt_workspace_bytes", "pmgt_pretrain_step", "pmgt_encode_ids",
-    "pmgt_encode_feats", "pmgt_optimizer_step", "pmgt_profile_begin", "pmgt_profile_end", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_op_gemm_nt",
+    "pmgt_encode_feats", "pmgt_encode_train", "pmgt_encode_backward", "pmgt_optimizer_step", "pmgt_profile_begin", "pmgt_profile_end", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_op_gemm_nt",
     "pmgt_op_gemm_tn_slab_elems", "pmgt_op_gemm_tn", "pmgt_op_colsum", "pmgt_op_layernorm_fwd",
     "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd", "pmgt_debug_force_valu_attention", "pmgt_debug_force_tile_gemm", "pmgt_debug_enable_nt_dma", "pmgt_debug_disable_last_layer_shortcut", "pmgt_op_linear",
 ]
@@ -96,6 +96,8 @@ def hip():
     L.pmgt_pretrain_step.argtypes = [vp, C.POINTER(TensorsC), C.POINTER(BatchC), C.POINTER(OutputsC), vp, i64, i, vp]
     L.pmgt_encode_ids.argtypes = [vp, C.POINTER(TensorsC), vp, vp, i, i, vp, vp, vp, vp, i64, vp]
     L.pmgt_encode_feats.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, i, i, vp, vp, vp, vp, i64, vp]
+    L.pmgt_encode_train.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, vp, i, i, vp, vp, i64, i, vp]
+    L.pmgt_encode_backward.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, i, i, vp, i64, i, vp]
     L.pmgt_optimizer_step.argtypes = [vp, C.POINTER(TensorsC), C.POINTER(AdamC), vp]
     L.pmgt_profile_begin.argtypes = [vp]
     L.pmgt_profile_end.argtypes = [vp, C.c_char_p, i]

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     f32x4 a1[NT][NT], a2[NT][NT];
     {
         bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
+        rho[lane] = 0.f;      // rows [16 NT, 64) are never written below but scale the (zero) padding rows of the C-hat tile
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             const int row = 16 * tt + r;
@@ -511,9 +512,10 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
         if (env_nw < 0) { const char* ev = getenv("PMGT_ATTN_BWD_NW"); env_nw = ev ? atoi(ev) : 0; }
         // waves per workgroup: 2 when that raises the LDS-limited wave count per CU (S=32/dh=32: 14.5 KiB per wave ->
         // 5 x 2 waves instead of 2 x 4; measured 476 vs 500 us at 98k (sequence, head) pairs), never 1 (slower)
-        int nw = per * 2 <= 150 * 1024 ? 2 : 1;
-        if ((160 * 1024 / (per * 4)) * 4 >= (160 * 1024 / (per * 2)) * 2) nw = 4;
-        if (env_nw == 1 || env_nw == 2 || env_nw == 4) nw = (per * env_nw <= 150 * 1024) ? env_nw : nw;
+        constexpr size_t LDS = 160 * 1024;
+        int nw = per * 2 <= LDS ? 2 : 1;
+        if (per * 4 <= LDS && (LDS / (per * 4)) * 4 > (LDS / (per * 2)) * 2) nw = 4;
+        if ((env_nw == 1 || env_nw == 2 || env_nw == 4) && per * env_nw <= LDS) nw = env_nw;
         const size_t shmem = per * nw;
         auto kern = attn_bwd_mfma_kernel<DH, NT>;
         if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

@@ -193,6 +193,7 @@ template <typename T> struct LayerBufs {
 };
 
 template <typename T> struct Bufs {
+    int64_t* rng_snap;  // [2] (seed, step) of the forward, replayed by pmgt_encode_backward
     int64_t* ids;      // [Tseq, S] concatenated node ids
     float* mask;       // [Tseq, S]
     T* mirror;
@@ -227,6 +228,7 @@ template <typename T>
 static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, int B, bool training) {
     const int d = e->d, I = e->I, L = e->L, F = e->Fv + e->Ft;
     const int64_t M = (int64_t)Tseq * S;
+    b.rng_snap = c.get<int64_t>(2);
     b.ids = c.get<int64_t>(M);
     b.mask = c.get<float>(M);
     b.mirror = c.get<T>(e->mirror_elems);
@@ -479,13 +481,13 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
 // ---- encoder backward: dcur (in b.bA) = d loss / d h_L; leaves parameter grads in t->grads ----------
 template <typename T>
 static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st,
-                            bool shortcut = false) {
+                            bool shortcut = false, bool train = true, const T* feat_v = nullptr, const T* feat_t = nullptr) {
     const int d = e->d, I = e->I, L = e->L, H = e->H;
     const int M = Tseq * S;
     const float* P = t->params;
     float* G = t->grads;
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
-    const bool dd = pd > 0.f;
+    const bool dd = train && pd > 0.f;
     const DropCfg nodrop = {nullptr, 0.f, 0};
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = e->layers[l];
@@ -505,7 +507,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         T* gbig = sc ? b.c_big : b.big;
         // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
         RUNP("bwd.layernorm", ln_bwd<T>(gA, tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
-                      dropcfg(t, true, pd, l, SITE_FO), st, mdev));
+                      dropcfg(t, train, pd, l, SITE_FO), st, mdev));
         RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln2g, acc, st));   // dgamma | dbeta | db2
         const T* dY2 = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
@@ -524,7 +526,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
         // LN1 backward
         RUNP("bwd.layernorm", ln_bwd<T>(gD, tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
-                      dropcfg(t, true, pd, l, SITE_AO), st, mdev));
+                      dropcfg(t, train, pd, l, SITE_AO), st, mdev));
         RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln1g, acc, st));   // dgamma | dbeta | dbo
         const T* dYo = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
@@ -542,8 +544,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         {
             AttnArgs a;
             a.qkvc = lb.qkvc; a.mask = b.mask; a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
-            a.drop1 = dropcfg(t, true, pa, l, SITE_A1);
-            a.drop2 = dropcfg(t, true, pa, l, SITE_A2);
+            a.drop1 = dropcfg(t, train, pa, l, SITE_A1);
+            a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             a.dctx = b.bD; a.dqkvc = b.big;
             RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
@@ -559,14 +561,14 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     {
         EmbedMix m;
         m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
-        m.stats = b.emb_stats; m.drop = dropcfg(t, true, pd, -1, SITE_EMB);
+        m.stats = b.emb_stats; m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
         m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB; m.part = b.part;
         RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
         RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
         RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
         RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, (const T*)t->table_v, e->Fv, b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
-        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, (const T*)t->table_t, e->Ft, b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
+        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
     }
     return 0;
 }
@@ -674,6 +676,51 @@ static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, con
     return 0;
 }
 
+
+// Training-mode encoder pass for a caller with its own head (PMGT_NCF, pmgt/pmgt_ncf/models.py:77-105): keeps the
+// activations in the workspace and snapshots the dropout counter so encode_backward can replay the masks.
+template <typename T>
+static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* fv, const void* ft,
+                        const float* mask, int Tseq, int S, void* last_hidden, void* ws, int64_t ws_bytes, int flags,
+                        hipStream_t st) {
+    const bool train = flags & PMGT_FLAG_TRAINING;
+    PMGT_CHECK(Tseq > 0 && S > 0, -2, "encode_train: empty input");
+    PMGT_CHECK(mask != nullptr, -2, "encode_train: attention_mask is required (pass ones for None)");
+    PMGT_CHECK((ids != nullptr) != (fv != nullptr && ft != nullptr), -2, "encode_train: pass node ids or both feature tensors");
+    Carver c(ws);
+    Bufs<T> b;
+    carve<T>(e, c, b, Tseq, S, 1, true);
+    PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
+    const int64_t M = (int64_t)Tseq * S;
+    PMGT_HIP(hipMemcpyAsync(b.rng_snap, t->rng_state, 16, hipMemcpyDeviceToDevice, st));
+    if (ids) PMGT_HIP(hipMemcpyAsync(b.ids, ids, M * 8, hipMemcpyDeviceToDevice, st));
+    PMGT_HIP(hipMemcpyAsync(b.mask, mask, M * 4, hipMemcpyDeviceToDevice, st));
+    RUN(build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUN(encoder_forward<T>(e, t, b, Tseq, S, ids ? b.ids : nullptr, (const T*)fv, (const T*)ft, b.mask, train, (T*)nullptr,
+                           (float*)nullptr, st));
+    if (last_hidden)
+        PMGT_HIP(hipMemcpyAsync(last_hidden, b.layer[e->L - 1].hout, (size_t)M * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (train) RUN(advance_rng(t->rng_state, st));
+    return 0;
+}
+
+template <typename T>
+static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv, const void* ft, const void* d_last,
+                           int Tseq, int S, void* ws, int64_t ws_bytes, int flags, hipStream_t st) {
+    const bool train = flags & PMGT_FLAG_TRAINING, acc = flags & PMGT_FLAG_ACCUMULATE;
+    PMGT_CHECK(Tseq > 0 && S > 0 && d_last != nullptr, -2, "encode_backward: empty input");
+    PMGT_CHECK((fv == nullptr) == (ft == nullptr), -2, "encode_backward: pass both feature tensors or neither");
+    Carver c(ws);
+    Bufs<T> b;
+    carve<T>(e, c, b, Tseq, S, 1, true);
+    PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
+    pmgt_tensors tt = *t;
+    tt.rng_state = (uint64_t*)b.rng_snap;          // the forward's (seed, step)
+    PMGT_HIP(hipMemcpyAsync(b.bA, d_last, (size_t)Tseq * S * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
+    RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, (const T*)fv, (const T*)ft));
+    return 0;
+}
+
 }  // namespace pmgt
 
 // ======================================================================================================
@@ -768,6 +815,25 @@ int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v,
     if (e->cfg.dtype == PMGT_DTYPE_BF16)
         return encode<bf16>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
     return encode<float>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* feat_v, const void* feat_t,
+                      const float* mask, int n_seq, int seq_len, void* last_hidden, void* workspace, int64_t workspace_bytes,
+                      int flags, void* stream) {
+    PMGT_CHECK(e && t && workspace && t->params && t->rng_state, -2, "pmgt_encode_train: NULL argument");
+    PMGT_CHECK(!ids || (t->table_v && t->table_t), -2, "pmgt_encode_train: feature tables are not set");
+    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+        return encode_train<bf16>(e, t, ids, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    return encode_train<float>(e, t, ids, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
+}
+
+int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t, const void* d_last_hidden,
+                         int n_seq, int seq_len, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
+    PMGT_CHECK(e && t && workspace && t->params && t->grads, -2, "pmgt_encode_backward: NULL argument");
+    PMGT_CHECK(feat_v || (t->table_v && t->table_t), -2, "pmgt_encode_backward: feature tables are not set");
+    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+        return encode_backward<bf16>(e, t, feat_v, feat_t, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    return encode_backward<float>(e, t, feat_v, feat_t, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 
 int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* a, void* stream) {

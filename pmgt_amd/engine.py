@@ -188,6 +188,40 @@ class Engine:
                                                   _ptr(hs), _ptr(pr), _ptr(ws), ws.numel(), _stream()))
         return last, hs, pr
 
+    # ---- PMGTModel.forward with activations kept for a backward driven by the caller's head ------------------
+    def encode_train(self, ids: Optional[torch.Tensor] = None, feats=None, attention_mask: Optional[torch.Tensor] = None,
+                     training: bool = True):
+        """Returns (last_hidden_state [n_seq, S, d] in the engine dtype, state) — pass `state` to encode_backward."""
+        if ids is not None:
+            n_seq, S = ids.shape
+            ids = ids.to(self.device).contiguous()
+            fv = ft = None
+        else:
+            n_seq, S = feats[0].shape[:2]
+            fv = feats[0].to(self.device, self.torch_dtype).contiguous()
+            ft = feats[1].to(self.device, self.torch_dtype).contiguous()
+        m = torch.ones(n_seq, S, dtype=torch.float32, device=self.device) if attention_mask is None else \
+            attention_mask.to(self.device, torch.float32).contiguous()
+        nbytes = int(self.lib.pmgt_workspace_bytes(self.h, n_seq, S, 1, 1))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)      # owned by this call's state, not the shared cache
+        last = torch.empty(n_seq, S, self.config.hidden_size, dtype=self.torch_dtype, device=self.device)
+        tc = self._tensors()
+        flags = _lib.FLAG_TRAINING if training else 0
+        _lib.check(self.lib.pmgt_encode_train(self.h, C.byref(tc), _ptr(ids), _ptr(fv), _ptr(ft), _ptr(m), n_seq, S, _ptr(last),
+                                              _ptr(ws), nbytes, flags, _stream()))
+        return last, dict(ws=ws, fv=fv, ft=ft, n_seq=n_seq, S=S, flags=flags)
+
+    def encode_backward(self, state: dict, d_last: torch.Tensor, accumulate: bool = False,
+                        grad_buffer: Optional[torch.Tensor] = None):
+        """d loss / d last_hidden_state -> gradients of the `bert.*` entries in self.grads (or grad_buffer)."""
+        d_last = d_last.to(self.device, self.torch_dtype).contiguous()
+        assert tuple(d_last.shape) == (state["n_seq"], state["S"], self.config.hidden_size)
+        tc = self._tensors(grad_buffer)
+        flags = state["flags"] | (_lib.FLAG_ACCUMULATE if accumulate else 0)
+        ws = state["ws"]
+        _lib.check(self.lib.pmgt_encode_backward(self.h, C.byref(tc), _ptr(state["fv"]), _ptr(state["ft"]), _ptr(d_last),
+                                                 state["n_seq"], state["S"], _ptr(ws), ws.numel(), flags, _stream()))
+
     # ---- clip + AdamW ----------------------------------------------------------------------------------
     def optimizer_step(self, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
         if self.exp_avg is None:

@@ -85,6 +85,30 @@ class PMGTPretrainedModel(nn.Module):
                     p.normal_(mean=0.0, std=std)
 
 
+class _EncoderFn(torch.autograd.Function):
+    """Autograd bridge for callers that put their own head on the encoder output (PMGT_NCF,
+    pmgt/pmgt_ncf/models.py:86-89): forward keeps the activations on the device, backward turns
+    d loss / d last_hidden_state into the `bert.*` parameter gradients with the HIP backward kernels."""
+
+    @staticmethod
+    def forward(ctx, engine, ids, feats, mask, training, names, *params):
+        last, state = engine.encode_train(ids=ids, feats=feats, attention_mask=mask, training=training)
+        ctx.engine, ctx.state, ctx.names = engine, state, names
+        return last.float()
+
+    @staticmethod
+    def backward(ctx, d_last):
+        eng = ctx.engine
+        scratch = torch.empty_like(eng.params)
+        eng.encode_backward(ctx.state, d_last, grad_buffer=scratch)
+        ctx.state = None
+        views = []
+        for n in ctx.names:
+            e = eng.entry(n)
+            views.append(scratch[e["offset"]: e["offset"] + e["numel"]].view(*e["shape"]).clone())
+        return (None, None, None, None, None, None, *views)
+
+
 class PMGTModel(PMGTPretrainedModel):
     """Encoder with the reference call signature.  `forward(*input_feat_embeds, attention_mask=...)` takes
     already-gathered features [T, S, F_m] (the compatible, materialised-input entry); the fused
@@ -119,6 +143,9 @@ class PMGTModel(PMGTPretrainedModel):
         output_attentions = output_attentions if output_attentions is not None else cfg.output_attentions
         output_hidden_states = output_hidden_states if output_hidden_states is not None else cfg.output_hidden_states
         return_dict = return_dict if return_dict is not None else cfg.use_return_dict
+        if self._wants_grad() and not (output_attentions or output_hidden_states):
+            last = self._with_grad(None, list(input_feat_embeds), attention_mask)
+            return self._wrap(last, None, None, return_dict)
         last, hs, pr = self.engine.encode(feats=list(input_feat_embeds), attention_mask=attention_mask,
                                           output_hidden_states=output_hidden_states, output_attentions=output_attentions)
         return self._wrap(last, hs, pr, return_dict)
@@ -126,9 +153,20 @@ class PMGTModel(PMGTPretrainedModel):
     def encode_ids(self, node_ids, attention_mask=None, output_attentions=False, output_hidden_states=False,
                    return_dict=True):
         """Same as forward() but on node ids: the feature gather is fused into the projection GEMM."""
+        if self._wants_grad() and not (output_attentions or output_hidden_states):
+            last = self._with_grad(node_ids, None, attention_mask)
+            return self._wrap(last, None, None, return_dict)
         last, hs, pr = self.engine.encode(ids=node_ids, attention_mask=attention_mask,
                                           output_hidden_states=output_hidden_states, output_attentions=output_attentions)
         return self._wrap(last, hs, pr, return_dict)
+
+    def _wants_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _with_grad(self, ids, feats, mask):
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        names = ["bert." + n for n, _ in named]
+        return _EncoderFn.apply(self.engine, ids, feats, mask, self.training, names, *[p for _, p in named])
 
     @staticmethod
     def _wrap(last, hs, pr, return_dict):

@@ -268,8 +268,58 @@ def make_model():
     np.savez_compressed(os.path.join(HERE, "init_stats.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+# G8: PMGT_NCF — the encoder boundary driven by a second caller (pmgt/pmgt_ncf/models.py:15-105)
+# ------------------------------------------------------------------------------------------
+def make_ncf():
+    from pmgt.pmgt.datasets import get_input_tensor
+    from pmgt.pmgt_ncf.models import PMGT_NCF
+    from tests import golden_util as gu
+
+    for name, (gname, cfgkw, S, B, users, factor, nl, mdl, sseed, pseed, hseed) in gu.NCF_CASES.items():
+        n, edges, w, g = graph(gname)
+        cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfgkw)
+        tables = po.synth_tables(n, cfg["feat_hidden_sizes"], 77)
+        model = PMGT_NCF(user_num=users, item_num=n, factor_num=factor, num_layers=nl, model=mdl, config=PMGTConfig(**cfg))
+        sd = model.state_dict()
+        for k, v in po.synth_params(cfg, pseed).items():
+            if k.startswith("bert."):
+                sd[k].copy_(v)
+        head = gu.ncf_head_params(users, n, factor, nl, mdl, hseed)
+        assert [k for k, p in model.named_parameters() if p.requires_grad and not k.startswith("bert.")] == list(head), "head order"
+        for k, v in head.items():
+            sd[k].copy_(v)
+        for i, t in enumerate(tables):
+            sd[f"feat_embeddings.{i}.weight"].copy_(t)
+        np.random.seed(sseed)
+        rs = np.random.RandomState(sseed + 50)
+        items = rs.choice(n, B, replace=False)
+        pairs = [get_input_tensor(g, int(i) + 2, [16, 8, 4], S - 1) for i in items]
+        item = {"node_ids": torch.stack([p[0] for p in pairs]), "attention_mask": torch.stack([p[1] for p in pairs])}
+        user = torch.from_numpy(rs.randint(0, users, B).astype(np.int64))
+        labels = torch.from_numpy((rs.random_sample(B) < 0.5).astype(np.float32))
+        out = {"item_ids": t2n(item["node_ids"]), "item_mask": t2n(item["attention_mask"]), "user": t2n(user), "labels": t2n(labels)}
+        model.train()                      # dropout probabilities are 0: train == eval numerically
+        model.zero_grad()
+        logits = model(user, item)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels)
+        loss.backward()
+        out["logits"], out["loss"] = t2n(logits), t2n(loss)
+        for nme, p in model.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None, nme
+                store(out, "grad/" + nme, t2n(p.grad))
+        assert all(p.grad is None for p in model.feat_embeddings.parameters())       # frozen tables (models.py:45-47)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        print("ncf", name, "loss", float(loss))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ncf":
+        make_ncf()
+        sys.exit(0)
     make_sampler()
     make_model()
+    make_ncf()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

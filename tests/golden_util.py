@@ -69,3 +69,46 @@ def check_stored(gold, key, arr, rtol, atol):
     else:
         np.testing.assert_allclose(a.ravel()[::STRIDE], gold[key + "@strided"], rtol=rtol, atol=atol, err_msg=key)
         np.testing.assert_allclose(np.sqrt((a ** 2).sum()), float(gold[key + "@norm"]), rtol=max(rtol, 1e-5), err_msg=key)
+
+
+# ---- second caller of the encoder boundary: PMGT_NCF (pmgt/pmgt_ncf/models.py:15-105) ------------------------
+NCF_CASES = {
+    # name: (graph, cfg kwargs, S, B, users, factor_num, num_layers, model, sampler seed, param seed, head seed)
+    "ncf_mlp": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5),
+                16, 6, 9, 16, 3, "MLP", 5, 21, 31),
+    "ncf_neumf": ("C", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, beta=0.5),
+                  16, 8, 13, 32, 3, "NeuMF-end", 6, 22, 32),
+}
+
+
+def ncf_head_shapes(user_num, item_num, factor_num, num_layers, model):
+    """Names/shapes of the NCF head parameters in the reference's named_parameters() order."""
+    shapes = [("mlp_user_embeddings.weight", (user_num, factor_num * 2 ** (num_layers - 1)))]
+    for i in range(num_layers):
+        n_in = factor_num * 2 ** (num_layers - i)
+        shapes += [(f"mlp_layers.{i}.linear.weight", (n_in // 2, n_in)), (f"mlp_layers.{i}.linear.bias", (n_in // 2,))]
+    if model == "NeuMF-end":
+        shapes += [("gmf_user_embeddings.weight", (user_num, factor_num)), ("gmf_item_embeddings.weight", (item_num, factor_num)),
+                   ("predict_layer.weight", (1, 2 * factor_num)), ("predict_layer.bias", (1,))]
+    else:
+        shapes += [("predict_layer.weight", (1, factor_num)), ("predict_layer.bias", (1,))]
+    return shapes
+
+
+def ncf_head_params(user_num, item_num, factor_num, num_layers, model, seed):
+    rs = np.random.RandomState(seed)
+    return {k: torch.from_numpy((rs.standard_normal(shp) * (0.02 if k.endswith("bias") else 0.1)).astype(np.float32))
+            for k, shp in ncf_head_shapes(user_num, item_num, factor_num, num_layers, model)}
+
+
+def ncf_case(name, dtype=torch.float32):
+    gname, cfgkw, S, B, users, factor, nl, model, sseed, pseed, hseed = NCF_CASES[name]
+    gold = load(name)
+    n = GRAPHS[gname]["n"]
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfgkw)
+    params = {k: v for k, v in po.synth_params(cfg, pseed, dtype).items() if k.startswith("bert.")}
+    tables = po.synth_tables(n, cfg["feat_hidden_sizes"], 77, dtype)
+    head = ncf_head_params(users, n, factor, nl, model, hseed)
+    item = {"node_ids": torch.from_numpy(gold["item_ids"]), "attention_mask": torch.from_numpy(gold["item_mask"])}
+    return dict(cfg=cfg, params=params, tables=tables, head=head, n_nodes=n, gold=gold, user=torch.from_numpy(gold["user"]),
+                item=item, labels=torch.from_numpy(gold["labels"]), users=users, factor=factor, num_layers=nl, model=model)

@@ -109,3 +109,22 @@ def test_oracle_optimizer_curve(name):
         po.adamw_step(p, grads, state, lr=1e-3, wd=1e-2)
     for k, v in p.items():
         gu.check_stored(gold, "final/" + k, v.numpy(), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("name", list(gu.NCF_CASES))
+def test_ncf_second_caller_matches_reference(name):
+    """PMGT_NCF (pmgt/pmgt_ncf/models.py) logits, BCE loss and every gradient — encoder and head — of the
+    restatement equal the reference's; the frozen tables receive no gradient."""
+    c = gu.ncf_case(name)
+    gold = c["gold"]
+    p = {k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+    head = {k: v.clone().requires_grad_(True) for k, v in c["head"].items()}
+    logits = po.ncf_forward(p, head, c["cfg"], c["tables"], c["user"], c["item"], c["num_layers"], c["model"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, c["labels"])
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), gold["logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), gold["loss"], rtol=1e-6)
+    for k, v in list(p.items()) + list(head.items()):
+        g = v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)
+        scale = float(np.sqrt((g.astype(np.float64) ** 2).mean())) + 1e-12
+        gu.check_stored(gold, "grad/" + k, g, 2e-4, 2e-4 * scale + 1e-9)       # key.bias grads are exactly 0 in theory

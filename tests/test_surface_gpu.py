@@ -53,7 +53,8 @@ def test_forward_outputs_index_like_the_reference():
     assert tup[3] is None and torch.equal(tup[2], out.last_hidden_state)
     inf = model(batch[0])                                       # inference: loss None -> [0] is last_hidden_state
     assert inf.loss is None
-    np.testing.assert_allclose(inf[0][:, 0].cpu().numpy(), gold["inf_cls"], rtol=1e-4, atol=1e-4)
+    assert inf[0].requires_grad                                 # like the reference: autograd reaches the encoder weights
+    np.testing.assert_allclose(inf[0][:, 0].detach().cpu().numpy(), gold["inf_cls"], rtol=1e-4, atol=1e-4)
     full = model(*batch, output_attentions=True, output_hidden_states=True)
     assert len(full.hidden_states) == 3 and len(full.attentions) == 2
     np.testing.assert_allclose(full.attentions[1].cpu().numpy(), gold["eval_attn_1"], rtol=1e-4, atol=1e-6)
@@ -62,7 +63,7 @@ def test_forward_outputs_index_like_the_reference():
     # PMGTModel.forward(*input_feat_embeds): the materialised-input entry of the reference
     feats = po.gather_feats(batch[0]["node_ids"], case["tables"])
     enc = model.bert(*feats, attention_mask=batch[0]["attention_mask"])
-    np.testing.assert_allclose(enc[0].cpu().numpy(), gold["eval_last_hidden"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(enc[0].detach().cpu().numpy(), gold["eval_last_hidden"], rtol=1e-4, atol=1e-4)
     assert model.bert(*feats, return_dict=False)[1] is None
 
 
@@ -125,3 +126,72 @@ def test_trainer_eval_export_and_live_pipeline():
     assert 0.0 <= ev["val/auc"] <= 1.0 and np.isfinite(ev["loss/val"])
     emb = export_embeddings(eng, smp, n, batch_size=256, threads=4)
     assert emb.shape == (n, 64) and emb.dtype == np.float32 and np.isfinite(emb).all()
+
+
+@pytest.mark.parametrize("name", list(gu.NCF_CASES))
+def test_ncf_second_caller_on_hip_encoder(name):
+    """PMGT_NCF with the item tower on the HIP engine (pmgt_encode_train / pmgt_encode_backward through autograd):
+    logits, loss, encoder gradients and head gradients equal the reference's (tests/golden/ncf_*.npz)."""
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.pmgt_ncf import PMGT_NCF
+    c = gu.ncf_case(name)
+    gold = c["gold"]
+    model = PMGT_NCF(user_num=c["users"], item_num=c["n_nodes"], factor_num=c["factor"], num_layers=c["num_layers"],
+                     model=c["model"], config=PMGTConfig(**c["cfg"]), dtype="fp32")
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in list(c["params"].items()) + list(c["head"].items()):
+            sd[k].copy_(v)
+    model.set_features([t.numpy() for t in c["tables"]])
+    model.train()
+    logits = model(c["user"], c["item"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, c["labels"].cuda())
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), gold["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.item(), gold["loss"], rtol=1e-4)
+    bad = []
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, k                   # frozen feature tables
+            continue
+        g = p.grad.cpu().numpy().astype(np.float64)
+        scale = float(np.sqrt((g ** 2).mean()))
+        try:
+            gu.check_stored(gold, "grad/" + k, g, 2e-3, 2e-3 * scale + 1e-8)
+        except AssertionError as e:
+            bad.append((k, str(e).splitlines()[3:6]))
+    assert not bad, bad
+    # eval-mode call without autograd goes through the plain inference entry and gives the same logits (dropout is 0)
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(c["user"], c["item"]).cpu().numpy(), gold["logits"], rtol=1e-4, atol=1e-5)
+
+
+def test_encoder_backward_on_materialised_features_matches_oracle():
+    """PMGTModel.forward(*input_feat_embeds) with autograd (the reference's own call form, pmgt_ncf/models.py:83-89)
+    against torch autograd through the CPU oracle: arbitrary upstream gradient on the whole last_hidden_state."""
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.modeling_pmgt import PMGTModel
+    case = gu.model_case("m2")
+    cfg = case["cfg"]
+    model = PMGTModel(PMGTConfig(**cfg), dtype="fp32")
+    with torch.no_grad():
+        sd = model.state_dict()
+        for k, v in case["params"].items():
+            if k.startswith("bert."):
+                sd[k[5:]].copy_(v)
+    tgt = case["batch"][1]
+    feats = po.gather_feats(tgt["node_ids"], case["tables"])
+    w = torch.from_numpy(np.random.RandomState(3).standard_normal(tuple(tgt["node_ids"].shape) + (cfg["hidden_size"],)).astype(np.float32))
+    out = model(*[f.cuda() for f in feats], attention_mask=tgt["attention_mask"].cuda())[0]
+    (out * w.cuda()).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items() if k.startswith("bert.")}
+    ref = po.encoder_fwd(p, cfg, feats, tgt["attention_mask"])[0]
+    (ref * w).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    grms = max(float(v.grad.double().pow(2).mean().sqrt()) for v in p.values())
+    for k, v in model.named_parameters():
+        a, b = v.grad.cpu().numpy(), p["bert." + k].grad.numpy()
+        scale = float(np.sqrt((b.astype(np.float64) ** 2).mean()))
+        # key.bias gradients are exactly 0 in theory (softmax shift invariance): absolute floor from the global scale
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * scale + 1e-5 * grms, err_msg=k)
