@@ -79,6 +79,19 @@ struct pmgt_engine {
     int mirror_tiles = 0;
     const void* zeros = nullptr;      // device zero page (padding source of the LDS-DMA kernels)
     pmgt::Profiler prof;
+    // Weight-gradient GEMMs are leaves of the backward graph: optionally they run on a second stream next to the
+    // dgrad chain (fork/join with events).  Opt-in: PMGT_OVERLAP=1 or pmgt_engine_set_overlap.
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> sync_ev;
+    size_t sync_next = 0;
+    bool overlap = false;     // measured: no gain (15.40 vs 15.32 ms/step at B=1024) -- both streams share one HBM-bound pool
+    hipEvent_t next_sync() {
+        if (sync_ev.empty()) {
+            sync_ev.resize(64);
+            for (auto& ev : sync_ev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        }
+        return sync_ev[sync_next++ % sync_ev.size()];
+    }
 };
 
 namespace pmgt {
@@ -203,6 +216,7 @@ template <typename T> struct Bufs {
     // backward temporaries
     T *bA, *bB, *bC, *bD, *big;
     float *slab, *part;     // gemm_tn slabs; LN / embed / colsum partials
+    float* part_side;       // bias partials of the wgrad kernels (their own buffer: they run on the side stream)
     float* possum;
     // losses
     int* off;
@@ -282,6 +296,7 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     part = std::max(part, colsum_slab_elems(cap, F));
     part = std::max(part, (int64_t)512 * std::max(std::max(I, 4 * d), F));     // wgrad bias slabs [splits <= 512][N1]
     b.part = c.get<float>(part);
+    b.part_side = c.get<float>((int64_t)512 * std::max(std::max(I, 4 * d), F));
     b.possum = c.get<float>((int64_t)S * d);
     b.sse_part = c.get<float>((int64_t)nfr_diff_parts(cap) * 2);
     b.nfr_masked = c.get<int64_t>((int64_t)B * S);
@@ -462,19 +477,49 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     return 0;
 }
 
-// wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs
+// wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs.  With overlap on, the two launches go to the side
+// stream behind an event recorded on `main` (their inputs are ready there); *done receives the event the caller
+// must wait on (join_side) before a main-stream kernel overwrites P or Q.
 template <typename T>
 static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
-                 int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t st,
-                 float* bias_dst = nullptr) {
+                 int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t main,
+                 float* bias_dst = nullptr, hipEvent_t* done = nullptr) {
+    pmgt_engine* em = const_cast<pmgt_engine*>(e);
+    const bool fork = em->overlap && em->side != nullptr;
+    hipStream_t st = fork ? em->side : main;
+    if (fork) {
+        hipEvent_t ev = em->next_sync();
+        PMGT_HIP(hipEventRecord(ev, main));
+        PMGT_HIP(hipStreamWaitEvent(st, ev, 0));
+    }
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
     g.slab = b.slab; g.m_dev = m_dev; g.zeros = e->zeros;
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
-    g.bias_slab = bias_dst ? b.part : nullptr;          // [splits][N1] (fits: part >= 64 * max N1)
+    g.bias_slab = bias_dst ? b.part_side : nullptr;          // [splits <= 512][N1]
     RUNP(name, gemm_tn<T>(g, st));
     RUNP("bwd.slab_reduce", slab_reduce(b.slab, g.splits, (int64_t)N1 * N2, dst, acc, st));
-    if (bias_dst) RUNP("bwd.slab_reduce", slab_reduce(b.part, g.splits, N1, bias_dst, acc, st));
+    if (bias_dst) RUNP("bwd.slab_reduce", slab_reduce(b.part_side, g.splits, N1, bias_dst, acc, st));
+    if (done) *done = nullptr;
+    if (fork) {
+        hipEvent_t ev = em->next_sync();
+        PMGT_HIP(hipEventRecord(ev, st));
+        if (done) *done = ev;
+    }
+    return 0;
+}
+static inline int join_side(hipStream_t main, hipEvent_t& ev) {
+    if (ev) PMGT_HIP(hipStreamWaitEvent(main, ev, 0));
+    ev = nullptr;
+    return 0;
+}
+// everything queued on the side stream so far is ordered before what `main` launches next
+static inline int join_side_all(const pmgt_engine* e, hipStream_t main) {
+    pmgt_engine* em = const_cast<pmgt_engine*>(e);
+    if (!(em->overlap && em->side)) return 0;
+    hipEvent_t ev = em->next_sync();
+    PMGT_HIP(hipEventRecord(ev, em->side));
+    PMGT_HIP(hipStreamWaitEvent(main, ev, 0));
     return 0;
 }
 
@@ -489,6 +534,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
     const bool dd = train && pd > 0.f;
     const DropCfg nodrop = {nullptr, 0.f, 0};
+    // completion events of the side-stream wgrads whose inputs are about to be overwritten on the main stream
+    hipEvent_t w_ffn2 = nullptr, w_ffn1 = nullptr, w_ao = nullptr, w_qkvc = nullptr;
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = e->layers[l];
         LayerBufs<T>& lb = b.layer[l];
@@ -506,18 +553,20 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         T* gD = sc ? b.c_bD : b.bD;
         T* gbig = sc ? b.c_big : b.big;
         // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
+        RUN(join_side(st, w_ao));          // previous layer's attn-out wgrad still reads bB / bC
         RUNP("bwd.layernorm", ln_bwd<T>(gA, tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
                       dropcfg(t, train, pd, l, SITE_FO), st, mdev));
         RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln2g, acc, st));   // dgamma | dbeta | db2
         const T* dY2 = dd ? gC : gB;
-        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
+        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st, nullptr, &w_ffn2));
+        RUN(join_side(st, w_qkvc));        // previous layer's qkvc wgrad still reads `big`
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
             GemmWS g;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = gbig; g.ldc = I; g.m_dev = mdev;
             g.M = Mt; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1));
+        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1, &w_ffn1));
         {   // du = dff W1 + residual branch
             GemmWS g;
             g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gD; g.ldc = d; g.m_dev = mdev;
@@ -525,16 +574,18 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
         }
         // LN1 backward
+        RUN(join_side(st, w_ffn2));        // reads gB / gC, rewritten here
         RUNP("bwd.layernorm", ln_bwd<T>(gD, tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
                       dropcfg(t, train, pd, l, SITE_AO), st, mdev));
         RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln1g, acc, st));   // dgamma | dbeta | dbo
         const T* dYo = dd ? gC : gB;
-        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
+        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st, nullptr, &w_ao));
         {   // dctx = dYo Wo
             GemmWS g;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = gD; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.m_dev = mdev;
             RUN(linear<T>(e, "bwd.dgrad_attn_out", g, st));
         }
+        RUN(join_side(st, w_ffn1));        // reads gbig (== b.big unless compacted), rewritten by the attention backward
         if (sc) {   // back to the full token layout: zero everywhere except the compacted rows
             PMGT_HIP(hipMemsetAsync(b.bD, 0, (size_t)M * d * sizeof(T), st));
             PMGT_HIP(hipMemsetAsync(b.bB, 0, (size_t)M * d * sizeof(T), st));
@@ -549,7 +600,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.dctx = b.bD; a.dqkvc = b.big;
             RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc));
+        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc, &w_qkvc));
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + o.mWqkvcT; g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
@@ -558,6 +609,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
     }
     // embeddings
+    RUN(join_side(st, w_ao));
+    RUN(join_side(st, w_qkvc));            // embed_mix_bwd rewrites big and bB
     {
         EmbedMix m;
         m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
@@ -570,6 +623,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
         RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
     }
+    RUN(join_side_all(e, st));             // the caller's stream sees every gradient
     return 0;
 }
 
@@ -751,6 +805,11 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
     build_layout(e);
     e->zeros = zero_page();
+    {
+        const char* ev = getenv("PMGT_OVERLAP");
+        e->overlap = ev && atoi(ev) == 1;
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
+    }
     if (!e->desc.empty()) {
         if (hipMalloc((void**)&e->desc_dev, e->desc.size() * sizeof(MirrorDesc)) != hipSuccess ||
             hipMemcpy(e->desc_dev, e->desc.data(), e->desc.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice) != hipSuccess) {
@@ -765,6 +824,8 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
 void pmgt_engine_destroy(pmgt_engine* e) {
     if (!e) return;
     if (e->desc_dev) (void)hipFree(e->desc_dev);
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    for (auto ev : e->sync_ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -953,6 +1014,7 @@ void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
 void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); }
 void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
+void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,

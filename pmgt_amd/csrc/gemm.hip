@@ -553,9 +553,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 // outside the matrix read from a zero page.  No row gather (the gather variant stays register-staged).
 // ------------------------------------------------------------------------------------------------
 
+// GATHER = true: rows of Q come through g.q_rows (the feature tables of the feature-projection wgrad).  The 32 row
+// indices of a stage are themselves fetched by LDS-DMA (one 4-byte-per-lane instruction, issued six stages ahead
+// by every wave into the same 256-byte slot of an 8-slot ring) and read back next to the fragments, three stages
+// before the data DMA that needs them: no register-destination load ever enters the counted vmcnt sequence.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_rows) {
     constexpr int BKM = 32, ROWB = 256, STAGE = 2 * BKM * ROWB, NST = 4;     // 16 KiB per stage (P + Q)
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    constexpr int IDX_SLOTS = 8, IDX_BYTES = BKM * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];              // NST * STAGE (+ IDX_SLOTS * IDX_BYTES)
     const int tn1 = (g.N1 + 127) / 128, tn2 = (g.N2 + 127) / 128, tiles = tn1 * tn2;
     const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
     const int tile = bidx % tiles, split = xcd + 8 * (bidx / tiles);
@@ -580,7 +586,9 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
     // this lane's part of a stage: rows 8 wave + 4 j + (lane >> 4), j = 0, 1; LDS chunk slot lane & 15 holds
     // global chunk (lane & 15) ^ swz(row)
     const char* zero = (const char*)g.zeros;
-    auto issue = [&](int kt) {
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    char* idx_ring = smem + NST * STAGE;
+    auto issue = [&](int kt, uint32_t q0, uint32_t q1) {
         const int mb = mbeg + kt * BKM;
         char* st = smem + (kt & (NST - 1)) * STAGE;
 #pragma unroll
@@ -589,19 +597,43 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
             const int ch = (lane & 15) ^ (tn_f(row) << 1);
             const int m = mb + row;
             const int cp = n1_0 + ch * 8, cq = n2_0 + ch * 8;
+            const int64_t qrow = GATHER ? (int64_t)(j == 0 ? q0 : q1) : (int64_t)m;
             const char* sp = (m < mend && cp < g.N1) ? (const char*)g.P + ((int64_t)m * g.ldp + cp) * 2 : zero;
-            const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + ((int64_t)m * g.ldq + cq) * 2 : zero;
+            const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + (qrow * g.ldq + cq) * 2 : zero;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (8 * wave + 4 * j) * ROWB), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (8 * wave + 4 * j) * ROWB), 16, 0, 0);
         }
     };
+    // index DMA of stage kt: lane l fetches dword l of q_rows[mb .. mb + 32) (clamped inside the array)
+    auto issue_idx = [&](int kt) {
+        const int64_t m = min((int64_t)mbeg + (int64_t)kt * BKM + (lane >> 1), (int64_t)g.M - 1);
+        const char* src = (const char*)(g.q_rows + m) + 4 * (lane & 1);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(idx_ring + (kt & (IDX_SLOTS - 1)) * IDX_BYTES), 4, 0, 0);
+    };
+    const uint32_t idx_off = (uint32_t)((8 * wave + (lane >> 4)) * 8);      // row of j = 0; j = 1 is 4 rows (32 B) further
 
     const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+    if constexpr (GATHER) {
+        if (nk > 0) {
+#pragma unroll
+            for (int kt = 0; kt < 6; ++kt) issue_idx(kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                uint32_t q0, q1;
+                const uint32_t ia = lds_base + (uint32_t)(NST * STAGE + kt * IDX_BYTES) + idx_off;
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1) : "v"(ia) : "memory");
+                if (kt < nk) issue(kt, q0, q1);
+            }
+        }
+    } else {
+        if (nk > 0) issue(0, 0, 0);
+        if (nk > 1) issue(1, 0, 0);
+        if (nk > 2) issue(2, 0, 0);
+    }
     // per-lane byte offsets of the 4 + 4 fragment reads inside a stage (row = 8 q + (r >> 2); +4 rows = +1024 B)
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
     uint32_t offa[4], offb[4];
     {
         const int row = 8 * q + (r >> 2);
@@ -614,13 +646,30 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
         }
     }
     for (int kt = 0; kt < nk; ++kt) {
-        // 4 DMA instructions per wave per stage; leave the younger stages in flight
+        // 4 DMA instructions per wave per stage; leave the younger stages in flight.  GATHER adds one index DMA per
+        // iteration (issued before the data DMAs of that iteration, for every kt, also past the end: clamped reads):
+        // younger-than-D(kt) operations = 4 * younger stages + the index DMAs of the last min(kt, 2) iterations.
         const int younger = min(2, nk - 1 - kt);
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (GATHER) {
+            switch (4 * younger + min(kt, 2)) {
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3);
+        if constexpr (GATHER) issue_idx(kt + 6);
+        else { if (kt + 3 < nk) issue(kt + 3, 0, 0); }
         // The fragment reads are inline asm on purpose: the compiler treats an in-flight LDS-DMA as a pending
         // store to LDS and would put s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring.
         // Ordering is ours: the counted vmcnt + s_barrier above retire stage kt; reads and their lgkmcnt(0) wait
@@ -650,6 +699,13 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
             : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
               "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
             : "memory");
+        if constexpr (GATHER) {     // row indices of stage kt + 3 (their DMA retired with the wait above), then its data DMAs
+            uint32_t q0, q1;
+            const uint32_t ia = lds_base + (uint32_t)(NST * STAGE + ((kt + 3) & (IDX_SLOTS - 1)) * IDX_BYTES) + idx_off;
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1) : "v"(ia) : "memory");
+            if (kt + 3 < nk) issue(kt + 3, q0, q1);
+        }
         bf16x8 fa[4], fb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -669,6 +725,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
         }
     }
 
+    if constexpr (GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // trailing index DMAs must land before the LDS is released
     if (do_bias && r == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -717,8 +774,20 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);
     dim3 grid(8 * tiles * cdiv(g.splits, 8));
     if constexpr (sizeof(T) == 2) {
-        if (!g_tn_no_dma && g.q_rows == nullptr && g.zeros != nullptr) {
-            hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(256), 0, st, g, chunk);
+        if (!g_tn_no_dma && g.zeros != nullptr) {
+            constexpr size_t ring = 4 * 2 * 32 * 256;
+            if (g.q_rows == nullptr) {
+                hipLaunchKernelGGL(gemm_tn_dma_kernel<false>, grid, dim3(256), ring, st, g, chunk);
+            } else {
+                PMGT_CHECK(g.M >= 1, -2, "gemm_tn: gather needs at least one row");
+                constexpr size_t smem = ring + 8 * 32 * 8;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(gemm_tn_dma_kernel<true>, grid, dim3(256), smem, st, g, chunk);
+            }
             PMGT_LAUNCH_OK();
             return 0;
         }

@@ -80,6 +80,22 @@ def tn(M, N1, N2, name=""):
           f"regstage {out[1][0]:.1f}us ({byts / out[1][0] / 1e6:.2f} TB/s)")
 
 
+def tn_gather(M, N1, N2, R, name=""):
+    Pm = torch.randn(M, 2 * N1, device="cuda").bfloat16()
+    table = torch.randn(R, N2, device="cuda").bfloat16()
+    rows = torch.randint(0, R, (M,), device="cuda")
+    slab = torch.empty(L.pmgt_op_gemm_tn_slab_elems(1, M, N1, N2), device="cuda")
+    o = torch.empty(N1, N2, device="cuda")
+    out = {}
+    for mode in (0, 1):
+        L.pmgt_debug_force_tile_gemm(mode)
+        f = lambda: _lib.check(L.pmgt_op_gemm_tn(1, P(Pm), 2 * N1, P(table), N2, P(rows), M, N1, N2, P(slab), P(o), 0, None, st()))
+        out[mode] = timeit(f)
+    L.pmgt_debug_force_tile_gemm(0)
+    print(f"TN-gather {name} M={M} N1={N1} N2={N2}: dma {out[0][0]:.1f}us ({2 * M * N1 * N2 / out[0][0] / 1e6:.0f} TF/s) | "
+          f"regstage {out[1][0]:.1f}us ({2 * M * N1 * N2 / out[1][0] / 1e6:.0f} TF/s)")
+
+
 def attn(T, S, H, dh, name=""):
     d = H * dh
     x = torch.randn(T, S, 4 * d, device="cuda").bfloat16()
@@ -108,3 +124,5 @@ if __name__ == "__main__":
     linear(M, 256, 256, name="dgrad_dxd")
     tn(M, 1024, 256, name="wgrad_qkvc")
     tn(M, 256, 256, name="wgrad_dxd")
+    tn_gather(M, 256, 1536, 7254, name="wgrad_featproj_v")
+    tn_gather(M, 256, 768, 7254, name="wgrad_featproj_t")
