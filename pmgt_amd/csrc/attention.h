@@ -19,7 +19,24 @@ struct AttnArgs {
 bool attn_mfma_supported(const AttnArgs& a);
 int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st);
 void attn_force_valu(int on);   // debugging / A-B: route bf16 through the generic VALU kernel
+bool attn_valu_forced();
 template <typename T> int attn_fwd(const AttnArgs& a, hipStream_t st);
 template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
+
+
+// Fused Q|K|V|C projection + attention forward (qkvc_attn.hip): bf16, S = 32, head size 32, hidden 256 or 128.
+struct QkvcAttn {
+    const void* X = nullptr; int64_t ldx = 0;     // [Tseq*32, d] layer input
+    const void* W = nullptr; int64_t ldw = 0;     // [4d, d]: rows q | k | v | c (nn.Linear layout)
+    const float* bias = nullptr;                  // [4d]
+    void* qkvc = nullptr; int64_t ldq = 0;        // [Tseq*32, 4d] out (kept for the backward pass)
+    void* ctx = nullptr; int64_t ldc = 0;         // [Tseq*32, d] out
+    const float* mask = nullptr;                  // [Tseq, 32] or NULL
+    int Tseq = 0, S = 0, H = 0, dh = 0;
+    float beta = 0.5f;
+    DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
+};
+bool qkvc_attn_supported(const QkvcAttn& a);
+int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st);
 
 }  // namespace pmgt

@@ -361,6 +361,7 @@ template <typename T, int DH> static int launch_gs(const AttnArgs& a, bool bwd, 
 
 static int g_force_valu = 0;
 void attn_force_valu(int on) { g_force_valu = on; }
+bool attn_valu_forced() { return g_force_valu != 0; }
 
 template <typename T> static int dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
     if (a.Tseq <= 0) return 0;

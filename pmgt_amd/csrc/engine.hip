@@ -365,6 +365,7 @@ static const void* zero_page() {
 }
 static int g_force_tile = 0;
 static int g_no_shortcut = 0;
+static int g_no_fused_qa = 0;
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -422,13 +423,26 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     for (int l = 0; l < L; ++l) {
         const LayerOff& o = e->layers[l];
         LayerBufs<T>& lb = b.layer[l];
-        {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
+        bool fused = false;
+        if constexpr (sizeof(T) == 2) {   // headline shape: projection + attention in one kernel (Q|K|V|C never re-read from HBM)
+            QkvcAttn f;
+            f.X = hin; f.ldx = d; f.W = b.mirror + o.mWqkvc; f.ldw = d; f.bias = P + o.bqkvc;
+            f.qkvc = lb.qkvc; f.ldq = 4 * d; f.ctx = lb.ctx; f.ldc = d; f.mask = mask;
+            f.Tseq = Tseq; f.S = S; f.H = H; f.dh = e->dh; f.beta = e->cfg.beta;
+            f.drop1 = dropcfg(t, train, pa, l, SITE_A1);
+            f.drop2 = dropcfg(t, train, pa, l, SITE_A2);
+            if (!g_no_fused_qa && !g_force_tile && !attn_probs && !attn_valu_forced() && qkvc_attn_supported(f)) {
+                RUNP("fwd.qkvc_attention", qkvc_attn_fwd(f, st));
+                fused = true;
+            }
+        }
+        if (!fused) {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
             GemmWS g;
             g.A = hin; g.lda = d; g.B = wsel<T>(e, t, b, o.Wqkvc, o.mWqkvc); g.ldb = d;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
             RUN(linear<T>(e, "fwd.gemm_qkvc", g, st));
         }
-        {
+        if (!fused) {
             AttnArgs a;
             a.qkvc = lb.qkvc; a.mask = mask; a.ctx = lb.ctx;
             a.probs = attn_probs ? attn_probs + (int64_t)l * Tseq * H * S * S : nullptr;
@@ -1014,6 +1028,7 @@ void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
 void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); }
 void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
+void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
@@ -1038,6 +1053,19 @@ int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* 
     a.ctx = ctx; a.probs = probs;
     if (dtype == PMGT_DTYPE_BF16) return attn_fwd<bf16>(a, (hipStream_t)stream);
     return attn_fwd<float>(a, (hipStream_t)stream);
+}
+
+int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx, int n_seq, int S,
+                               int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream) {
+    QkvcAttn f;
+    const int d = H * dh;
+    f.X = x; f.ldx = d; f.W = w; f.ldw = d; f.bias = bias; f.qkvc = qkvc; f.ldq = 4 * d; f.ctx = ctx; f.ldc = d; f.mask = mask;
+    f.Tseq = n_seq; f.S = S; f.H = H; f.dh = dh; f.beta = beta;
+    f.drop1 = DropCfg{rng, drop_p, site1};
+    f.drop2 = DropCfg{rng, drop_p, site2};
+    PMGT_CHECK(x && w && qkvc && ctx, -2, "pmgt_op_qkvc_attention_fwd: NULL argument");
+    PMGT_CHECK(qkvc_attn_supported(f), -3, "pmgt_op_qkvc_attention_fwd: unsupported shape (needs bf16, S = 32, dh = 32, d in {128, 256})");
+    return qkvc_attn_fwd(f, (hipStream_t)stream);
 }
 
 int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq, int S,

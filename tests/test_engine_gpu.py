@@ -182,3 +182,29 @@ def test_side_stream_wgrads_give_identical_gradients():
         torch.cuda.synchronize()
         assert out["loss"].item() == out0["loss"].item()
         assert torch.equal(eng.grads, ref.grads)
+
+
+@pytest.mark.parametrize("name", ["m3"])
+def test_fused_qkvc_attention_in_the_engine_matches_unfused(name):
+    """bf16 engine at the headline shape (d=256, H=8, S=32): the fused projection+attention forward is on by
+    default; switching it off must give the same loss and gradients up to bf16 round-off of the context."""
+    from pmgt_amd import _lib
+    L = _lib.hip()
+    case = gu.model_case(name)
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = {}
+    for off in (0, 1):
+        L.pmgt_debug_disable_fused_qkvc_attention(off)
+        try:
+            eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+            eng.profile_begin()
+            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+            prof = eng.profile_end()
+            res[off] = (out["loss"].item(), eng.grads.clone(), prof)
+        finally:
+            L.pmgt_debug_disable_fused_qkvc_attention(0)
+    assert "fwd.qkvc_attention" in res[0][2] and "fwd.qkvc_attention" not in res[1][2]
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-3)
+    rel = ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item()
+    assert rel < 1e-2, rel

@@ -386,3 +386,48 @@ def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, 
         if ln:
             lref = torch.nn.functional.layer_norm(ws[0].double(), (N,), gam.double(), bet.double(), 1e-12)
             assert rel_err(ws[2], lref) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------- fused projection + attention
+@pytest.mark.parametrize("T,H,beta,drop", [(7, 8, 0.5, 0.0), (64, 8, 0.3, 0.0), (5, 4, 1.0, 0.0), (2, 8, 0.0, 0.0),
+                                           (33, 8, 0.5, 0.1), (130, 4, 0.5, 0.1)])
+def test_fused_qkvc_attention_matches_the_two_kernel_path(T, H, beta, drop):
+    """qkvc_attn.hip (one kernel: x W^T + b -> Q|K|V|C -> dual-softmax attention) against the unfused pair
+    (streaming GEMM, then the MFMA attention kernel) on the same inputs, and both against fp64 torch.  The two HIP
+    paths round at the same points (bf16 Q|K|V|C, fp32 softmax), so they must agree to bf16 round-off of ctx;
+    with dropout on they must also draw the same masks (same counter-based keys)."""
+    _lib, L = _setup()
+    S, dh = 32, 32
+    d = H * dh
+    g = torch.Generator().manual_seed(T * 10 + H)
+    x = torch.randn(T, S, d, generator=g)
+    W = torch.randn(4 * d, d, generator=g) / math.sqrt(d)
+    bias = torch.randn(4 * d, generator=g) * 0.1
+    mask = torch.ones(T, S)
+    for t in range(T):
+        mask[t, 1 + (t * 7) % S:] = 0
+    mask[0] = 1
+    xd, Wd, bd, md = to_dev(x, torch.bfloat16), to_dev(W, torch.bfloat16), bias.cuda(), mask.cuda()
+    rng = torch.tensor([1234, 5], dtype=torch.int64, device="cuda")
+    q1 = torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16)
+    c1 = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.pmgt_op_qkvc_attention_fwd(P(xd), P(Wd), P(bd), P(md), P(q1), P(c1), T, S, H, dh, beta, drop, 17, 18, P(rng), stream()))
+    q2 = torch.empty_like(q1)
+    c2 = torch.empty_like(c1)
+    M = T * S
+    _lib.check(L.pmgt_op_linear(1, P(xd), d, P(Wd), d, P(q2), 4 * d, M, 4 * d, d, P(bd), 0, None, 0, None, 0, 0.0, 0, None,
+                                None, None, None, None, 1e-12, stream()))
+    _lib.check(L.pmgt_op_attention_fwd(1, P(q2), P(md), P(c2), None, T, S, H, dh, beta, drop, 17, 18, P(rng), stream()))
+    assert torch.equal(q1, q2)                           # same products, same accumulation order, same rounding
+    assert rel_err(c1, c2) < 1e-3 and (c1.float() - c2.float()).abs().max().item() <= 2 ** -6 * c2.float().abs().max().item()
+    if drop == 0.0:
+        qr = rounded(x, torch.bfloat16).reshape(M, d) @ rounded(W, torch.bfloat16).T + bias.double()
+        assert rel_err(q1.reshape(M, 4 * d), qr) < 4e-3
+        ref, _ = _attn_ref(q1.float().cpu().double(), mask.double(), H, beta)
+        assert rel_err(c1, ref) < tol("bf16")
+    # no mask pointer == all ones
+    _lib.check(L.pmgt_op_qkvc_attention_fwd(P(xd), P(Wd), P(bd), None, P(q1), P(c1), T, S, H, dh, beta, 0.0, 0, 0, None, stream()))
+    ref1, _ = _attn_ref(q1.float().cpu().double(), torch.ones(T, S, dtype=torch.float64), H, beta)
+    assert rel_err(c1, ref1) < tol("bf16")
+    # unsupported shapes are refused, not silently mis-computed
+    assert L.pmgt_op_qkvc_attention_fwd(P(xd), P(Wd), P(bd), None, P(q1), P(c1), T, 16, H, dh, beta, 0.0, 0, 0, None, stream()) == -3

@@ -96,6 +96,26 @@ def tn_gather(M, N1, N2, R, name=""):
           f"regstage {out[1][0]:.1f}us ({2 * M * N1 * N2 / out[1][0] / 1e6:.0f} TF/s)")
 
 
+def fused(T, H, name=""):
+    S, dh = 32, 32
+    d = H * dh
+    x = torch.randn(T, S, d, device="cuda").bfloat16()
+    W = (torch.randn(4 * d, d, device="cuda") / d ** 0.5).bfloat16()
+    bias = torch.zeros(4 * d, device="cuda")
+    qk = torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16)
+    ctx = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
+    rng = torch.tensor([1, 2], dtype=torch.int64, device="cuda")
+    M = T * S
+    f = lambda: _lib.check(L.pmgt_op_qkvc_attention_fwd(P(x), P(W), P(bias), None, P(qk), P(ctx), T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st()))
+
+    def two():
+        _lib.check(L.pmgt_op_linear(1, P(x), d, P(W), d, P(qk), 4 * d, M, 4 * d, d, P(bias), 0, None, 0, None, 0, 0.0, 0, None,
+                                    None, None, None, None, 1e-12, st()))
+        _lib.check(L.pmgt_op_attention_fwd(1, P(qk), None, P(ctx), None, T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st()))
+    tf, tt = timeit(f), timeit(two)
+    print(f"FUSED qkvc+attn {name} T={T} H={H}: fused {tf[0]:.1f}us ({M * 6 * d * 2 / tf[0] / 1e6:.2f} TB/s algorithmic) | gemm+attention {tt[0]:.1f}us")
+
+
 def attn(T, S, H, dh, name=""):
     d = H * dh
     x = torch.randn(T, S, 4 * d, device="cuda").bfloat16()
@@ -117,6 +137,9 @@ if __name__ == "__main__":
         sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     M = 12 * B * 32
+    if len(sys.argv) > 2 and sys.argv[2] == "fused":
+        fused(12 * B, 8)
+        sys.exit(0)
     nt(M, 256, 1024, res=True, name="dgrad_qkvc")
     nt(M, 256, 256, res=False, name="dxd")
     linear(M, 1024, 256, name="qkvc_fwd")
