@@ -195,6 +195,8 @@ void pmgt_debug_force_valu_attention(int on);
 int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,
                                int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
                                const uint64_t* rng, void* stream);
+/* A/B switch: 1 projects features per token even when the whole table is smaller than half the batch's tokens */
+void pmgt_debug_disable_table_projection(int on);
 /* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */
 void pmgt_debug_disable_fused_qkvc_attention(int on);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,

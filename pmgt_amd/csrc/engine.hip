@@ -211,6 +211,7 @@ template <typename T> struct Bufs {
     float* mask;       // [Tseq, S]
     T* mirror;
     T *E, *emb_pre, *h0;
+    bool e_by_id = false;   // E holds the projection of the whole table (rows = node ids) instead of one row per token
     float *a, *emb_stats;
     std::vector<LayerBufs<T>> layer;
     // backward temporaries
@@ -366,6 +367,7 @@ static const void* zero_page() {
 static int g_force_tile = 0;
 static int g_no_shortcut = 0;
 static int g_no_fused_qa = 0;
+static int g_no_table_proj = 0;
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -385,6 +387,10 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
     return 0;
 }
 
+static inline bool use_table_projection(const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {
+    return by_ids && !g_no_table_proj && t->n_nodes > 0 && (t->n_nodes + 2) * 2 <= n_tokens;
+}
+
 // ---- encoder forward ---------------------------------------------------------------------------
 template <typename T>
 static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, const int64_t* ids,
@@ -396,23 +402,30 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     PMGT_CHECK(S <= e->cfg.max_position_embeddings, -2, "sequence length %d exceeds max_position_embeddings %d", S,
                e->cfg.max_position_embeddings);
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
-    // feature projections (gather fused into the A-operand load)
+    // Feature projections.  Token mode: gather fused into the A-operand load, one projected row per token.
+    // Table mode (small graphs: every node appears many times in a batch): project the WHOLE table once,
+    // [N+2, F] -> [N+2, 2d], and let the mix kernel pick rows by node id -- M / (N+2) times fewer flops and
+    // table bytes, same value per token (a row's projection does not depend on which rows share its tile).
+    const int64_t n_rows = t->n_nodes + 2;
+    const bool table_mode = use_table_projection(t, M, ids != nullptr);
+    b.e_by_id = table_mode;
     for (int mod = 0; mod < 2; ++mod) {
         GemmNT g;
         const int F = mod == 0 ? e->Fv : e->Ft;
-        if (ids) { g.A = mod == 0 ? t->table_v : t->table_t; g.a_rows = ids; }
+        if (ids) { g.A = mod == 0 ? t->table_v : t->table_t; g.a_rows = table_mode ? nullptr : ids; }
         else g.A = mod == 0 ? (const void*)feat_v : (const void*)feat_t;
         g.lda = F;
         g.B = wsel<T>(e, t, b, mod == 0 ? e->Wv : e->Wt, mod == 0 ? e->mWv : e->mWt);
         g.ldb = F;
         g.C = b.E + mod * d; g.ldc = 2 * d;
-        g.M = M; g.N = d; g.K = F;
+        g.M = table_mode ? (int)n_rows : M; g.N = d; g.K = F;
         g.bias = P + e->bvt + mod * d;
         RUNP("fwd.gemm_featproj", gemm_nt<T>(g, st));
     }
     {
         EmbedMix m;
-        m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
+        m.M = M; m.S = S; m.d = d; m.E = b.E; m.e_rows = table_mode ? ids : nullptr;
+        m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
         m.gamma = P + e->ln_g; m.beta = P + e->ln_b; m.eps = e->cfg.layer_norm_eps;
         m.a = b.a; m.pre = b.emb_pre; m.stats = b.emb_stats; m.h0 = b.h0;
         m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
@@ -627,7 +640,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     RUN(join_side(st, w_qkvc));            // embed_mix_bwd rewrites big and bB
     {
         EmbedMix m;
-        m.M = M; m.S = S; m.d = d; m.E = b.E; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
+        m.M = M; m.S = S; m.d = d; m.E = b.E; m.e_rows = b.e_by_id ? b.ids : nullptr;
+        m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
         m.stats = b.emb_stats; m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
         m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB; m.part = b.part;
         RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
@@ -784,6 +798,7 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv
     PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
     pmgt_tensors tt = *t;
     tt.rng_state = (uint64_t*)b.rng_snap;          // the forward's (seed, step)
+    b.e_by_id = use_table_projection(t, (int64_t)Tseq * S, fv == nullptr);      // same decision as the forward took
     PMGT_HIP(hipMemcpyAsync(b.bA, d_last, (size_t)Tseq * S * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
     RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, (const T*)fv, (const T*)ft));
     return 0;
@@ -1029,6 +1044,7 @@ void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma
 void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }
+void pmgt_debug_disable_table_projection(int on) { g_no_table_proj = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

@@ -22,6 +22,7 @@ inline int ln_bwd_parts(int M) { return cdiv(M, 64); }
 struct EmbedMix {
     int M = 0, S = 0, d = 0;
     const void* E = nullptr;       // [M, 2d]: e_v | e_t (bias already added by the GEMM epilogue)
+    const int64_t* e_rows = nullptr;   // optional: token m reads row e_rows[m] of E (E = projection of the whole table)
     const float* Wa = nullptr;     // [2, 2d]
     const float* ba = nullptr;     // [2]
     const float* pos = nullptr;    // [max_pos, d]

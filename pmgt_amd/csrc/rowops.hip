@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     if (m >= p.M) return;
     const int d = p.d, nch = d >> 2;
     const int s = m % p.S;
-    const T* E = (const T*)p.E + (int64_t)m * 2 * d;
+    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * 2 * d;
     f32x4 ev[NCH], et[NCH];
     float z0 = 0.f, z1 = 0.f;
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
         // df = gradient wrt the pre-LN sum; then through f = a0 e_v + a1 e_t
         f32x4 df[NCH], ev[NCH], et[NCH];
         float da0 = 0.f, da1 = 0.f;
-        const T* E = (const T*)p.E + (int64_t)m * 2 * d;
+        const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * 2 * d;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;

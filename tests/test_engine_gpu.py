@@ -208,3 +208,28 @@ def test_fused_qkvc_attention_in_the_engine_matches_unfused(name):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-3)
     rel = ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item()
     assert rel < 1e-2, rel
+
+
+@pytest.mark.parametrize("name,dtype", [("m1", "fp32"), ("m3", "fp32"), ("m3", "bf16")])
+def test_table_projection_mode_matches_per_token_projection(name, dtype):
+    """Small graphs: the engine projects the whole feature table once and gathers projected rows by node id
+    (default whenever 2 (N+2) <= tokens).  The per-token path (large graphs) must give the same loss/gradients."""
+    from pmgt_amd import _lib
+    L = _lib.hip()
+    case = gu.model_case(name)
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = {}
+    for off in (0, 1):
+        L.pmgt_debug_disable_table_projection(off)
+        try:
+            eng = make_engine(case, dtype=dtype)
+            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
+            res[off] = (out["loss"].item(), out["last_hidden_state"].float().clone(), eng.grads.clone())
+        finally:
+            L.pmgt_debug_disable_table_projection(0)
+    if dtype == "fp32":
+        np.testing.assert_allclose(res[0][0], case["gold"]["train_loss"], rtol=1e-4)
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])       # identical forward values
+    rel = ((res[0][2] - res[1][2]).norm() / res[1][2].norm()).item()
+    assert rel < 1e-6, rel
