@@ -24,6 +24,7 @@ struct GemmNT {
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
 void gemm_nt_disable_dma(int on);     // A/B: force the register-staged tile kernel
+void gemm_nt_disable_big(int on);     // A/B: never use the 256 x 256 tile
 
 // Weight-stationary streaming variant for K <= 256 in bf16 (gemm_ws.hip); optional fused LayerNorm of the
 // output row when N == 256: ln_out = LN(C) with C the (bf16-rounded) epilogue result, stats = {mean, rstd}.

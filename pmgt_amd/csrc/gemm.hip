@@ -312,6 +312,183 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT g) {
     nt_epilogue<T, BM, BN>(g, acc, smem, m0, n0, Mlim, tid, wm, wn, r, q);
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT, bf16, 256 x 256 tile, 512 threads (8 waves as 2 x 4, 128 x 64 outputs each), same 4-stage LDS-DMA ring
+// (K-step 32).  The 128 x 128 kernels re-read the W tile once per 128 rows and A once per 128 columns, all
+// through L2 (for dX = dQKVC W at M = 393k, K = 1024, N = 256 that is 3.2 GB of L2 -> CU traffic for 1.2 GB of
+// HBM bytes); this tile halves both.  No row gather, no device row count (those stay on the small tile).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT g) {
+    typedef bf16 T;
+    constexpr int BM = 256, BN = 256, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = 4;     // 32 KiB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int num_n = g.N / BN;
+    const int num_m = (g.M + BM - 1) / BM;
+    const int b = blockIdx.x;
+    const int grp = b / (8 * num_n), within = b % (8 * num_n);
+    const int m_tile = grp * 8 + (within & 7), n_tile = within >> 3;
+    if (m_tile >= num_m) return;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+
+    const char* asrc[2];
+    const char* bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * wave + 16 * j + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = min(m0 + row, g.M - 1);
+        asrc[j] = (const char*)g.A + (int64_t)m * g.lda * 2 + ch * 16;
+        bsrc[j] = (const char*)g.B + (int64_t)(n0 + row) * g.ldb * 2 + ch * 16;
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & (NST - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + (int64_t)kt * ROWB),
+                                             (lds_void_t*)(st + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + (int64_t)kt * ROWB),
+                                             (lds_void_t*)(st + BM * ROWB + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    uint32_t offa[8], offb[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ra = wm * 128 + i * 16 + r;
+        offa[i] = (uint32_t)(ra * ROWB + ((q ^ ((ra >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rb = wn * 64 + j * 16 + r;
+        offb[j] = (uint32_t)(BM * ROWB + rb * ROWB + ((q ^ ((rb >> 2) & 3)) << 4));
+    }
+    const int nk = g.K / 32;
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = min(2, nk - 1 - kt);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3);
+        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
+        u32x4 t[12];
+        asm volatile(
+            "ds_read_b128 %0, %12\n\t"
+            "ds_read_b128 %1, %13\n\t"
+            "ds_read_b128 %2, %14\n\t"
+            "ds_read_b128 %3, %15\n\t"
+            "ds_read_b128 %4, %16\n\t"
+            "ds_read_b128 %5, %17\n\t"
+            "ds_read_b128 %6, %18\n\t"
+            "ds_read_b128 %7, %19\n\t"
+            "ds_read_b128 %8, %20\n\t"
+            "ds_read_b128 %9, %21\n\t"
+            "ds_read_b128 %10, %22\n\t"
+            "ds_read_b128 %11, %23\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+              "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
+            : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
+              "v"(sbase + offa[4]), "v"(sbase + offa[5]), "v"(sbase + offa[6]), "v"(sbase + offa[7]),
+              "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
+            : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i]), __builtin_bit_cast(bf16x8, t[8 + j]),
+                                                                    acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();       // the ring becomes the staging buffer
+
+    // ---- epilogue: four passes of 64 rows through an fp32 staging tile, then 32 lanes per row, 8 columns per lane
+    const DropKey dk = make_drop_key(g.drop);
+    T* Cp = (T*)g.C;
+    const T* R = (const T*)g.res;
+    T* AUX = (T*)g.aux;
+    constexpr int ES = BN + 4;
+    float* stage = (float*)smem;
+    const int er = tid >> 5, ec = (tid & 31) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        if (wm == (pass >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(ii * 16 + 4 * q + e) * ES + wn * 64 + j * 16 + r] = acc[(pass & 1) * 4 + ii][j][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = er + 16 * it;
+            const int m = m0 + pass * 64 + row;
+            const int n = n0 + ec;
+            if (m < g.M) {
+                const f32x4 s0 = *(const f32x4*)(stage + row * ES + ec), s1 = *(const f32x4*)(stage + row * ES + ec + 4);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
+                if (g.bias) {
+                    const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (g.epi == EPI_GELU) {
+                    bf16x8 pre;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_erf((float)pre[e]); }
+                    *(bf16x8*)(AUX + (int64_t)m * g.ldaux + n) = pre;
+                } else if (g.epi == EPI_GELU_GRAD) {
+                    const bf16x8 pre = *(const bf16x8*)(AUX + (int64_t)m * g.ldaux + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)pre[e]);
+                }
+                if (dk.on) {
+                    float d0[4], d1[4];
+                    drop_mul4(dk, (uint32_t)m, (uint32_t)n >> 2, d0);
+                    drop_mul4(dk, (uint32_t)m, ((uint32_t)n >> 2) + 1, d1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+                }
+                if (R) {
+                    const bf16x8 rv = *(const bf16x8*)(R + (int64_t)m * g.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int g_nt_no_big = 0;
+void gemm_nt_disable_big(int on) { g_nt_no_big = on; }
+static bool nt_big_ok(const GemmNT& g) {
+    return !g_nt_no_big && g.a_rows == nullptr && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 256 == 0 && g.K % 32 == 0 &&
+           g.K >= 128 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
+           (g.aux == nullptr || g.ldaux % 8 == 0) && ((uintptr_t)g.C % 16) == 0 && (g.res == nullptr || ((uintptr_t)g.res % 16) == 0) &&
+           (g.aux == nullptr || ((uintptr_t)g.aux % 16) == 0) && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0);
+}
+
 // The LDS-DMA NT kernel measures the same as the register-staged tile kernel on this model's shapes (both are
 // bound by re-reading A for the second N tile), so the simpler kernel stays the default; PMGT_NT_DMA=1 or
 // gemm_nt_disable_dma(0) selects it (tests run both).
@@ -333,6 +510,18 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     const int num_m = cdiv(g.M, BM), num_n = cdiv(g.N, BN);
     const int grid = cdiv(num_m, 8) * 8 * num_n;
     if constexpr (sizeof(T) == 2) {
+        if (nt_big_ok(g)) {
+            constexpr int smem = 4 * (256 + 256) * 64;
+            static bool attr_set = false;
+            if (!attr_set) {
+                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_set = true;
+            }
+            const int nm = cdiv(g.M, 256), nn = g.N / 256;
+            hipLaunchKernelGGL(gemm_nt_big_kernel, dim3(cdiv(nm, 8) * 8 * nn), dim3(512), smem, st, g);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
         if (g_nt_no_dma < 0) { const char* ev = getenv("PMGT_NT_DMA"); g_nt_no_dma = (ev && atoi(ev) == 1) ? 0 : 1; }
         if (!g_nt_no_dma && g.K % 32 == 0 && g.K >= 64) {
             hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(grid), dim3(256), 0, st, g);

@@ -431,3 +431,46 @@ def test_fused_qkvc_attention_matches_the_two_kernel_path(T, H, beta, drop):
     assert rel_err(c1, ref1) < tol("bf16")
     # unsupported shapes are refused, not silently mis-computed
     assert L.pmgt_op_qkvc_attention_fwd(P(xd), P(Wd), P(bd), None, P(q1), P(c1), T, 16, H, dh, beta, 0.0, 0, 0, None, stream()) == -3
+
+
+# ------------------------------------------------------------------------------------------- 256 x 256 NT tile
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 1024), (5001, 512, 160), (4100, 256, 128)])
+def test_gemm_nt_big_tile_epilogues(M, N, K):
+    """The 256 x 256 LDS-DMA tile (bf16, M >= 4096, N % 256 == 0, K % 32 == 0) against fp64 torch for every
+    epilogue it implements, and against the 128 x 128 kernel for the dropout mask (same counter-based keys)."""
+    _lib, L = _setup()
+    tdt = torch.bfloat16
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) * 0.3
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    Ad, Bd, bd, rd = to_dev(A, tdt), to_dev(B, tdt), bias.cuda(), to_dev(res, tdt)
+    Cd = torch.full((M, N), float("nan"), device="cuda", dtype=tdt)
+    aux = torch.zeros(M, N, device="cuda", dtype=tdt)
+    base = rounded(A, tdt) @ rounded(B, tdt).T
+    # bias + residual
+    _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, P(bd), 0, None, 0, P(rd), N, 0.0, 0, None, None, stream()))
+    assert rel_err(Cd, base + bias.double() + rounded(res, tdt)) < tol("bf16")
+    # bias + GELU (stores the pre-activation)
+    _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, P(bd), 1, P(aux), N, None, 0, 0.0, 0, None, None, stream()))
+    pre = base + bias.double()
+    assert rel_err(aux, pre) < tol("bf16")
+    assert rel_err(Cd, torch.nn.functional.gelu(rounded(pre.float(), tdt))) < tol("bf16")
+    # GELU' of the stored pre-activation
+    _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, None, 2, P(aux), N, None, 0, 0.0, 0, None, None, stream()))
+    x = aux.double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(Cd, base * x.grad) < tol("bf16")
+    # dropout: identical mask and values as the small-tile kernel
+    rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+    _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, P(bd), 0, None, 0, P(rd), N, 0.25, 21, P(rng), None, stream()))
+    C2 = torch.empty_like(Cd)
+    L.pmgt_debug_force_tile_gemm(1)
+    try:
+        _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(C2), N, M, N, K, P(bd), 0, None, 0, P(rd), N, 0.25, 21, P(rng), None, stream()))
+    finally:
+        L.pmgt_debug_force_tile_gemm(0)
+    assert rel_err(Cd, C2.double()) < 1e-3
+    kept = ((Cd.double() - rounded(res, tdt).cuda()).abs() > 1e-6).double().mean().item()
+    assert abs(kept - 0.75) < 0.02
