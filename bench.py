@@ -217,6 +217,19 @@ def main():
                                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                                    "avg_launch_ms": round(avg_s * 1e3, 5), "algorithmic_mb_per_launch": round(byts / 1e6, 3)}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them
+    # in separate passes, tools/gpu_profile.sh); the committed summary of the last such run is quoted when it is for
+    # this workload, else traffic stays null.
+    if rank == 0 and "roofline" in out:
+        try:
+            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+            ph = tr["phases"].get(out["roofline"]["kernel"])
+            if ph and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate:
+                out["roofline"]["traffic"] = ph["hbm_mb_per_launch"]
+                out["roofline"]["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
+        except (OSError, KeyError, ValueError):
+            pass
+
     # ---- end-to-end with the live host sampler (optional, reported separately)
     if args.end_to_end and rank == 0:
         out["end_to_end"] = trainer.run_live(sampler, shard, B, steps=min(args.steps, 10), threads=threads)
