@@ -190,6 +190,8 @@ void pmgt_debug_enable_nt_dma(int on);
 void pmgt_debug_force_tile_gemm(int on);
 /* A/B switch: 1 routes bf16 attention through the generic fp32-VALU kernel instead of the MFMA one */
 void pmgt_debug_force_valu_attention(int on);
+/* A/B switch: 1 = one wave per (sequence, head) in the MFMA attention backward instead of NT cooperating waves */
+void pmgt_debug_disable_coop_attention_bwd(int on);
 /* Fused Q|K|V|C projection + attention forward (bf16; S = 32, dh = 32, hidden 128 or 256; returns -3 otherwise):
  * x [n_seq*S, d], w [4d, d] (rows q | k | v | c), bias [4d] fp32 -> qkvc [n_seq*S, 4d], ctx [n_seq*S, d]. */
 int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,

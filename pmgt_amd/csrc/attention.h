@@ -20,6 +20,7 @@ bool attn_mfma_supported(const AttnArgs& a);
 int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st);
 void attn_force_valu(int on);   // debugging / A-B: route bf16 through the generic VALU kernel
 bool attn_valu_forced();
+void attn_bwd_disable_coop(int on);   // A/B: one wave per (sequence, head) in the MFMA backward instead of NT cooperating waves
 template <typename T> int attn_fwd(const AttnArgs& a, hipStream_t st);
 template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
 

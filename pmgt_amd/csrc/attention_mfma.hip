@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     }
 }
 
+static int g_bwd_no_coop = 0;
+void attn_bwd_disable_coop(int on) { g_bwd_no_coop = on; }
+
 template <int DH, int NT> struct BwdSmem {
     static constexpr int SP = NT * 16, SP2 = (SP + 31) / 32 * 32;
     static constexpr int TILE = SP2 * DH * 2;         // Q, K, dO, C-hat
@@ -499,14 +502,441 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, cooperative form: NT waves per (sequence, head); wave `it` owns query tile it in the first half
+// (scores, both softmax backward passes, dQ, first half of dC) and key tile it in the second half (dV, dK, second
+// half of dC).  The LDS tiles/images of the unit are shared, so LDS and VGPRs per wave drop by ~NT (S = 64,
+// dh = 64: 57 KiB + 360 VGPRs per WAVE before, per 4 waves now; S = 32, dh = 32: 20 waves per CU instead of 10).
+// Every wave loads the K / C / V fragments of all key tiles itself (L1/L2 hits) and writes only its own 16 rows
+// of the Q, K, dO, C-hat tiles, so the first barrier is the only dependency between the waves' loads.
+// ------------------------------------------------------------------------------------------------
+template <int NT> __device__ __forceinline__ bf16x8 pack_col(const f32x4 (&x)[NT], int ks) {
+    bf16x8 b;
+    const f32x4 lo = x[2 * ks];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = (bf16)lo[e];
+    if (2 * ks + 1 < NT) {
+        const f32x4 hi = x[(2 * ks + 1 < NT) ? 2 * ks + 1 : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[4 + e] = (bf16)hi[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[4 + e] = (bf16)0.f;
+    }
+    return b;
+}
+
+template <int NT> struct CoopCfg { static constexpr int G = NT == 1 ? 4 : (NT == 2 ? 2 : 1), THREADS = 64 * NT * G; };
+
+template <int DH, int NT>
+__global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(AttnArgs a) {
+    using SM = BwdSmem<DH, NT>;
+    constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2, G = CoopCfg<NT>::G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int ul = wave / NT, it = wave % NT;
+    const int gidx = blockIdx.x * G + ul;
+    const int S = a.S, H = a.H, d = H * DH;
+    const bool act = gidx < a.Tseq * H;
+    const int t = act ? gidx / H : 0, h = act ? gidx % H : 0;
+    char* base = smem + ul * SM::BYTES;
+    char* tQ = base;
+    char* tK = tQ + SM::TILE;
+    char* tO = tK + SM::TILE;
+    char* tC = tO + SM::TILE;
+    char* iP = tC + SM::TILE;
+    char* iS1 = iP + SM::IMG;
+    char* iS2 = iS1 + SM::IMG;
+    float* rho = (float*)(iS2 + SM::IMG);
+    float* madd = rho + 64;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
+    bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
+    const int64_t ld = 4 * d;
+    const int Sv = act ? S : 0;
+    const float isq = rsqrtf((float)DH);
+    const int x = 16 * it + r;                  // this lane's row (query i in the first half, key j in the second)
+
+    // ---- all global loads of the wave, unconditional and clamped
+    bf16x8 fq[KD], fo[KD], fko[KD], fco[KD], fk[NT][KD], fc[NT][KD], fv[NT][KD];
+#pragma unroll
+    for (int ks = 0; ks < KD; ++ks) {
+        fq[ks] = ld_rows(X, ld, x, Sv, 32 * ks + 8 * q);
+        fko[ks] = ld_rows(X + d, ld, x, Sv, 32 * ks + 8 * q);
+        fco[ks] = ld_rows(X + 3 * d, ld, x, Sv, 32 * ks + 8 * q);
+        fo[ks] = ld_rows(DO, d, x, Sv, 32 * ks + 8 * q);
+    }
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            fk[jt][ks] = ld_rows(X + d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fv[jt][ks] = ld_rows(X + 2 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fc[jt][ks] = ld_rows(X + 3 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+        }
+    // own rows: inverse norm, mask term, and the four tiles
+    float rho_x;
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = (float)fco[ks][e]; ss = fmaf(c, c, ss); }
+        ss = red_q<NT>(ss, false);
+        rho_x = x < Sv ? rsqrtf(ss) : 0.f;
+        if (q == 0) rho[x] = rho_x;
+        if (lane < 16) {
+            const int j = 16 * it + lane;
+            madd[j] = (j < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + j]) * -10000.f : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const int off = x * (DH * 2) + (32 * ks + 8 * q) * 2;
+            *(bf16x8*)(tQ + off) = fq[ks];
+            *(bf16x8*)(tK + off) = fko[ks];
+            *(bf16x8*)(tO + off) = fo[ks];
+            bf16x8 ch;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ch[e] = (bf16)((float)fco[ks][e] * rho_x);
+            *(bf16x8*)(tC + off) = ch;
+        }
+        if (SP2 > SP && it == NT - 1) {        // zero rows [SP, SP2) of the four tiles (k padding of the transposed reads)
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int idx = lane; idx < (SP2 - SP) * (DH / 8); idx += 64) {
+                const int off = (SP + idx / (DH / 8)) * (DH * 2) + (idx % (DH / 8)) * 16;
+                *(bf16x8*)(tQ + off) = z;
+                *(bf16x8*)(tK + off) = z;
+                *(bf16x8*)(tO + off) = z;
+                *(bf16x8*)(tC + off) = z;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- first half: query tile `it`
+    f32x4 a1[NT], a2[NT], dp[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1, x3 = x1;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt][ks], fco[ks], x1, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt][ks], fq[ks], x2, 0, 0, 0);
+            x3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt][ks], fo[ks], x3, 0, 0, 0);
+        }
+        a1[jt] = x1; a2[jt] = x2; dp[jt] = x3;
+    }
+    {
+        const bool iv = x < Sv;
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const bool ok = iv && j < Sv;
+                const float v1 = ok ? (1.f - a1[jt][e] * (rho_x * rho[j]) + (x == j ? 1.f : 0.f) + madd[j]) : -INFINITY;
+                const float v2 = ok ? (a2[jt][e] * isq + madd[j]) : -INFINITY;
+                a1[jt][e] = v1;
+                a2[jt][e] = v2;
+                m1 = fmaxf(m1, v1);
+                m2 = fmaxf(m2, v2);
+            }
+        m1 = red_q<NT>(m1, true);
+        m2 = red_q<NT>(m2, true);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e1 = iv ? __expf(a1[jt][e] - m1) : 0.f;
+                const float e2 = iv ? __expf(a2[jt][e] - m2) : 0.f;
+                a1[jt][e] = e1;
+                a2[jt][e] = e2;
+                s1 += e1;
+                s2 += e2;
+            }
+        s1 = red_q<NT>(s1, false);
+        s2 = red_q<NT>(s2, false);
+        const float i1 = iv ? __frcp_rn(s1) : 0.f, i2 = iv ? __frcp_rn(s2) : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) { a1[jt] *= i1; a2[jt] *= i2; }
+    }
+    {   // softmax backward of both branches; images of P^T, dS1^T, dS2^T (columns of this query tile)
+        const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
+        const float beta = a.beta, omb = 1.f - a.beta;
+        const uint64_t hbase = ((uint64_t)t * H + h) * S;
+        float rd1 = 0.f, rd2 = 0.f;
+        f32x4 g1[NT], g2[NT], pm[NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            if (k1.on) {
+                drop_mul4(k1, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d1);
+                drop_mul4(k2, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float m1 = beta * d1[e], m2 = omb * d2[e];
+                const float x1 = m1 * dp[jt][e], x2 = m2 * dp[jt][e];
+                g1[jt][e] = x1;
+                g2[jt][e] = x2;
+                pm[jt][e] = m1 * a1[jt][e] + m2 * a2[jt][e];
+                rd1 = fmaf(a1[jt][e], x1, rd1);
+                rd2 = fmaf(a2[jt][e], x2, rd2);
+            }
+        }
+        rd1 = red_q<NT>(rd1, false);
+        rd2 = red_q<NT>(rd2, false);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const float ds1 = a1[jt][e] * (g1[jt][e] - rd1);     // a == 0 on padding -> ds == 0
+                const float ds2 = a2[jt][e] * (g2[jt][e] - rd2);
+                a1[jt][e] = ds1;
+                a2[jt][e] = ds2;
+                *(bf16*)(iP + (j * SP2 + x) * 2) = (bf16)pm[jt][e];
+                *(bf16*)(iS1 + (j * SP2 + x) * 2) = (bf16)ds1;
+                *(bf16*)(iS2 + (j * SP2 + x) * 2) = (bf16)ds2;
+            }
+        if (SP2 > SP && it == NT - 1) {     // zero the padding columns i in [SP, SP2) of the images
+            for (int idx = lane; idx < SP * (SP2 - SP); idx += 64) {
+                const int j = idx / (SP2 - SP), i = SP + idx % (SP2 - SP);
+                *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
+                *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
+                *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
+            }
+        }
+    }
+    // dQ^T and the accumulator-operand half of dC^T for this query tile
+    f32x4 dch[CT];
+    {
+        bf16x8 b2[KS], b1[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { b2[ks] = pack_col<NT>(a2, ks); b1[ks] = pack_col<NT>(a1, ks); }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
+                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+            }
+            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);
+            dch[ct] = dc;
+        }
+    }
+    __syncthreads();
+
+    // ---- second half: rows x of the images (x as key index)
+    {
+        bf16x8 bt[KS], bp[KS], bs[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = (x * SP2 + 32 * ks + 8 * q) * 2;
+            bt[ks] = *(const bf16x8*)(iS1 + off);
+            bp[ks] = *(const bf16x8*)(iP + off);
+            bs[ks] = *(const bf16x8*)(iS2 + off);
+        }
+        float dt = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 dc = dch[ct], dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
+            }
+            if (x < Sv) {
+                store4<bf16>(DX + (int64_t)x * ld + 2 * d + 16 * ct + 4 * q, dv);
+                store4<bf16>(DX + (int64_t)x * ld + d + 16 * ct + 4 * q, dk * isq);
+            }
+            dch[ct] = -dc;       // dN = -dS1
+            const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+            dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
+        }
+        dt = red_q<NT>(dt, false);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 3 * d + 16 * ct + 4 * q, (dch[ct] - ch * dt) * rho_x);
+        }
+    }
+}
+
+// Forward, cooperative form: wave `it` of the NT waves of a (sequence, head) owns query tile it; the V tile is
+// shared through LDS (each wave stores its own 16 rows), everything else stays in registers.
+template <int DH, int NT>
+__global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(AttnArgs a) {
+    using SM = FwdSmem<DH, NT>;
+    constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2, G = CoopCfg<NT>::G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int ul = wave / NT, it = wave % NT;
+    const int gidx = blockIdx.x * G + ul;
+    const int S = a.S, H = a.H, d = H * DH;
+    const bool act = gidx < a.Tseq * H;
+    const int t = act ? gidx / H : 0, h = act ? gidx % H : 0;
+    char* base = smem + ul * SM::BYTES;
+    char* tV = base;
+    float* rho = (float*)(base + SM::TILE);
+    float* madd = rho + 64;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    const int64_t ld = 4 * d;
+    const int Sv = act ? S : 0;
+    const int x = 16 * it + r;
+
+    bf16x8 fq[KD], fco[KD], fvo[KD], fk[NT][KD], fc[NT][KD];
+#pragma unroll
+    for (int ks = 0; ks < KD; ++ks) {
+        fq[ks] = ld_rows(X, ld, x, Sv, 32 * ks + 8 * q);
+        fvo[ks] = ld_rows(X + 2 * d, ld, x, Sv, 32 * ks + 8 * q);
+        fco[ks] = ld_rows(X + 3 * d, ld, x, Sv, 32 * ks + 8 * q);
+    }
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            fk[jt][ks] = ld_rows(X + d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fc[jt][ks] = ld_rows(X + 3 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+        }
+    float rho_x;
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = (float)fco[ks][e]; ss = fmaf(c, c, ss); }
+        ss = red_q<NT>(ss, false);
+        rho_x = x < Sv ? rsqrtf(ss) : 0.f;
+        if (q == 0) rho[x] = rho_x;
+        if (lane < 16) {
+            const int j = 16 * it + lane;
+            madd[j] = (j < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + j]) * -10000.f : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) *(bf16x8*)(tV + x * (DH * 2) + (32 * ks + 8 * q) * 2) = fvo[ks];
+        if (SP2 > SP && it == NT - 1) {
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int idx = lane; idx < (SP2 - SP) * (DH / 8); idx += 64)
+                *(bf16x8*)(tV + (SP + idx / (DH / 8)) * (DH * 2) + (idx % (DH / 8)) * 16) = z;
+        }
+    }
+    __syncthreads();
+
+    f32x4 a1[NT], a2[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt][ks], fco[ks], x1, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt][ks], fq[ks], x2, 0, 0, 0);
+        }
+        a1[jt] = x1; a2[jt] = x2;
+    }
+    {
+        const bool iv = x < Sv;
+        const float isq = rsqrtf((float)DH);
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const bool ok = iv && j < Sv;
+                const float v1 = ok ? (1.f - a1[jt][e] * (rho_x * rho[j]) + (x == j ? 1.f : 0.f) + madd[j]) : -INFINITY;
+                const float v2 = ok ? (a2[jt][e] * isq + madd[j]) : -INFINITY;
+                a1[jt][e] = v1;
+                a2[jt][e] = v2;
+                m1 = fmaxf(m1, v1);
+                m2 = fmaxf(m2, v2);
+            }
+        m1 = red_q<NT>(m1, true);
+        m2 = red_q<NT>(m2, true);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e1 = iv ? __expf(a1[jt][e] - m1) : 0.f;
+                const float e2 = iv ? __expf(a2[jt][e] - m2) : 0.f;
+                a1[jt][e] = e1;
+                a2[jt][e] = e2;
+                s1 += e1;
+                s2 += e2;
+            }
+        s1 = red_q<NT>(s1, false);
+        s2 = red_q<NT>(s2, false);
+        const float i1 = iv ? __frcp_rn(s1) : 0.f, i2 = iv ? __frcp_rn(s2) : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) { a1[jt] *= i1; a2[jt] *= i2; }
+    }
+    {   // mix + dropout -> P^T (in a1)
+        const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
+        const float beta = a.beta, omb = 1.f - a.beta;
+        const uint64_t hbase = ((uint64_t)t * H + h) * S;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            if (k1.on) {
+                drop_mul4(k1, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d1);
+                drop_mul4(k2, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const float p = beta * d1[e] * a1[jt][e] + omb * d2[e] * a2[jt][e];
+                a1[jt][e] = p;
+                if (a.probs && x < Sv && j < Sv) a.probs[(hbase + x) * S + j] = p;
+            }
+        }
+    }
+    bf16x8 pb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) pb[ks] = pack_col<NT>(a1, ks);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q), pb[ks], o, 0, 0, 0);
+        if (x < Sv) store4<bf16>((bf16*)a.ctx + ((int64_t)t * S + x) * d + h * DH + 16 * ct + 4 * q, o);
+    }
+}
+
 template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
     const int groups = a.Tseq * a.H;
+    static int coop = -1;
+    if (coop < 0) { const char* ev = getenv("PMGT_ATTN_COOP"); coop = ev ? atoi(ev) : 1; }
+    // NT cooperating waves per (sequence, head) everywhere except S in 17..32 with head size 32, where the
+    // one-wave form measures faster (464 vs 555 us backward at 98k pairs: the shared loads outweigh the occupancy)
+    const bool use_coop = coop && !g_bwd_no_coop && !(NT == 2 && DH == 32);
+    if (!bwd && use_coop) {
+        constexpr int G = CoopCfg<NT>::G;
+        const size_t shmem = (size_t)FwdSmem<DH, NT>::BYTES * G;
+        hipLaunchKernelGGL((attn_fwd_coop_kernel<DH, NT>), dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);
+        PMGT_LAUNCH_OK();
+        return 0;
+    }
     if (!bwd) {
         const size_t shmem = (size_t)FwdSmem<DH, NT>::BYTES * 4;
         auto kern = attn_fwd_mfma_kernel<DH, NT>;
         if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(kern, dim3(cdiv(groups, 4)), dim3(256), shmem, st, a);
     } else {
+        if (use_coop) {
+            constexpr int G = CoopCfg<NT>::G;
+            const size_t shmem = (size_t)BwdSmem<DH, NT>::BYTES * G;
+            auto kern = attn_bwd_coop_kernel<DH, NT>;
+            if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL(kern, dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
         const size_t per = BwdSmem<DH, NT>::BYTES;
         static int env_nw = -1;
         if (env_nw < 0) { const char* ev = getenv("PMGT_ATTN_BWD_NW"); env_nw = ev ? atoi(ev) : 0; }

@@ -235,11 +235,14 @@ def _attn_ref(qkvc, mask, H, beta):
     return (w @ v).permute(0, 2, 1, 3).reshape(T, S, d), w
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "bf16-wave"])     # bf16-wave: the one-wave-per-(sequence, head) backward
 @pytest.mark.parametrize("T,S,H,dh,beta", [(5, 16, 4, 16, 0.5), (7, 32, 8, 32, 0.5), (3, 6, 2, 64, 0.3), (2, 64, 2, 64, 0.5),
-                                           (4, 32, 1, 128, 1.0), (6, 20, 4, 32, 0.0), (9, 33, 2, 32, 0.7)])
+                                           (4, 32, 1, 128, 1.0), (6, 20, 4, 32, 0.0), (9, 33, 2, 32, 0.7), (5, 48, 3, 64, 0.5),
+                                           (11, 64, 8, 32, 0.4), (3, 17, 2, 64, 0.6)])
 def test_attention_fwd_bwd(dt, T, S, H, dh, beta):
     _lib, L = _setup()
+    L.pmgt_debug_disable_coop_attention_bwd(1 if dt == "bf16-wave" else 0)
+    dt = dt.split("-")[0]
     code, tdt = DT[dt]
     d = H * dh
     g = torch.Generator().manual_seed(S * 100 + dh)
@@ -267,6 +270,7 @@ def test_attention_fwd_bwd(dt, T, S, H, dh, beta):
     _lib.check(L.pmgt_op_attention_fwd(code, P(xd), None, P(ctx), None, T, S, H, dh, beta, 0.0, 0, 0, None, stream()))
     ref1, _ = _attn_ref(rounded(x, tdt), torch.ones(T, S, dtype=torch.float64), H, beta)
     assert rel_err(ctx, ref1) < tol(dt)
+    L.pmgt_debug_disable_coop_attention_bwd(0)
 
 
 def test_attention_dropout_forward_backward_consistent():

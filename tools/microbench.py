@@ -134,6 +134,10 @@ def attn(T, S, H, dh, name=""):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "attn":
         attn(12 * int(sys.argv[1]), 32, 8, 32)
+        attn(3 * int(sys.argv[1]), 64, 8, 64)
+        attn(3 * int(sys.argv[1]), 64, 8, 32)
+        attn(6 * int(sys.argv[1]), 48, 8, 32)
+        attn(24 * int(sys.argv[1]), 16, 8, 32)
         sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     M = 12 * B * 32
