@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/pmgt_capi.h"
@@ -17,6 +18,7 @@
 #include "loss.h"
 #include "optim.h"
 #include "rowops.h"
+#include "segsum.h"
 
 namespace pmgt {
 
@@ -217,6 +219,12 @@ template <typename T> struct Bufs {
     // backward temporaries
     T *bA, *bB, *bC, *bD, *big;
     float *slab, *part;     // gemm_tn slabs; LN / embed / colsum partials
+    // segment-sum scratch (table mode backward)
+    uint32_t *sg_keys = nullptr, *sg_vals = nullptr, *sg_skeys = nullptr, *sg_perm = nullptr;
+    int* sg_off = nullptr;
+    void* sg_tmp = nullptr;
+    int64_t sg_tmp_bytes = 0;
+    float* sg_part = nullptr;
     float* part_side;       // bias partials of the wgrad kernels (their own buffer: they run on the side stream)
     float* possum;
     // losses
@@ -233,6 +241,15 @@ template <typename T> struct Bufs {
     LayerBufs<T> ctail;
     T *c_dh = nullptr, *c_bB = nullptr, *c_bC = nullptr, *c_bD = nullptr, *c_big = nullptr;
 };
+
+static int64_t sort_temp_bytes(int M) {      // rocPRIM's size query, cached per token count
+    static std::map<int, int64_t> cache;
+    auto itr = cache.find(M);
+    if (itr != cache.end()) return itr->second;
+    const int64_t v = seg_sort_temp_bytes(M);
+    cache[M] = v;
+    return v;
+}
 
 static int64_t tn_slab_elems(int dtype, int M, int N1, int N2) {
     const int bkm = dtype == PMGT_DTYPE_BF16 ? 64 : 32;
@@ -298,6 +315,11 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     part = std::max(part, (int64_t)512 * std::max(std::max(I, 4 * d), F));     // wgrad bias slabs [splits <= 512][N1]
     b.part = c.get<float>(part);
     b.part_side = c.get<float>((int64_t)512 * std::max(std::max(I, 4 * d), F));
+    b.sg_keys = c.get<uint32_t>(M); b.sg_vals = c.get<uint32_t>(M); b.sg_skeys = c.get<uint32_t>(M); b.sg_perm = c.get<uint32_t>(M);
+    b.sg_off = c.get<int>(M / 2 + 4);                     // table mode implies N + 2 <= M / 2
+    b.sg_tmp_bytes = sort_temp_bytes((int)M);
+    b.sg_tmp = c.raw(b.sg_tmp_bytes);
+    b.sg_part = c.get<float>(seg_part_elems((int)M, 2 * d));
     b.possum = c.get<float>((int64_t)S * d);
     b.sse_part = c.get<float>((int64_t)nfr_diff_parts(cap) * 2);
     b.nfr_masked = c.get<int64_t>((int64_t)B * S);
@@ -368,6 +390,7 @@ static int g_force_tile = 0;
 static int g_no_shortcut = 0;
 static int g_no_fused_qa = 0;
 static int g_no_table_proj = 0;
+static int g_no_segsum = 0;
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -648,8 +671,17 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
         RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
         RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
-        RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+        if (b.e_by_id && !g_no_segsum) {
+            // table mode: dW_m = (sum of dE rows per node id)^T x table_m -- a GEMM over N+2 rows instead of M tokens
+            const int n_rows = (int)t->n_nodes + 2;
+            RUNP("bwd.segsum_featproj", seg_sort(b.ids, M, n_rows, b.sg_keys, b.sg_vals, b.sg_skeys, b.sg_perm, b.sg_off, b.sg_tmp, b.sg_tmp_bytes, st));
+            RUNP("bwd.segsum_featproj", seg_sum<T>(b.big, 2 * d, b.sg_skeys, b.sg_perm, b.sg_off, M, n_rows, 2 * d, b.bC, b.sg_part, st));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bC, 2 * d, (const T*)t->table_v, e->Fv, nullptr, n_rows, n_rows, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bC + d, 2 * d, (const T*)t->table_t, e->Ft, nullptr, n_rows, n_rows, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+        } else {
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+        }
     }
     RUN(join_side_all(e, st));             // the caller's stream sees every gradient
     return 0;
@@ -1046,6 +1078,7 @@ void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }
 void pmgt_debug_disable_table_projection(int on) { g_no_table_proj = on; }
+void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

@@ -222,14 +222,51 @@ def test_table_projection_mode_matches_per_token_projection(name, dtype):
     res = {}
     for off in (0, 1):
         L.pmgt_debug_disable_table_projection(off)
+        L.pmgt_debug_disable_segment_sum(1)           # isolate the forward: same per-token weight-gradient GEMM in both runs
         try:
             eng = make_engine(case, dtype=dtype)
             out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
             res[off] = (out["loss"].item(), out["last_hidden_state"].float().clone(), eng.grads.clone())
         finally:
             L.pmgt_debug_disable_table_projection(0)
+            L.pmgt_debug_disable_segment_sum(0)
     if dtype == "fp32":
         np.testing.assert_allclose(res[0][0], case["gold"]["train_loss"], rtol=1e-4)
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])       # identical forward values
     rel = ((res[0][2] - res[1][2]).norm() / res[1][2].norm()).item()
     assert rel < 1e-6, rel
+
+
+@pytest.mark.parametrize("name,dtype", [("m1", "fp32"), ("m1_pad", "fp32"), ("m3", "fp32"), ("m3", "bf16")])
+def test_segment_sum_wgrad_matches_per_token_wgrad(name, dtype):
+    """Table mode backward: the feature-projection weight gradient goes through a stable sort by node id + ordered
+    segment sums + a GEMM over N+2 rows.  Must equal the per-token GEMM (and the reference), run to run identical."""
+    from pmgt_amd import _lib
+    L = _lib.hip()
+    case = gu.model_case(name)
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = {}
+    for off in (0, 1, 0):
+        L.pmgt_debug_disable_segment_sum(off)
+        try:
+            eng = make_engine(case, dtype=dtype)
+            eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
+            res.setdefault(off, []).append(eng.grads.clone())
+        finally:
+            L.pmgt_debug_disable_segment_sum(0)
+    assert torch.equal(res[0][0], res[0][1])                      # deterministic
+    for k in ("bert.embeddings.feat_linear.0.weight", "bert.embeddings.feat_linear.1.weight", "bert.embeddings.feat_linear.0.bias"):
+        e = eng.entry(k)
+        a = res[0][0][e["offset"]: e["offset"] + e["numel"]]
+        b = res[1][0][e["offset"]: e["offset"] + e["numel"]]
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < (2e-6 if dtype == "fp32" else 6e-3), (k, rel)
+        if dtype == "fp32":
+            gu.check_stored(case["gold"], "grad/" + k, a.view(*e["shape"]).cpu().numpy(), 2e-3, 2e-3 * float(b.abs().mean()) + 1e-9)
+    other = torch.ones_like(res[0][0], dtype=torch.bool)
+    for k in ("bert.embeddings.feat_linear.0.weight", "bert.embeddings.feat_linear.1.weight", "bert.embeddings.feat_linear.0.bias",
+              "bert.embeddings.feat_linear.1.bias"):
+        e = eng.entry(k)
+        other[e["offset"]: e["offset"] + e["numel"]] = False
+    assert torch.equal(res[0][0][other], res[1][0][other])      # nothing else changes
