@@ -169,7 +169,8 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
             if (q == 0) rho[16 * jt + r] = rsqrtf(ss);       // 1 / |c_row|
         }
         if (lane < 32) madd[lane] = (act && a.mask) ? (1.f - a.mask[(int64_t)t * 32 + lane]) * -10000.f : 0.f;
-        __syncthreads();                 // rho / madd visible (uniform: inactive waves take part)
+        // rho / madd are private to this wave: LDS operations of one wave execute in order, no barrier needed
+        __builtin_amdgcn_wave_barrier();
         f32x4 a1[2], a2[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {

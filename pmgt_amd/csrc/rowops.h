@@ -16,7 +16,9 @@ int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
            int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr);
-inline int ln_bwd_parts(int M) { return cdiv(M, 64); }
+// rows per workgroup: 64, or 256 for large M (4x fewer partial rows to write and reduce; still >= 6 workgroups per CU)
+inline int ln_bwd_rows(int M) { return M >= 65536 ? 256 : 64; }
+inline int ln_bwd_parts(int M) { return cdiv(M, ln_bwd_rows(M)); }
 
 // ---- embedding mix (pmgt/pmgt/modeling_pmgt.py:199-208) ----------------------------------------
 struct EmbedMix {
@@ -43,7 +45,7 @@ struct EmbedMix {
 };
 template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st);
 template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st);
-inline int embed_bwd_parts(int M) { return cdiv(M, 64); }
+inline int embed_bwd_parts(int M) { return cdiv(M, ln_bwd_rows(M)); }
 // dpos[s,:] = colsum over sequences (given as possum [S*d]); drole[0] = possum[0], drole[1] = sum_{s>=1}
 int pos_role_finish(const float* possum, int S, int d, int max_pos, float* dpos, float* drole, bool accumulate,
                     hipStream_t st);

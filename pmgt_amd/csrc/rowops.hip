@@ -81,7 +81,7 @@ template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
-                                                     int M, int d, DropCfg in_drop, DropCfg out_drop, const int* m_dev) {
+                                                     int M, int d, DropCfg in_drop, DropCfg out_drop, const int* m_dev, int rpb) {
     __shared__ float red[3 * 1024];
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         gam[i] = ch < nch ? *(const f32x4*)(gamma + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
         dgam[i] = dbet[i] = dbia[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int it = 0; it < 16; ++it) {
-        const int m = blockIdx.x * 64 + it * 4 + wave;
+    for (int it = 0; it < rpb / 4; ++it) {
+        const int m = blockIdx.x * rpb + it * 4 + wave;
         if (m >= M) break;
         const float mean = stats[2 * (int64_t)m], rstd = stats[2 * (int64_t)m + 1];
         f32x4 g[NCH], xh[NCH];
@@ -168,9 +168,9 @@ int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* d
     if (M <= 0) return 0;
     PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_bwd: hidden size %d must be a multiple of 4 and <= 1024", d);
     dim3 grid(ln_bwd_parts(M)), block(256);
-    if (d <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev);
-    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev);
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev);
+    if (d <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, ln_bwd_rows(M));
+    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, ln_bwd_rows(M));
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, ln_bwd_rows(M));
     PMGT_LAUNCH_OK();
     return 0;
 }
@@ -291,8 +291,9 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
         w1t[i] = ok ? *(const f32x4*)(p.Wa + 3 * d + 4 * ch) : z;
         dgam[i] = dbet[i] = dw0v[i] = dw0t[i] = dw1v[i] = dw1t[i] = z;
     }
-    for (int it = 0; it < 16; ++it) {
-        const int m = blockIdx.x * 64 + it * 4 + wave;
+    const int rpb = ln_bwd_rows(p.M);
+    for (int it = 0; it < rpb / 4; ++it) {
+        const int m = blockIdx.x * rpb + it * 4 + wave;
         if (m >= p.M) break;
         const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
         const float a0 = p.a[2 * (int64_t)m], a1 = p.a[2 * (int64_t)m + 1];
