@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -122,6 +124,7 @@ struct Scratch {     // per-thread sampling state
     std::vector<int64_t> cur, nxt, hop_order;
     std::vector<std::pair<int64_t, int64_t>> scores;      // (node, score) in first-scored order
     std::vector<int64_t> perm;
+    std::vector<int32_t> order;
     void ensure(int64_t n) {
         if ((int64_t)cnt.size() < n) {
             cnt.assign(n, 0); cnt_ver.assign(n, 0); sc_idx.assign(n, 0); sc_ver.assign(n, 0);
@@ -136,9 +139,16 @@ struct pmgt_sampler {
     int64_t n_nodes = 0;
     std::vector<int64_t> indptr, indices;
     std::vector<double> cdf;          // per-edge: normalised cumulative softmax of the row
+    // guide[b + k] = first index i of the row with cdf[i] > k / deg: the exact searchsorted(cdf, u, 'right') of a draw
+    // u in [k / deg, (k + 1) / deg) is found by scanning forward from there (1-2 compares instead of a binary search)
+    std::vector<int32_t> guide;
     std::vector<int> hops;
     int max_ctx = 0, max_total = 10, min_neg = 5;
     Scratch main;                      // the sequential (reference-order) stream
+    // scratch objects of the threaded entry, kept across calls (their dense per-node stamp arrays are 16 B per node:
+    // re-creating them per call costs more than the sampling itself on million-node graphs)
+    std::mutex pool_mu;
+    std::vector<std::unique_ptr<Scratch>> pool;
     // sorted adjacency for the negative-sampling membership test
     std::vector<int64_t> sorted_idx;
 
@@ -169,10 +179,15 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
             const int64_t b = s->indptr[node], dg = s->indptr[node + 1] - b;
             if (dg <= 0) { set_err("node %lld has no neighbours (the reference raises here)", (long long)node); return -3; }
             const double* cdf = s->cdf.data() + b;
+            const int32_t* guide = s->guide.data() + b;
             for (int r = 0; r < size; ++r) {
                 const double u = sc.rng.next_double();
                 // searchsorted(cdf, u, side='right') = first index with cdf[i] > u
-                const int64_t idx = std::upper_bound(cdf, cdf + dg, u) - cdf;
+                int64_t k = (int64_t)(u * (double)dg);
+                if (k >= dg) k = dg - 1;
+                if ((double)k / (double)dg > u) --k;           // u * dg may round up across a bucket edge
+                int64_t idx = guide[k];
+                while (idx < dg && cdf[idx] <= u) ++idx;
                 sc.nxt.push_back(s->indices[b + (idx < dg ? idx : dg - 1)]);
             }
         }
@@ -197,11 +212,18 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
         sc.cur.swap(sc.nxt);
     }
     if (sc.scores.empty()) { set_err("target %lld has no scored neighbour (reference raises at datasets.py:42)", (long long)target); return -3; }
-    std::stable_sort(sc.scores.begin(), sc.scores.end(),
-                     [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) { return a.second > b.second; });
+    // sorted(scores.items(), key=score, reverse=True)[:max_ctx] with Python's stable sort: ties keep first-scored order.
+    // Only the first max_ctx entries are read, so select them with the strict order (score desc, position asc) instead of
+    // sorting everything (same result, n log k instead of n log n).
     const int num = (int)std::min<int64_t>((int64_t)sc.scores.size(), s->max_ctx);
+    sc.order.resize(sc.scores.size());
+    for (size_t i = 0; i < sc.scores.size(); ++i) sc.order[i] = (int32_t)i;
+    const auto& scv = sc.scores;
+    std::partial_sort(sc.order.begin(), sc.order.begin() + num, sc.order.end(), [&scv](int32_t a, int32_t b) {
+        return scv[a].second > scv[b].second || (scv[a].second == scv[b].second && a < b);
+    });
     ids[0] = target;
-    for (int i = 0; i < s->max_ctx; ++i) ids[1 + i] = i < num ? sc.scores[i].first : 0;
+    for (int i = 0; i < s->max_ctx; ++i) ids[1 + i] = i < num ? sc.scores[sc.order[i]].first : 0;
     for (int i = 0; i < S; ++i) mask[i] = i <= num ? 1.f : 0.f;
     return num;
 }
@@ -281,6 +303,7 @@ pmgt_sampler* pmgt_sampler_create(int64_t n_nodes, const int64_t* indptr, const 
     s->max_total = max_total_samples;
     s->min_neg = min_neg_samples;
     s->cdf.resize(nnz);
+    s->guide.resize(nnz);
     s->sorted_idx = s->indices;
     std::vector<double> ex;
     for (int64_t v = 0; v < n_nodes + 2; ++v) {
@@ -301,6 +324,8 @@ pmgt_sampler* pmgt_sampler_create(int64_t n_nodes, const int64_t* indptr, const 
         for (int64_t i = 0; i < dg; ++i) { run += ex[i] / tot; s->cdf[b + i] = run; }
         const double last = s->cdf[b + dg - 1];
         for (int64_t i = 0; i < dg; ++i) s->cdf[b + i] /= last;
+        for (int64_t k = 0; k < dg; ++k)
+            s->guide[b + k] = (int32_t)(std::upper_bound(s->cdf.data() + b, s->cdf.data() + b + dg, (double)k / (double)dg) - (s->cdf.data() + b));
         std::sort(s->sorted_idx.begin() + b, s->sorted_idx.begin() + b + dg);
     }
     s->main.rng.seed(0);
@@ -345,7 +370,17 @@ int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mo
     std::atomic<int> next(0), fail(0);
     std::vector<std::string> errs(n_threads);
     auto work = [&](int tid) {
-        Scratch sc;
+        std::unique_ptr<Scratch> own;
+        {
+            std::lock_guard<std::mutex> lk(s->pool_mu);
+            if (!s->pool.empty()) { own = std::move(s->pool.back()); s->pool.pop_back(); }
+        }
+        if (!own) own.reset(new Scratch());
+        Scratch& sc = *own;
+        struct Return {
+            pmgt_sampler* s; std::unique_ptr<Scratch>& o;
+            ~Return() { std::lock_guard<std::mutex> lk(s->pool_mu); s->pool.push_back(std::move(o)); }
+        } ret{s, own};
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n || fail.load()) break;
