@@ -41,13 +41,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int c0, int 
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) {
-    // combine the 4 lanes (q = 0..3) that share a query column
-    float o = __shfl_xor(v, 16, 64);
-    v = is_max ? fmaxf(v, o) : v + o;
-    o = __shfl_xor(v, 32, 64);
-    return is_max ? fmaxf(v, o) : v + o;
+// Combine the 4 lanes (q = 0..3) that share a query column: lanes l, l^16, l^32, l^48.  gfx950's
+// v_permlane16_swap / v_permlane32_swap do the two exchanges in the VALU (vdst = src = v: afterwards the two results
+// hold the even-row / odd-row, resp. lower-half / upper-half, copies) instead of two ds_bpermute round trips
+// through the LDS crossbar -- these reductions sit on the dependent chain max -> exp -> sum -> reciprocal.
+__device__ __forceinline__ float xchg16(float v, bool is_max) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float a = __builtin_bit_cast(float, r[0]), b = __builtin_bit_cast(float, r[1]);
+    return is_max ? fmaxf(a, b) : a + b;
 }
+__device__ __forceinline__ float xchg32(float v, bool is_max) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = __builtin_bit_cast(float, r[0]), b = __builtin_bit_cast(float, r[1]);
+    return is_max ? fmaxf(a, b) : a + b;
+}
+template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) { return xchg32(xchg16(v, is_max), is_max); }
 
 // Recompute both normalised probability matrices (transposed, fp32, in registers).
 // fq/fk/fc: NT-form fragments of Q, K, C rows; rho[] holds the INVERSE norms 1/|c_row|, isq = 1/sqrt(dh).  On return a1/a2[jt][it][e] = A[i = 16 it + r][j = 16 jt + 4 q + e]

@@ -39,6 +39,18 @@ template <int KS> struct QaCfg {
     static constexpr int SMEM = 2 * TILEB + QTB + 8 * 64 * 4; // A ring + projection tile + per-wave {rho[32], madd[32]}
 };
 
+// reduction over the 4 lanes l, l^16, l^32, l^48 in the VALU (v_permlane16/32_swap, see attention_mfma.hip)
+__device__ __forceinline__ float qred(float v, bool is_max) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    float a = __builtin_bit_cast(float, r[0]), b = __builtin_bit_cast(float, r[1]);
+    v = is_max ? fmaxf(a, b) : a + b;
+    u = __builtin_bit_cast(unsigned, v);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __builtin_bit_cast(float, r[0]); b = __builtin_bit_cast(float, r[1]);
+    return is_max ? fmaxf(a, b) : a + b;
+}
+
 // byte address of 16-byte chunk `ch` (0..31) of row `row` inside the swizzled projection tile
 __device__ __forceinline__ int qt_addr(int row, int ch) { return row * 512 + ((ch ^ (row & 15)) << 4); }
 
@@ -164,8 +176,7 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
             float ss = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float c = (float)fc[jt][e]; ss = fmaf(c, c, ss); }
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss = qred(ss, false);
             if (q == 0) rho[16 * jt + r] = rsqrtf(ss);       // 1 / |c_row|
         }
         if (lane < 32) madd[lane] = (act && a.mask) ? (1.f - a.mask[(int64_t)t * 32 + lane]) * -10000.f : 0.f;
@@ -194,8 +205,8 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
                     m1 = fmaxf(m1, v1);
                     m2 = fmaxf(m2, v2);
                 }
-            m1 = fmaxf(m1, __shfl_xor(m1, 16, 64)); m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
-            m2 = fmaxf(m2, __shfl_xor(m2, 16, 64)); m2 = fmaxf(m2, __shfl_xor(m2, 32, 64));
+            m1 = qred(m1, true);
+            m2 = qred(m2, true);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
@@ -207,8 +218,8 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
                     s1 += e1;
                     s2 += e2;
                 }
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            s1 = qred(s1, false);
+            s2 = qred(s2, false);
             const float i1 = __frcp_rn(s1), i2 = __frcp_rn(s2);
             a1[0] *= i1; a1[1] *= i1;
             a2[0] *= i2; a2[1] *= i2;

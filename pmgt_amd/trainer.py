@@ -67,6 +67,34 @@ class Trainer:
             self._micro = 0
         return loss
 
+    # ---- the whole step as ONE hipGraph ---------------------------------------------------------------------------
+    def capture_step(self, batch, warmup: int = 2):
+        """Captures train_step(batch) (mask -> forward -> losses -> backward -> clip + AdamW) into a hipGraph and
+        returns `replay()`: the library never syncs or allocates and keeps every data-dependent count (masked rows,
+        dropout step, AdamW step) on the device, so the captured launches stay valid step after step.  New batches
+        are fed by copying into the tensors of `batch` (static input buffers), as with any captured graph.
+        `warmup` eager steps run first (one-time kernel attribute calls are not capturable).  Single-GPU step only:
+        the gradient all-reduce is not captured."""
+        assert self.world_size == 1 and self.accum == 1, "capture covers the single-GPU, non-accumulating step"
+        dev = self.engine.device
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            for _ in range(warmup):
+                self.train_step(batch)
+            st.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                loss = self.train_step(batch)
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+        def replay():
+            graph.replay()
+            self.last_loss = loss
+            return loss
+        replay.graph = graph
+        return replay
+
     # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
     def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3):
         eng = self.engine

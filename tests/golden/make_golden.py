@@ -314,12 +314,60 @@ def make_ncf():
         print("ncf", name, "loss", float(loss))
 
 
+# ------------------------------------------------------------------------------------------
+# G9: a 30-step pre-training loss curve over FRESH batches (reference sampler + model + clip + DenseSparseAdamW)
+# ------------------------------------------------------------------------------------------
+def make_curve():
+    name, gname, S, B, steps, sseed, pseed = "curve_c", "C", 16, 6, 30, 9, 41
+    cfgkw = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)
+    n, edges, w, g = graph(gname)
+    cfg, model, tables = ref_model(n, cfgkw, pseed)
+    np.random.seed(sseed)                                   # the sampler's process-global stream (pmgt/utils/base.py:37)
+    ds = PMGTDataset(g, np.arange(2, n + 2), max_ctx_neigh=S - 1)
+    order = np.random.RandomState(sseed + 1).permutation(n)
+    no_decay = ["bias", "LayerNorm.weight"]
+    groups = [
+        {"params": [p for nme, p in model.named_parameters() if p.requires_grad and not any(nd in nme for nd in no_decay)],
+         "weight_decay": 1e-2, "lr": 1e-3},
+        {"params": [p for nme, p in model.named_parameters() if p.requires_grad and any(nd in nme for nd in no_decay)],
+         "weight_decay": 0.0, "lr": 1e-3},
+    ]
+    opt = DenseSparseAdamW(groups)
+    model.train()
+    out = {"S": np.int64(S), "B": np.int64(B), "steps": np.int64(steps), "sseed": np.int64(sseed), "pseed": np.int64(pseed),
+           "order": order}
+    losses, norms = [], []
+    for step in range(steps):
+        idx = order[(step * B) % (n - B): (step * B) % (n - B) + B]
+        batch = pmgt_collate_fn([ds[int(i)] for i in idx])
+        model.zero_grad()
+        torch.manual_seed(3000 + step)
+        o = model(*batch)
+        o.loss.backward()
+        r1, repl, r2 = draw_nfr(3000 + step, batch[0]["node_ids"], n)
+        out[f"r1_{step}"], out[f"repl_{step}"], out[f"r2_{step}"] = t2n(r1), t2n(repl), t2n(r2)
+        tn = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 5.0)
+        opt.step()
+        losses.append(float(o.loss.detach()))
+        norms.append(float(tn))
+        if step in (0, steps - 1):
+            out[f"tgt_ids_{step}"] = t2n(batch[0]["node_ids"])
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["gradnorms"] = np.array(norms, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("curve", losses[:3], "...", losses[-3:])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "curve":
+        make_curve()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ncf":
         make_ncf()
         sys.exit(0)
     make_sampler()
     make_model()
     make_ncf()
+    make_curve()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

@@ -112,3 +112,31 @@ def ncf_case(name, dtype=torch.float32):
     item = {"node_ids": torch.from_numpy(gold["item_ids"]), "attention_mask": torch.from_numpy(gold["item_mask"])}
     return dict(cfg=cfg, params=params, tables=tables, head=head, n_nodes=n, gold=gold, user=torch.from_numpy(gold["user"]),
                 item=item, labels=torch.from_numpy(gold["labels"]), users=users, factor=factor, num_layers=nl, model=model)
+
+
+# ---- G9: 30-step loss curve over fresh batches ---------------------------------------------------------------
+def curve_case(dtype=torch.float32):
+    gold = load("curve_c")
+    gname = "C"
+    n = GRAPHS[gname]["n"]
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, hidden_size=64, num_attention_heads=4,
+                         num_hidden_layers=2, intermediate_size=64, beta=0.5)
+    params = po.synth_params(cfg, int(gold["pseed"]), dtype)
+    tables = po.synth_tables(n, cfg["feat_hidden_sizes"], 77, dtype)
+    return dict(cfg=cfg, params=params, tables=tables, n_nodes=n, gold=gold, gname=gname)
+
+
+def curve_batches(case):
+    """The batches the reference drew (sequential numpy-legacy stream), regenerated by the C++ sampler."""
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    from pmgt_amd.graph import CSRGraph
+    gold = case["gold"]
+    n, edges, w = graph(case["gname"])
+    S, B, steps = int(gold["S"]), int(gold["B"]), int(gold["steps"])
+    smp = MCNSampler(CSRGraph.from_edge_list(n, edges, w), max_ctx_neigh=S - 1)
+    smp.seed(int(gold["sseed"]))
+    order = gold["order"]
+    for step in range(steps):
+        lo = (step * B) % (n - B)
+        tgt, pair, num_pairs, labels = smp.batch(order[lo: lo + B] + 2, MODE_TRAIN, threads=0)
+        yield step, ({k: v.clone() for k, v in tgt.items()}, {k: v.clone() for k, v in pair.items()}, num_pairs.clone(), labels.clone())

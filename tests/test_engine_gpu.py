@@ -270,3 +270,56 @@ def test_segment_sum_wgrad_matches_per_token_wgrad(name, dtype):
         e = eng.entry(k)
         other[e["offset"]: e["offset"] + e["numel"]] = False
     assert torch.equal(res[0][0][other], res[1][0][other])      # nothing else changes
+
+
+def test_whole_step_replays_as_one_hip_graph():
+    """The training step (NFR masks on device, forward, losses, backward, clip + AdamW) captured once into a hipGraph:
+    replays must walk the same parameter trajectory as eager steps (device-side step counters keep advancing)."""
+    from pmgt_amd.trainer import Trainer
+    case = gu.model_case("m3")
+    batch = dev_batch(case["batch"])
+
+    def fresh():
+        eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        return eng, Trainer(eng, lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
+
+    eng_a, tr_a = fresh()
+    la = [tr_a.train_step(batch).item() for _ in range(2 + 1 + 4)]          # warm-up + captured step + 4 replays
+    torch.cuda.synchronize()
+    eng_b, tr_b = fresh()
+    replay = tr_b.capture_step(batch, warmup=2)                             # 2 eager steps, then the capture (records, does not run)
+    lb = [replay().item() for _ in range(5)]
+    torch.cuda.synchronize()
+    # capture itself does not execute: eager trajectory steps 3..7 == replays 1..5
+    np.testing.assert_allclose(lb, la[2:], rtol=0, atol=0)
+    assert torch.equal(eng_a.params, eng_b.params)
+    assert np.all(np.diff(lb) != 0)                                         # not one frozen step replayed
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_thirty_step_loss_curve_matches_reference(dtype):
+    """north_star: "pre-training loss curve matching the reference within 1e-3".  G9 = 30 optimizer steps of the
+    reference (its sampler, model, clip, DenseSparseAdamW) on fresh batches; here: C++ sampler (regenerates the same
+    batches from the seed) -> HIP engine through the C ABI.  fp32 mode must stay within 1e-3 relative at every step
+    (measured 1.4e-7); the bf16 throughput mode holds the same 1e-3 bound (measured 1.5e-4)."""
+    c = gu.curve_case()
+    gold = c["gold"]
+    eng = make_engine(dict(cfg=c["cfg"], params=c["params"], tables=c["tables"]), dtype=dtype)
+    losses, norms = [], []
+    for step, batch in gu.curve_batches(c):
+        ids = batch[0]["node_ids"]
+        masked, m2, tidx = po.nfr_masking(ids, c["n_nodes"], torch.from_numpy(gold[f"r1_{step}"]),
+                                          torch.from_numpy(gold[f"repl_{step}"]), torch.from_numpy(gold[f"r2_{step}"]))
+        full = torch.full_like(ids, -1)
+        full[:, 1:][m2] = tidx
+        out = eng.pretrain_step(dev_batch(batch), training=True, backward=True, nfr_inject=(masked.cuda(), full.cuda()))
+        eng.optimizer_step(lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
+        losses.append(out["loss"].item())
+        norms.append(eng.grad_norm().item())
+    rel = np.abs(np.array(losses) / gold["losses"] - 1.0)
+    if dtype == "fp32":
+        assert rel.max() < 1e-3, rel.max()
+        np.testing.assert_allclose(norms, gold["gradnorms"], rtol=5e-3)
+    else:
+        assert rel.max() < 1e-3, rel.max()
+    print(f"loss-curve max relative deviation ({dtype}): {rel.max():.2e}")

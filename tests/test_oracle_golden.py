@@ -128,3 +128,29 @@ def test_ncf_second_caller_matches_reference(name):
         g = v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)
         scale = float(np.sqrt((g.astype(np.float64) ** 2).mean())) + 1e-12
         gu.check_stored(gold, "grad/" + k, g, 2e-4, 2e-4 * scale + 1e-9)       # key.bias grads are exactly 0 in theory
+
+
+def test_loss_curve_over_fresh_batches_matches_reference():
+    """G9: 30 steps of sampler -> PMGT.forward -> backward -> clip 5.0 -> DenseSparseAdamW on fresh batches.  The C++
+    sampler regenerates the reference's batches from the seed alone (bit-exact stream), the oracle reproduces the
+    loss curve and gradient norms (CPU, first 8 steps to keep the suite short)."""
+    c = gu.curve_case()
+    gold = c["gold"]
+    p = {k: v.clone() for k, v in c["params"].items()}
+    state = {}
+    for step, batch in gu.curve_batches(c):
+        if step in (0, int(gold["steps"]) - 1):
+            np.testing.assert_array_equal(batch[0]["node_ids"].numpy(), gold[f"tgt_ids_{step}"])
+        if step >= 8:
+            continue
+        pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        inj = po.nfr_masking(batch[0]["node_ids"], c["n_nodes"], torch.from_numpy(gold[f"r1_{step}"]),
+                             torch.from_numpy(gold[f"repl_{step}"]), torch.from_numpy(gold[f"r2_{step}"]))
+        out = po.pretrain_forward(pp, c["cfg"], c["tables"], batch, training=True, nfr_inject=inj)
+        out["loss"].backward()
+        grads = {k: v.grad for k, v in pp.items()}
+        norm = po.clip_grad_norm(grads, 5.0)
+        p = {k: v.detach() for k, v in pp.items()}
+        po.adamw_step(p, grads, state, lr=1e-3, wd=1e-2)           # in place
+        np.testing.assert_allclose(out["loss"].item(), gold["losses"][step], rtol=2e-5)
+        np.testing.assert_allclose(norm, gold["gradnorms"][step], rtol=2e-4)

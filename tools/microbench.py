@@ -134,6 +134,7 @@ def attn(T, S, H, dh, name=""):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "attn":
         attn(12 * int(sys.argv[1]), 32, 8, 32)
+        attn(12 * int(sys.argv[1]), 32, 4, 64)
         attn(3 * int(sys.argv[1]), 64, 8, 64)
         attn(3 * int(sys.argv[1]), 64, 8, 32)
         attn(6 * int(sys.argv[1]), 48, 8, 32)
