@@ -45,16 +45,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int c0, int 
 // v_permlane16_swap / v_permlane32_swap do the two exchanges in the VALU (vdst = src = v: afterwards the two results
 // hold the even-row / odd-row, resp. lower-half / upper-half, copies) instead of two ds_bpermute round trips
 // through the LDS crossbar -- these reductions sit on the dependent chain max -> exp -> sum -> reciprocal.
+// (inline asm on two copies of v: the builtins fold when both operands are the same value; "s_nop 1" covers the
+// VALU-write -> permlane-read hazard, cdna_hip_programming.md T21)
 __device__ __forceinline__ float xchg16(float v, bool is_max) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float a = __builtin_bit_cast(float, r[0]), b = __builtin_bit_cast(float, r[1]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return is_max ? fmaxf(a, b) : a + b;
 }
 __device__ __forceinline__ float xchg32(float v, bool is_max) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const float a = __builtin_bit_cast(float, r[0]), b = __builtin_bit_cast(float, r[1]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return is_max ? fmaxf(a, b) : a + b;
 }
 template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) { return xchg32(xchg16(v, is_max), is_max); }

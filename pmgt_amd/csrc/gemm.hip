@@ -318,9 +318,14 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT g) {
 // through L2 (for dX = dQKVC W at M = 393k, K = 1024, N = 256 that is 3.2 GB of L2 -> CU traffic for 1.2 GB of
 // HBM bytes); this tile halves both.  No row gather, no device row count (those stay on the small tile).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT g) {
+// BN = 256 / 8 waves: one workgroup per CU (128 KiB ring).  BN = 128 / 4 waves: 72 KiB ring (3 stages), TWO workgroups
+// per CU, so one's prologue / epilogue overlaps the other's main loop.
+template <int BN, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
     typedef bf16 T;
-    constexpr int BM = 256, BN = 256, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = 4;     // 32 KiB per stage
+    constexpr int BM = 256, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = BN == 256 ? 4 : 3;
+    constexpr int WN = BN / 64, AI = 16 / NW, BI = BN / 16 / NW, PER = AI + BI;     // DMA instructions per wave per stage
+    static_assert(NW / WN == 2, "two wave rows of 128 output rows each");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int num_n = g.N / BN;
     const int num_m = (g.M + BM - 1) / BM;
@@ -330,28 +335,34 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT g) {
     if (m_tile >= num_m) return;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, q = lane >> 4;
 
-    const char* asrc[2];
-    const char* bsrc[2];
+    const char* asrc[AI];
+    const char* bsrc[BI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 32 * wave + 16 * j + (lane >> 2);
+    for (int j = 0; j < AI; ++j) {
+        const int row = 16 * (AI * wave + j) + (lane >> 2);
         const int ch = (lane & 3) ^ ((row >> 2) & 3);
         const int m = min(m0 + row, g.M - 1);
         asrc[j] = (const char*)g.A + (int64_t)m * g.lda * 2 + ch * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = 16 * (BI * wave + j) + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
         bsrc[j] = (const char*)g.B + (int64_t)(n0 + row) * g.ldb * 2 + ch * 16;
     }
     auto issue = [&](int kt) {
-        char* st = smem + (kt & (NST - 1)) * STAGE;
+        char* st = smem + (kt % NST) * STAGE;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < AI; ++j)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + (int64_t)kt * ROWB),
-                                             (lds_void_t*)(st + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
+                                             (lds_void_t*)(st + 16 * (AI * wave + j) * ROWB), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BI; ++j)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + (int64_t)kt * ROWB),
-                                             (lds_void_t*)(st + BM * ROWB + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
-        }
+                                             (lds_void_t*)(st + BM * ROWB + 16 * (BI * wave + j) * ROWB), 16, 0, 0);
     };
     f32x4 acc[8][4];
 #pragma unroll
@@ -372,17 +383,17 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT g) {
         offb[j] = (uint32_t)(BM * ROWB + rb * ROWB + ((q ^ ((rb >> 2) & 3)) << 4));
     }
     const int nk = g.K / 32;
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+#pragma unroll
+    for (int kt = 0; kt < NST - 1; ++kt)
+        if (kt < nk) issue(kt);
     for (int kt = 0; kt < nk; ++kt) {
-        const int younger = min(2, nk - 1 - kt);
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const int younger = min(NST - 2, nk - 1 - kt);
+        if (younger == 2) { if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else if (younger == 1) { if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3);
-        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
+        if (kt + NST - 1 < nk) issue(kt + NST - 1);
+        const uint32_t sbase = lds_base + (uint32_t)((kt % NST) * STAGE);
         u32x4 t[12];
         asm volatile(
             "ds_read_b128 %0, %12\n\t"
@@ -420,7 +431,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT g) {
     T* AUX = (T*)g.aux;
     constexpr int ES = BN + 4;
     float* stage = (float*)smem;
-    const int er = tid >> 5, ec = (tid & 31) * 8;
+    constexpr int LPR = BN / 8;                     // lanes per output row
+    const int er = tid / LPR, ec = (tid % LPR) * 8;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         if (wm == (pass >> 1)) {
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT g) {
 static int g_nt_no_big = 0;
 void gemm_nt_disable_big(int on) { g_nt_no_big = on; }
 static bool nt_big_ok(const GemmNT& g) {
-    return !g_nt_no_big && g.a_rows == nullptr && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 256 == 0 && g.K % 32 == 0 &&
+    return !g_nt_no_big && g.a_rows == nullptr && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 128 == 0 && g.K % 32 == 0 &&
            g.K >= 128 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
            (g.aux == nullptr || g.ldaux % 8 == 0) && ((uintptr_t)g.C % 16) == 0 && (g.res == nullptr || ((uintptr_t)g.res % 16) == 0) &&
            (g.aux == nullptr || ((uintptr_t)g.aux % 16) == 0) && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0);
@@ -511,14 +523,26 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     const int grid = cdiv(num_m, 8) * 8 * num_n;
     if constexpr (sizeof(T) == 2) {
         if (nt_big_ok(g)) {
-            constexpr int smem = 4 * (256 + 256) * 64;
-            static bool attr_set = false;
-            if (!attr_set) {
-                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_set = true;
+            static int narrow = -1;
+            if (narrow < 0) { const char* ev = getenv("PMGT_NT_BIG_BN"); narrow = ev ? atoi(ev) : 0; }
+            const int nm = cdiv(g.M, 256);
+            if (g.N % 256 == 0 && narrow != 128) {
+                constexpr int smem = 4 * (256 + 256) * 64;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_big_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8>), dim3(cdiv(nm, 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
+            } else {
+                constexpr int smem = 3 * (256 + 128) * 64;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_big_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((gemm_nt_big_kernel<128, 4>), dim3(cdiv(nm, 8) * 8 * (g.N / 128)), dim3(256), smem, st, g);
             }
-            const int nm = cdiv(g.M, 256), nn = g.N / 256;
-            hipLaunchKernelGGL(gemm_nt_big_kernel, dim3(cdiv(nm, 8) * 8 * nn), dim3(512), smem, st, g);
             PMGT_LAUNCH_OK();
             return 0;
         }

@@ -41,13 +41,11 @@ template <int KS> struct QaCfg {
 
 // reduction over the 4 lanes l, l^16, l^32, l^48 in the VALU (v_permlane16/32_swap, see attention_mfma.hip)
 __device__ __forceinline__ float qred(float v, bool is_max) {
-    unsigned u = __builtin_bit_cast(unsigned, v);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    float a = __builtin_bit_cast(float, r[0]), b = __builtin_bit_cast(float, r[1]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     v = is_max ? fmaxf(a, b) : a + b;
-    u = __builtin_bit_cast(unsigned, v);
-    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    a = __builtin_bit_cast(float, r[0]); b = __builtin_bit_cast(float, r[1]);
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return is_max ? fmaxf(a, b) : a + b;
 }
 

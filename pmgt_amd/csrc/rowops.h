@@ -17,7 +17,7 @@ template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
            int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr);
 // rows per workgroup: 64, or 256 for large M (4x fewer partial rows to write and reduce; still >= 6 workgroups per CU)
-inline int ln_bwd_rows(int M) { return M >= 65536 ? 256 : 64; }
+__host__ __device__ inline int ln_bwd_rows(int M) { return M >= 65536 ? 256 : 64; }
 inline int ln_bwd_parts(int M) { return cdiv(M, ln_bwd_rows(M)); }
 
 // ---- embedding mix (pmgt/pmgt/modeling_pmgt.py:199-208) ----------------------------------------

@@ -145,6 +145,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "fused":
         fused(12 * B, 8)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "nt":
+        nt(M, 256, 1024, res=True, name="dgrad_qkvc")
+        M4 = 12 * 256 * 64
+        nt(M4, 2048, 512, name="c4 qkvc fwd")
+        nt(M4, 512, 2048, res=True, name="c4 dgrad_qkvc")
+        nt(M4, 512, 512, res=True, name="c4 d x d")
+        sys.exit(0)
     nt(M, 256, 1024, res=True, name="dgrad_qkvc")
     nt(M, 256, 256, res=False, name="dxd")
     linear(M, 1024, 256, name="qkvc_fwd")
