@@ -288,7 +288,10 @@ template <int DH, int NT> struct BwdSmem {
     static constexpr int BYTES = 4 * TILE + 3 * IMG + 2 * 64 * 4;
 };
 
-template <int DH, int NT>
+// FULL: S == 16 NT (no padded rows or keys): the sequence length is a compile-time constant, every bounds select folds
+// away (the kernel is VALU-issue-bound: ~1600 VALU instructions per (sequence, head)); idle waves of the last
+// workgroup recompute pair 0 and only their stores are predicated off.
+template <int DH, int NT, bool FULL>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     using SM = BwdSmem<DH, NT>;
     constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     const int nw = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int gidx = blockIdx.x * nw + wave;
-    const int S = a.S, H = a.H, d = H * DH;
+    const int S = FULL ? NT * 16 : a.S, H = a.H, d = H * DH;
     const bool act = gidx < a.Tseq * H;
     const int t = act ? gidx / H : 0, h = act ? gidx % H : 0;
     char* base = smem + wave * SM::BYTES;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
     bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
     const int64_t ld = 4 * d;
-    const int Sv = act ? S : 0;
+    const int Sv = FULL ? NT * 16 : (act ? S : 0);
     const float isq = rsqrtf((float)DH);
 
     // NT <= 2: every global load of the kernel is issued here, before anything is consumed
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
                 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
             }
-            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);
+            if (act && x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);
             dch[ct] = -dc;       // dN = -dS1
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
             dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
-            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 3 * d + 16 * ct + 4 * q, (dch[ct] - ch * dt) * inv);
+            if (act && x < Sv) store4<bf16>(DX + (int64_t)x * ld + 3 * d + 16 * ct + 4 * q, (dch[ct] - ch * dt) * inv);
         }
     }
     // ---- products with the key index on the lane: dV^T[c][j] = sum_i dO[i][c] P[i][j], dK^T[c][j] = sum_i Q[i][c] dS2[i][j]
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
                 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
             }
-            if (j < Sv) {
+            if (act && j < Sv) {
                 store4<bf16>(DX + (int64_t)j * ld + 2 * d + 16 * ct + 4 * q, dv);
                 store4<bf16>(DX + (int64_t)j * ld + d + 16 * ct + 4 * q, dk * isq);
             }
@@ -957,7 +960,8 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
         if (per * 4 <= LDS && (LDS / (per * 4)) * 4 > (LDS / (per * 2)) * 2) nw = 4;
         if ((env_nw == 1 || env_nw == 2 || env_nw == 4) && per * env_nw <= LDS) nw = env_nw;
         const size_t shmem = per * nw;
-        auto kern = attn_bwd_mfma_kernel<DH, NT>;
+        const bool full = a.S == NT * 16 && NT % 2 == 0;
+        auto kern = full ? attn_bwd_mfma_kernel<DH, NT, true> : attn_bwd_mfma_kernel<DH, NT, false>;
         if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(kern, dim3(cdiv(groups, nw)), dim3(64 * nw), shmem, st, a);
     }
