@@ -447,12 +447,21 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     }
     {
         EmbedMix m;
-        m.M = M; m.S = S; m.d = d; m.E = b.E; m.e_rows = table_mode ? ids : nullptr;
-        m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
+        m.S = S; m.d = d; m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
         m.gamma = P + e->ln_g; m.beta = P + e->ln_b; m.eps = e->cfg.layer_norm_eps;
-        m.a = b.a; m.pre = b.emb_pre; m.stats = b.emb_stats; m.h0 = b.h0;
+        m.a = b.a; m.stats = b.emb_stats; m.h0 = b.h0;
         m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
-        RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
+        if (table_mode && !g_no_segsum) {
+            // the modality mix a0 e_v + a1 e_t depends on the node only: once per node, then one [d] row per token
+            T* F_all = b.E + n_rows * 2 * d;                 // fits: (N + 2) * 3d <= M * 2d
+            m.phase = 1; m.M = (int)n_rows; m.E = b.E; m.pre = F_all;
+            RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
+            m.phase = 2; m.M = M; m.E = F_all; m.e_rows = ids; m.pre = b.emb_pre;
+            RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
+        } else {
+            m.M = M; m.E = b.E; m.e_rows = table_mode ? ids : nullptr; m.pre = b.emb_pre;
+            RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
+        }
     }
     if (hidden_states) PMGT_HIP(hipMemcpyAsync(hidden_states, b.h0, (size_t)M * d * sizeof(T), hipMemcpyDeviceToDevice, st));
     const T* hin = b.h0;
@@ -663,22 +672,33 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     RUN(join_side(st, w_qkvc));            // embed_mix_bwd rewrites big and bB
     {
         EmbedMix m;
-        m.M = M; m.S = S; m.d = d; m.E = b.E; m.e_rows = b.e_by_id ? b.ids : nullptr;
-        m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a; m.pre = b.emb_pre;
+        m.S = S; m.d = d; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a;
         m.stats = b.emb_stats; m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
-        m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB; m.part = b.part;
-        RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
-        RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
-        RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-        if (b.e_by_id && !g_no_segsum) {
-            // table mode: dW_m = (sum of dE rows per node id)^T x table_m -- a GEMM over N+2 rows instead of M tokens
+        m.part = b.part;
+        const bool by_node = b.e_by_id && !g_no_segsum;
+        if (by_node) {
+            // Table mode: per token only the LayerNorm backward (dF); the segment sums of dF per node id feed the
+            // per-node backward of the modality mix, whose dE [N+2, 2d] is the P operand of the weight-gradient GEMM.
             const int n_rows = (int)t->n_nodes + 2;
+            m.phase = 2; m.M = M; m.dh0 = b.bA; m.pre = b.emb_pre; m.dF = b.bB;
+            RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
+            RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
+            RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
+            RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
             RUNP("bwd.segsum_featproj", seg_sort(b.ids, M, n_rows, b.sg_keys, b.sg_vals, b.sg_skeys, b.sg_perm, b.sg_off, b.sg_tmp, b.sg_tmp_bytes, st));
-            RUNP("bwd.segsum_featproj", seg_sum<T>(b.big, 2 * d, b.sg_skeys, b.sg_perm, b.sg_off, M, n_rows, 2 * d, b.bC, b.sg_part, st));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bC, 2 * d, (const T*)t->table_v, e->Fv, nullptr, n_rows, n_rows, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bC + d, 2 * d, (const T*)t->table_t, e->Ft, nullptr, n_rows, n_rows, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+            RUNP("bwd.segsum_featproj", (seg_sum<T, float>(b.bB, d, b.sg_skeys, b.sg_perm, b.sg_off, M, n_rows, d, (float*)b.bC, b.sg_part, st)));     // (N+2) d fp32 <= M d bf16
+            m.phase = 1; m.M = n_rows; m.E = b.E; m.e_rows = nullptr; m.dF = b.bC; m.dF_f32 = true; m.dE = b.bD;
+            RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
+            RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(n_rows), 6 * d + 4, G + e->ln_g, true, st));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD, 2 * d, (const T*)t->table_v, e->Fv, nullptr, n_rows, n_rows, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD + d, 2 * d, (const T*)t->table_t, e->Ft, nullptr, n_rows, n_rows, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
         } else {
+            m.M = M; m.E = b.E; m.e_rows = b.e_by_id ? b.ids : nullptr; m.pre = b.emb_pre;
+            m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB;
+            RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
+            RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
+            RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
+            RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
             RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
             RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
         }

@@ -25,6 +25,13 @@ struct EmbedMix {
     int M = 0, S = 0, d = 0;
     const void* E = nullptr;       // [M, 2d]: e_v | e_t (bias already added by the GEMM epilogue)
     const int64_t* e_rows = nullptr;   // optional: token m reads row e_rows[m] of E (E = projection of the whole table)
+    // Table mode splits the work (the modality mix depends on the NODE only):
+    //   phase 1 (rows = nodes):  fwd: a[n], F[n] = a0 e_v + a1 e_t -> `pre` used as F_all [rows, d];
+    //                            bwd: df read from `dF` (= segment sums per node), writes dE [rows, 2d] + dWa / dba partials
+    //   phase 2 (rows = tokens): fwd: x = F_all[e_rows[m]] (read through `E`, row stride d) + pos + role -> LN -> dropout;
+    //                            bwd: LayerNorm backward only: writes dF, dgamma / dbeta partials
+    int phase = 0;
+    bool dF_f32 = false;           // phase 1 backward: `dF` holds fp32 segment sums
     const float* Wa = nullptr;     // [2, 2d]
     const float* ba = nullptr;     // [2]
     const float* pos = nullptr;    // [max_pos, d]

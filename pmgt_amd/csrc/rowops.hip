@@ -188,30 +188,48 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     if (m >= p.M) return;
     const int d = p.d, nch = d >> 2;
     const int s = m % p.S;
-    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * 2 * d;
+    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * (p.phase == 2 ? d : 2 * d);
     f32x4 ev[NCH], et[NCH];
-    float z0 = 0.f, z1 = 0.f;
+    float a0 = 1.f, a1 = 0.f;
+    if (p.phase != 2) {
+        float z0 = 0.f, z1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-            ev[i] = load4<T>(E + 4 * ch);
-            et[i] = load4<T>(E + d + 4 * ch);
-            f32x4 tv, tt;
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                ev[i] = load4<T>(E + 4 * ch);
+                et[i] = load4<T>(E + d + 4 * ch);
+                f32x4 tv, tt;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { tv[e] = tanhf(ev[i][e]); tt[e] = tanhf(et[i][e]); }
-            z0 += sum4(tv * *(const f32x4*)(p.Wa + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + d + 4 * ch));
-            z1 += sum4(tv * *(const f32x4*)(p.Wa + 2 * d + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + 3 * d + 4 * ch));
-        } else {
-            ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e) { tv[e] = tanhf(ev[i][e]); tt[e] = tanhf(et[i][e]); }
+                z0 += sum4(tv * *(const f32x4*)(p.Wa + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + d + 4 * ch));
+                z1 += sum4(tv * *(const f32x4*)(p.Wa + 2 * d + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + 3 * d + 4 * ch));
+            } else {
+                ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        z0 = wave_sum(z0) + p.ba[0];
+        z1 = wave_sum(z1) + p.ba[1];
+        const float zm = fmaxf(z0, z1);
+        const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+        a0 = e0 / (e0 + e1); a1 = e1 / (e0 + e1);
+        if (lane == 0) { p.a[2 * (int64_t)m] = a0; p.a[2 * (int64_t)m + 1] = a1; }
+        if (p.phase == 1) {         // per-node mix only: F[n] = a0 e_v + a1 e_t
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) store4<T>((T*)p.pre + (int64_t)m * d + 4 * ch, ev[i] * a0 + et[i] * a1);
+            }
+            return;
+        }
+    } else {                        // token phase: the mixed feature of the node, already weighted
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            ev[i] = ch < nch ? load4<T>(E + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    z0 = wave_sum(z0) + p.ba[0];
-    z1 = wave_sum(z1) + p.ba[1];
-    const float zm = fmaxf(z0, z1);
-    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
-    const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
-    if (lane == 0) { p.a[2 * (int64_t)m] = a0; p.a[2 * (int64_t)m + 1] = a1; }
 
     f32x4 x[NCH];
     float sum = 0.f;
@@ -295,48 +313,67 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
     for (int it = 0; it < rpb / 4; ++it) {
         const int m = blockIdx.x * rpb + it * 4 + wave;
         if (m >= p.M) break;
-        const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
-        const float a0 = p.a[2 * (int64_t)m], a1 = p.a[2 * (int64_t)m + 1];
-        f32x4 g[NCH], xh[NCH];
-        float sg = 0.f, sgx = 0.f;
+        const float a0 = p.phase == 2 ? 0.f : p.a[2 * (int64_t)m], a1 = p.phase == 2 ? 0.f : p.a[2 * (int64_t)m + 1];
+        f32x4 df[NCH], ev[NCH], et[NCH];
+        if (p.phase != 1) {     // LayerNorm backward of token m -> df (gradient wrt the pre-LN sum)
+            const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
+            f32x4 g[NCH], xh[NCH];
+            float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < nch) {
-                f32x4 dyv = load4<T>((const T*)p.dh0 + (int64_t)m * d + 4 * ch);
-                if (ik.on) {
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    f32x4 dyv = load4<T>((const T*)p.dh0 + (int64_t)m * d + 4 * ch);
+                    if (ik.on) {
 { float dm[4]; drop_mul4(ik, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
+                        for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
+                    }
+                    xh[i] = (load4<T>((const T*)p.pre + (int64_t)m * d + 4 * ch) - mean) * rstd;
+                    g[i] = dyv * gam[i];
+                    dgam[i] += dyv * xh[i];
+                    dbet[i] += dyv;
+                    sg += sum4(g[i]);
+                    sgx += sum4(g[i] * xh[i]);
+                } else {
+                    g[i] = xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                xh[i] = (load4<T>((const T*)p.pre + (int64_t)m * d + 4 * ch) - mean) * rstd;
-                g[i] = dyv * gam[i];
-                dgam[i] += dyv * xh[i];
-                dbet[i] += dyv;
-                sg += sum4(g[i]);
-                sgx += sum4(g[i] * xh[i]);
-            } else {
-                g[i] = xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            sg = wave_sum(sg) / (float)d;
+            sgx = wave_sum(sgx) / (float)d;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    df[i] = (g[i] - sg - xh[i] * sgx) * rstd;
+                    store4<T>((T*)p.dF + (int64_t)m * d + 4 * ch, df[i]);
+                } else {
+                    df[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (p.phase == 2) continue;      // token phase of the table mode: the mix is differentiated per node
+        } else {                // node phase: df = sum of the token gradients of node m
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                df[i] = ch >= nch ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                                  : (p.dF_f32 ? *(const f32x4*)((const float*)p.dF + (int64_t)m * d + 4 * ch)
+                                              : load4<T>((const T*)p.dF + (int64_t)m * d + 4 * ch));
             }
         }
-        sg = wave_sum(sg) / (float)d;
-        sgx = wave_sum(sgx) / (float)d;
-        // df = gradient wrt the pre-LN sum; then through f = a0 e_v + a1 e_t
-        f32x4 df[NCH], ev[NCH], et[NCH];
+        // through f = a0 e_v + a1 e_t
         float da0 = 0.f, da1 = 0.f;
         const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * 2 * d;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                df[i] = (g[i] - sg - xh[i] * sgx) * rstd;
-                store4<T>((T*)p.dF + (int64_t)m * d + 4 * ch, df[i]);
                 ev[i] = load4<T>(E + 4 * ch);
                 et[i] = load4<T>(E + d + 4 * ch);
                 da0 += sum4(df[i] * ev[i]);
                 da1 += sum4(df[i] * et[i]);
             } else {
-                df[i] = ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         da0 = wave_sum(da0);

@@ -10,8 +10,8 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
              void* temp, int64_t temp_bytes, hipStream_t st);
 int64_t seg_part_elems(int M, int cols);
 // out[n, :cols] = sum of src[perm[p], :cols] over the sorted positions p of segment n (zeros for empty segments)
-template <typename T>
+template <typename T, typename TO>
 int seg_sum(const T* src, int64_t ld, const uint32_t* skeys, const uint32_t* perm, const int* seg_off, int M, int n_rows, int cols,
-            T* out, float* part, hipStream_t st);
+            TO* out, float* part, hipStream_t st);
 
 }  // namespace pmgt

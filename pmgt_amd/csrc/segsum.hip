@@ -36,10 +36,10 @@ __global__ void seg_bounds_kernel(const uint32_t* __restrict__ skeys, int M, int
 // One workgroup per chunk of SEG_CH sorted positions; thread c owns columns 2c, 2c+1 (+ 512 g).
 // A run [a, b) of equal keys is COMPLETE when it is the whole segment: written to out[key].  Otherwise its partial sum
 // goes to part[chunk][slot]: slot 0 if the run starts at the chunk start, else slot 1 (then it ends at the chunk end).
-template <typename T, int CG>
+template <typename T, typename TO, int CG>
 __global__ __launch_bounds__(256) void seg_sum_kernel(const T* __restrict__ src, int64_t lds_, const uint32_t* __restrict__ skeys,
                                                       const uint32_t* __restrict__ perm, const int* __restrict__ seg_off, int M,
-                                                      int cols, T* __restrict__ out, float* __restrict__ part) {
+                                                      int cols, TO* __restrict__ out, float* __restrict__ part) {
     __shared__ uint32_t sk[SEG_CH], sp[SEG_CH];
     const int tid = threadIdx.x;
     const int p0 = blockIdx.x * SEG_CH, p1 = min(M, p0 + SEG_CH);
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const T* __restrict__ src,
             const int c = 2 * (tid + 256 * g);
             if (c < cols) {
                 if (complete) {
-                    if constexpr (sizeof(T) == 2) {
+                    if constexpr (sizeof(TO) == 2) {
                         typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                         *(bf16x2_t*)(out + (int64_t)cur * cols + c) = (bf16x2_t){(bf16)acc[g][0], (bf16)acc[g][1]};
                     } else {
@@ -177,30 +177,31 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
 
 int64_t seg_part_elems(int M, int cols) { return (int64_t)cdiv(M, SEG_CH) * 2 * cols; }
 
-template <typename T>
+template <typename T, typename TO>
 int seg_sum(const T* src, int64_t ld, const uint32_t* skeys, const uint32_t* perm, const int* seg_off, int M, int n_rows, int cols,
-            T* out, float* part, hipStream_t st) {
+            TO* out, float* part, hipStream_t st) {
     PMGT_CHECK(cols % 2 == 0 && cols <= 2048, -2, "seg_sum: cols=%d must be even and <= 2048", cols);
     const int chunks = cdiv(M, SEG_CH);
     const int cg = cdiv(cols, 512);
     switch (cg) {
         case 1:
-            hipLaunchKernelGGL((seg_sum_kernel<T, 1>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
-            hipLaunchKernelGGL((seg_fix_kernel<T, 1>), dim3(n_rows), dim3(256), 0, st, seg_off, n_rows, cols, part, out);
+            hipLaunchKernelGGL((seg_sum_kernel<T, TO, 1>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
+            hipLaunchKernelGGL((seg_fix_kernel<TO, 1>), dim3(n_rows), dim3(256), 0, st, seg_off, n_rows, cols, part, out);
             break;
         case 2:
-            hipLaunchKernelGGL((seg_sum_kernel<T, 2>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
-            hipLaunchKernelGGL((seg_fix_kernel<T, 2>), dim3(n_rows), dim3(256), 0, st, seg_off, n_rows, cols, part, out);
+            hipLaunchKernelGGL((seg_sum_kernel<T, TO, 2>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
+            hipLaunchKernelGGL((seg_fix_kernel<TO, 2>), dim3(n_rows), dim3(256), 0, st, seg_off, n_rows, cols, part, out);
             break;
         default:
-            hipLaunchKernelGGL((seg_sum_kernel<T, 4>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
-            hipLaunchKernelGGL((seg_fix_kernel<T, 4>), dim3(n_rows), dim3(256), 0, st, seg_off, n_rows, cols, part, out);
+            hipLaunchKernelGGL((seg_sum_kernel<T, TO, 4>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
+            hipLaunchKernelGGL((seg_fix_kernel<TO, 4>), dim3(n_rows), dim3(256), 0, st, seg_off, n_rows, cols, part, out);
             break;
     }
     PMGT_LAUNCH_OK();
     return 0;
 }
-template int seg_sum<float>(const float*, int64_t, const uint32_t*, const uint32_t*, const int*, int, int, int, float*, float*, hipStream_t);
-template int seg_sum<bf16>(const bf16*, int64_t, const uint32_t*, const uint32_t*, const int*, int, int, int, bf16*, float*, hipStream_t);
+template int seg_sum<float, float>(const float*, int64_t, const uint32_t*, const uint32_t*, const int*, int, int, int, float*, float*, hipStream_t);
+template int seg_sum<bf16, bf16>(const bf16*, int64_t, const uint32_t*, const uint32_t*, const int*, int, int, int, bf16*, float*, hipStream_t);
+template int seg_sum<bf16, float>(const bf16*, int64_t, const uint32_t*, const uint32_t*, const int*, int, int, int, float*, float*, hipStream_t);
 
 }  // namespace pmgt
