@@ -213,6 +213,7 @@ template <typename T> struct Bufs {
     float* mask;       // [Tseq, S]
     T* mirror;
     T *E, *emb_pre, *h0;
+    hipEvent_t sort_done = nullptr;   // set when the token sort of this step already runs on the side stream
     bool e_by_id = false;   // E holds the projection of the whole table (rows = node ids) instead of one row per token
     float *a, *emb_stats;
     std::vector<LayerBufs<T>> layer;
@@ -685,7 +686,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
             RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
             RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-            RUNP("bwd.segsum_featproj", seg_sort(b.ids, M, n_rows, b.sg_keys, b.sg_vals, b.sg_skeys, b.sg_perm, b.sg_off, b.sg_tmp, b.sg_tmp_bytes, st));
+            if (b.sort_done) PMGT_HIP(hipStreamWaitEvent(st, b.sort_done, 0));
+            else RUNP("bwd.segsum_featproj", seg_sort(b.ids, M, n_rows, b.sg_keys, b.sg_vals, b.sg_skeys, b.sg_perm, b.sg_off, b.sg_tmp, b.sg_tmp_bytes, st));
             RUNP("bwd.segsum_featproj", (seg_sum<T, float>(b.bB, d, b.sg_skeys, b.sg_perm, b.sg_off, M, n_rows, d, (float*)b.bC, b.sg_part, st)));     // (N+2) d fp32 <= M d bf16
             m.phase = 1; m.M = n_rows; m.E = b.E; m.e_rows = nullptr; m.dF = b.bC; m.dF_f32 = true; m.dE = b.bD;
             RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
@@ -737,6 +739,17 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         }
         PMGT_HIP(hipMemcpyAsync(b.mask + bs + ps, bt->tgt_mask, bs * 4, hipMemcpyDeviceToDevice, st));   // models.py:153-156
         RUN(nfr_compact(b.nfr_tgt, B, S, B + Pn, b.nfr_rows, b.nfr_tids, b.nfr_count, st));
+    }
+    // Table mode backward needs the tokens ordered by node id; the ids are final here, so the (latency-bound, many small
+    // launches) stable sort runs on the engine's side stream next to the whole forward pass.
+    b.sort_done = nullptr;
+    if (bwd && use_table_projection(t, (int64_t)Tseq * S, true) && !g_no_segsum && e->side) {
+        hipEvent_t ev = e->next_sync();
+        PMGT_HIP(hipEventRecord(ev, st));
+        PMGT_HIP(hipStreamWaitEvent(e->side, ev, 0));
+        RUN(seg_sort(b.ids, Tseq * S, (int)t->n_nodes + 2, b.sg_keys, b.sg_vals, b.sg_skeys, b.sg_perm, b.sg_off, b.sg_tmp, b.sg_tmp_bytes, e->side));
+        b.sort_done = e->next_sync();
+        PMGT_HIP(hipEventRecord(b.sort_done, e->side));
     }
     RUNP("mirror", build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
     // Training fast path: the caller does not ask for last_hidden_state, so the last layer's attn-out/FFN blocks

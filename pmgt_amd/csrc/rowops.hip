@@ -181,17 +181,17 @@ template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, 
 // Embedding mix forward: a = softmax(Wa tanh([e_v;e_t]) + ba); x = a0 e_v + a1 e_t + pos[s] + role[s>0];
 // h0 = dropout(LN(x)).   (pmgt/pmgt/modeling_pmgt.py:199-208)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NCH>
+template <typename T, int NCH, int PHASE>
 __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
     if (m >= p.M) return;
     const int d = p.d, nch = d >> 2;
     const int s = m % p.S;
-    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * (p.phase == 2 ? d : 2 * d);
+    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * (PHASE == 2 ? d : 2 * d);
     f32x4 ev[NCH], et[NCH];
     float a0 = 1.f, a1 = 0.f;
-    if (p.phase != 2) {
+    if (PHASE != 2) {
         float z0 = 0.f, z1 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
         const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
         a0 = e0 / (e0 + e1); a1 = e1 / (e0 + e1);
         if (lane == 0) { p.a[2 * (int64_t)m] = a0; p.a[2 * (int64_t)m + 1] = a1; }
-        if (p.phase == 1) {         // per-node mix only: F[n] = a0 e_v + a1 e_t
+        if (PHASE == 1) {         // per-node mix only: F[n] = a0 e_v + a1 e_t
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + 64 * i;
@@ -276,9 +276,16 @@ template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st) {
     if (e.M <= 0) return 0;
     PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_fwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
     dim3 grid(cdiv(e.M, 4)), block(256);
-    if (e.d <= 256) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 1>), grid, block, 0, st, e);
-    else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 2>), grid, block, 0, st, e);
-    else hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 4>), grid, block, 0, st, e);
+#define PMGT_EMB_FWD(PH)                                                                                          \
+    do {                                                                                                          \
+        if (e.d <= 256) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 1, PH>), grid, block, 0, st, e);              \
+        else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 2, PH>), grid, block, 0, st, e);         \
+        else hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 4, PH>), grid, block, 0, st, e);                         \
+    } while (0)
+    if (e.phase == 1) PMGT_EMB_FWD(1);
+    else if (e.phase == 2) PMGT_EMB_FWD(2);
+    else PMGT_EMB_FWD(0);
+#undef PMGT_EMB_FWD
     PMGT_LAUNCH_OK();
     return 0;
 }
@@ -288,7 +295,7 @@ template int embed_mix_fwd<bf16>(const EmbedMix&, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // Embedding mix backward.  Partials per block: dgamma[d] | dbeta[d] | dWa[2][2d] | dba[2] (+2 pad)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NCH>
+template <typename T, int NCH, int PHASE>
 __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
     __shared__ float red[6 * 1024 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -313,9 +320,9 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
     for (int it = 0; it < rpb / 4; ++it) {
         const int m = blockIdx.x * rpb + it * 4 + wave;
         if (m >= p.M) break;
-        const float a0 = p.phase == 2 ? 0.f : p.a[2 * (int64_t)m], a1 = p.phase == 2 ? 0.f : p.a[2 * (int64_t)m + 1];
+        const float a0 = PHASE == 2 ? 0.f : p.a[2 * (int64_t)m], a1 = PHASE == 2 ? 0.f : p.a[2 * (int64_t)m + 1];
         f32x4 df[NCH], ev[NCH], et[NCH];
-        if (p.phase != 1) {     // LayerNorm backward of token m -> df (gradient wrt the pre-LN sum)
+        if (PHASE != 1) {     // LayerNorm backward of token m -> df (gradient wrt the pre-LN sum)
             const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
             f32x4 g[NCH], xh[NCH];
             float sg = 0.f, sgx = 0.f;
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
                     df[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
-            if (p.phase == 2) continue;      // token phase of the table mode: the mix is differentiated per node
+            if (PHASE == 2) continue;      // token phase of the table mode: the mix is differentiated per node
         } else {                // node phase: df = sum of the token gradients of node m
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -430,9 +437,16 @@ template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st) {
     if (e.M <= 0) return 0;
     PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_bwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
     dim3 grid(embed_bwd_parts(e.M)), block(256);
-    if (e.d <= 256) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 1>), grid, block, 0, st, e);
-    else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 2>), grid, block, 0, st, e);
-    else hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 4>), grid, block, 0, st, e);
+#define PMGT_EMB_BWD(PH)                                                                                          \
+    do {                                                                                                          \
+        if (e.d <= 256) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 1, PH>), grid, block, 0, st, e);              \
+        else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 2, PH>), grid, block, 0, st, e);         \
+        else hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 4, PH>), grid, block, 0, st, e);                         \
+    } while (0)
+    if (e.phase == 1) PMGT_EMB_BWD(1);
+    else if (e.phase == 2) PMGT_EMB_BWD(2);
+    else PMGT_EMB_BWD(0);
+#undef PMGT_EMB_BWD
     PMGT_LAUNCH_OK();
     return 0;
 }
