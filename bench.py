@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--intermediate", type=int, default=0, help="override intermediate size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-profile", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="weight-gradient GEMMs on the engine's side stream (A/B; no gain measured)")
+    ap.add_argument("--overlap", action="store_true", help="partial-sum reductions on the engine's side stream (A/B; measured neutral)")
     ap.add_argument("--sampler-threads", type=int, default=0)
     ap.add_argument("--end-to-end", action="store_true", help="also time steps fed by the live host sampler")
     return ap.parse_args()
@@ -177,7 +177,7 @@ def main():
                                f"dropout {args.dropout}, clip 5.0, AdamW lr 1e-4 wd 1e-2",
                    "parallelism": f"dp{world}", "global_batch": world * B, "seq_len": S},
         "loss_last": round(loss_last, 5),
-        "wgrad_side_stream": bool(args.overlap),
+        "side_stream_reductions": bool(args.overlap),
         "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count()},
     }
 

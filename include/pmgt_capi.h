@@ -180,9 +180,11 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
                    const float* ln_beta, float ln_eps, void* stream);
 /* A/B switch: 1 runs the last layer on every token even when last_hidden is not requested */
 void pmgt_debug_disable_last_layer_shortcut(int on);
-/* Weight-gradient GEMMs run on an engine-owned second HIP stream next to the dgrad chain (fork/join by events,
- * joined before the call returns control of `stream`) when this is 1.  Default 0 = every launch on `stream`
- * (measured: no gain on MI355X, the two streams share one HBM-bound pool); PMGT_OVERLAP=1 turns it on at creation. */
+/* The engine owns a second HIP stream for work that is off the dependent chain: the partial-sum reductions of the
+ * backward pass (weight-gradient slabs, bias and LayerNorm partials; double-buffered, fork/join by events) and the token
+ * sort of the table mode.  Everything is joined before the call returns control of `stream`.  The sort always
+ * overlaps the forward pass; the reductions move only with on = 1 (or PMGT_OVERLAP=1 at engine creation): measured
+ * neutral on MI355X (the launch queue already hides them). */
 void pmgt_engine_set_overlap(pmgt_engine* e, int on);
 /* A/B switch: 1 selects the LDS-DMA variant of the tiled NT kernel (default: register-staged; same speed) */
 void pmgt_debug_enable_nt_dma(int on);

@@ -81,12 +81,12 @@ struct pmgt_engine {
     int mirror_tiles = 0;
     const void* zeros = nullptr;      // device zero page (padding source of the LDS-DMA kernels)
     pmgt::Profiler prof;
-    // Weight-gradient GEMMs are leaves of the backward graph: optionally they run on a second stream next to the
-    // dgrad chain (fork/join with events).  Opt-in: PMGT_OVERLAP=1 or pmgt_engine_set_overlap.
+    // Side stream: the partial-sum reductions of the backward pass and the token sort of the table mode run here
+    // (fork/join with events); the reductions only with PMGT_OVERLAP=1 / pmgt_engine_set_overlap(e, 1).
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> sync_ev;
     size_t sync_next = 0;
-    bool overlap = false;     // measured: no gain (15.40 vs 15.32 ms/step at B=1024) -- both streams share one HBM-bound pool
+    bool overlap = false;     // partial-sum reductions on the side stream (see SideReduce): measured neutral, opt-in
     hipEvent_t next_sync() {
         if (sync_ev.empty()) {
             sync_ev.resize(64);
@@ -226,7 +226,12 @@ template <typename T> struct Bufs {
     void* sg_tmp = nullptr;
     int64_t sg_tmp_bytes = 0;
     float* sg_part = nullptr;
-    float* part_side;       // bias partials of the wgrad kernels (their own buffer: they run on the side stream)
+    float* part_side;       // bias partials of the wgrad kernels
+    // double-buffered partials + completion events of their side-stream reductions
+    int64_t slab_elems = 0, part_side_elems = 0, ln_part_elems = 0;
+    float* ln_part = nullptr;
+    int wg_idx = 0, ln_idx = 0;
+    hipEvent_t wg_done[2] = {nullptr, nullptr}, ln_done[2] = {nullptr, nullptr};
     float* possum;
     // losses
     int* off;
@@ -306,7 +311,8 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Fv));
     slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Ft));
     slab = std::max(slab, tn_slab_elems(dt, std::max(256, cap / 5), F, d));
-    b.slab = c.get<float>(slab);
+    b.slab_elems = align_up(slab, 64);
+    b.slab = c.get<float>(2 * b.slab_elems);
     int64_t part = 0;
     part = std::max(part, (int64_t)ln_bwd_parts((int)M) * 3 * d);
     part = std::max(part, (int64_t)embed_bwd_parts((int)M) * (6 * d + 4));
@@ -315,7 +321,10 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     part = std::max(part, colsum_slab_elems(cap, F));
     part = std::max(part, (int64_t)512 * std::max(std::max(I, 4 * d), F));     // wgrad bias slabs [splits <= 512][N1]
     b.part = c.get<float>(part);
-    b.part_side = c.get<float>((int64_t)512 * std::max(std::max(I, 4 * d), F));
+    b.part_side_elems = (int64_t)512 * std::max(std::max(I, 4 * d), F);
+    b.part_side = c.get<float>(2 * b.part_side_elems);
+    b.ln_part_elems = align_up((int64_t)ln_bwd_parts((int)M) * 3 * d, 64);
+    b.ln_part = c.get<float>(2 * b.ln_part_elems);
     b.sg_keys = c.get<uint32_t>(M); b.sg_vals = c.get<uint32_t>(M); b.sg_skeys = c.get<uint32_t>(M); b.sg_perm = c.get<uint32_t>(M);
     b.sg_off = c.get<int>(M / 2 + 4);                     // table mode implies N + 2 <= M / 2
     b.sg_tmp_bytes = sort_temp_bytes((int)M);
@@ -537,46 +546,85 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     return 0;
 }
 
-// wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs.  With overlap on, the two launches go to the side
-// stream behind an event recorded on `main` (their inputs are ready there); *done receives the event the caller
-// must wait on (join_side) before a main-stream kernel overwrites P or Q.
+// Partial-sum reductions (weight-gradient slabs, bias partials, LayerNorm partials) are tiny launches that sit between
+// two big kernels of the dependent chain; with `overlap` on (opt-in: A/B on one box 82.5k / 81.4k vs 81.2k / 81.8k nodes/s,
+// i.e. neutral -- the launch queue already hides them) they run on the engine's side stream: the
+// producer kernel records an event on `main`, the side stream waits for it and reduces, and the partial buffers are
+// double-buffered so the next producer never waits (the one after next waits on an event that is long signalled).
+struct SideReduce {
+    pmgt_engine* e;
+    hipStream_t main;
+    bool on;
+    SideReduce(const pmgt_engine* eng, hipStream_t m) : e(const_cast<pmgt_engine*>(eng)), main(m), on(eng->overlap && eng->side != nullptr) {}
+    // before a producer overwrites a partial buffer: the reduction that last read it is done
+    int acquire(hipEvent_t& done) {
+        if (done) PMGT_HIP(hipStreamWaitEvent(main, done, 0));
+        done = nullptr;
+        return 0;
+    }
+    // after the producer launch: returns the stream the reductions go to
+    int begin(hipStream_t* st) {
+        *st = main;
+        if (!on) return 0;
+        hipEvent_t ev = e->next_sync();
+        PMGT_HIP(hipEventRecord(ev, main));
+        PMGT_HIP(hipStreamWaitEvent(e->side, ev, 0));
+        *st = e->side;
+        return 0;
+    }
+    int end(hipEvent_t& done) {
+        done = nullptr;
+        if (!on) return 0;
+        done = e->next_sync();
+        PMGT_HIP(hipEventRecord(done, e->side));
+        return 0;
+    }
+};
+
+// wgrad helper: dst[N1,N2] (+)= P^T Q through the split slabs
 template <typename T>
 static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
                  int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t main,
-                 float* bias_dst = nullptr, hipEvent_t* done = nullptr) {
-    pmgt_engine* em = const_cast<pmgt_engine*>(e);
-    const bool fork = em->overlap && em->side != nullptr;
-    hipStream_t st = fork ? em->side : main;
-    if (fork) {
-        hipEvent_t ev = em->next_sync();
-        PMGT_HIP(hipEventRecord(ev, main));
-        PMGT_HIP(hipStreamWaitEvent(st, ev, 0));
-    }
+                 float* bias_dst = nullptr) {
+    SideReduce sr(e, main);
+    const int slot = b.wg_idx++ & 1;
+    float* slab = b.slab + (int64_t)slot * b.slab_elems;
+    float* bpart = b.part_side + (int64_t)slot * b.part_side_elems;
+    RUN(sr.acquire(b.wg_done[slot]));
+    hipStream_t st = main;
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
-    g.slab = b.slab; g.m_dev = m_dev; g.zeros = e->zeros;
+    g.slab = slab; g.m_dev = m_dev; g.zeros = e->zeros;
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
-    g.bias_slab = bias_dst ? b.part_side : nullptr;          // [splits <= 512][N1]
+    g.bias_slab = bias_dst ? bpart : nullptr;          // [splits <= 512][N1]
     RUNP(name, gemm_tn<T>(g, st));
-    RUNP("bwd.slab_reduce", slab_reduce(b.slab, g.splits, (int64_t)N1 * N2, dst, acc, st));
-    if (bias_dst) RUNP("bwd.slab_reduce", slab_reduce(b.part_side, g.splits, N1, bias_dst, acc, st));
-    if (done) *done = nullptr;
-    if (fork) {
-        hipEvent_t ev = em->next_sync();
-        PMGT_HIP(hipEventRecord(ev, st));
-        if (done) *done = ev;
-    }
+    RUN(sr.begin(&st));
+    RUNP("bwd.slab_reduce", slab_reduce(slab, g.splits, (int64_t)N1 * N2, dst, acc, st));
+    if (bias_dst) RUNP("bwd.slab_reduce", slab_reduce(bpart, g.splits, N1, bias_dst, acc, st));
+    RUN(sr.end(b.wg_done[slot]));
     return 0;
 }
-static inline int join_side(hipStream_t main, hipEvent_t& ev) {
-    if (ev) PMGT_HIP(hipStreamWaitEvent(main, ev, 0));
-    ev = nullptr;
+// LayerNorm backward + the reduction of its dgamma | dbeta | dbias partials
+template <typename T>
+static int ln_bwd_reduce(const pmgt_engine* e, Bufs<T>& b, const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop,
+                         int Mt, int d, DropCfg out_drop, const int* mdev, float* dst, bool acc, hipStream_t main) {
+    SideReduce sr(e, main);
+    const int slot = b.ln_idx++ & 1;
+    float* part = b.ln_part + (int64_t)slot * b.ln_part_elems;
+    RUN(sr.acquire(b.ln_done[slot]));
+    hipStream_t st = main;
+    RUNP("bwd.layernorm", ln_bwd<T>(dy, x, stats, gamma, dx, dx_drop, part, Mt, d, DropCfg{nullptr, 0.f, 0}, out_drop, st, mdev));
+    RUN(sr.begin(&st));
+    RUNP("bwd.slab_reduce", slab_reduce(part, ln_bwd_parts(Mt), 3 * d, dst, acc, st));
+    RUN(sr.end(b.ln_done[slot]));
     return 0;
 }
 // everything queued on the side stream so far is ordered before what `main` launches next
-static inline int join_side_all(const pmgt_engine* e, hipStream_t main) {
+template <typename T>
+static inline int join_side_all(const pmgt_engine* e, Bufs<T>& b, hipStream_t main) {
     pmgt_engine* em = const_cast<pmgt_engine*>(e);
-    if (!(em->overlap && em->side)) return 0;
+    for (int i = 0; i < 2; ++i) { b.wg_done[i] = nullptr; b.ln_done[i] = nullptr; }
+    if (!em->side) return 0;
     hipEvent_t ev = em->next_sync();
     PMGT_HIP(hipEventRecord(ev, em->side));
     PMGT_HIP(hipStreamWaitEvent(main, ev, 0));
@@ -593,9 +641,6 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     float* G = t->grads;
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
     const bool dd = train && pd > 0.f;
-    const DropCfg nodrop = {nullptr, 0.f, 0};
-    // completion events of the side-stream wgrads whose inputs are about to be overwritten on the main stream
-    hipEvent_t w_ffn2 = nullptr, w_ffn1 = nullptr, w_ao = nullptr, w_qkvc = nullptr;
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = e->layers[l];
         LayerBufs<T>& lb = b.layer[l];
@@ -613,20 +658,17 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         T* gD = sc ? b.c_bD : b.bD;
         T* gbig = sc ? b.c_big : b.big;
         // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
-        RUN(join_side(st, w_ao));          // previous layer's attn-out wgrad still reads bB / bC
-        RUNP("bwd.layernorm", ln_bwd<T>(gA, tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
-                      dropcfg(t, train, pd, l, SITE_FO), st, mdev));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln2g, acc, st));   // dgamma | dbeta | db2
+        RUN(ln_bwd_reduce<T>(e, b, gA, tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d, dropcfg(t, train, pd, l, SITE_FO),
+                             mdev, G + o.ln2g, acc, st));                                              // dgamma | dbeta | db2
         const T* dY2 = dd ? gC : gB;
-        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st, nullptr, &w_ffn2));
-        RUN(join_side(st, w_qkvc));        // previous layer's qkvc wgrad still reads `big`
+        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
             GemmWS g;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = gbig; g.ldc = I; g.m_dev = mdev;
             g.M = Mt; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1, &w_ffn1));
+        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1));
         {   // du = dff W1 + residual branch
             GemmWS g;
             g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gD; g.ldc = d; g.m_dev = mdev;
@@ -634,18 +676,15 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
         }
         // LN1 backward
-        RUN(join_side(st, w_ffn2));        // reads gB / gC, rewritten here
-        RUNP("bwd.layernorm", ln_bwd<T>(gD, tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, b.part, Mt, d, nodrop,
-                      dropcfg(t, train, pd, l, SITE_AO), st, mdev));
-        RUNP("bwd.slab_reduce", slab_reduce(b.part, ln_bwd_parts(Mt), 3 * d, G + o.ln1g, acc, st));   // dgamma | dbeta | dbo
+        RUN(ln_bwd_reduce<T>(e, b, gD, tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d, dropcfg(t, train, pd, l, SITE_AO),
+                             mdev, G + o.ln1g, acc, st));                                              // dgamma | dbeta | dbo
         const T* dYo = dd ? gC : gB;
-        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st, nullptr, &w_ao));
+        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
         {   // dctx = dYo Wo
             GemmWS g;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = gD; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.m_dev = mdev;
             RUN(linear<T>(e, "bwd.dgrad_attn_out", g, st));
         }
-        RUN(join_side(st, w_ffn1));        // reads gbig (== b.big unless compacted), rewritten by the attention backward
         if (sc) {   // back to the full token layout: zero everywhere except the compacted rows
             PMGT_HIP(hipMemsetAsync(b.bD, 0, (size_t)M * d * sizeof(T), st));
             PMGT_HIP(hipMemsetAsync(b.bB, 0, (size_t)M * d * sizeof(T), st));
@@ -660,7 +699,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.dctx = b.bD; a.dqkvc = b.big;
             RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc, &w_qkvc));
+        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc));
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + o.mWqkvcT; g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
@@ -669,8 +708,6 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
     }
     // embeddings
-    RUN(join_side(st, w_ao));
-    RUN(join_side(st, w_qkvc));            // embed_mix_bwd rewrites big and bB
     {
         EmbedMix m;
         m.S = S; m.d = d; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a;
@@ -705,7 +742,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
         }
     }
-    RUN(join_side_all(e, st));             // the caller's stream sees every gradient
+    RUN(join_side_all<T>(e, b, st));       // the caller's stream sees every gradient
     return 0;
 }
 

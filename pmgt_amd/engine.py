@@ -234,7 +234,7 @@ class Engine:
         _lib.check(self.lib.pmgt_optimizer_step(self.h, C.byref(tc), C.byref(ac), _stream()))
 
     def set_overlap(self, on: bool):
-        """Weight-gradient GEMMs on the engine's side stream (default) or everything on the caller's stream."""
+        """Partial-sum reductions of the backward pass on the engine's side stream (default) or on the caller's stream."""
         self.lib.pmgt_engine_set_overlap(self.h, 1 if on else 0)
 
     # ---- phase timers -------------------------------------------------------------------------------------

@@ -165,18 +165,20 @@ def test_last_layer_shortcut_matches_full_path(name, dtype):
     assert rel < (1e-5 if dtype == "fp32" else 3e-2), rel
 
 
-def test_side_stream_wgrads_give_identical_gradients():
-    """Opt-in overlap (weight-gradient GEMMs on the engine's second stream, fork/join by events) must be a pure
-    scheduling change: losses and every gradient bit-identical to the single-stream run, repeated to catch races."""
+def test_side_stream_reductions_give_identical_gradients():
+    """Partial-sum reductions on the engine's second stream (opt-in; double-buffered slabs, fork/join by events) must
+    be a pure scheduling change: losses and every gradient bit-identical to the single-stream run, repeated to catch
+    races."""
     case = gu.model_case("m3")
     batch = dev_batch(case["batch"])
     inj, _ = inject_for(case)
     ref = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    ref.set_overlap(False)
     out0 = ref.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
     torch.cuda.synchronize()
     eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     eng.set_overlap(True)
-    for _ in range(5):
+    for _ in range(8):
         eng.rng_state[1] = 0
         out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
         torch.cuda.synchronize()
