@@ -12,6 +12,9 @@ struct AttnArgs {
     int Tseq = 0, S = 0, H = 0, dh = 0;
     float beta = 0.5f;
     DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
+    // Last layer of the training fast path: sequences t < cls_only_seqs are read by the loss at row 0 only, so only their
+    // first 16-query tile needs attention output (forward) / carries a gradient (backward); 0 = every query matters.
+    int cls_only_seqs = 0;
     const void* dctx = nullptr;   // backward: [Tseq*S, d]
     void* dqkvc = nullptr;        // backward: [Tseq*S, 4d]
 };
@@ -36,6 +39,7 @@ struct QkvcAttn {
     int Tseq = 0, S = 0, H = 0, dh = 0;
     float beta = 0.5f;
     DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
+    int cls_only_seqs = 0;                        // see AttnArgs
 };
 bool qkvc_attn_supported(const QkvcAttn& a);
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st);

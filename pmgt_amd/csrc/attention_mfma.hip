@@ -65,22 +65,25 @@ template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) {
 template <int NT, int KD>
 __device__ __forceinline__ void probs_T(const bf16x8 (&fq)[NT][KD], const bf16x8 (&fk)[NT][KD], const bf16x8 (&fc)[NT][KD],
                                         const float* rho, const float* madd, int S, int r, int q, float isq,
-                                        f32x4 (&a1)[NT][NT], f32x4 (&a2)[NT][NT]) {
+                                        f32x4 (&a1)[NT][NT], f32x4 (&a2)[NT][NT], int ntq = NT) {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
             f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1;
+            if (it < ntq) {          // (wave-uniform) query tiles >= ntq carry no gradient: their probabilities stay 0
 #pragma unroll
-            for (int ks = 0; ks < KD; ++ks) {
-                x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt][ks], fc[it][ks], x1, 0, 0, 0);
-                x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt][ks], fq[it][ks], x2, 0, 0, 0);
+                for (int ks = 0; ks < KD; ++ks) {
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt][ks], fc[it][ks], x1, 0, 0, 0);
+                    x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt][ks], fq[it][ks], x2, 0, 0, 0);
+                }
             }
             a1[jt][it] = x1;
             a2[jt][it] = x2;
         }
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
+        if (it >= ntq) continue;
         const int i = 16 * it + r;
         const bool iv = i < S;
         const float rho_i = rho[i];
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
     const int64_t ld = 4 * d;
     const int Sv = FULL ? NT * 16 : (act ? S : 0);
+    const int ntq = t < a.cls_only_seqs ? 1 : NT;      // query tiles that carry a gradient (wave-uniform)
     const float isq = rsqrtf((float)DH);
 
     // NT <= 2: every global load of the kernel is issued here, before anything is consumed
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             rO.commit(tO, lane, nullptr);
         }
         __syncthreads();
-        probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, isq, a1, a2);
+        probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, isq, a1, a2, ntq);
     }
     // C-hat tile (rows scaled by the inverse norms)
     if constexpr (PRE) rC.commit(tC, lane, rho);
@@ -395,8 +399,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
             for (int it = 0; it < NT; ++it) {
                 f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (it < ntq) {
 #pragma unroll
-                for (int ks = 0; ks < KD; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt][ks], fo[it][ks], x, 0, 0, 0);
+                    for (int ks = 0; ks < KD; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt][ks], fo[it][ks], x, 0, 0, 0);
+                }
                 dp[jt][it] = x;
             }
     }
@@ -407,6 +413,18 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
         const int i = 16 * it + r;
+        if (it >= ntq) {        // no gradient through these queries: zero columns in the three images (a1 / a2 are already 0)
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 16 * jt + 4 * q + e;
+                    *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
+                    *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
+                    *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
+                }
+            continue;
+        }
         float rd1 = 0.f, rd2 = 0.f;
         f32x4 g1[NT], g2[NT], pm[NT];
 #pragma unroll
@@ -472,8 +490,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
-                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+                if (it < ntq) {
+                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+                }
                 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
             }
             if (act && x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);

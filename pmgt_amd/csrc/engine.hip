@@ -428,7 +428,7 @@ static inline bool use_table_projection(const pmgt_tensors* t, int64_t n_tokens,
 template <typename T>
 static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, const int64_t* ids,
                            const T* feat_v, const T* feat_t, const float* mask, bool train, T* hidden_states,
-                           float* attn_probs, hipStream_t st, bool shortcut = false) {
+                           float* attn_probs, hipStream_t st, bool shortcut = false, int n_cls_only = 0) {
     const int d = e->d, I = e->I, L = e->L, H = e->H;
     const int M = Tseq * S;
     const float* P = t->params;
@@ -486,6 +486,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             f.Tseq = Tseq; f.S = S; f.H = H; f.dh = e->dh; f.beta = e->cfg.beta;
             f.drop1 = dropcfg(t, train, pa, l, SITE_A1);
             f.drop2 = dropcfg(t, train, pa, l, SITE_A2);
+            f.cls_only_seqs = (shortcut && l == L - 1) ? n_cls_only : 0;
             if (!g_no_fused_qa && !g_force_tile && !attn_probs && !attn_valu_forced() && qkvc_attn_supported(f)) {
                 RUNP("fwd.qkvc_attention", qkvc_attn_fwd(f, st));
                 fused = true;
@@ -634,7 +635,8 @@ static inline int join_side_all(const pmgt_engine* e, Bufs<T>& b, hipStream_t ma
 // ---- encoder backward: dcur (in b.bA) = d loss / d h_L; leaves parameter grads in t->grads ----------
 template <typename T>
 static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st,
-                            bool shortcut = false, bool train = true, const T* feat_v = nullptr, const T* feat_t = nullptr) {
+                            bool shortcut = false, bool train = true, const T* feat_v = nullptr, const T* feat_t = nullptr,
+                            int n_cls_only = 0) {
     const int d = e->d, I = e->I, L = e->L, H = e->H;
     const int M = Tseq * S;
     const float* P = t->params;
@@ -697,6 +699,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.drop1 = dropcfg(t, train, pa, l, SITE_A1);
             a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             a.dctx = b.bD; a.dqkvc = b.big;
+            a.cls_only_seqs = sc ? n_cls_only : 0;       // their dctx is non-zero at row 0 only (scatter_rows above)
             RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
         RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc));
@@ -794,7 +797,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     const bool sc = train && !g_no_shortcut && o->last_hidden == nullptr;
     if (sc) RUN(build_need_rows(B, Pn, S, b.nfr_rows, b.nfr_count, b.need_rows, b.need_cnt, st));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, (const T*)nullptr, (const T*)nullptr, b.mask, train, (T*)nullptr,
-                           (float*)nullptr, st, sc));
+                           (float*)nullptr, st, sc, B + Pn));
     T* hL = sc ? b.ctail.hout : b.layer[e->L - 1].hout;
     T* dhL = sc ? b.c_dh : b.bA;
     const int M = Tseq * S;
@@ -833,7 +836,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         g.C = sc ? dhL + (int64_t)(B + Pn) * d : b.dq; g.ldc = d;      // compacted: the masked rows ARE rows B+P.. of dhL
         RUNP("bwd.dgrad_nfr", gemm_nt<T>(g, st));
         if (!sc) RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
-        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc));
+        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc, true, (const T*)nullptr, (const T*)nullptr, B + Pn));
     }
     if (train) RUN(advance_rng(t->rng_state, st));
     return 0;

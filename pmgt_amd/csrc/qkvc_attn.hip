@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
         // ---- (b) attention of (sequence 2 mt + us, head h, queries 16 it .. 16 it + 15)
         const int t = 2 * mt + us;
         const bool act = t < a.Tseq;
+        if (it == 1 && t < a.cls_only_seqs) return;      // (wave-uniform) only query row 0 of this sequence is ever read
         const int R0 = 32 * us;
         bf16x8 fq, fk[2], fc[2];
         fq = *(const bf16x8*)(qt + qt_addr(R0 + 16 * it + r, blk(0)));
