@@ -203,6 +203,9 @@ int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, 
 void pmgt_debug_disable_table_projection(int on);
 /* A/B switch: 1 keeps the per-token weight-gradient GEMM of the feature projection in table mode (no segment sums) */
 void pmgt_debug_disable_segment_sum(int on);
+/* A/B switch: 1 keeps Q|K|V|C in q | k | v | c column order between the fused forward and the attention backward
+ * (default in training: head-major, 4 * dh contiguous elements per (row, head)) */
+void pmgt_debug_disable_head_major(int on);
 /* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */
 void pmgt_debug_disable_fused_qkvc_attention(int on);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,

@@ -52,7 +52,7 @@ HIP_SYMBOLS = [
     "pmgt_param_num_entries", "pmgt_param_entry", "pmgt_workspace_bytes", "pmgt_pretrain_step", "pmgt_encode_ids",
     "pmgt_encode_feats", "pmgt_encode_train", "pmgt_encode_backward", "pmgt_optimizer_step", "pmgt_profile_begin", "pmgt_profile_end", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_op_gemm_nt",
     "pmgt_op_gemm_tn_slab_elems", "pmgt_op_gemm_tn", "pmgt_op_colsum", "pmgt_op_layernorm_fwd",
-    "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd", "pmgt_debug_force_valu_attention", "pmgt_debug_force_tile_gemm", "pmgt_debug_enable_nt_dma", "pmgt_engine_set_overlap", "pmgt_op_qkvc_attention_fwd", "pmgt_debug_disable_fused_qkvc_attention", "pmgt_debug_disable_table_projection", "pmgt_debug_disable_segment_sum", "pmgt_debug_disable_coop_attention_bwd", "pmgt_debug_disable_last_layer_shortcut", "pmgt_op_linear",
+    "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd", "pmgt_debug_force_valu_attention", "pmgt_debug_force_tile_gemm", "pmgt_debug_enable_nt_dma", "pmgt_engine_set_overlap", "pmgt_op_qkvc_attention_fwd", "pmgt_debug_disable_fused_qkvc_attention", "pmgt_debug_disable_table_projection", "pmgt_debug_disable_segment_sum", "pmgt_debug_disable_head_major", "pmgt_debug_disable_coop_attention_bwd", "pmgt_debug_disable_last_layer_shortcut", "pmgt_op_linear",
 ]
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
@@ -115,6 +115,8 @@ def hip():
     L.pmgt_op_qkvc_attention_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
     L.pmgt_debug_disable_coop_attention_bwd.argtypes = [i]
     L.pmgt_debug_disable_coop_attention_bwd.restype = None
+    L.pmgt_debug_disable_head_major.argtypes = [i]
+    L.pmgt_debug_disable_head_major.restype = None
     L.pmgt_debug_disable_segment_sum.argtypes = [i]
     L.pmgt_debug_disable_segment_sum.restype = None
     L.pmgt_debug_disable_table_projection.argtypes = [i]

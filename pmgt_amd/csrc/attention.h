@@ -15,6 +15,10 @@ struct AttnArgs {
     // Last layer of the training fast path: sequences t < cls_only_seqs are read by the loss at row 0 only, so only their
     // first 16-query tile needs attention output (forward) / carries a gradient (backward); 0 = every query matters.
     int cls_only_seqs = 0;
+    // Head-major Q|K|V|C (and dQ|dK|dV|dC): column of (matrix m, head h, w) is (h * 4 + m) * dh + w instead of
+    // m * d + h * dh + w, i.e. 4 * dh contiguous elements per (row, head).  Written by the fused forward, understood by
+    // the one-wave MFMA backward (the only pair used together).
+    bool hm = false;
     const void* dctx = nullptr;   // backward: [Tseq*S, d]
     void* dqkvc = nullptr;        // backward: [Tseq*S, 4d]
 };
@@ -40,6 +44,7 @@ struct QkvcAttn {
     float beta = 0.5f;
     DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
     int cls_only_seqs = 0;                        // see AttnArgs
+    bool hm = false;                              // write Q|K|V|C head-major (see AttnArgs)
 };
 bool qkvc_attn_supported(const QkvcAttn& a);
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st);

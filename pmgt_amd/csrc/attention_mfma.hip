@@ -270,14 +270,17 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) pb[ks] = pack_b<NT>(a1, it, ks);
         const int i = 16 * it + r;
+        f32x4 o[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q), pb[ks], o, 0, 0, 0);
-            if (i < Sv) store4<bf16>((bf16*)a.ctx + ((int64_t)t * S + i) * d + h * DH + 16 * ct + 4 * q, o);
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q), pb[ks], o[ct], 0, 0, 0);
         }
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp)
+            store_row32((bf16*)a.ctx + ((int64_t)t * S + min(i, S - 1)) * d + h * DH + 32 * cp, o[2 * cp], o[2 * cp + 1], q, i < Sv);
     }
 }
 
@@ -315,9 +318,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     char* iS2 = iS1 + SM::IMG;
     float* rho = (float*)(iS2 + SM::IMG);
     float* madd = rho + 64;
-    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    // matrix m of head h starts at column h * DH + m * d (q | k | v | c blocks) or, head-major, at (4 h + m) * DH
+    const int hoff = a.hm ? 4 * h * DH : h * DH, ms = a.hm ? DH : d;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + hoff;
     const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
-    bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
+    bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + hoff;
     const int64_t ld = 4 * d;
     const int Sv = FULL ? NT * 16 : (act ? S : 0);
     const int ntq = t < a.cls_only_seqs ? 1 : NT;      // query tiles that carry a gradient (wave-uniform)
@@ -329,21 +334,21 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     bf16x8 fv[NT][KD], fo[NT][KD];
     if constexpr (PRE) {
         rQ.issue(X, ld, Sv, lane);
-        rK.issue(X + d, ld, Sv, lane);
+        rK.issue(X + ms, ld, Sv, lane);
         rO.issue(DO, d, Sv, lane);
-        rC.issue(X + 3 * d, ld, Sv, lane);
+        rC.issue(X + 3 * ms, ld, Sv, lane);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             const int row = 16 * tt + r;
 #pragma unroll
             for (int ks = 0; ks < KD; ++ks) {
-                fv[tt][ks] = ld_rows(X + 2 * d, ld, row, Sv, 32 * ks + 8 * q);
+                fv[tt][ks] = ld_rows(X + 2 * ms, ld, row, Sv, 32 * ks + 8 * q);
                 fo[tt][ks] = ld_rows(DO, d, row, Sv, 32 * ks + 8 * q);
             }
         }
     } else {
         load_tile<DH>(tQ, X, ld, SP2, Sv, lane, nullptr);
-        load_tile<DH>(tK, X + d, ld, SP2, Sv, lane, nullptr);
+        load_tile<DH>(tK, X + ms, ld, SP2, Sv, lane, nullptr);
         load_tile<DH>(tO, DO, d, SP2, Sv, lane, nullptr);
     }
     f32x4 a1[NT][NT], a2[NT][NT];
@@ -358,8 +363,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KD; ++ks) {
                 fq[tt][ks] = ld_rows(X, ld, row, Sv, 32 * ks + 8 * q);
-                fk[tt][ks] = ld_rows(X + d, ld, row, Sv, 32 * ks + 8 * q);
-                fc[tt][ks] = ld_rows(X + 3 * d, ld, row, Sv, 32 * ks + 8 * q);
+                fk[tt][ks] = ld_rows(X + ms, ld, row, Sv, 32 * ks + 8 * q);
+                fc[tt][ks] = ld_rows(X + 3 * ms, ld, row, Sv, 32 * ks + 8 * q);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
             }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     }
     // C-hat tile (rows scaled by the inverse norms)
     if constexpr (PRE) rC.commit(tC, lane, rho);
-    else load_tile<DH>(tC, X + 3 * d, ld, SP2, Sv, lane, rho);
+    else load_tile<DH>(tC, X + 3 * ms, ld, SP2, Sv, lane, rho);
 
     // dP^T[j][i] = sum_c V[j][c] dO[i][c]
     f32x4 dp[NT][NT];
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 const bool ok = row < Sv;
 #pragma unroll
                 for (int ks = 0; ks < KD; ++ks) {
-                    fv[tt][ks] = ld_rows(X + 2 * d, ld, row, Sv, 32 * ks + 8 * q);
+                    fv[tt][ks] = ld_rows(X + 2 * ms, ld, row, Sv, 32 * ks + 8 * q);
                     fo[tt][ks] = ld_rows(DO, d, row, Sv, 32 * ks + 8 * q);
                 }
             }
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             bt[ks] = *(const bf16x8*)(iS1 + ((16 * it + r) * SP2 + 32 * ks + 8 * q) * 2);
         }
         const int x = 16 * it + r;
-        f32x4 dch[CT];
+        f32x4 dch[CT], dqv[CT];
         float dt = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 }
                 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
             }
-            if (act && x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);
+            dqv[ct] = dq * isq;
             dch[ct] = -dc;       // dN = -dS1
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
             dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
@@ -506,7 +511,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
-            if (act && x < Sv) store4<bf16>(DX + (int64_t)x * ld + 3 * d + 16 * ct + 4 * q, (dch[ct] - ch * dt) * inv);
+            dch[ct] = (dch[ct] - ch * dt) * inv;
+        }
+        bf16* rowx = DX + (int64_t)min(x, S - 1) * ld;
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) {
+            store_row32(rowx + 32 * cp, dqv[2 * cp], dqv[2 * cp + 1], q, act && x < Sv);
+            store_row32(rowx + 3 * ms + 32 * cp, dch[2 * cp], dch[2 * cp + 1], q, act && x < Sv);
         }
     }
     // ---- products with the key index on the lane: dV^T[c][j] = sum_i dO[i][c] P[i][j], dK^T[c][j] = sum_i Q[i][c] dS2[i][j]
@@ -519,6 +530,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             bs[ks] = *(const bf16x8*)(iS2 + ((16 * jt + r) * SP2 + 32 * ks + 8 * q) * 2);
         }
         const int j = 16 * jt + r;
+        f32x4 dvv[CT], dkv[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
@@ -527,10 +539,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
                 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
             }
-            if (act && j < Sv) {
-                store4<bf16>(DX + (int64_t)j * ld + 2 * d + 16 * ct + 4 * q, dv);
-                store4<bf16>(DX + (int64_t)j * ld + d + 16 * ct + 4 * q, dk * isq);
-            }
+            dvv[ct] = dv;
+            dkv[ct] = dk * isq;
+        }
+        bf16* rowj = DX + (int64_t)min(j, S - 1) * ld;
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) {
+            store_row32(rowj + 2 * ms + 32 * cp, dvv[2 * cp], dvv[2 * cp + 1], q, act && j < Sv);
+            store_row32(rowj + ms + 32 * cp, dkv[2 * cp], dkv[2 * cp + 1], q, act && j < Sv);
         }
     }
 }

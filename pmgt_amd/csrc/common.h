@@ -67,6 +67,23 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = r;
 }
 
+// Two adjacent 16-column MFMA output blocks of one row-per-lane result (C/D layout transposed products: lane (r, q)
+// holds columns 4q..4q+3 of block 0 in v0 and of block 1 in v1, for row r): v_permlane16_swap exchanges the odd
+// 16-lane rows of v0 with the even rows of v1, after which every lane owns 8 CONSECUTIVE columns -> one 16-byte store
+// per lane, 64 contiguous bytes per row, instead of two 8-byte stores per lane that put 16 x 32-byte segments on the
+// write path (the attention backward spent 40 % of its time in such stores).  `row_c0` = address of column 0 of block 0
+// in this lane's row (16-byte aligned); all 64 lanes must call (the predicate covers the store only).
+__device__ __forceinline__ void store_row32(bf16* row_c0, f32x4 v0, f32x4 v1, int q, bool pred) {
+    const bf16x4 p0 = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3]};
+    const bf16x4 p1 = {(bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t a = __builtin_bit_cast(u32x2_t, p0), b = __builtin_bit_cast(u32x2_t, p1);
+    uint32_t ax = a[0], ay = a[1], bx = b[0], by = b[1];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(ax), "+v"(bx), "+v"(ay), "+v"(by));
+    const int cb = ((q & 1) << 4) | ((q & 2) << 2);          // q = 0, 1, 2, 3 -> columns 0, 16, 8, 24
+    if (pred) *(u32x4*)(row_c0 + cb) = (u32x4){ax, ay, bx, by};
+}
+
 // ---- wave64 reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -61,6 +61,7 @@ struct LayerOff {
     int64_t Wqkvc, bqkvc, Wo, bo, ln1g, ln1b, W1, b1, W2, b2, ln2g, ln2b;
     // mirror offsets (elements of T); -1 = not mirrored (fp32 reads the master copy)
     int64_t mWqkvc, mWqkvcT, mWo, mWoT, mW1, mW1T, mW2, mW2T;
+    int64_t mWqkvcT_hm = -1;     // transposed copy with the 4d index in head-major order (dgrad of a head-major Q|K|V|C)
 };
 
 }  // namespace pmgt
@@ -161,13 +162,20 @@ static void build_layout(pmgt_engine* e) {
     const bool half = e->cfg.dtype == PMGT_DTYPE_BF16;
     int64_t mc = 0;
     int tiles = 0;
-    auto add_m = [&](int64_t src, int rows, int cols, bool copy, bool transpose, int64_t* dst, int64_t* dst_t) {
+    auto add_m = [&](int64_t src, int rows, int cols, bool copy, bool transpose, int64_t* dst, int64_t* dst_t, int64_t* dst_t_hm = nullptr) {
         MirrorDesc m;
         m.src = src; m.rows = rows; m.cols = cols;
         m.dst = copy ? mc : -1;
         if (copy) mc += align_up((int64_t)rows * cols, 8);
         m.dst_t = transpose ? mc : -1;
         if (transpose) mc += align_up((int64_t)rows * cols, 8);
+        m.dst_t_hm = -1; m.hm_d = 1; m.hm_dh = 1;
+        if (dst_t_hm && transpose) {
+            m.dst_t_hm = mc;
+            mc += align_up((int64_t)rows * cols, 8);
+            m.hm_d = e->d; m.hm_dh = e->dh;
+            *dst_t_hm = m.dst_t_hm;
+        }
         m.tile_start = tiles;
         tiles += cdiv(rows, 32) * cdiv(cols, 32);
         if (dst) *dst = m.dst;
@@ -179,7 +187,7 @@ static void build_layout(pmgt_engine* e) {
     add_m(e->Wt, d, Ft, half, false, &e->mWt, nullptr);
     for (int l = 0; l < e->L; ++l) {
         LayerOff& o = e->layers[l];
-        add_m(o.Wqkvc, 4 * d, d, half, true, &o.mWqkvc, &o.mWqkvcT);
+        add_m(o.Wqkvc, 4 * d, d, half, true, &o.mWqkvc, &o.mWqkvcT, half ? &o.mWqkvcT_hm : nullptr);
         add_m(o.Wo, d, d, half, true, &o.mWo, &o.mWoT);
         add_m(o.W1, I, d, half, true, &o.mW1, &o.mW1T);
         add_m(o.W2, d, I, half, true, &o.mW2, &o.mW2T);
@@ -214,6 +222,7 @@ template <typename T> struct Bufs {
     T* mirror;
     T *E, *emb_pre, *h0;
     hipEvent_t sort_done = nullptr;   // set when the token sort of this step already runs on the side stream
+    bool qkvc_hm = false;   // Q|K|V|C (and its gradient) are stored head-major (fused forward + one-wave MFMA backward)
     bool e_by_id = false;   // E holds the projection of the whole table (rows = node ids) instead of one row per token
     float *a, *emb_stats;
     std::vector<LayerBufs<T>> layer;
@@ -399,6 +408,7 @@ static const void* zero_page() {
 static int g_force_tile = 0;
 static int g_no_shortcut = 0;
 static int g_no_fused_qa = 0;
+static int g_no_hm = 0;
 static int g_no_table_proj = 0;
 static int g_no_segsum = 0;
 
@@ -418,6 +428,14 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
         RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
                                         DropCfg{nullptr, 0.f, 0}, st, g.m_dev));
     return 0;
+}
+
+// whether encoder_forward takes the fused projection + attention kernel (and, in training, stores Q|K|V|C head-major):
+// a pure function of the configuration, the shape and the debug switches, so a separate backward call can re-derive it
+template <typename T>
+static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool want_probs) {
+    if (sizeof(T) != 2 || g_no_fused_qa || g_force_tile || want_probs || attn_valu_forced()) return false;
+    return S == 32 && e->dh == 32 && (e->d == 256 || e->d == 128) && e->H % 2 == 0 && Tseq >= 2;
 }
 
 static inline bool use_table_projection(const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {
@@ -487,9 +505,11 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             f.drop1 = dropcfg(t, train, pa, l, SITE_A1);
             f.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             f.cls_only_seqs = (shortcut && l == L - 1) ? n_cls_only : 0;
-            if (!g_no_fused_qa && !g_force_tile && !attn_probs && !attn_valu_forced() && qkvc_attn_supported(f)) {
+            f.hm = train && !g_no_hm;        // the backward that reads it understands the layout; inference keeps q | k | v | c
+            if (fused_qa_applies<T>(e, Tseq, S, attn_probs != nullptr) && qkvc_attn_supported(f)) {
                 RUNP("fwd.qkvc_attention", qkvc_attn_fwd(f, st));
                 fused = true;
+                b.qkvc_hm = f.hm;
             }
         }
         if (!fused) {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
@@ -586,7 +606,7 @@ struct SideReduce {
 template <typename T>
 static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
                  int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t main,
-                 float* bias_dst = nullptr) {
+                 float* bias_dst = nullptr, int perm_d = 0, int perm_dh = 0) {
     SideReduce sr(e, main);
     const int slot = b.wg_idx++ & 1;
     float* slab = b.slab + (int64_t)slot * b.slab_elems;
@@ -595,7 +615,7 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
     hipStream_t st = main;
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
-    g.slab = slab; g.m_dev = m_dev; g.zeros = e->zeros;
+    g.slab = slab; g.m_dev = m_dev; g.zeros = e->zeros; g.perm_d = perm_d; g.perm_dh = perm_dh;
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
     g.bias_slab = bias_dst ? bpart : nullptr;          // [splits <= 512][N1]
     RUNP(name, gemm_tn<T>(g, st));
@@ -700,12 +720,14 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             a.dctx = b.bD; a.dqkvc = b.big;
             a.cls_only_seqs = sc ? n_cls_only : 0;       // their dctx is non-zero at row 0 only (scatter_rows above)
+            a.hm = b.qkvc_hm;
             RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc));
+        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc,
+                     b.qkvc_hm ? d : 0, b.qkvc_hm ? e->dh : 0));
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
-            g.A = b.big; g.lda = 4 * d; g.B = b.mirror + o.mWqkvcT; g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
+            g.A = b.big; g.lda = 4 * d; g.B = b.mirror + (b.qkvc_hm ? o.mWqkvcT_hm : o.mWqkvcT); g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
             g.M = M; g.N = d; g.K = 4 * d; g.res = b.bB; g.ldr = d;
             RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
         }
@@ -903,7 +925,8 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv
     PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
     pmgt_tensors tt = *t;
     tt.rng_state = (uint64_t*)b.rng_snap;          // the forward's (seed, step)
-    b.e_by_id = use_table_projection(t, (int64_t)Tseq * S, fv == nullptr);      // same decision as the forward took
+    b.e_by_id = use_table_projection(t, (int64_t)Tseq * S, fv == nullptr);      // same decisions as the forward took
+    b.qkvc_hm = train && !g_no_hm && fused_qa_applies<T>(e, Tseq, S, false);
     PMGT_HIP(hipMemcpyAsync(b.bA, d_last, (size_t)Tseq * S * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
     RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, (const T*)fv, (const T*)ft));
     return 0;
@@ -1152,6 +1175,7 @@ void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }
 void pmgt_debug_disable_table_projection(int on) { g_no_table_proj = on; }
 void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
+void pmgt_debug_disable_head_major(int on) { g_no_hm = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

@@ -51,6 +51,9 @@ struct GemmTN {
     int splits = 1;
     const int* m_dev = nullptr;
     const void* zeros = nullptr;                // >= 16 B of device zeros: enables the LDS-DMA kernel (bf16, no gather)
+    // P's columns are in head-major order (head, matrix, w) of a [4 x perm_d] block structure with head size perm_dh:
+    // output row n1 is written to row (matrix * perm_d + head * perm_dh + w) of the slab.  0 = identity.
+    int perm_d = 0, perm_dh = 0;
 };
 void gemm_tn_disable_dma(int on);
 template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st);

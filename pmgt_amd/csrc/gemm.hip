@@ -939,13 +939,18 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
     }
 
     if constexpr (GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // trailing index DMAs must land before the LDS is released
+    auto rowmap = [&](int n1) {       // head-major column of P -> row of dW in q | k | v | c order
+        if (g.perm_dh <= 0) return n1;
+        const int w = n1 % g.perm_dh, hm = n1 / g.perm_dh;
+        return (hm & 3) * g.perm_d + (hm >> 2) * g.perm_dh + w;
+    };
     if (do_bias && r == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
-                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + n1] = accb[i][e];
+                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + rowmap(n1)] = accb[i][e];
             }
     }
     float* out = g.slab + (int64_t)split * g.N1 * g.N2;
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
-                if (n1 < g.N1) out[(int64_t)n1 * g.N2 + n2] = acc[i][j][e];
+                if (n1 < g.N1) out[(int64_t)rowmap(n1) * g.N2 + n2] = acc[i][j][e];
             }
         }
 }
@@ -982,6 +987,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     PMGT_CHECK(g.ldp % EPC == 0 && g.ldq % EPC == 0, -2, "gemm_tn: leading dims must be multiples of %d", EPC);
     PMGT_CHECK(((uintptr_t)g.P % 16) == 0 && ((uintptr_t)g.Q % 16) == 0, -2, "gemm_tn: operands must be 16-byte aligned");
     PMGT_CHECK(g.splits >= 1 && g.slab, -2, "gemm_tn: bad splits/slab");
+    PMGT_CHECK(g.perm_dh == 0 || (sizeof(T) == 2 && !g_tn_no_dma && g.zeros != nullptr), -2, "gemm_tn: the row permutation needs the LDS-DMA kernel");
     const int bkm = gemm_tn_bkm<T>();
     int chunk = cdiv(cdiv(std::max(g.M, 1), g.splits), bkm) * bkm;
     const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);

@@ -22,6 +22,9 @@ struct MirrorDesc {
     int rows, cols;
     int64_t dst;      // offset (elements) of the same-layout copy in the mirror, or -1
     int64_t dst_t;    // offset of the transposed copy [cols, rows], or -1
+    int64_t dst_t_hm; // offset of a second transposed copy whose COLUMNS (= rows r of W = q|k|v|c x head x w) are in
+                      // head-major order (head, matrix, w), or -1; hm_d / hm_dh = hidden and head size of that order
+    int hm_d, hm_dh;
     int tile_start;   // first 32x32 tile index of this tensor in the launch
 };
 template <typename T>

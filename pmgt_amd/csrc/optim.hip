@@ -115,6 +115,16 @@ __global__ __launch_bounds__(256) void mirror_kernel(const float* __restrict__ p
             if (c < dsc.cols && r < dsc.rows) mirror[dsc.dst_t + (int64_t)c * dsc.rows + r] = from_f<T>(tile[tx][i]);
         }
     }
+    if (dsc.dst_t_hm >= 0) {
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, r = r0 + tx;
+            if (c < dsc.cols && r < dsc.rows) {
+                const int m = r / dsc.hm_d, h = (r % dsc.hm_d) / dsc.hm_dh, w = r % dsc.hm_dh;
+                const int rh = (h * 4 + m) * dsc.hm_dh + w;
+                mirror[dsc.dst_t_hm + (int64_t)c * dsc.rows + rh] = from_f<T>(tile[tx][i]);
+            }
+        }
+    }
 }
 
 template <typename T>

@@ -70,6 +70,8 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
     const int num_mt = (M + 63) / 64;
     // local column c of the slab -> column of q | k | v | c
     auto gcol = [&](int c) { return (c >> 6) * d + (2 * y + ((c >> 5) & 1)) * 32 + (c & 31); };
+    // ... and the column it is STORED at: the same, or head-major (head, matrix, w): 256 contiguous bytes per (row, head)
+    auto ocol = [&](int c) { return a.hm ? ((2 * y + ((c >> 5) & 1)) * 4 + (c >> 6)) * 32 + (c & 31) : gcol(c); };
 
     // ---- resident W fragments (A operand now): rows n = gcol(32 wave + 16 j + r), k = 32 ks + 8 q
     bf16x8 wf[2][KS];
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
         for (int ps = 0; ps < 4; ++ps) {
             const int row = erow + 16 * ps;
             const int m = mt * 64 + row;
-            if (m < M) *(u32x4*)(QKVC + (int64_t)m * a.ldq + gcol(8 * ech)) = *(const u32x4*)(qt + qt_addr(row, ech));
+            if (m < M) *(u32x4*)(QKVC + (int64_t)m * a.ldq + ocol(8 * ech)) = *(const u32x4*)(qt + qt_addr(row, ech));
         }
         // ---- (b) attention of (sequence 2 mt + us, head h, queries 16 it .. 16 it + 15)
         const int t = 2 * mt + us;

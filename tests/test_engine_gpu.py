@@ -337,3 +337,33 @@ def test_thirty_step_loss_curve_matches_reference(dtype):
     else:
         assert rel.max() < 1e-3, rel.max()
     print(f"loss-curve max relative deviation ({dtype}): {rel.max():.2e}")
+
+
+def test_head_major_qkvc_layout_is_transparent():
+    """Training at the headline shape stores Q|K|V|C (and its gradient) head-major between the fused forward and the
+    attention backward; the data-gradient GEMM reads a column-permuted W^T copy and the weight-gradient GEMM writes
+    its rows back in q | k | v | c order.  Switching the layout off changes nothing but summation order."""
+    from pmgt_amd import _lib
+    L = _lib.hip()
+    case = gu.model_case("m3")
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = {}
+    for off in (0, 1):
+        L.pmgt_debug_disable_head_major(off)
+        try:
+            eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+            res[off] = (out["loss"].item(), eng.grads.clone())
+        finally:
+            L.pmgt_debug_disable_head_major(0)
+    assert res[0][0] == res[1][0]                      # the forward is bit-identical
+    # the data-gradient GEMM sums its K = 4d products in permuted order: bf16 round-off of dX, then propagated
+    rel = ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item()
+    assert rel < 5e-3, rel
+    eng = make_engine(case, dtype="bf16")
+    for k in ("bert.encoder.layer.3.attention.self.query.weight", "bert.encoder.layer.3.attention.self.ctx_attention.bias",
+              "bert.encoder.layer.0.attention.self.value.weight"):
+        e = eng.entry(k)
+        a, b = res[0][1][e["offset"]: e["offset"] + e["numel"]], res[1][1][e["offset"]: e["offset"] + e["numel"]]
+        assert ((a - b).norm() / b.norm()).item() < 1e-2, k      # rows land at the right q | k | v | c positions
