@@ -759,22 +759,29 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
             }
         }
     }
-    // dQ^T and the accumulator-operand half of dC^T for this query tile
+    // dQ^T and the accumulator-operand half of dC^T for this query tile (two 16-column blocks at a time: one 64-byte row store)
     f32x4 dch[CT];
     {
         bf16x8 b2[KS], b1[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { b2[ks] = pack_col<NT>(a2, ks); b1[ks] = pack_col<NT>(a1, ks); }
+        bf16* rowq = DX + (int64_t)min(x, S - 1) * ld;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
+        for (int cp = 0; cp < CT / 2; ++cp) {
+            f32x4 dqv[2];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
-                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                const int ct = 2 * cp + u;
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+                }
+                dqv[u] = dq * isq;
+                dch[ct] = dc;
             }
-            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 16 * ct + 4 * q, dq * isq);
-            dch[ct] = dc;
+            store_row32(rowq + 32 * cp, dqv[0], dqv[1], q, x < Sv);
         }
     }
     __syncthreads();
@@ -790,29 +797,37 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
             bs[ks] = *(const bf16x8*)(iS2 + off);
         }
         float dt = 0.f;
+        bf16* rowx = DX + (int64_t)min(x, S - 1) * ld;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            f32x4 dc = dch[ct], dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
+        for (int cp = 0; cp < CT / 2; ++cp) {
+            f32x4 dvv[2], dkv[2];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
-                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                const int ct = 2 * cp + u;
+                f32x4 dc = dch[ct], dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
+                    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
+                }
+                dvv[u] = dv;
+                dkv[u] = dk * isq;
+                dch[ct] = -dc;       // dN = -dS1
+                const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+                dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
             }
-            if (x < Sv) {
-                store4<bf16>(DX + (int64_t)x * ld + 2 * d + 16 * ct + 4 * q, dv);
-                store4<bf16>(DX + (int64_t)x * ld + d + 16 * ct + 4 * q, dk * isq);
-            }
-            dch[ct] = -dc;       // dN = -dS1
-            const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
-            dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
+            store_row32(rowx + 2 * d + 32 * cp, dvv[0], dvv[1], q, x < Sv);
+            store_row32(rowx + d + 32 * cp, dkv[0], dkv[1], q, x < Sv);
         }
         dt = red_q<NT>(dt, false);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
-            if (x < Sv) store4<bf16>(DX + (int64_t)x * ld + 3 * d + 16 * ct + 4 * q, (dch[ct] - ch * dt) * rho_x);
+            dch[ct] = (dch[ct] - ch * dt) * rho_x;
         }
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) store_row32(rowx + 3 * d + 32 * cp, dch[2 * cp], dch[2 * cp + 1], q, x < Sv);
     }
 }
 
@@ -947,14 +962,17 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
     bf16x8 pb[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) pb[ks] = pack_col<NT>(a1, ks);
+    f32x4 o[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q), pb[ks], o, 0, 0, 0);
-        if (x < Sv) store4<bf16>((bf16*)a.ctx + ((int64_t)t * S + x) * d + h * DH + 16 * ct + 4 * q, o);
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q), pb[ks], o[ct], 0, 0, 0);
     }
+#pragma unroll
+    for (int cp = 0; cp < CT / 2; ++cp)
+        store_row32((bf16*)a.ctx + ((int64_t)t * S + min(x, S - 1)) * d + h * DH + 32 * cp, o[2 * cp], o[2 * cp + 1], q, x < Sv);
 }
 
 template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {

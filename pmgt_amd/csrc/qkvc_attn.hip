@@ -241,6 +241,7 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
             }
         }
         // O^T[c][i] = sum_j V[j][c] P[i][j]: A operand = transposed read of the V block (rows = keys)
+        f32x4 o[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int row_lo = R0 + 4 * q + (r >> 2), row_hi = row_lo + 16;
@@ -249,9 +250,10 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_hi, cb >> 4) + (cb & 15)));
             const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, z, 0, 0, 0);
-            if (act) store4<bf16>(CTX + ((int64_t)t * 32 + i) * a.ldc + h * 32 + 16 * ct + 4 * q, o);
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, z, 0, 0, 0);
         }
+        // one 16-byte store per lane: the 64 bytes of this (row, head) leave as one run (common.h: store_row32)
+        store_row32(CTX + ((int64_t)min(t, a.Tseq - 1) * 32 + i) * a.ldc + h * 32, o[0], o[1], q, act);
         // The next tile_step's first barrier orders this phase's LDS reads before the next projection-tile
         // writes (which come after that step's second barrier anyway).
     };
