@@ -330,13 +330,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 
     // NT <= 2: every global load of the kernel is issued here, before anything is consumed
     constexpr bool PRE = NT <= 2;
-    TileRegs<DH, PRE ? SP2 : 64 / (DH / 8)> rQ, rK, rO, rC;
+    // (the row-major LDS tiles of Q, K, dO, C-hat are written from the FRAGMENT registers: lane (r, q) of fragment
+    // (tt, ks) holds exactly the 16 bytes of tile row 16 tt + r at byte 64 ks + 16 q -- no second set of global loads)
     bf16x8 fv[NT][KD], fo[NT][KD];
     if constexpr (PRE) {
-        rQ.issue(X, ld, Sv, lane);
-        rK.issue(X + ms, ld, Sv, lane);
-        rO.issue(DO, d, Sv, lane);
-        rC.issue(X + 3 * ms, ld, Sv, lane);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             const int row = 16 * tt + r;
@@ -354,6 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     f32x4 a1[NT][NT], a2[NT][NT];
     {
         bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
+        float rho_own[NT];
         rho[lane] = 0.f;      // rows [16 NT, 64) are never written below but scale the (zero) padding rows of the C-hat tile
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -369,20 +367,43 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
             }
             ss = red_q<NT>(ss, false);
-            if (q == 0) rho[row] = ok ? rsqrtf(ss) : 0.f;    // 1 / |c_row|
+            rho_own[tt] = ok ? rsqrtf(ss) : 0.f;             // 1 / |c_row| (all four q lanes of the row hold it)
+            if (q == 0) rho[row] = rho_own[tt];
         }
         madd[lane] = (lane < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : 0.f;
         if constexpr (PRE) {
-            rQ.commit(tQ, lane, nullptr);
-            rK.commit(tK, lane, nullptr);
-            rO.commit(tO, lane, nullptr);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int row = 16 * tt + r;
+                const float rr = rho_own[tt];
+#pragma unroll
+                for (int ks = 0; ks < KD; ++ks) {
+                    const int off = row * (DH * 2) + (32 * ks + 8 * q) * 2;
+                    *(bf16x8*)(tQ + off) = fq[tt][ks];
+                    *(bf16x8*)(tK + off) = fk[tt][ks];
+                    *(bf16x8*)(tO + off) = fo[tt][ks];
+                    bf16x8 ch;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ch[e] = (bf16)((float)fc[tt][ks][e] * rr);
+                    *(bf16x8*)(tC + off) = ch;
+                }
+            }
+            if (SP2 > SP) {        // zero rows [SP, SP2) of the four tiles (k padding of the transposed reads)
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int idx = lane; idx < (SP2 - SP) * (DH / 8); idx += 64) {
+                    const int off = (SP + idx / (DH / 8)) * (DH * 2) + (idx % (DH / 8)) * 16;
+                    *(bf16x8*)(tQ + off) = z;
+                    *(bf16x8*)(tK + off) = z;
+                    *(bf16x8*)(tO + off) = z;
+                    *(bf16x8*)(tC + off) = z;
+                }
+            }
         }
         __syncthreads();
         probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, isq, a1, a2, ntq);
     }
-    // C-hat tile (rows scaled by the inverse norms)
-    if constexpr (PRE) rC.commit(tC, lane, rho);
-    else load_tile<DH>(tC, X + 3 * ms, ld, SP2, Sv, lane, rho);
+    // C-hat tile (rows scaled by the inverse norms): written above from the fragments when PRE
+    if constexpr (!PRE) load_tile<DH>(tC, X + 3 * ms, ld, SP2, Sv, lane, rho);
 
     // dP^T[j][i] = sum_c V[j][c] dO[i][c]
     f32x4 dp[NT][NT];
