@@ -66,6 +66,8 @@ def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
         "fwd.gemm_ffn1": (g(M, I, d), M * (d + 2 * I) * esz),
         "fwd.gemm_ffn2": (g(M, d, I), M * (I + 2 * d) * esz),
         "fwd.attention": (6.0 * M * S * d, M * 5 * d * esz),
+        # fused projection + attention: reads x (1U), writes Q|K|V|C (4U, kept for the backward) and ctx (1U)
+        "fwd.qkvc_attention": (g(M, 4 * d, d) + 6.0 * M * S * d, M * 6 * d * esz),
         "bwd.attention": (16.0 * M * S * d, M * 9 * d * esz),
         "bwd.dgrad_ffn2": (g(M, I, d), M * (d + 2 * I) * esz),
         "bwd.dgrad_ffn1": (g(M, d, I), M * (I + 2 * d) * esz),
@@ -199,7 +201,7 @@ def main():
         out["phases"] = phases
         esz = 2 if args.dtype == "bf16" else 4
         M = 12 * B * S
-        dom = next(iter(phases))
+        dom = next((k for k in phases if phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz) is not None), next(iter(phases)))
         w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz)
         cnt, ms = prof[dom]
         avg_s = ms / cnt / 1e3
