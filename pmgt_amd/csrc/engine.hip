@@ -1169,7 +1169,7 @@ static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, i
 
 void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
 void pmgt_debug_disable_coop_attention_bwd(int on) { attn_bwd_disable_coop(on); }
-void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); gemm_nt_disable_big(on); }
+void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); gemm_nt_disable_big(on); gemm_tn_disable_big(on); }
 void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
 void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
 void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }

@@ -56,6 +56,7 @@ struct GemmTN {
     int perm_d = 0, perm_dh = 0;
 };
 void gemm_tn_disable_dma(int on);
+void gemm_tn_disable_big(int on);     // A/B: never use the 256 x 256 weight-gradient tile
 template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st);
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm);
 template <typename T> int gemm_tn_bkm();

@@ -968,10 +968,180 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN, bf16, 256 x 256 output tile, 512 threads (8 waves as 2 x 4, 128 x 64 outputs each), same 4-stage LDS-DMA ring
+// (32 rows of P and of Q per stage, 512-byte rows).  The 128 x 128 kernel re-reads P once per 128 columns of Q and Q
+// once per 128 columns of P through L2 (dW_qkvc at M = 393k: 3.2 GB of L2 -> CU traffic for 1 GB of HBM bytes, i.e.
+// 10.8 TB/s in 295 us: L2-bound); this tile halves both.  No row gather.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_rows) {
+    constexpr int BKM = 32, ROWB = 512, STAGE = 2 * BKM * ROWB, NST = 4;     // 32 KiB per stage (P + Q)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tn1 = (g.N1 + 255) / 256, tn2 = (g.N2 + 255) / 256, tiles = tn1 * tn2;
+    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+    const int tile = bidx % tiles, split = xcd + 8 * (bidx / tiles);
+    if (split >= g.splits) return;
+    const int n1_0 = (tile / tn2) * 256, n2_0 = (tile % tn2) * 256;
+    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = g.bias_slab != nullptr && n2_0 == 0 && wn == 0;
+    f32x4 accb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane's part of a stage: rows 4 wave + 2 j + (lane >> 5), j = 0, 1; LDS chunk slot lane & 31 holds global
+    // chunk (lane & 31) ^ swz(row)
+    const char* zero = (const char*)g.zeros;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    auto issue = [&](int kt) {
+        const int mb = mbeg + kt * BKM;
+        char* st = smem + (kt & (NST - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 4 * wave + 2 * j + (lane >> 5);
+            const int ch = (lane & 31) ^ (tn_f(row) << 1);
+            const int m = mb + row;
+            const int cp = n1_0 + ch * 8, cq = n2_0 + ch * 8;
+            const char* sp = (m < mend && cp < g.N1) ? (const char*)g.P + ((int64_t)m * g.ldp + cp) * 2 : zero;
+            const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + ((int64_t)m * g.ldq + cq) * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (4 * wave + 2 * j) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (4 * wave + 2 * j) * ROWB), 16, 0, 0);
+        }
+    };
+    const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    // per-lane byte offsets of the fragment reads inside a stage (row = 8 q + (r >> 2); +4 rows = +2048 B)
+    uint32_t offa[8], offb[4];
+    {
+        const int row = 8 * q + (r >> 2);
+        const int sw = tn_f(row) << 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ca = wm * 128 + i * 16 + 4 * (r & 3);
+            offa[i] = (uint32_t)(row * ROWB + (((ca >> 3) ^ sw) << 4) + ((ca & 7) << 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cb = wn * 64 + j * 16 + 4 * (r & 3);
+            offb[j] = (uint32_t)(BKM * ROWB + row * ROWB + (((cb >> 3) ^ sw) << 4) + ((cb & 7) << 1));
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = min(2, nk - 1 - kt);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3);
+        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
+        u32x2 ta[16], tb[8];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\t"
+            "ds_read_b64_tr_b16 %1, %16 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\t"
+            "ds_read_b64_tr_b16 %3, %17 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\t"
+            "ds_read_b64_tr_b16 %5, %18 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\t"
+            "ds_read_b64_tr_b16 %7, %19 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %8, %20\n\t"
+            "ds_read_b64_tr_b16 %9, %20 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %10, %21\n\t"
+            "ds_read_b64_tr_b16 %11, %21 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %12, %22\n\t"
+            "ds_read_b64_tr_b16 %13, %22 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %14, %23\n\t"
+            "ds_read_b64_tr_b16 %15, %23 offset:2048\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]), "=&v"(ta[7]),
+              "=&v"(ta[8]), "=&v"(ta[9]), "=&v"(ta[10]), "=&v"(ta[11]), "=&v"(ta[12]), "=&v"(ta[13]), "=&v"(ta[14]), "=&v"(ta[15])
+            : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
+              "v"(sbase + offa[4]), "v"(sbase + offa[5]), "v"(sbase + offa[6]), "v"(sbase + offa[7])
+            : "memory");
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\t"
+            "ds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\t"
+            "ds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %4, %10\n\t"
+            "ds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %6, %11\n\t"
+            "ds_read_b64_tr_b16 %7, %11 offset:2048\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7])
+            : "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
+            : "memory");
+        bf16x8 fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fb[j] = __builtin_bit_cast(bf16x8, (u32x4){tb[2 * j][0], tb[2 * j][1], tb[2 * j + 1][0], tb[2 * j + 1][1]});
+        const bf16 one = (bf16)1.f;
+        const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * i][0], ta[2 * i][1], ta[2 * i + 1][0], ta[2 * i + 1][1]});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+            if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, accb[i], 0, 0, 0);
+        }
+    }
+    auto rowmap = [&](int n1) {
+        if (g.perm_dh <= 0) return n1;
+        const int w = n1 % g.perm_dh, hm = n1 / g.perm_dh;
+        return (hm & 3) * g.perm_d + (hm >> 2) * g.perm_dh + w;
+    };
+    if (do_bias && r == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n1 = n1_0 + wm * 128 + i * 16 + 4 * q + e;
+                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + rowmap(n1)] = accb[i][e];
+            }
+    }
+    float* out = g.slab + (int64_t)split * g.N1 * g.N2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = n2_0 + wn * 64 + j * 16 + r;
+            if (n2 >= g.N2) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n1 = n1_0 + wm * 128 + i * 16 + 4 * q + e;
+                if (n1 < g.N1) out[(int64_t)rowmap(n1) * g.N2 + n2] = acc[i][j][e];
+            }
+        }
+}
+
 static int g_tn_no_dma = 0;
 void gemm_tn_disable_dma(int on) { g_tn_no_dma = on; }
 
+static int g_tn_no_big = 0;
+void gemm_tn_disable_big(int on) { g_tn_no_big = on; }
+// the 256 x 256 tile pays off when the 128 x 128 kernel would re-read its operands through L2 four times or more
+static bool tn_big_shape(int M, int N1, int N2, int bkm) {
+    return bkm == 64 && !g_tn_no_big && !g_tn_no_dma && M >= 65536 && N1 % 256 == 0 && N2 % 256 == 0 && N1 * N2 >= 4 * 256 * 256;
+}
+
 int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
+    if (tn_big_shape(M, N1, N2, bkm)) {
+        const int tiles = (N1 / 256) * (N2 / 256);
+        int splits = cdiv(256, tiles);                   // one 8-wave workgroup per CU
+        splits = std::max(8, splits / 8 * 8);
+        return splits;
+    }
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
     int splits = cdiv(512, tiles);                       // ~2 workgroups per CU; slab traffic = splits * N1 * N2 * 4 B
     const int max_by_rows = std::max(1, M / (4 * bkm));  // at least 4 K-steps per split
@@ -993,6 +1163,20 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);
     dim3 grid(8 * tiles * cdiv(g.splits, 8));
     if constexpr (sizeof(T) == 2) {
+        if (g.q_rows == nullptr && g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm) &&
+            g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm)) {
+            constexpr int smem = 4 * 2 * 32 * 512;
+            static bool attr_set = false;
+            if (!attr_set) {
+                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_set = true;
+            }
+            const int tiles256 = (g.N1 / 256) * (g.N2 / 256);
+            int chunk256 = cdiv(cdiv(std::max(g.M, 1), g.splits), 32) * 32;
+            hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
         if (!g_tn_no_dma && g.zeros != nullptr) {
             constexpr size_t ring = 4 * 2 * 32 * 256;
             if (g.q_rows == nullptr) {

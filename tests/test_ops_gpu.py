@@ -109,7 +109,8 @@ def test_gemm_nt_epilogues_and_gather(dt, K):
 # ------------------------------------------------------------------------------------------- gemm_tn
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("M,N1,N2", [(500, 64, 96), (4096, 256, 256), (130, 24, 1536), (3000, 1024, 256),
-                                     (40000, 128, 256), (70001, 128, 128)])      # long splits: steady state of the DMA rings
+                                     (40000, 128, 256), (70001, 128, 128),      # long splits: steady state of the DMA rings
+                                     (70016, 1024, 256), (66000, 512, 512)])      # 256 x 256 tile (bf16, M >= 65536)
 def test_gemm_tn(dt, M, N1, N2):
     _lib, L = _setup()
     code, tdt = DT[dt]
