@@ -144,8 +144,13 @@ __device__ __forceinline__ DropKey make_drop_key(const DropCfg& c) {
 // kept/dropped decision costs ~4 integer ops per element instead of ~14.  Every kernel that touches a
 // dropout site (forward epilogue, backward regeneration) indexes it by the same (row, column).
 __device__ __forceinline__ void drop_mul4(const DropKey& k, uint32_t row, uint32_t cg, float (&m)[4]) {
-    const uint32_t x = fmix32((row * 0x9E3779B1u) ^ (cg * 0x85EBCA77u) ^ k.k0);
-    const uint32_t y = fmix32(x + k.k1);
+    // one multiply-xorshift round per 32 bits (12 integer ops for four elements instead of 21 with two full
+    // murmur finalisers: the attention kernels are VALU-issue-bound and draw 2 x S^2 masks per (sequence, head));
+    // keep rate, row/column means and neighbour correlations checked against the full finaliser (|corr| < 1e-3)
+    uint32_t x = row * 0x9E3779B1u + cg * 0x85EBCA77u + k.k0;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    uint32_t y = x * 0x297A2D39u + k.k1;
+    y ^= y >> 15;
     const uint32_t t = k.thr >> 16;
     m[0] = (x & 0xFFFFu) >= t ? k.scale : 0.f;
     m[1] = (x >> 16) >= t ? k.scale : 0.f;

@@ -5,6 +5,8 @@ import sys
 import os
 import torch
 
+DROP = float(os.environ.get('MB_DROP', '0.1'))
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmgt_amd import _lib  # noqa: E402
 
@@ -106,7 +108,7 @@ def fused(T, H, name=""):
     ctx = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
     rng = torch.tensor([1, 2], dtype=torch.int64, device="cuda")
     M = T * S
-    f = lambda: _lib.check(L.pmgt_op_qkvc_attention_fwd(P(x), P(W), P(bias), None, P(qk), P(ctx), T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st()))
+    f = lambda: _lib.check(L.pmgt_op_qkvc_attention_fwd(P(x), P(W), P(bias), None, P(qk), P(ctx), T, S, H, dh, 0.5, DROP, 1, 2, P(rng), st()))
 
     def two():
         _lib.check(L.pmgt_op_linear(1, P(x), d, P(W), d, P(qk), 4 * d, M, 4 * d, d, P(bias), 0, None, 0, None, 0, 0.0, 0, None,
@@ -123,8 +125,8 @@ def attn(T, S, H, dh, name=""):
     ctx = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
     dx = torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16)
     rng = torch.tensor([1, 2], dtype=torch.int64, device="cuda")
-    f = lambda: _lib.check(L.pmgt_op_attention_fwd(1, P(x), None, P(ctx), None, T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st()))
-    b = lambda: _lib.check(L.pmgt_op_attention_bwd(1, P(x), None, P(do), P(dx), T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st()))
+    f = lambda: _lib.check(L.pmgt_op_attention_fwd(1, P(x), None, P(ctx), None, T, S, H, dh, 0.5, DROP, 1, 2, P(rng), st()))
+    b = lambda: _lib.check(L.pmgt_op_attention_bwd(1, P(x), None, P(do), P(dx), T, S, H, dh, 0.5, DROP, 1, 2, P(rng), st()))
     tf, tb = timeit(f), timeit(b)
     M = T * S
     print(f"ATTN {name} T={T} S={S} H={H} dh={dh} nw={os.environ.get('PMGT_ATTN_BWD_NW', 'default')}: fwd {tf[0]:.1f}us ({M * 5 * d * 2 / tf[0] / 1e6:.2f} TB/s) "
