@@ -69,7 +69,7 @@ def build_sampler(force=False):
     out = sampler_lib_path()
     hdr = os.path.join(os.path.dirname(HERE), "include", "pmgt_capi.h")
     if force or _newer(out, [src, hdr]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
+        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src])
     return out
 
 

@@ -41,6 +41,7 @@ void set_err(const char* fmt, ...) {
 // ---- numpy legacy MT19937 --------------------------------------------------------------------------
 struct MT19937 {
     uint32_t key[624];
+    uint32_t out[624];                 // tempered outputs of the current state block (filled by gen(), vectorisable)
     int pos;
     void seed(uint32_t s) {            // numpy _legacy_seeding(int) -> mt19937_seed (init_genrand)
         for (int i = 0; i < 624; ++i) {
@@ -63,16 +64,19 @@ struct MT19937 {
         }
         y = (key[623] & UPPER) | (key[0] & LOWER);
         key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+        for (i = 0; i < 624; ++i) {    // tempering of the whole block at once
+            uint32_t t = key[i];
+            t ^= (t >> 11);
+            t ^= (t << 7) & 0x9d2c5680u;
+            t ^= (t << 15) & 0xefc60000u;
+            t ^= (t >> 18);
+            out[i] = t;
+        }
         pos = 0;
     }
     inline uint32_t next32() {
         if (pos == 624) gen();
-        uint32_t y = key[pos++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        return out[pos++];
     }
     inline double next_double() {
         const uint32_t a = next32() >> 5, b = next32() >> 6;
@@ -180,12 +184,13 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
             if (dg <= 0) { set_err("node %lld has no neighbours (the reference raises here)", (long long)node); return -3; }
             const double* cdf = s->cdf.data() + b;
             const int32_t* guide = s->guide.data() + b;
+            const double dgd = (double)dg;
             for (int r = 0; r < size; ++r) {
                 const double u = sc.rng.next_double();
                 // searchsorted(cdf, u, side='right') = first index with cdf[i] > u
-                int64_t k = (int64_t)(u * (double)dg);
+                int64_t k = (int64_t)(u * dgd);
                 if (k >= dg) k = dg - 1;
-                if ((double)k / (double)dg > u) --k;           // u * dg may round up across a bucket edge
+                if ((double)k / dgd > u) --k;                  // u * dg may round up across a bucket edge
                 int64_t idx = guide[k];
                 while (idx < dg && cdf[idx] <= u) ++idx;
                 sc.nxt.push_back(s->indices[b + (idx < dg ? idx : dg - 1)]);
