@@ -14,7 +14,7 @@
 
 namespace pmgt {
 
-static constexpr int SEG_CH = 256;      // sorted positions per workgroup
+static constexpr int SEG_CH = 64;       // sorted positions per WAVE (a chunk); a 256-thread workgroup walks four chunks
 
 __global__ void seg_keys_kernel(const int64_t* __restrict__ ids, int M, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,74 +33,55 @@ __global__ void seg_bounds_kernel(const uint32_t* __restrict__ skeys, int M, int
     seg_off[n] = lo;
 }
 
-// One workgroup per chunk of SEG_CH sorted positions; thread c owns columns 2c, 2c+1 (+ 512 g).
+// One WAVE per chunk of SEG_CH sorted positions; lane l owns columns 4l .. 4l+3 (+ 256 g): a row is read with 8-byte
+// (bf16) / 16-byte (fp32) accesses by all 64 lanes, eight rows in flight.
 // A run [a, b) of equal keys is COMPLETE when it is the whole segment: written to out[key].  Otherwise its partial sum
 // goes to part[chunk][slot]: slot 0 if the run starts at the chunk start, else slot 1 (then it ends at the chunk end).
 template <typename T, typename TO, int CG>
 __global__ __launch_bounds__(256) void seg_sum_kernel(const T* __restrict__ src, int64_t lds_, const uint32_t* __restrict__ skeys,
                                                       const uint32_t* __restrict__ perm, const int* __restrict__ seg_off, int M,
                                                       int cols, TO* __restrict__ out, float* __restrict__ part) {
-    __shared__ uint32_t sk[SEG_CH], sp[SEG_CH];
-    const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * SEG_CH, p1 = min(M, p0 + SEG_CH);
-    for (int i = tid; i < SEG_CH; i += 256) {
-        const int p = min(p0 + i, M - 1);
-        sk[i] = skeys[p];
-        sp[i] = perm[p];
+    __shared__ uint32_t sk_all[4][SEG_CH], sp_all[4][SEG_CH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x * 4 + wave;
+    const int p0 = chunk * SEG_CH, p1 = min(M, p0 + SEG_CH);
+    if (p0 >= M) return;
+    uint32_t* sk = sk_all[wave];
+    uint32_t* sp = sp_all[wave];
+    {
+        const int p = min(p0 + lane, M - 1);
+        sk[lane] = skeys[p];
+        sp[lane] = perm[p];
     }
-    __syncthreads();
-    float acc[CG][2];
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[CG];
 #pragma unroll
-    for (int g = 0; g < CG; ++g) acc[g][0] = acc[g][1] = 0.f;
+    for (int g = 0; g < CG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int a = p0;
     uint32_t cur = sk[0];
     auto flush = [&](int b) {
         const bool complete = a == seg_off[cur] && b == seg_off[cur + 1];
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
-            const int c = 2 * (tid + 256 * g);
+            const int c = 4 * (lane + 64 * g);
             if (c < cols) {
-                if (complete) {
-                    if constexpr (sizeof(TO) == 2) {
-                        typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                        *(bf16x2_t*)(out + (int64_t)cur * cols + c) = (bf16x2_t){(bf16)acc[g][0], (bf16)acc[g][1]};
-                    } else {
-                        out[(int64_t)cur * cols + c] = acc[g][0];
-                        out[(int64_t)cur * cols + c + 1] = acc[g][1];
-                    }
-                } else {
-                    float* pr = part + ((int64_t)blockIdx.x * 2 + (a == p0 ? 0 : 1)) * cols + c;
-                    pr[0] = acc[g][0];
-                    pr[1] = acc[g][1];
-                }
+                if (complete) store4<TO>(out + (int64_t)cur * cols + c, acc[g]);
+                else *(f32x4*)(part + ((int64_t)chunk * 2 + (a == p0 ? 0 : 1)) * cols + c) = acc[g];
             }
-            acc[g][0] = acc[g][1] = 0.f;
+            acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     const int n = p1 - p0;
     for (int i0 = 0; i0 < n; i0 += 8) {
-        // eight rows in flight
-        float v[8][CG][2];
+        f32x4 v[8][CG];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = min(i0 + u, n - 1);
             const T* row = src + (int64_t)sp[i] * lds_;
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
-                const int c = 2 * (tid + 256 * g);
-                if (c < cols) {
-                    if constexpr (sizeof(T) == 2) {
-                        typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                        const bf16x2_t x = *(const bf16x2_t*)(row + c);
-                        v[u][g][0] = (float)x[0];
-                        v[u][g][1] = (float)x[1];
-                    } else {
-                        v[u][g][0] = row[c];
-                        v[u][g][1] = row[c + 1];
-                    }
-                } else {
-                    v[u][g][0] = v[u][g][1] = 0.f;
-                }
+                const int c = 4 * (lane + 64 * g);
+                v[u][g] = c < cols ? load4<T>(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -113,7 +94,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const T* __restrict__ src,
                     cur = sk[i];
                 }
 #pragma unroll
-                for (int g = 0; g < CG; ++g) { acc[g][0] += v[u][g][0]; acc[g][1] += v[u][g][1]; }
+                for (int g = 0; g < CG; ++g) acc[g] += v[u][g];
             }
         }
     }
@@ -180,9 +161,9 @@ int64_t seg_part_elems(int M, int cols) { return (int64_t)cdiv(M, SEG_CH) * 2 * 
 template <typename T, typename TO>
 int seg_sum(const T* src, int64_t ld, const uint32_t* skeys, const uint32_t* perm, const int* seg_off, int M, int n_rows, int cols,
             TO* out, float* part, hipStream_t st) {
-    PMGT_CHECK(cols % 2 == 0 && cols <= 2048, -2, "seg_sum: cols=%d must be even and <= 2048", cols);
-    const int chunks = cdiv(M, SEG_CH);
-    const int cg = cdiv(cols, 512);
+    PMGT_CHECK(cols % 4 == 0 && cols <= 1024 && ld % 4 == 0, -2, "seg_sum: cols=%d must be a multiple of 4 and <= 1024", cols);
+    const int chunks = cdiv(cdiv(M, SEG_CH), 4);      // workgroups of four wave-chunks
+    const int cg = cdiv(cols, 256);
     switch (cg) {
         case 1:
             hipLaunchKernelGGL((seg_sum_kernel<T, TO, 1>), dim3(chunks), dim3(256), 0, st, src, ld, skeys, perm, seg_off, M, cols, out, part);
