@@ -456,6 +456,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const int j = 16 * jt + 4 * q + e;
                     *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
+                    a1[jt][it][e] = 0.f;
+                    a2[jt][it][e] = 0.f;
                     if constexpr (SM::ALIAS) {
                         pmr[jt][it][e] = 0.f;
                     } else {
