@@ -310,6 +310,9 @@ template <int DH, int NT, bool FULL>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     using SM = BwdSmemW<DH, NT>;
     constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2;
+    // every wave works in its own LDS region: the LDS pipeline executes one wave's operations in order, so a compiler
+    // barrier (no s_barrier: the waves of a workgroup are independent and must not march in lockstep) orders them
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nw = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, isq, a1, a2, ntq);
     }
     // C-hat tile (rows scaled by the inverse norms): written above from the fragments when PRE
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             }
         }
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- products with the query / "x" index on the lane
 #pragma unroll
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         }
     }
     if constexpr (SM::ALIAS) {      // the K and C-hat tiles are dead: they become the P^T and dS2^T images
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     // ---- products with the key index on the lane: dV^T[c][j] = sum_i dO[i][c] P[i][j], dK^T[c][j] = sum_i Q[i][c] dS2[i][j]
 #pragma unroll

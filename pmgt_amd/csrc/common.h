@@ -171,6 +171,47 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     // d/dx [x Phi(x)] = Phi(x) + x phi(x)
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
+// bf16 mode: erfc(|x| / sqrt 2) = 2^(-a p(a)), a = min(|x|, 5.75), p a degree-5 polynomial fitted to an absolute error of
+// 2.9e-7 (tools/fit_gelu.py) -- 1000x below the bf16 rounding of the result, and branch-free: 11 VALU operations per
+// element instead of erff's two divergent branches (~38).  gelu(x) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2) keeps the
+// RELATIVE accuracy of the negative tail.  The fp32 parity mode keeps erff.
+__device__ __forceinline__ float erfc_abs_fast(float ax) {
+    const float a = fminf(ax, 5.75f);
+    float p = -1.775498822e-05f;
+    p = fmaf(p, a, 6.477578427e-04f);
+    p = fmaf(p, a, -7.724046707e-03f);
+    p = fmaf(p, a, 5.292674527e-02f);
+    p = fmaf(p, a, 4.590827227e-01f);
+    p = fmaf(p, a, 1.151116848e+00f);
+    return __builtin_amdgcn_exp2f(-(p * a));
+}
+__device__ __forceinline__ float gelu_fast(float x) { return fmaf(-0.5f * fabsf(x), erfc_abs_fast(fabsf(x)), fmaxf(x, 0.f)); }
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+    const float hc = 0.5f * erfc_abs_fast(fabsf(x));
+    const float cdf = x > 0.f ? 1.f - hc : hc;
+    return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f), cdf);
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
+    if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
+}
+template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
+    if constexpr (sizeof(T) == 2) return gelu_fast_grad(x); else return gelu_erf_grad(x);
+}
+
+// Sum over the 32 consecutive lanes [0, 32) / [32, 64) of a wave, result in every lane: four DPP row rotations (VALU, no
+// LDS round trip as ds_bpermute would need) for the 16-lane rows, one v_permlane16_swap for the neighbouring row.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum_lanes32(float v) {
+    v = dpp_add<0x121>(v);      // row_ror:1
+    v = dpp_add<0x122>(v);      // row_ror:2
+    v = dpp_add<0x124>(v);      // row_ror:4
+    v = dpp_add<0x128>(v);      // row_ror:8
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -75,11 +75,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& g, f32x4 (&acc)[BM / 3
                             for (int e = 0; e < 4; ++e) pre[e] = to_f<T>(from_f<T>(v[e]));
                             store4<T>(AUX + (int64_t)m * g.ldaux + n, pre);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(pre[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_fwd<T>(pre[e]);
                         } else if (g.epi == EPI_GELU_GRAD) {
                             f32x4 pre = load4<T>(AUX + (int64_t)m * g.ldaux + n);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(pre[e]);
+                            for (int e = 0; e < 4; ++e) v[e] *= gelu_bwd<T>(pre[e]);
                         }
                         if (dk.on) {
                             float dm[4];
@@ -463,12 +463,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
                 if (g.epi == EPI_GELU) {
                     bf16x8 pre;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_erf((float)pre[e]); }
+                    for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_fast((float)pre[e]); }
                     *(bf16x8*)(AUX + (int64_t)m * g.ldaux + n) = pre;
                 } else if (g.epi == EPI_GELU_GRAD) {
                     const bf16x8 pre = *(const bf16x8*)(AUX + (int64_t)m * g.ldaux + n);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)pre[e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)pre[e]);
                 }
                 if (dk.on) {
                     float d0[4], d1[4];

@@ -169,12 +169,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
                 if constexpr (MODE == WS_GELU) {
                     bf16x8 pre;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_erf((float)pre[e]); }
+                    for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_fast((float)pre[e]); }
                     *(bf16x8*)(AUX + (int64_t)m * g.ldaux + n) = pre;
                 } else if constexpr (MODE == WS_GELU_GRAD) {
                     const bf16x8 pre = pf[ps];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)pre[e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)pre[e]);
                 }
                 if ((MODE == WS_RES || MODE == WS_RES_LN) && dk.on) {
                     float d0[4], d1[4];
@@ -200,14 +200,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[e];
-#pragma unroll
-                for (int o2 = 16; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2, 64);
+                s = sum_lanes32(s);
                 const float mean = s * (1.f / 256.f);
                 float ss = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
-#pragma unroll
-                for (int o2 = 16; o2 > 0; o2 >>= 1) ss += __shfl_xor(ss, o2, 64);
+                ss = sum_lanes32(ss);
                 const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + g.ln_eps);
                 if (ok) {
                     if ((tid & 31) == 0) { g.ln_stats[2 * (int64_t)m] = mean; g.ln_stats[2 * (int64_t)m + 1] = rstd; }
