@@ -157,6 +157,18 @@ __device__ __forceinline__ void drop_mul4(const DropKey& k, uint32_t row, uint32
     m[2] = (y & 0xFFFFu) >= t ? k.scale : 0.f;
     m[3] = (y >> 16) >= t ? k.scale : 0.f;
 }
+// the same decisions as drop_mul4, as predicates (the caller folds k.scale into another factor)
+__device__ __forceinline__ void drop_keep4(const DropKey& k, uint32_t row, uint32_t cg, bool (&keep)[4]) {
+    uint32_t x = row * 0x9E3779B1u + cg * 0x85EBCA77u + k.k0;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    uint32_t y = x * 0x297A2D39u + k.k1;
+    y ^= y >> 15;
+    const uint32_t t = k.thr >> 16;
+    keep[0] = (x & 0xFFFFu) >= t;
+    keep[1] = (x >> 16) >= t;
+    keep[2] = (y & 0xFFFFu) >= t;
+    keep[3] = (y >> 16) >= t;
+}
 __device__ __forceinline__ float drop_mul1(const DropKey& k, uint32_t row, uint32_t col) {
     float m[4];
     drop_mul4(k, row, col >> 2, m);

@@ -26,6 +26,32 @@ namespace pmgt {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
+#ifdef PMGT_QA_PROF
+// cycles (s_memtime) per phase of the tile steps of two workgroups, accumulated in SGPRs: [block slot][wave][phase];
+// phase 7 = number of steps
+__device__ unsigned int g_qa_prof[2][8][8];
+#define QA_STAMP(k)                                                   \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pacc[k] += (unsigned int)(now_ - plast);                      \
+        plast = now_;                                                 \
+    } while (0)
+#define QA_PROF_DECL                                                                                        \
+    const int pslot = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 + 3 ? 1 : -1);                     \
+    unsigned int pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                        \
+    unsigned long long plast = __builtin_readcyclecounter();
+#define QA_PROF_FLUSH                                                                                       \
+    do {                                                                                                    \
+        if (lane == 0 && pslot >= 0) {                                                                      \
+            for (int k_ = 0; k_ < 8; ++k_) g_qa_prof[pslot][wave][k_] = pacc[k_];                           \
+        }                                                                                                   \
+    } while (0)
+#else
+#define QA_STAMP(k) do { } while (0)
+#define QA_PROF_DECL
+#define QA_PROF_FLUSH do { } while (0)
+#endif
+
 template <int KS> struct QaCfg {
     static constexpr int K = 32 * KS;
     static constexpr int ROWB = K * 2;
@@ -39,18 +65,163 @@ template <int KS> struct QaCfg {
     static constexpr int SMEM = 2 * TILEB + QTB + 8 * 64 * 4; // A ring + projection tile + per-wave {rho[32], madd[32]}
 };
 
+// v_max_f32 without the canonicalising self-max clang adds in front of fmaxf for values of unknown origin
+__device__ __forceinline__ float raw_max(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 // reduction over the 4 lanes l, l^16, l^32, l^48 in the VALU (v_permlane16/32_swap, see attention_mfma.hip)
 __device__ __forceinline__ float qred(float v, bool is_max) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    v = is_max ? fmaxf(a, b) : a + b;
+    v = is_max ? raw_max(a, b) : a + b;
     a = v; b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return is_max ? fmaxf(a, b) : a + b;
+    return is_max ? raw_max(a, b) : a + b;
 }
 
 // byte address of 16-byte chunk `ch` (0..31) of row `row` inside the swizzled projection tile
 __device__ __forceinline__ int qt_addr(int row, int ch) { return row * 512 + ((ch ^ (row & 15)) << 4); }
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// max over the whole wave (every lane gets it): DPP row rotations + the two permlane swaps
+__device__ __forceinline__ float qa_wave_max(float v) {
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+    return qred(v, true);
+}
+
+// Attention of ONE (sequence, head, 16-query tile) by one wave, straight from the swizzled projection tile in LDS
+// (rows R0 .. R0 + 31 = the sequence; uh = head inside the slab).  The phase is VALU-issue-bound (in-kernel
+// timestamps: ~390 VALU instructions for 2 x 8 score elements per lane), so the arithmetic is arranged to be short:
+//   * scores live in the log2 domain from the start (log2 e folded into 1/sqrt(dh), rho_i and the mask term), so an
+//     exponential is one v_exp_f32;
+//   * the cosine branch needs no row maximum: -cos + I <= 2 and the mask term is shifted by its maximum over the
+//     keys (softmax is shift-invariant; the constant 1 of "1 - cos + I" is dropped for the same reason);
+//   * the "+ I" enters as the initial accumulator of the C^ C^T MFMA (-|c_i|^2 on the diagonal: |c_i|^2 rho_i^2 = 1);
+//   * |c|^2 with v_dot2c_f32_bf16; softmax normalisation, beta and the dropout scale are ONE factor per branch, the
+//     dropout decisions are predicates (v_cndmask), not multipliers.
+struct QaAttnConst {
+    DropKey k1, k2;
+    float c_beta, c_omb;        // beta / (1 - p), (1 - beta) / (1 - p)
+    bool dg[4];                 // lane-constant: key 4 q + e is the query r (diagonal of a 16 x 16 block)
+};
+
+__device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* qt, int R0, int uh, int it, int t, int h, int H,
+                                            const float* mask, float* rho, float* madd, bf16* ctx_row, bool act, int r, int q,
+                                            int lane) {
+    constexpr float L2E = 1.4426950408889634f;
+    auto blk = [&](int mtx) { return 4 * (2 * mtx + uh) + q; };
+    bf16x8 fq, fk[2], fc[2];
+    float ss[2], rho_own[2];
+    fq = *(const bf16x8*)(qt + qt_addr(R0 + 16 * it + r, blk(0)));
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        fk[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(1)));
+        fc[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(3)));
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16x2_t c2 = {fc[jt][2 * e], fc[jt][2 * e + 1]};
+            s = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, s, false);
+        }
+        ss[jt] = qred(s, false);
+        rho_own[jt] = __builtin_amdgcn_rsqf(ss[jt]);     // 1 / |c_row|
+        if (q == 0) rho[16 * jt + r] = rho_own[jt];
+    }
+    const bool has_mask = mask != nullptr;               // (uniform)
+    if (has_mask) {
+        const float mv = act ? (1.f - mask[(int64_t)t * 32 + (lane & 31)]) * -10000.f : 0.f;
+        const float mm = qa_wave_max(mv);
+        if (lane < 32) madd[lane] = (mv - mm) * L2E;
+    }
+    // rho / madd are private to this wave: LDS operations of one wave execute in order, no barrier needed
+    __builtin_amdgcn_wave_barrier();
+    f32x4 a1[2], a2[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        f32x4 z1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z1[e] = (kc.dg[e] && it == jt) ? -ss[jt] : 0.f;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        a1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt], it == 0 ? fc[0] : fc[1], z1, 0, 0, 0);
+        a2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq, z, 0, 0, 0);
+    }
+    const float rl = (it == 0 ? rho_own[0] : rho_own[1]) * L2E;
+    constexpr float isql = 0.17677669529663687f * L2E;      // log2(e) / sqrt(32)
+    float m2 = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const f32x4 rj = *(const f32x4*)(rho + 16 * jt + 4 * q);
+        f32x4 mj = {0.f, 0.f, 0.f, 0.f};
+        if (has_mask) mj = *(const f32x4*)(madd + 16 * jt + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a1[jt][e] = fmaf(-a1[jt][e], rl * rj[e], mj[e]);
+            a2[jt][e] = fmaf(a2[jt][e], isql, mj[e]);
+            m2 = raw_max(m2, a2[jt][e]);
+        }
+    }
+    m2 = qred(m2, true);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a1[jt][e] = __builtin_amdgcn_exp2f(a1[jt][e]);
+            a2[jt][e] = __builtin_amdgcn_exp2f(a2[jt][e] - m2);
+            s1 += a1[jt][e];
+            s2 += a2[jt][e];
+        }
+    s1 = qred(s1, false);
+    s2 = qred(s2, false);
+    const float c1 = kc.c_beta * __builtin_amdgcn_rcpf(s1), c2 = kc.c_omb * __builtin_amdgcn_rcpf(s2);
+    // mix + dropout -> P^T, packed as the B operand (k slot e of lane (r, q): key 16 (e >> 2) + 4 q + (e & 3))
+    bf16x8 pb;
+    const int i = 16 * it + r;
+    {
+        const uint32_t hrow = (uint32_t)((((uint64_t)t * H + h) * 32) + i);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            bool kp1[4] = {true, true, true, true}, kp2[4] = {true, true, true, true};
+            if (kc.k1.on) {
+                drop_keep4(kc.k1, hrow, (uint32_t)(4 * jt + q), kp1);
+                drop_keep4(kc.k2, hrow, (uint32_t)(4 * jt + q), kp2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pb[4 * jt + e] = (bf16)fmaf(c1, kp1[e] ? a1[jt][e] : 0.f, kp2[e] ? c2 * a2[jt][e] : 0.f);
+        }
+    }
+    // O^T[c][i] = sum_j V[j][c] P[i][j]: A operand = transposed read of the V block (rows = keys)
+    f32x4 o[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int row_lo = R0 + 4 * q + (r >> 2), row_hi = row_lo + 16;
+        const int cb = (2 * 2 + uh) * 64 + (16 * ct + 4 * (r & 3)) * 2;      // byte column inside the row: V block of this head
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_lo, cb >> 4) + (cb & 15)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_hi, cb >> 4) + (cb & 15)));
+        const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, z, 0, 0, 0);
+    }
+    // one 16-byte store per lane: the 64 bytes of this (row, head) leave as one run (common.h: store_row32)
+    store_row32(ctx_row, o[0], o[1], q, act);
+}
+
+__device__ __forceinline__ QaAttnConst qa_attn_const(const QkvcAttn& a, int r, int q) {
+    QaAttnConst kc;
+    kc.k1 = make_drop_key(a.drop1);
+    kc.k2 = make_drop_key(a.drop2);
+    kc.c_beta = a.beta * kc.k1.scale;
+    kc.c_omb = (1.f - a.beta) * kc.k2.scale;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kc.dg[e] = (4 * q + e) == r;
+    return kc;
+}
 
 template <int KS>
 __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
@@ -108,25 +279,27 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
         }
     };
 
-    const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
-    const float beta = a.beta, omb = 1.f - a.beta;
-    const float isq = 0.17677669529663687f;     // 1 / sqrt(32)
+    const QaAttnConst kc = qa_attn_const(a, r, q);
     // attention role of this wave
     const int us = wave >> 2, uh = (wave >> 1) & 1, it = wave & 1;
     const int h = 2 * y + uh;
     float* rho = wl + wave * 64;
     float* madd = rho + 32;
-    // 16-byte chunk index of (matrix mtx, this wave's head) at k-chunk q inside a projection-tile row
-    auto blk = [&](int mtx) { return 4 * (2 * mtx + uh) + q; };
     bf16* QKVC = (bf16*)a.qkvc;
     bf16* CTX = (bf16*)a.ctx;
     const int erow = tid >> 5, ech = tid & 31;
 
+    QA_PROF_DECL
     auto tile_step = [&](auto Pc, int mt) {
         constexpr int P = decltype(Pc)::value;
+#ifdef PMGT_QA_PROF
+        ++pacc[7];
+#endif
+        QA_STAMP(0);
         sstore(P, P);
         if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
         __syncthreads();                 // A tile visible; every wave is past the previous tile's attention phase
+        QA_STAMP(1);
         f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
@@ -145,6 +318,7 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
                 acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], fa[i], acc[i][1], 0, 0, 0);
             }
         }
+        QA_STAMP(2);
         // ---- + bias, bf16, into the projection tile (8 bytes per lane per block)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -155,7 +329,9 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
                 bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *(bf16x4*)(qt + qt_addr(row, 4 * wave + 2 * j + (q >> 1)) + 8 * (q & 1)) = o;
             }
+        QA_STAMP(3);
         __syncthreads();
+        QA_STAMP(4);
         // ---- (a) projection tile -> HBM, 16 bytes per lane, rows contiguous inside each 64-byte head block
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -163,97 +339,14 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
             const int m = mt * 64 + row;
             if (m < M) *(u32x4*)(QKVC + (int64_t)m * a.ldq + ocol(8 * ech)) = *(const u32x4*)(qt + qt_addr(row, ech));
         }
+        QA_STAMP(5);
         // ---- (b) attention of (sequence 2 mt + us, head h, queries 16 it .. 16 it + 15)
         const int t = 2 * mt + us;
         const bool act = t < a.Tseq;
         if (it == 1 && t < a.cls_only_seqs) return;      // (wave-uniform) only query row 0 of this sequence is ever read
-        const int R0 = 32 * us;
-        bf16x8 fq, fk[2], fc[2];
-        fq = *(const bf16x8*)(qt + qt_addr(R0 + 16 * it + r, blk(0)));
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            fk[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(1)));
-            fc[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(3)));
-            float ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float c = (float)fc[jt][e]; ss = fmaf(c, c, ss); }
-            ss = qred(ss, false);
-            if (q == 0) rho[16 * jt + r] = rsqrtf(ss);       // 1 / |c_row|
-        }
-        if (lane < 32) madd[lane] = (act && a.mask) ? (1.f - a.mask[(int64_t)t * 32 + lane]) * -10000.f : 0.f;
-        // rho / madd are private to this wave: LDS operations of one wave execute in order, no barrier needed
-        __builtin_amdgcn_wave_barrier();
-        f32x4 a1[2], a2[2];
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            a1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt], it == 0 ? fc[0] : fc[1], z, 0, 0, 0);
-            a2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq, z, 0, 0, 0);
-        }
-        const int i = 16 * it + r;
-        {
-            const float rho_i = rho[i];
-            float m1 = -INFINITY, m2 = -INFINITY;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = 16 * jt + 4 * q + e;
-                    const float v1 = 1.f - a1[jt][e] * (rho_i * rho[j]) + (i == j ? 1.f : 0.f) + madd[j];
-                    const float v2 = a2[jt][e] * isq + madd[j];
-                    a1[jt][e] = v1;
-                    a2[jt][e] = v2;
-                    m1 = fmaxf(m1, v1);
-                    m2 = fmaxf(m2, v2);
-                }
-            m1 = qred(m1, true);
-            m2 = qred(m2, true);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float e1 = __expf(a1[jt][e] - m1), e2 = __expf(a2[jt][e] - m2);
-                    a1[jt][e] = e1;
-                    a2[jt][e] = e2;
-                    s1 += e1;
-                    s2 += e2;
-                }
-            s1 = qred(s1, false);
-            s2 = qred(s2, false);
-            const float i1 = __frcp_rn(s1), i2 = __frcp_rn(s2);
-            a1[0] *= i1; a1[1] *= i1;
-            a2[0] *= i2; a2[1] *= i2;
-        }
-        // mix + dropout -> P^T, packed as the B operand (k slot e of lane (r, q): key 16 (e >> 2) + 4 q + (e & 3))
-        bf16x8 pb;
-        {
-            const uint64_t hbase = ((uint64_t)t * a.H + h) * 32;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
-                if (k1.on) {
-                    drop_mul4(k1, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d1);
-                    drop_mul4(k2, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d2);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pb[4 * jt + e] = (bf16)(beta * d1[e] * a1[jt][e] + omb * d2[e] * a2[jt][e]);
-            }
-        }
-        // O^T[c][i] = sum_j V[j][c] P[i][j]: A operand = transposed read of the V block (rows = keys)
-        f32x4 o[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int row_lo = R0 + 4 * q + (r >> 2), row_hi = row_lo + 16;
-            const int cb = (2 * 2 + uh) * 64 + (16 * ct + 4 * (r & 3)) * 2;      // byte column inside the row: V block of this head
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_lo, cb >> 4) + (cb & 15)));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_hi, cb >> 4) + (cb & 15)));
-            const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, z, 0, 0, 0);
-        }
-        // one 16-byte store per lane: the 64 bytes of this (row, head) leave as one run (common.h: store_row32)
-        store_row32(CTX + ((int64_t)min(t, a.Tseq - 1) * 32 + i) * a.ldc + h * 32, o[0], o[1], q, act);
+        qa_attention(kc, qt, 32 * us, uh, it, min(t, a.Tseq - 1), h, a.H, a.mask, rho, madd,
+                     CTX + ((int64_t)min(t, a.Tseq - 1) * 32 + 16 * it + r) * a.ldc + h * 32, act, r, q, lane);
+        QA_STAMP(6);
         // The next tile_step's first barrier orders this phase's LDS reads before the next projection-tile
         // writes (which come after that step's second barrier anyway).
     };
@@ -268,6 +361,153 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
         tile_step(std::integral_constant<int, 1>{}, mt);
         mt += gx;
     }
+    QA_PROF_FLUSH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU form.  In-kernel timestamps of the kernel above (PMGT_QA_PROF) show its tile step as a
+// SEQUENCE of phases bound by different units -- projection (MFMA pipe + LDS fragment reads, ~2850 cycles for the two
+// waves of a SIMD), attention (VALU issue: ~390 instructions x 4 cycles x 2 waves, ~3700 cycles) -- that one 8-wave
+// workgroup marches through in lockstep, so the MFMA pipe idles during attention and the VALU during projection.
+// Here a workgroup has FOUR waves, each holding a 64-column block of the slab's W (128 VGPRs), and works on one
+// sequence (32 rows) per step; two such workgroups share a CU (256 VGPRs per wave, 49 KB LDS each) and drift out of
+// phase, so one's projection overlaps the other's attention.  Every A-tile fragment read now feeds 8 MFMAs instead of
+// 4: half the LDS traffic per row.
+//   wave w = (head uh = w >> 1, matrix pair mh = w & 1: {Q, K} or {V, C});  attention role (head uh, query half w & 1).
+template <int KS> struct QaCfg2 {
+    static constexpr int K = 32 * KS;
+    static constexpr int ROWB = K * 2;
+    static constexpr int CPR = K / 8;
+    static constexpr int TILEB = 32 * ROWB;
+    static constexpr int LPT = 32 * CPR / 256;
+    static_assert(LPT * 256 == 32 * CPR, "tile must be a whole number of chunks per thread");
+    static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
+    static constexpr int QTB = 32 * 512;                      // projection tile: 32 rows x 256 bf16
+    static constexpr int SMEM = 2 * TILEB + QTB + 4 * 64 * 4 + 256 * 4;     // A ring + projection tile + per-wave {rho, madd} + bias
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qkvc_attn_fwd2_kernel(QkvcAttn a) {
+    using C = QaCfg2<KS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* qt = smem + 2 * C::TILEB;
+    float* wl = (float*)(qt + C::QTB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int d = a.H * 32;
+    const int ny = a.H / 2;
+    const int b = blockIdx.x;
+    const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
+    const int gx = gridDim.x / ny;
+    const int num_mt = a.Tseq;                  // one sequence per step
+    const int uh = wave >> 1, mh = wave & 1, it = wave & 1;
+    const int h = 2 * y + uh;
+    auto gcol = [&](int c) { return (c >> 6) * d + (2 * y + ((c >> 5) & 1)) * 32 + (c & 31); };
+    auto ocol = [&](int c) { return a.hm ? ((2 * y + ((c >> 5) & 1)) * 4 + (c >> 6)) * 32 + (c & 31) : gcol(c); };
+    // local column of this wave's 16-column block cb: matrix 2 mh + (cb >> 1), head uh, half cb & 1
+    auto cbase = [&](int cb) { return 64 * (2 * mh + (cb >> 1)) + 32 * uh + 16 * (cb & 1); };
+
+    bf16x8 wf[4][KS];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int n = gcol(cbase(cb) + r);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[cb][ks] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 32 * ks + 8 * q);
+    }
+    float* bias_l = wl + 4 * 64;          // bias of the slab's 256 local columns (LDS: 16 VGPRs fewer)
+    bias_l[tid] = a.bias ? a.bias[gcol(tid)] : 0.f;
+
+    u32x4 ra[1][C::LPT];
+    auto gload = [&](int mt, int set) {
+#pragma unroll
+        for (int i = 0; i < C::LPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            ra[set][i] = *(const u32x4*)((const char*)a.X + ((int64_t)(mt * 32 + row) * a.ldx) * 2 + ch * 16);
+        }
+    };
+    auto sstore = [&](int buf, int set) {
+#pragma unroll
+        for (int i = 0; i < C::LPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
+        }
+    };
+
+    const QaAttnConst kc = qa_attn_const(a, r, q);
+    float* rho = wl + wave * 64;
+    float* madd = rho + 32;
+    bf16* QKVC = (bf16*)a.qkvc;
+    bf16* CTX = (bf16*)a.ctx;
+    const int erow = tid >> 5, ech = tid & 31;
+
+    QA_PROF_DECL
+    auto tile_step = [&](int P, int mt) {
+#ifdef PMGT_QA_PROF
+        ++pacc[7];
+#endif
+        QA_STAMP(0);
+        __syncthreads();                 // A tile visible; every wave is past the previous step's attention phase
+        QA_STAMP(1);
+        // the next tile travels through registers only during the projection phase (the attention phase, where register
+        // pressure peaks, never holds it): loaded here, parked in the other LDS buffer after the second barrier
+        const bool more = mt + gx < num_mt;
+        if (more) gload(mt + gx, 0);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[i][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* a_base = sA + P * C::TILEB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 16 * i + r;
+                fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)      // D[n = 4 q + e][m = r]: acc[i][cb][e] = out[16 i + r][cbase(cb) + 4 q + e]
+                    acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0);
+        }
+        QA_STAMP(2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int row = 16 * i + r;
+                const f32x4 v = acc[i][cb] + *(const f32x4*)(bias_l + cbase(cb) + 4 * q);
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *(bf16x4*)(qt + qt_addr(row, (cbase(cb) >> 3) + (q >> 1)) + 8 * (q & 1)) = o;
+            }
+        QA_STAMP(3);
+        __syncthreads();
+        QA_STAMP(4);
+        if (more) sstore(P ^ 1, 0);      // that buffer was last read in the previous step's projection phase
+        // ---- (a) projection tile -> HBM
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = erow + 8 * ps;
+            *(u32x4*)(QKVC + (int64_t)(mt * 32 + row) * a.ldq + ocol(8 * ech)) = *(const u32x4*)(qt + qt_addr(row, ech));
+        }
+        QA_STAMP(5);
+        // ---- (b) attention of (sequence mt, head h, queries 16 it .. 16 it + 15)
+        const int t = mt;
+        if (it == 1 && t < a.cls_only_seqs) return;      // (wave-uniform) only query row 0 of this sequence is ever read
+        qa_attention(kc, qt, 0, uh, it, t, h, a.H, a.mask, rho, madd, CTX + ((int64_t)t * 32 + 16 * it + r) * a.ldc + h * 32, true, r, q,
+                     lane);
+        QA_STAMP(6);
+    };
+
+    int mt = x;
+    if (mt < num_mt) { gload(mt, 0); sstore(0, 0); }
+    for (int P = 0; mt < num_mt; mt += gx, P ^= 1) tile_step(P, mt);
+    QA_PROF_FLUSH;
 }
 
 bool qkvc_attn_supported(const QkvcAttn& a) {
@@ -292,10 +532,37 @@ template <int KS> static int launch_qa(const QkvcAttn& a, hipStream_t st) {
     return 0;
 }
 
+template <int KS> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
+    using C = QaCfg2<KS>;
+    auto kern = qkvc_attn_fwd2_kernel<KS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+        attr_done = true;
+    }
+    const int ny = a.H / 2;
+    const int gx = std::max(8, std::min(512 / ny, a.Tseq) / 8 * 8);       // two workgroups per CU
+    hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(256), C::SMEM, st, a);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+static bool qa_form1() {
+    static const bool v = [] { const char* e = getenv("PMGT_QA_FORM"); return e && atoi(e) == 1; }();
+    return v;
+}
+
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
     if (a.Tseq <= 0) return 0;
     PMGT_CHECK(qkvc_attn_supported(a), -2, "qkvc_attn_fwd: unsupported shape S=%d dh=%d H=%d", a.S, a.dh, a.H);
-    return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
+    if (qa_form1()) return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
+    return a.H * 32 == 256 ? launch_qa2<8>(a, st) : launch_qa2<4>(a, st);
 }
 
 }  // namespace pmgt
+
+#ifdef PMGT_QA_PROF
+extern "C" int pmgt_debug_qa_prof_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_qa_prof), sizeof(pmgt::g_qa_prof));
+}
+#endif

@@ -424,7 +424,10 @@ def test_fused_qkvc_attention_matches_the_two_kernel_path(T, H, beta, drop):
                                 None, None, None, None, 1e-12, stream()))
     _lib.check(L.pmgt_op_attention_fwd(1, P(q2), P(md), P(c2), None, T, S, H, dh, beta, drop, 17, 18, P(rng), stream()))
     assert torch.equal(q1, q2)                           # same products, same accumulation order, same rounding
-    assert rel_err(c1, c2) < 1e-3 and (c1.float() - c2.float()).abs().max().item() <= 2 ** -6 * c2.float().abs().max().item()
+    # The fused kernel evaluates the softmaxes in the log2 domain and folds normalisation, beta and the dropout scale into
+    # one factor, so the two paths differ by fp32 round-off BEFORE P is rounded to bf16: single-ulp flips of P and ctx
+    # (bf16 eps = 3.9e-3) are expected; a different dropout mask or a wrong score would be orders of magnitude larger.
+    assert rel_err(c1, c2) < 3e-3 and (c1.float() - c2.float()).abs().max().item() <= 2 ** -6 * c2.float().abs().max().item()
     if drop == 0.0:
         qr = rounded(x, torch.bfloat16).reshape(M, d) @ rounded(W, torch.bfloat16).T + bias.double()
         assert rel_err(q1.reshape(M, 4 * d), qr) < 4e-3
@@ -436,6 +439,30 @@ def test_fused_qkvc_attention_matches_the_two_kernel_path(T, H, beta, drop):
     assert rel_err(c1, ref1) < tol("bf16")
     # unsupported shapes are refused, not silently mis-computed
     assert L.pmgt_op_qkvc_attention_fwd(P(xd), P(Wd), P(bd), None, P(q1), P(c1), T, 16, H, dh, beta, 0.0, 0, 0, None, stream()) == -3
+
+
+def test_fused_qkvc_attention_fully_masked_sequence():
+    """A sequence whose mask is all zero: every key carries -10000, which cancels in both softmaxes (the reference
+    gives softmax(scores)).  The fused kernel shifts the mask term by its maximum over the keys and skips the row
+    maximum of the bounded cosine branch -- this is the case that shift exists for."""
+    _lib, L = _setup()
+    T, S, H, dh = 6, 32, 8, 32
+    d = H * dh
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(T, S, d, generator=g)
+    W = torch.randn(4 * d, d, generator=g) / math.sqrt(d)
+    mask = torch.ones(T, S)
+    mask[1] = 0                       # fully masked
+    mask[2, 5:] = 0
+    mask[4, 1:] = 0                   # only the target node is valid
+    xd, Wd, md = to_dev(x, torch.bfloat16), to_dev(W, torch.bfloat16), mask.cuda()
+    q1 = torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16)
+    c1 = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.pmgt_op_qkvc_attention_fwd(P(xd), P(Wd), None, P(md), P(q1), P(c1), T, S, H, dh, 0.5, 0.0, 0, 0, None, stream()))
+    ref, _ = _attn_ref(q1.float().cpu().double(), mask.double(), H, 0.5)
+    assert torch.isfinite(c1.float()).all()
+    for t in range(T):
+        assert rel_err(c1[t], ref[t]) < tol("bf16"), t
 
 
 # ------------------------------------------------------------------------------------------- 256 x 256 NT tile

@@ -1,0 +1,38 @@
+"""Cycles per phase inside the fused forward kernels (library built with -DPMGT_QA_PROF)."""
+import ctypes as C, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pmgt_amd import _lib
+L = _lib.hip()
+P = lambda t: C.c_void_p(t.data_ptr())
+T, S, H, dh = 12288, 32, 8, 32
+d = H * dh
+NS = 4
+xs = [torch.randn(T, S, d, device="cuda").bfloat16() for _ in range(NS)]
+W = (torch.randn(4 * d, d, device="cuda") / d ** 0.5).bfloat16()
+bias = torch.zeros(4 * d, device="cuda")
+qks = [torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16) for _ in range(NS)]
+ctxs = [torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16) for _ in range(NS)]
+rng = torch.tensor([1, 2], dtype=torch.int64, device="cuda")
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+for k in range(9):
+    i = k % NS
+    if k == 8: ev[0].record()
+    _lib.check(L.pmgt_op_qkvc_attention_fwd(P(xs[i]), P(W), P(bias), None, P(qks[i]), P(ctxs[i]), T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st))
+ev[1].record()
+torch.cuda.synchronize()
+print("last launch: %.1f us" % (ev[0].elapsed_time(ev[1]) * 1e3))
+buf = np.zeros((2, 8, 8), dtype=np.uint32)
+raw = C.CDLL(_lib._build.hip_lib_path())
+raw.pmgt_debug_qa_prof_read.argtypes = [C.c_void_p]
+assert raw.pmgt_debug_qa_prof_read(buf.ctypes.data) == 0
+b = buf.astype(np.float64)
+lab = ["attn-end->0", "0->1 sstore,gload,bar1", "1->2 frags+MFMA", "2->3 bias,qt writes", "3->4 bar2", "4->5 copy-out", "5->6 attention"]
+for slot in range(2):
+    print("block slot", slot)
+    for w in range(8):
+        n = b[slot, w, 7]
+        if n == 0: continue
+        per = b[slot, w, :7] / n
+        print(f"  wave {w}: steps {int(n)} total/step {per.sum():7.0f} | " + " | ".join(f"{lab[k].split()[0]} {per[k]:6.0f}" for k in range(7)))
