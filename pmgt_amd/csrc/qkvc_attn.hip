@@ -30,6 +30,8 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 // cycles (s_memtime) per phase of the tile steps of two workgroups, accumulated in SGPRs: [block slot][wave][phase];
 // phase 7 = number of steps
 __device__ unsigned int g_qa_prof[2][8][8];
+// per workgroup: start / end time (s_memrealtime, 100 MHz), HW_ID, XCC_ID
+__device__ unsigned long long g_qa_blk[1024][4];
 #define QA_STAMP(k)                                                   \
     do {                                                              \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -37,6 +39,7 @@ __device__ unsigned int g_qa_prof[2][8][8];
         plast = now_;                                                 \
     } while (0)
 #define QA_PROF_DECL                                                                                        \
+    const unsigned long long pstart = __builtin_amdgcn_s_memrealtime();                                     \
     const int pslot = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 + 3 ? 1 : -1);                     \
     unsigned int pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                        \
     unsigned long long plast = __builtin_readcyclecounter();
@@ -44,6 +47,12 @@ __device__ unsigned int g_qa_prof[2][8][8];
     do {                                                                                                    \
         if (lane == 0 && pslot >= 0) {                                                                      \
             for (int k_ = 0; k_ < 8; ++k_) g_qa_prof[pslot][wave][k_] = pacc[k_];                           \
+        }                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                        \
+            g_qa_blk[blockIdx.x][0] = pstart;                                                               \
+            g_qa_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                                     \
+            g_qa_blk[blockIdx.x][2] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);                        \
+            g_qa_blk[blockIdx.x][3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 20);                       \
         }                                                                                                   \
     } while (0)
 #else
@@ -455,6 +464,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // pressure peaks, never holds it): loaded here, parked in the other LDS buffer after the second barrier
         const bool more = mt + gx < num_mt;
         if (more) gload(mt + gx, 0);
+        // the projection phase issues one MFMA per 16 cycles: give it priority over the other workgroup's VALU-bound
+        // attention phase, so the MFMA pipe never waits for an issue slot (and the younger workgroup of the CU is
+        // not starved by oldest-first arbitration)
+        __builtin_amdgcn_s_setprio(3);
         f32x4 acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -485,6 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *(bf16x4*)(qt + qt_addr(row, (cbase(cb) >> 3) + (q >> 1)) + 8 * (q & 1)) = o;
             }
+        __builtin_amdgcn_s_setprio(0);
         QA_STAMP(3);
         __syncthreads();
         QA_STAMP(4);
@@ -564,5 +578,8 @@ int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
 #ifdef PMGT_QA_PROF
 extern "C" int pmgt_debug_qa_prof_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_qa_prof), sizeof(pmgt::g_qa_prof));
+}
+extern "C" int pmgt_debug_qa_blk_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_qa_blk), sizeof(pmgt::g_qa_blk));
 }
 #endif

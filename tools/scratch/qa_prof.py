@@ -36,3 +36,31 @@ for slot in range(2):
         if n == 0: continue
         per = b[slot, w, :7] / n
         print(f"  wave {w}: steps {int(n)} total/step {per.sum():7.0f} | " + " | ".join(f"{lab[k].split()[0]} {per[k]:6.0f}" for k in range(7)))
+blk = np.zeros((1024, 4), dtype=np.uint64)
+raw.pmgt_debug_qa_blk_read.argtypes = [C.c_void_p]
+assert raw.pmgt_debug_qa_blk_read(blk.ctypes.data) == 0
+nb = int((blk[:, 1] > 0).sum())
+b = blk[:nb].astype(np.int64)
+t0 = b[:, 0].min()
+st_, en_ = (b[:, 0] - t0) / 100.0, (b[:, 1] - t0) / 100.0     # us
+hw = b[:, 2]; xcc = b[:, 3] & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+print(f"blocks {nb}: start min/median/max {st_.min():.1f}/{np.median(st_):.1f}/{st_.max():.1f} us, end min/median/max {en_.min():.1f}/{np.median(en_):.1f}/{en_.max():.1f} us, "
+      f"lifetime median {np.median(en_ - st_):.1f} us")
+uniq, cnt = np.unique(cuid, return_counts=True)
+print(f"distinct CUs {len(uniq)}, blocks per CU: " + ", ".join(f"{k}x{int((cnt == k).sum())}" for k in sorted(set(cnt))))
+late = st_ > 20
+print(f"blocks starting later than 20 us: {int(late.sum())}")
+life = en_ - st_
+for x_ in range(8):
+    m_ = xcc == x_
+    if m_.any(): print(f"  xcc {x_}: blocks {int(m_.sum())} lifetime min/median/max {life[m_].min():.0f}/{np.median(life[m_]):.0f}/{life[m_].max():.0f} us; blockIdx%8 -> {sorted(set((np.arange(nb)[m_] % 8).tolist()))}")
+ny_ = 4
+yy = (np.arange(nb) >> 3) % ny_
+for y_ in range(ny_):
+    print(f"  slab {y_}: lifetime median {np.median(life[yy == y_]):.0f} max {life[yy == y_].max():.0f}")
+m_ = (xcc == 0)
+idx = np.arange(nb)[m_]
+print("xcc0 lifetimes by block order:", " ".join(f"{int(v)}" for v in life[m_]))
+print("xcc0 (se,sh,cu):", " ".join(f"{int(a_)}{int(b_)}{int(c_):x}" for a_, b_, c_ in zip(se[m_], sh[m_], cu[m_])))
