@@ -16,7 +16,21 @@
 
 namespace pmgt {
 
+#ifdef PMGT_AB_PROF
+// cycles (s_memtime) per phase of the wave backward kernel, summed over the waves of workgroups 0 and 777
+__device__ unsigned int g_ab_prof[2][4][10];
+#define AB_STAMP(k)                                                   \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pacc[k] = (unsigned int)(now_ - plast);                       \
+        plast = now_;                                                 \
+    } while (0)
+#else
+#define AB_STAMP(k) do { } while (0)
+#endif
+
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 // Row `row` of a [S][ld] matrix, 8 elements at column `col`; rows >= S read as zero.  The load itself is
 // UNCONDITIONAL on a clamped row (a branch around a load makes the compiler wait for it at the join, which
@@ -47,15 +61,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int c0, int 
 // through the LDS crossbar -- these reductions sit on the dependent chain max -> exp -> sum -> reciprocal.
 // (inline asm on two copies of v: the builtins fold when both operands are the same value; "s_nop 1" covers the
 // VALU-write -> permlane-read hazard, cdna_hip_programming.md T21)
+// v_max_f32 without the canonicalising self-max clang puts in front of fmaxf for values of unknown origin
+__device__ __forceinline__ float raw_max(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ float xchg16(float v, bool is_max) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return is_max ? fmaxf(a, b) : a + b;
+    return is_max ? raw_max(a, b) : a + b;
 }
 __device__ __forceinline__ float xchg32(float v, bool is_max) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return is_max ? fmaxf(a, b) : a + b;
+    return is_max ? raw_max(a, b) : a + b;
 }
 template <int NT> __device__ __forceinline__ float red_q(float v, bool is_max) { return xchg32(xchg16(v, is_max), is_max); }
 
@@ -127,6 +147,97 @@ __device__ __forceinline__ void probs_T(const bf16x8 (&fq)[NT][KD], const bf16x8
 }
 
 // pack an accumulator-layout matrix column block `it` into B fragments (k-step ks covers key tiles 2ks, 2ks+1)
+// The same two probability matrices with a shorter VALU chain (the backward kernel is VALU-issue-bound: 1350 VALU
+// instructions per (sequence, head), 3.5 waves per SIMD):
+//   * scores in the log2 domain (log2 e folded into 1/sqrt(dh), rho_i and the mask term `madd`, which the caller
+//     has ALREADY scaled by log2 e and shifted by its maximum over the keys), so an exponential is one v_exp_f32;
+//   * no row maximum for the cosine branch: -cos + I <= 2 (the constant 1 of "1 - cos + I" drops out of the softmax);
+//   * "+ I" enters through the initial accumulator of the C^ C^T MFMA: -|c_i|^2 on the diagonal (|c_i|^2 rho_i^2 = 1);
+//   * v_rcp_f32 instead of an IEEE division.
+// ssq[tt] = |c_row|^2 and rho_own[tt] = 1/|c_row| of row 16 tt + r (every q lane holds them).
+template <int NT, int KD, bool HAS_MASK>
+__device__ __forceinline__ void probs_T2(const bf16x8 (&fq)[NT][KD], const bf16x8 (&fk)[NT][KD], const bf16x8 (&fc)[NT][KD],
+                                         const float (&ssq)[NT], const float (&rho_own)[NT], const float* rho, const float* madd,
+                                         int S, int r, int q, float isq, f32x4 (&a1)[NT][NT], f32x4 (&a2)[NT][NT], int ntq) {
+    constexpr float L2E = 1.4426950408889634f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1;
+            if (it < ntq) {          // (wave-uniform) query tiles >= ntq carry no gradient: their probabilities stay 0
+                if (jt == it) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x1[e] = (4 * q + e == r) ? -ssq[it] : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KD; ++ks) {
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt][ks], fc[it][ks], x1, 0, 0, 0);
+                    x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt][ks], fq[it][ks], x2, 0, 0, 0);
+                }
+            }
+            a1[jt][it] = x1;
+            a2[jt][it] = x2;
+        }
+    const float isql = isq * L2E;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        if (it >= ntq) continue;
+        const int i = 16 * it + r;
+        const bool iv = i < S;
+        const float rl = rho_own[it] * L2E;
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 rj = *(const f32x4*)(rho + 16 * jt + 4 * q);
+            f32x4 mj = {0.f, 0.f, 0.f, 0.f};
+            if (HAS_MASK) mj = *(const f32x4*)(madd + 16 * jt + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = iv && 16 * jt + 4 * q + e < S;
+                const float v1 = fmaf(-a1[jt][it][e], rl * rj[e], mj[e]);
+                const float v2 = fmaf(a2[jt][it][e], isql, mj[e]);
+                a1[jt][it][e] = ok ? v1 : -INFINITY;
+                a2[jt][it][e] = ok ? v2 : -INFINITY;
+                m2 = raw_max(m2, a2[jt][it][e]);
+            }
+        }
+        m2 = red_q<NT>(m2, true);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e1 = __builtin_amdgcn_exp2f(a1[jt][it][e]);
+                const float e2 = iv ? __builtin_amdgcn_exp2f(a2[jt][it][e] - m2) : 0.f;
+                a1[jt][it][e] = e1;
+                a2[jt][it][e] = e2;
+                s1 += e1;
+                s2 += e2;
+            }
+        s1 = red_q<NT>(s1, false);
+        s2 = red_q<NT>(s2, false);
+        const float i1 = iv ? __builtin_amdgcn_rcpf(s1) : 0.f, i2 = iv ? __builtin_amdgcn_rcpf(s2) : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            a1[jt][it] *= i1;
+            a2[jt][it] *= i2;
+        }
+    }
+}
+
+// A operand / B operand fragment of an [i][j] bf16 image (row stride LDB bytes) whose k index runs down the ROWS:
+// element e of lane (r, q) = img[k0 + 8 q + e][c0 + r]  (ds_read_b64_tr_b16, as tr_frag<., false> does for the tiles)
+template <int LDB>
+__device__ __forceinline__ bf16x8 img_frag(const char* img, int k0, int c0, int r, int q) {
+    const int row_lo = k0 + 8 * q + (r >> 2), row_hi = row_lo + 4;
+    const int colb = (c0 + 4 * (r & 3)) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + row_lo * LDB + colb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + row_hi * LDB + colb));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x4 pack4(const f32x4& v) { return (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
+
 template <int NT>
 __device__ __forceinline__ bf16x8 pack_b(const f32x4 (&x)[NT][NT], int it, int ks) {
     bf16x8 b;
@@ -310,6 +421,8 @@ template <int DH, int NT, bool FULL>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     using SM = BwdSmemW<DH, NT>;
     constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2;
+    constexpr int LDI = SP * 2;      // the three images are [i (query, SP2 rows, zero beyond SP)][j (key, SP)] bf16: a lane's four
+                                     // consecutive keys leave as ONE 8-byte write; the products read them with transpose reads
     // every wave works in its own LDS region: the LDS pipeline executes one wave's operations in order, so a compiler
     // barrier (no s_barrier: the waves of a workgroup are independent and must not march in lockstep) orders them
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
@@ -340,6 +453,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     const int ntq = t < a.cls_only_seqs ? 1 : NT;      // query tiles that carry a gradient (wave-uniform)
     const float isq = rsqrtf((float)DH);
 
+#ifdef PMGT_AB_PROF
+    unsigned int pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long plast = __builtin_readcyclecounter();
+#endif
     // NT <= 2: every global load of the kernel is issued here, before anything is consumed
     constexpr bool PRE = NT <= 2;
     // (the row-major LDS tiles of Q, K, dO, C-hat are written from the FRAGMENT registers: lane (r, q) of fragment
@@ -361,9 +478,20 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         load_tile<DH>(tO, DO, d, SP2, Sv, lane, nullptr);
     }
     f32x4 a1[NT][NT], a2[NT][NT];
+    bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            fq[tt][ks] = ld_rows(X, ld, 16 * tt + r, Sv, 32 * ks + 8 * q);
+            fk[tt][ks] = ld_rows(X + ms, ld, 16 * tt + r, Sv, 32 * ks + 8 * q);
+            fc[tt][ks] = ld_rows(X + 3 * ms, ld, 16 * tt + r, Sv, 32 * ks + 8 * q);
+        }
+    // dropout keys: AFTER the fragment loads are in flight (their scalar loads of {seed, step} would otherwise hold the
+    // vector loads back), long before their first use
+    const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
     {
-        bf16x8 fq[NT][KD], fk[NT][KD], fc[NT][KD];
-        float rho_own[NT];
+        float rho_own[NT], ssq[NT];
         rho[lane] = 0.f;      // rows [16 NT, 64) are never written below but scale the (zero) padding rows of the C-hat tile
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -372,17 +500,30 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             float ss = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KD; ++ks) {
-                fq[tt][ks] = ld_rows(X, ld, row, Sv, 32 * ks + 8 * q);
-                fk[tt][ks] = ld_rows(X + ms, ld, row, Sv, 32 * ks + 8 * q);
-                fc[tt][ks] = ld_rows(X + 3 * ms, ld, row, Sv, 32 * ks + 8 * q);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float c = (float)fc[tt][ks][e]; ss = fmaf(c, c, ss); }
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2_t c2 = {fc[tt][ks][2 * e], fc[tt][ks][2 * e + 1]};
+                    ss = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, ss, false);
+                }
             }
             ss = red_q<NT>(ss, false);
-            rho_own[tt] = ok ? rsqrtf(ss) : 0.f;             // 1 / |c_row| (all four q lanes of the row hold it)
+            ssq[tt] = ss;
+            rho_own[tt] = ok ? __builtin_amdgcn_rsqf(ss) : 0.f;   // 1 / |c_row| (all four q lanes of the row hold it)
             if (q == 0) rho[row] = rho_own[tt];
         }
-        madd[lane] = (lane < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : 0.f;
+        const bool has_mask = a.mask != nullptr;     // (uniform)
+        if (has_mask) {     // mask term in the log2 domain, shifted by its maximum over the keys (see probs_T2)
+            const float mv = lane < Sv ? (1.f - a.mask[(int64_t)t * S + lane]) * -10000.f : -INFINITY;
+            float mm = mv;
+            mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x121, 0xf, 0xf, false)));
+            mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x122, 0xf, 0xf, false)));
+            mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x124, 0xf, 0xf, false)));
+            mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x128, 0xf, 0xf, false)));
+            mm = red_q<NT>(mm, true);
+            madd[lane] = lane < Sv ? (mv - mm) * 1.4426950408889634f : 0.f;
+        } else {
+            madd[lane] = 0.f;
+        }
         if constexpr (PRE) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -411,9 +552,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 }
             }
         }
+        AB_STAMP(0);
         wave_sync();
-        probs_T<NT, KD>(fq, fk, fc, rho, madd, Sv, r, q, isq, a1, a2, ntq);
+        AB_STAMP(1);
+        probs_T2<NT, KD, true>(fq, fk, fc, ssq, rho_own, rho, madd, Sv, r, q, isq, a1, a2, ntq);
     }
+    AB_STAMP(2);
     // C-hat tile (rows scaled by the inverse norms): written above from the fragments when PRE
     if constexpr (!PRE) load_tile<DH>(tC, X + 3 * ms, ld, SP2, Sv, lane, rho);
 
@@ -444,48 +588,45 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 dp[jt][it] = x;
             }
     }
+    AB_STAMP(3);
     // softmax backward (both branches) in registers; images of P^T, dS1^T, dS2^T to LDS
     f32x4 pmr[SM::ALIAS ? NT : 1][SM::ALIAS ? NT : 1];      // P^T kept in registers until its (aliased) image can be written
-    const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
-    const float beta = a.beta, omb = 1.f - a.beta;
+    const float cb = a.beta * k1.scale, co = (1.f - a.beta) * k2.scale;     // branch weight x dropout scale
     const uint64_t hbase = ((uint64_t)t * H + h) * S;
+    const bf16x4 z4 = {0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
         const int i = 16 * it + r;
-        if (it >= ntq) {        // no gradient through these queries: zero columns in the three images (a1 / a2 are already 0)
+        if (it >= ntq) {        // no gradient through these queries: zero rows in the three images (a1 / a2 are set to 0)
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = 16 * jt + 4 * q + e;
-                    *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
-                    a1[jt][it][e] = 0.f;
-                    a2[jt][it][e] = 0.f;
-                    if constexpr (SM::ALIAS) {
-                        pmr[jt][it][e] = 0.f;
-                    } else {
-                        *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
-                        *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
-                    }
+            for (int jt = 0; jt < NT; ++jt) {
+                *(bf16x4*)(iS1 + i * LDI + (16 * jt + 4 * q) * 2) = z4;
+                a1[jt][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                a2[jt][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (SM::ALIAS) {
+                    pmr[jt][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+                    *(bf16x4*)(iP + i * LDI + (16 * jt + 4 * q) * 2) = z4;
+                    *(bf16x4*)(iS2 + i * LDI + (16 * jt + 4 * q) * 2) = z4;
                 }
+            }
             continue;
         }
         float rd1 = 0.f, rd2 = 0.f;
         f32x4 g1[NT], g2[NT], pm[NT];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
-            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            bool kp1[4] = {true, true, true, true}, kp2[4] = {true, true, true, true};
             if (k1.on) {
-                drop_mul4(k1, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d1);
-                drop_mul4(k2, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), d2);
+                drop_keep4(k1, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), kp1);
+                drop_keep4(k2, (uint32_t)(hbase + i), (uint32_t)(4 * jt + q), kp2);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float m1 = beta * d1[e], m2 = omb * d2[e];
-                const float x1 = m1 * dp[jt][it][e], x2 = m2 * dp[jt][it][e];
+                const float x1 = kp1[e] ? cb * dp[jt][it][e] : 0.f, x2 = kp2[e] ? co * dp[jt][it][e] : 0.f;
                 g1[jt][e] = x1;
                 g2[jt][e] = x2;
-                pm[jt][e] = m1 * a1[jt][it][e] + m2 * a2[jt][it][e];
+                pm[jt][e] = fmaf(cb, kp1[e] ? a1[jt][it][e] : 0.f, kp2[e] ? co * a2[jt][it][e] : 0.f);
                 rd1 = fmaf(a1[jt][it][e], x1, rd1);
                 rd2 = fmaf(a2[jt][it][e], x2, rd2);
             }
@@ -493,35 +634,34 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         rd1 = red_q<NT>(rd1, false);
         rd2 = red_q<NT>(rd2, false);
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int j = 16 * jt + 4 * q + e;
-                const float ds1 = a1[jt][it][e] * (g1[jt][e] - rd1);     // a == 0 on padding -> ds == 0
-                const float ds2 = a2[jt][it][e] * (g2[jt][e] - rd2);
-                a1[jt][it][e] = ds1;
-                a2[jt][it][e] = ds2;
-                *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)ds1;
-                if constexpr (SM::ALIAS) {
-                    pmr[jt][it][e] = pm[jt][e];
-                } else {
-                    *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)pm[jt][e];
-                    *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)ds2;
-                }
+                a1[jt][it][e] = a1[jt][it][e] * (g1[jt][e] - rd1);     // dS1; a == 0 on padding -> ds == 0
+                a2[jt][it][e] = a2[jt][it][e] * (g2[jt][e] - rd2);     // dS2
             }
+            *(bf16x4*)(iS1 + i * LDI + (16 * jt + 4 * q) * 2) = pack4(a1[jt][it]);
+            if constexpr (SM::ALIAS) {
+                pmr[jt][it] = pm[jt];
+            } else {
+                *(bf16x4*)(iP + i * LDI + (16 * jt + 4 * q) * 2) = pack4(pm[jt]);
+                *(bf16x4*)(iS2 + i * LDI + (16 * jt + 4 * q) * 2) = pack4(a2[jt][it]);
+            }
+        }
     }
-    if (SP2 > SP) {     // zero the padding columns i in [SP, SP2) of the images
-        for (int idx = lane; idx < SP * (SP2 - SP); idx += 64) {
-            const int j = idx / (SP2 - SP), i = SP + idx % (SP2 - SP);
-            *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
+    if (SP2 > SP) {     // zero the padding rows i in [SP, SP2) of the images (k padding of the products that sum over i)
+        for (int idx = lane; idx < (SP2 - SP) * (SP / 4); idx += 64) {
+            const int off = (SP + idx / (SP / 4)) * LDI + (idx % (SP / 4)) * 8;
+            *(bf16x4*)(iS1 + off) = z4;
             if constexpr (!SM::ALIAS) {
-                *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
-                *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
+                *(bf16x4*)(iP + off) = z4;
+                *(bf16x4*)(iS2 + off) = z4;
             }
         }
     }
     wave_sync();
 
+    AB_STAMP(4);
     // ---- products with the query / "x" index on the lane
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
@@ -530,8 +670,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         for (int ks = 0; ks < KS; ++ks) {
             b2[ks] = pack_b<NT>(a2, it, ks);
             b1[ks] = pack_b<NT>(a1, it, ks);
-            // dS1 with the roles swapped: B[k = y][n = x] = dS1^T[x][y]  (image row x, 8 consecutive y)
-            bt[ks] = *(const bf16x8*)(iS1 + ((16 * it + r) * SP2 + 32 * ks + 8 * q) * 2);
+            // dS1 with the roles swapped: B[k = y][n = x] = dS1[y][x]  (image rows y, column x)
+            bt[ks] = img_frag<LDI>(iS1, 32 * ks, 16 * it, r, q);
         }
         const int x = 16 * it + r;
         f32x4 dch[CT], dqv[CT];
@@ -566,35 +706,35 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             store_row32(rowx + 3 * ms + 32 * cp, dch[2 * cp], dch[2 * cp + 1], q, act && x < Sv);
         }
     }
-    if constexpr (SM::ALIAS) {      // the K and C-hat tiles are dead: they become the P^T and dS2^T images
+    AB_STAMP(5);
+    if constexpr (SM::ALIAS) {      // the K and C-hat tiles are dead: they become the P and dS2 images
         wave_sync();
 #pragma unroll
         for (int it = 0; it < NT; ++it)
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 16 * it + r, j = 16 * jt + 4 * q + e;
-                    *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)pmr[jt][it][e];
-                    *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)a2[jt][it][e];
-                }
+            for (int jt = 0; jt < NT; ++jt) {
+                const int off = (16 * it + r) * LDI + (16 * jt + 4 * q) * 2;
+                *(bf16x4*)(iP + off) = pack4(pmr[jt][it]);
+                *(bf16x4*)(iS2 + off) = pack4(a2[jt][it]);
+            }
         if (SP2 > SP) {
-            for (int idx = lane; idx < SP * (SP2 - SP); idx += 64) {
-                const int j = idx / (SP2 - SP), i = SP + idx % (SP2 - SP);
-                *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
-                *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
+            for (int idx = lane; idx < (SP2 - SP) * (SP / 4); idx += 64) {
+                const int off = (SP + idx / (SP / 4)) * LDI + (idx % (SP / 4)) * 8;
+                *(bf16x4*)(iP + off) = z4;
+                *(bf16x4*)(iS2 + off) = z4;
             }
         }
         wave_sync();
     }
+    AB_STAMP(6);
     // ---- products with the key index on the lane: dV^T[c][j] = sum_i dO[i][c] P[i][j], dK^T[c][j] = sum_i Q[i][c] dS2[i][j]
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
         bf16x8 bp[KS], bs[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bp[ks] = *(const bf16x8*)(iP + ((16 * jt + r) * SP2 + 32 * ks + 8 * q) * 2);
-            bs[ks] = *(const bf16x8*)(iS2 + ((16 * jt + r) * SP2 + 32 * ks + 8 * q) * 2);
+            bp[ks] = img_frag<LDI>(iP, 32 * ks, 16 * jt, r, q);        // B[k = i][n = j] = P[i][j]
+            bs[ks] = img_frag<LDI>(iS2, 32 * ks, 16 * jt, r, q);
         }
         const int j = 16 * jt + r;
         f32x4 dvv[CT], dkv[CT];
@@ -616,6 +756,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
             store_row32(rowj + ms + 32 * cp, dkv[2 * cp], dkv[2 * cp + 1], q, act && j < Sv);
         }
     }
+    AB_STAMP(7);
+#ifdef PMGT_AB_PROF
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 777) && wave < 4)
+        for (int k_ = 0; k_ < 8; ++k_) g_ab_prof[blockIdx.x == 0 ? 0 : 1][wave][k_] = pacc[k_];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1109,3 +1254,9 @@ int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
 }
 
 }  // namespace pmgt
+
+#ifdef PMGT_AB_PROF
+extern "C" int pmgt_debug_ab_prof_read(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_ab_prof), sizeof(pmgt::g_ab_prof));
+}
+#endif

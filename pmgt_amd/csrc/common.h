@@ -131,7 +131,13 @@ __device__ __forceinline__ DropKey make_drop_key(const DropCfg& c) {
     k.on = c.p > 0.f;
     k.k0 = k.k1 = k.thr = 0; k.scale = 1.f;
     if (k.on) {
-        uint64_t seed = c.rng[0], step = c.rng[1];
+        // {seed, step} is written by an EARLIER kernel only: read it through the constant address space, so that the
+        // compiler emits one scalar s_load_dwordx4 (scalar cache, shared by the CU) instead of a vector global load
+        // followed by s_waitcnt vmcnt(0) -- a full memory round trip that drains every other load of the wave and,
+        // in kernels that build the key mid-way (GEMM epilogues, attention backward), sat on the critical path twice
+        typedef const __attribute__((address_space(4))) uint64_t* rng_cptr;
+        const rng_cptr rp = (rng_cptr)(uintptr_t)c.rng;
+        const uint64_t seed = rp[0], step = rp[1];
         k.k0 = fmix32((uint32_t)seed ^ (c.site * 0x9E3779B1u));
         k.k1 = fmix32((uint32_t)(seed >> 32) + (uint32_t)step * 0x7FEB352Du + (uint32_t)(step >> 32) + c.site);
         double t = (double)c.p * 4294967296.0;
