@@ -394,8 +394,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         __builtin_amdgcn_s_barrier();
         if (kt + NST - 1 < nk) issue(kt + NST - 1);
         const uint32_t sbase = lds_base + (uint32_t)((kt % NST) * STAGE);
+        // the four B fragments go out first, then the eight A fragments; the MFMAs of A-fragment i start as soon as it
+        // has landed (LDS returns in order), so most of the LDS latency hides behind the matrix pipe
         u32x4 t[12];
         asm volatile(
+            "ds_read_b128 %8, %20\n\t"
+            "ds_read_b128 %9, %21\n\t"
+            "ds_read_b128 %10, %22\n\t"
+            "ds_read_b128 %11, %23\n\t"
             "ds_read_b128 %0, %12\n\t"
             "ds_read_b128 %1, %13\n\t"
             "ds_read_b128 %2, %14\n\t"
@@ -403,24 +409,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
             "ds_read_b128 %4, %16\n\t"
             "ds_read_b128 %5, %17\n\t"
             "ds_read_b128 %6, %18\n\t"
-            "ds_read_b128 %7, %19\n\t"
-            "ds_read_b128 %8, %20\n\t"
-            "ds_read_b128 %9, %21\n\t"
-            "ds_read_b128 %10, %22\n\t"
-            "ds_read_b128 %11, %23\n\t"
-            "s_waitcnt lgkmcnt(0)"
+            "ds_read_b128 %7, %19"
             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
               "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
             : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
               "v"(sbase + offa[4]), "v"(sbase + offa[5]), "v"(sbase + offa[6]), "v"(sbase + offa[7]),
               "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
             : "memory");
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[0]));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            if (i == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(t[1]));
+            if (i == 2) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(t[2]));
+            if (i == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t[3]));
+            if (i == 4) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(t[4]));
+            if (i == 5) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(t[5]));
+            if (i == 6) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(t[6]));
+            if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[7]));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i]), __builtin_bit_cast(bf16x8, t[8 + j]),
                                                                     acc[i][j], 0, 0, 0);
+        }
     }
     __builtin_amdgcn_s_barrier();       // the ring becomes the staging buffer
 
@@ -1045,7 +1055,22 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
         __builtin_amdgcn_s_barrier();
         if (kt + 3 < nk) issue(kt + 3);
         const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
+        // all 24 transposed fragment reads of the step go out back to back (B first), and the MFMAs of A-fragment i start
+        // as soon as ITS two reads have landed (LDS returns in order: lgkmcnt counts down), so the tail of the LDS
+        // traffic overlaps the matrix pipe instead of preceding it
         u32x2 ta[16], tb[8];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\t"
+            "ds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\t"
+            "ds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %4, %10\n\t"
+            "ds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %6, %11\n\t"
+            "ds_read_b64_tr_b16 %7, %11 offset:2048"
+            : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7])
+            : "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
+            : "memory");
         asm volatile(
             "ds_read_b64_tr_b16 %0, %16\n\t"
             "ds_read_b64_tr_b16 %1, %16 offset:2048\n\t"
@@ -1062,26 +1087,16 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
             "ds_read_b64_tr_b16 %12, %22\n\t"
             "ds_read_b64_tr_b16 %13, %22 offset:2048\n\t"
             "ds_read_b64_tr_b16 %14, %23\n\t"
-            "ds_read_b64_tr_b16 %15, %23 offset:2048\n\t"
-            "s_waitcnt lgkmcnt(0)"
+            "ds_read_b64_tr_b16 %15, %23 offset:2048"
             : "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]), "=&v"(ta[7]),
               "=&v"(ta[8]), "=&v"(ta[9]), "=&v"(ta[10]), "=&v"(ta[11]), "=&v"(ta[12]), "=&v"(ta[13]), "=&v"(ta[14]), "=&v"(ta[15])
             : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
               "v"(sbase + offa[4]), "v"(sbase + offa[5]), "v"(sbase + offa[6]), "v"(sbase + offa[7])
             : "memory");
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %8\n\t"
-            "ds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %2, %9\n\t"
-            "ds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %4, %10\n\t"
-            "ds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %6, %11\n\t"
-            "ds_read_b64_tr_b16 %7, %11 offset:2048\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7])
-            : "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
-            : "memory");
+        // B fragments + A fragment 0 have landed when at most 14 reads are outstanding
+        asm volatile("s_waitcnt lgkmcnt(14)"
+                     : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(tb[4]), "+v"(tb[5]), "+v"(tb[6]), "+v"(tb[7]),
+                       "+v"(ta[0]), "+v"(ta[1]));
         bf16x8 fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1090,6 +1105,13 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
         const bf16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            if (i == 1) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(ta[2]), "+v"(ta[3]));
+            if (i == 2) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(ta[4]), "+v"(ta[5]));
+            if (i == 3) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ta[6]), "+v"(ta[7]));
+            if (i == 4) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ta[8]), "+v"(ta[9]));
+            if (i == 5) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ta[10]), "+v"(ta[11]));
+            if (i == 6) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ta[12]), "+v"(ta[13]));
+            if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[14]), "+v"(ta[15]));
             const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * i][0], ta[2 * i][1], ta[2 * i + 1][0], ta[2 * i + 1][1]});
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
