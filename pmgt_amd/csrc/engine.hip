@@ -707,11 +707,11 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = gD; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.m_dev = mdev;
             RUN(linear<T>(e, "bwd.dgrad_attn_out", g, st));
         }
-        if (sc) {   // back to the full token layout: zero everywhere except the compacted rows
+        if (sc) {   // back to the full token layout: dctx is zero everywhere except the compacted rows; the residual branch
+                    // (non-zero on those rows only) is ADDED to them after the dense dgrad below instead of travelling as
+                    // a dense, mostly-zero residual operand
             PMGT_HIP(hipMemsetAsync(b.bD, 0, (size_t)M * d * sizeof(T), st));
-            PMGT_HIP(hipMemsetAsync(b.bB, 0, (size_t)M * d * sizeof(T), st));
             RUN(scatter_rows<T>(gD, b.need_rows, b.need_cnt, Mt, d, b.bD, st));
-            RUN(scatter_rows<T>(gB, b.need_rows, b.need_cnt, Mt, d, b.bB, st));
         }
         {
             AttnArgs a;
@@ -728,8 +728,9 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + (b.qkvc_hm ? o.mWqkvcT_hm : o.mWqkvcT); g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
-            g.M = M; g.N = d; g.K = 4 * d; g.res = b.bB; g.ldr = d;
+            g.M = M; g.N = d; g.K = 4 * d; g.res = sc ? nullptr : b.bB; g.ldr = d;
             RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
+            if (sc) RUN(scatter_rows<T>(gB, b.need_rows, b.need_cnt, Mt, d, b.bA, st, true));
         }
     }
     // embeddings

@@ -34,7 +34,7 @@ struct NfrDiffArgs {
 inline int nfr_diff_parts(int cap) { return cdiv(cap, 8); }
 template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st);
 template <typename T>
-int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st);
+int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st, bool add = false);
 // rows the loss reads from the last layer: CLS of the B targets, CLS of the P pairs, then the masked rows
 int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
                     hipStream_t st);

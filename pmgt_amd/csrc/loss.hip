@@ -242,25 +242,29 @@ template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st) {
 template int nfr_diff<float>(const NfrDiffArgs&, hipStream_t);
 template int nfr_diff<bf16>(const NfrDiffArgs&, hipStream_t);
 
-// dst[rows[k], :] = src[k, :] for k < *count
+// dst[rows[k], :] = src[k, :] (or += with `add`; the rows are distinct) for k < *count
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ rows,
-                                                           const int* __restrict__ count, int d, T* __restrict__ dst) {
+                                                           const int* __restrict__ count, int d, T* __restrict__ dst, int add) {
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= *count) return;
     const int lane = threadIdx.x & 63;
     const int64_t r = rows[k];
-    for (int c4 = lane * 4; c4 < d; c4 += 256) store4<T>(dst + r * d + c4, load4<T>(src + (int64_t)k * d + c4));
+    for (int c4 = lane * 4; c4 < d; c4 += 256) {
+        f32x4 v = load4<T>(src + (int64_t)k * d + c4);
+        if (add) v += load4<T>(dst + r * d + c4);
+        store4<T>(dst + r * d + c4, v);
+    }
 }
 template <typename T>
-int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st) {
+int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st, bool add) {
     if (cap <= 0) return 0;
-    hipLaunchKernelGGL((scatter_rows_kernel<T>), dim3(cdiv(cap, 4)), dim3(256), 0, st, src, rows, count, d, dst);
+    hipLaunchKernelGGL((scatter_rows_kernel<T>), dim3(cdiv(cap, 4)), dim3(256), 0, st, src, rows, count, d, dst, add ? 1 : 0);
     PMGT_LAUNCH_OK();
     return 0;
 }
-template int scatter_rows<float>(const float*, const int64_t*, const int*, int, int, float*, hipStream_t);
-template int scatter_rows<bf16>(const bf16*, const int64_t*, const int*, int, int, bf16*, hipStream_t);
+template int scatter_rows<float>(const float*, const int64_t*, const int*, int, int, float*, hipStream_t, bool);
+template int scatter_rows<bf16>(const bf16*, const int64_t*, const int*, int, int, bf16*, hipStream_t, bool);
 
 __global__ void build_need_rows_kernel(int B, int P, int S, const int64_t* __restrict__ nfr_rows,
                                        const int* __restrict__ nfr_count, int64_t* __restrict__ rows, int* __restrict__ count) {

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the committed PMC summaries of one profile set.
+
+Usage: tools/make_traffic.py profiles/r01/<tag>    (reads <tag>_pmc_fetch_size.txt and <tag>_pmc_write_size.txt)
+
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (counters in KiB; gfx950 tallies 128-B read requests at 64 B,
+/opt/skills/guides/MI355X_MICROARCH.md).  bench.py quotes the entry of its dominant phase as `roofline.traffic`."""
+import json
+import os
+import re
+import sys
+
+PHASE_KERNELS = {           # bench.py phase name -> substring of the kernel that dominates it
+    "fwd.qkvc_attention": "qkvc_attn_fwd",
+    "bwd.attention": "attn_bwd_mfma_kernel",
+    "bwd.dgrad_qkvc": "gemm_nt_big_kernel",
+    "bwd.wgrad_qkvc": "gemm_tn_big_kernel",
+    "bwd.layernorm": "ln_bwd_kernel",
+}
+
+
+def parse(path):
+    rows = {}
+    for line in open(path).read().splitlines()[1:]:
+        m = re.match(r"^(.*?)\s+(\d+)\s+([0-9.]+)\s*$", line)
+        if m:
+            rows[m.group(1).strip()] = float(m.group(3))
+    return rows
+
+
+def main():
+    prefix = sys.argv[1]
+    fetch, write = parse(prefix + "_pmc_fetch_size.txt"), parse(prefix + "_pmc_write_size.txt")
+    phases = {}
+    for ph, sub in PHASE_KERNELS.items():
+        kf = next((k for k in fetch if sub in k), None)
+        kw = next((k for k in write if sub in k), None)
+        if kf is None or kw is None:
+            continue
+        mb = (2.0 * fetch[kf] + write[kw]) * 1024.0 / 1e6
+        phases[ph] = {"kernel": kf, "fetch_size_kib": round(fetch[kf], 1), "write_size_kib": round(write[kw], 1),
+                      "hbm_mb_per_launch": round(mb, 1)}
+    out = {
+        "workload": "c2", "batch": 1024,
+        "source": f"{prefix}_pmc_fetch_size.txt + {os.path.basename(prefix)}_pmc_write_size.txt "
+                  "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+        "correction": "HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE; counters in KiB",
+        "phases": phases,
+    }
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(phases, indent=1))
+
+
+if __name__ == "__main__":
+    main()
