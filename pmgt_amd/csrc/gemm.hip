@@ -1165,7 +1165,11 @@ int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
         return splits;
     }
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
-    int splits = cdiv(512, tiles);                       // ~2 workgroups per CU; slab traffic = splits * N1 * N2 * 4 B
+    // one workgroup per CU: the LDS-DMA ring hides the latency by itself, and the slab traffic (splits * N1 * N2 * 4 B
+    // written here, read again by slab_reduce) halves against two per CU -- measured 11.49 vs 11.57 ms/step (c2, B = 1024)
+    static int target = 0;
+    if (!target) { const char* ev = getenv("PMGT_TN_WGS"); target = ev ? std::max(64, atoi(ev)) : 256; }
+    int splits = cdiv(target, tiles);
     const int max_by_rows = std::max(1, M / (4 * bkm));  // at least 4 K-steps per split
     splits = std::max(1, std::min(splits, max_by_rows));
     if (splits > 8) splits = splits / 8 * 8;             // whole XCD groups (see the block mapping in the kernel)
