@@ -320,6 +320,10 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT g) {
 // ------------------------------------------------------------------------------------------------
 // BN = 256 / 8 waves: one workgroup per CU (128 KiB ring).  BN = 128 / 4 waves: 72 KiB ring (3 stages), TWO workgroups
 // per CU, so one's prologue / epilogue overlaps the other's main loop.
+#ifdef PMGT_TN_PROF
+// cycles of gemm_nt_big_kernel: [block slot][wave][0 vmcnt wait | 1 barrier | 2 DMA issue | 3 LDS reads + MFMA | 4 prologue | 5 epilogue]
+__device__ unsigned int g_nt_prof[2][8][6];
+#endif
 template <int BN, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
     typedef bf16 T;
@@ -383,16 +387,26 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         offb[j] = (uint32_t)(BM * ROWB + rb * ROWB + ((q ^ ((rb >> 2) & 3)) << 4));
     }
     const int nk = g.K / 32;
+#ifdef PMGT_TN_PROF
+    unsigned int pacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long plast = __builtin_readcyclecounter();
+#define NT_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc[k_] += (unsigned int)(n_ - plast); plast = n_; } while (0)
+#else
+#define NT_STAMP(k_) do { } while (0)
+#endif
 #pragma unroll
     for (int kt = 0; kt < NST - 1; ++kt)
         if (kt < nk) issue(kt);
+    NT_STAMP(4);
     for (int kt = 0; kt < nk; ++kt) {
         const int younger = min(NST - 2, nk - 1 - kt);
         if (younger == 2) { if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
         else if (younger == 1) { if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NT_STAMP(0);
         __builtin_amdgcn_s_barrier();
-        if (kt + NST - 1 < nk) issue(kt + NST - 1);
+        NT_STAMP(1);
+        NT_STAMP(2);
         const uint32_t sbase = lds_base + (uint32_t)((kt % NST) * STAGE);
         // the four B fragments go out first, then the eight A fragments; the MFMAs of A-fragment i start as soon as it
         // has landed (LDS returns in order), so most of the LDS latency hides behind the matrix pipe
@@ -430,8 +444,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i]), __builtin_bit_cast(bf16x8, t[8 + j]),
                                                                     acc[i][j], 0, 0, 0);
+            // the next stage's DMA goes out behind the MFMAs queued above (its ring slot was last read in step kt - 1, and
+            // every wave has passed this step's barrier)
+            if (i == 3 && kt + NST - 1 < nk) issue(kt + NST - 1);
         }
     }
+    NT_STAMP(3);
     __builtin_amdgcn_s_barrier();       // the ring becomes the staging buffer
 
     // ---- epilogue: four passes of 64 rows through an fp32 staging tile, then 32 lanes per row, 8 columns per lane
@@ -443,8 +461,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
     float* stage = (float*)smem;
     constexpr int LPR = BN / 8;                     // lanes per output row
     const int er = tid / LPR, ec = (tid % LPR) * 8;
+    // residual rows travel one pass ahead (the workgroup is alone on its CU: a load issued where it is consumed costs a
+    // full memory round trip per pass -- in-kernel timestamps put the epilogue at 30 % of the tile time)
+    bf16x8 rv[2][4];
+    auto load_res = [&](int pass, bf16x8 (&dst)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = min(m0 + pass * 64 + er + 16 * it, g.M - 1);
+            dst[it] = *(const bf16x8*)(R + (int64_t)m * g.ldr + n0 + ec);
+        }
+    };
+    if (R) load_res(0, rv[0]);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
+        if (R && pass < 3) load_res(pass + 1, rv[(pass + 1) & 1]);
         if (wm == (pass >> 1)) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
@@ -488,9 +518,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
                     for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
                 }
                 if (R) {
-                    const bf16x8 rv = *(const bf16x8*)(R + (int64_t)m * g.ldr + n);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[pass & 1][it][e];
                 }
                 bf16x8 o;
 #pragma unroll
@@ -500,6 +529,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         }
         __syncthreads();
     }
+#ifdef PMGT_TN_PROF
+    NT_STAMP(5);
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
+        for (int k_ = 0; k_ < 6; ++k_) g_nt_prof[blockIdx.x == 0 ? 0 : 1][wave][k_] = pacc[k_];
+#endif
 }
 
 static int g_nt_no_big = 0;
@@ -984,6 +1018,15 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
 // once per 128 columns of P through L2 (dW_qkvc at M = 393k: 3.2 GB of L2 -> CU traffic for 1 GB of HBM bytes, i.e.
 // 10.8 TB/s in 295 us: L2-bound); this tile halves both.  No row gather.
 // ------------------------------------------------------------------------------------------------
+// swizzle of the 32-row stages of gemm_tn_big_kernel: a transposed fragment read touches rows 8 q + (r >> 2) (+ 4), i.e.
+// row bits {0, 1} and {3, 4} -- all four must enter the XOR, or rows 16 apart land on the same banks (2-way conflict on
+// every ds_read_b64_tr_b16: the kernel was LDS-bound at 1536 of its 2150 cycles per step)
+__device__ __forceinline__ int tn_f5(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
+
+#ifdef PMGT_TN_PROF
+// cycles per k-step phase of gemm_tn_big_kernel: [block slot][wave][0 vmcnt wait | 1 barrier | 2 DMA issue | 3 LDS reads + MFMA]
+__device__ unsigned int g_tn_prof[2][8][4];
+#endif
 __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_rows) {
     constexpr int BKM = 32, ROWB = 512, STAGE = 2 * BKM * ROWB, NST = 4;     // 32 KiB per stage (P + Q)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1003,26 +1046,42 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = g.bias_slab != nullptr && n2_0 == 0 && wn == 0;
-    f32x4 accb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // column sums of P (the bias gradient) ride along as MFMAs against a ones fragment: wave (wm, wn) of the n2 = 0 tile
+    // sums the A fragments i = 2 wn, 2 wn + 1 of its row half (two extra MFMAs per step on every wave, not eight on one)
+    const bool do_bias = g.bias_slab != nullptr && n2_0 == 0;
+    f32x4 accb[2];
+    accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // this lane's part of a stage: rows 4 wave + 2 j + (lane >> 5), j = 0, 1; LDS chunk slot lane & 31 holds global
-    // chunk (lane & 31) ^ swz(row)
+    // chunk (lane & 31) ^ swz(row).  The source pointers advance by one stage per step; only the LAST stage of a split
+    // (rows beyond `mend`) and out-of-range column chunks read the zero page instead.
     const char* zero = (const char*)g.zeros;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    const char* sp0[2];
+    const char* sq0[2];
+    bool okp[2], okq[2];
+    int rowj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 4 * wave + 2 * j + (lane >> 5);
+        const int ch = (lane & 31) ^ (tn_f5(row) << 1);
+        const int cp = n1_0 + ch * 8, cq = n2_0 + ch * 8;
+        rowj[j] = row;
+        okp[j] = cp < g.N1;
+        okq[j] = cq < g.N2;
+        sp0[j] = (const char*)g.P + ((int64_t)(mbeg + row) * g.ldp + cp) * 2;
+        sq0[j] = (const char*)g.Q + ((int64_t)(mbeg + row) * g.ldq + cq) * 2;
+    }
+    const int64_t stp = (int64_t)BKM * g.ldp * 2, stq = (int64_t)BKM * g.ldq * 2;
     auto issue = [&](int kt) {
         const int mb = mbeg + kt * BKM;
         char* st = smem + (kt & (NST - 1)) * STAGE;
+        const bool full = mb + BKM <= mend;          // (uniform) every row of the stage exists
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int row = 4 * wave + 2 * j + (lane >> 5);
-            const int ch = (lane & 31) ^ (tn_f(row) << 1);
-            const int m = mb + row;
-            const int cp = n1_0 + ch * 8, cq = n2_0 + ch * 8;
-            const char* sp = (m < mend && cp < g.N1) ? (const char*)g.P + ((int64_t)m * g.ldp + cp) * 2 : zero;
-            const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + ((int64_t)m * g.ldq + cq) * 2 : zero;
+            const bool in = full || mb + rowj[j] < mend;
+            const char* sp = (in && okp[j]) ? sp0[j] + kt * stp : zero;
+            const char* sq = (in && okq[j]) ? sq0[j] + kt * stq : zero;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (4 * wave + 2 * j) * ROWB), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (4 * wave + 2 * j) * ROWB), 16, 0, 0);
         }
@@ -1035,7 +1094,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
     uint32_t offa[8], offb[4];
     {
         const int row = 8 * q + (r >> 2);
-        const int sw = tn_f(row) << 1;
+        const int sw = tn_f5(row) << 1;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ca = wm * 128 + i * 16 + 4 * (r & 3);
@@ -1047,13 +1106,23 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
             offb[j] = (uint32_t)(BKM * ROWB + row * ROWB + (((cb >> 3) ^ sw) << 4) + ((cb & 7) << 1));
         }
     }
+#ifdef PMGT_TN_PROF
+    unsigned int pacc[4] = {0, 0, 0, 0};
+    unsigned long long plast = __builtin_readcyclecounter();
+#define TN_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc[k_] += (unsigned int)(n_ - plast); plast = n_; } while (0)
+#else
+#define TN_STAMP(k_) do { } while (0)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        TN_STAMP(3);
         const int younger = min(2, nk - 1 - kt);
         if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TN_STAMP(0);
         __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3);
+        TN_STAMP(1);
+        TN_STAMP(2);
         const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
         // all 24 transposed fragment reads of the step go out back to back (B first), and the MFMAs of A-fragment i start
         // as soon as ITS two reads have landed (LDS returns in order: lgkmcnt counts down), so the tail of the LDS
@@ -1115,9 +1184,18 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
             const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * i][0], ta[2 * i][1], ta[2 * i + 1][0], ta[2 * i + 1][1]});
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
-            if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, accb[i], 0, 0, 0);
+            if (do_bias && (i >> 1) == wn) accb[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, accb[i & 1], 0, 0, 0);
+            // the next stage's DMA goes out while the matrix pipe works through the MFMAs queued above: its address
+            // arithmetic costs VALU issue slots only (ring slot (kt + 3) % 4 was last read in step kt - 1, and every wave
+            // has passed this step's barrier)
+            if (i == 3 && kt + 3 < nk) issue(kt + 3);
         }
     }
+#ifdef PMGT_TN_PROF
+    TN_STAMP(3);
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
+        for (int k_ = 0; k_ < 4; ++k_) g_tn_prof[blockIdx.x == 0 ? 0 : 1][wave][k_] = pacc[k_];
+#endif
     auto rowmap = [&](int n1) {
         if (g.perm_dh <= 0) return n1;
         const int w = n1 % g.perm_dh, hm = n1 / g.perm_dh;
@@ -1125,11 +1203,11 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
     };
     if (do_bias && r == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int n1 = n1_0 + wm * 128 + i * 16 + 4 * q + e;
-                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + rowmap(n1)] = accb[i][e];
+                const int n1 = n1_0 + wm * 128 + (2 * wn + ib) * 16 + 4 * q + e;
+                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + rowmap(n1)] = accb[ib][e];
             }
     }
     float* out = g.slab + (int64_t)split * g.N1 * g.N2;
@@ -1344,3 +1422,12 @@ template int colsum<float>(const float*, int64_t, int, int, float*, float*, bool
 template int colsum<bf16>(const bf16*, int64_t, int, int, float*, float*, bool, const int*, hipStream_t);
 
 }  // namespace pmgt
+
+#ifdef PMGT_TN_PROF
+extern "C" int pmgt_debug_nt_prof_read(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_nt_prof), sizeof(pmgt::g_nt_prof));
+}
+extern "C" int pmgt_debug_tn_prof_read(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_tn_prof), sizeof(pmgt::g_tn_prof));
+}
+#endif
