@@ -35,6 +35,14 @@ template <int KS> struct WsCfg {
 //   3 bias + dropout + residual | 4 = 3 + fused LayerNorm of the row
 enum { WS_PLAIN = 0, WS_GELU = 1, WS_GELU_GRAD = 2, WS_RES = 3, WS_RES_LN = 4 };
 
+#ifdef PMGT_WS_PROF
+// cycles per tile phase of gemm_ws_kernel: [block slot][wave][phase], phase 7 = tiles
+__device__ unsigned int g_ws_prof[2][8][8];
+#define WS_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc[k_] += (unsigned int)(n_ - plast); plast = n_; } while (0)
+#else
+#define WS_STAMP(k_) do { } while (0)
+#endif
+
 template <int KS, int MODE>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
     constexpr bool HAS_PF = MODE == WS_GELU_GRAD || MODE == WS_RES || MODE == WS_RES_LN;
@@ -106,8 +114,16 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
     // One tile: register set / LDS buffer index P is a compile-time constant (the loop below is unrolled by
     // two), so the two prefetch register sets never get copied into each other and the compiler can leave the
     // younger tile's loads in flight (counted vmcnt) while this tile is consumed.
+#ifdef PMGT_WS_PROF
+    unsigned int pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long plast = __builtin_readcyclecounter();
+#endif
     auto tile_step = [&](auto Pc, int mt) {
         constexpr int P = decltype(Pc)::value;
+#ifdef PMGT_WS_PROF
+        ++pacc[7];
+#endif
+        WS_STAMP(0);
         // epilogue operand (residual, or the saved pre-activation for GELU') of this tile: issued first so it
         // is OLDER than the A prefetch below; the epilogue can then wait for it with a counted vmcnt and leave
         // the prefetch in flight.
@@ -121,7 +137,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
         }
         sstore(P, P);
         if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
+        WS_STAMP(1);
         __syncthreads();
+        WS_STAMP(2);
         f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
@@ -140,6 +158,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
                 acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], wf[1][ks], acc[i][1], 0, 0, 0);
             }
         }
+        WS_STAMP(3);
         // ---- stage the 64 x 256 fp32 tile (row = 16 i + 4 q + e, col = 32 wave + 16 j + r)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -148,7 +167,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     stage[(16 * i + 4 * q + e) * C::ES + 32 * wave + 16 * j + r] = acc[i][j][e];
+        WS_STAMP(4);
         __syncthreads();
+        WS_STAMP(5);
         // ---- row-contiguous epilogue: 16 rows per pass, 4 passes
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -235,6 +256,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
         tile_step(std::integral_constant<int, 1>{}, mt);
         mt += gx;
     }
+#ifdef PMGT_WS_PROF
+    WS_STAMP(6);
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
+        for (int k_ = 0; k_ < 8; ++k_) g_ws_prof[blockIdx.x == 0 ? 0 : 1][wave][k_] = pacc[k_];
+#endif
 }
 
 static int ws_mode(const GemmWS& g) {
@@ -290,3 +316,9 @@ int gemm_ws(const GemmWS& g, hipStream_t st) {
 }
 
 }  // namespace pmgt
+
+#ifdef PMGT_WS_PROF
+extern "C" int pmgt_debug_ws_prof_read(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_ws_prof), sizeof(pmgt::g_ws_prof));
+}
+#endif
