@@ -79,6 +79,10 @@ def hip():
     global _hip
     if _hip is not None:
         return _hip
+    # PyTorch-ROCm first: it brings its own libamdhip64 / libhsa-runtime64.  If this library is loaded before torch, the
+    # loader binds the system ROCm runtime instead and torch's later import mixes the two (device init then fails with
+    # "no usable HIP device"); loaded after torch, the same SONAME resolves to the copy torch already mapped.
+    import torch  # noqa: F401
     L = _load(_build.hip_lib_path(), "HIP engine library")
     vp, i, i64, f, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
     L.pmgt_last_error.restype = C.c_char_p
