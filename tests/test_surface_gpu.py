@@ -2,6 +2,7 @@
 PMGTForPreTrainingOutput / get_optimizer + DenseSparseAdamW / trainer step, written the way the
 reference's own callers use them (pmgt/pmgt/trainer.py:118-160, pmgt/base_trainer.py:35-68), checked
 against the golden vectors."""
+import os
 import types
 
 import numpy as np
@@ -222,3 +223,16 @@ def test_lightning_style_checkpoint_roundtrip(tmp_path):
     pio.load_checkpoint(c, a.state_dict())
     with torch.no_grad():
         assert torch.equal(c(*case["batch"]).prediction_logits, oa.prediction_logits)
+
+
+@pytest.mark.gpu
+def test_graft_entry_build_then_smoke_in_one_process():
+    """build() loads the HIP library before smoke() touches torch.cuda: the library must bind PyTorch-ROCm's HIP runtime,
+    not the system one (a process that mapped the system runtime first could not initialise the device)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "smoke ok" in r.stdout
