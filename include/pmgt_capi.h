@@ -23,6 +23,11 @@ extern "C" {
 
 #define PMGT_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 #define PMGT_DTYPE_BF16 1 /* perf mode: bf16 activations/weight copies, fp32 accumulate + master weights */
+/* fp8 mode (BASELINE.json config 5): the bf16 engine with OCP e4m3 where the north star names it -- frozen feature tables
+ * stored as e4m3 (one scale per table), feature-projection and Q|K|V|C projections on v_mfma_f32_16x16x32_fp8_fp8 with
+ * weights quantised per output channel and activations per row; every other tensor, the attention, the backward GEMMs and
+ * the optimizer as in PMGT_DTYPE_BF16. */
+#define PMGT_DTYPE_FP8 2
 
 /* Mirrors PMGTConfig (pmgt/pmgt/configuration_pmgt.py:11-41). */
 typedef struct pmgt_config {
@@ -65,10 +70,13 @@ int64_t pmgt_workspace_bytes(const pmgt_engine* e, int n_seq, int seq_len, int n
 typedef struct pmgt_tensors {
     float* params;       /* [pmgt_param_count] fp32 master weights */
     float* grads;        /* same shape; written (or accumulated) by pmgt_pretrain_step */
-    const void* table_v; /* [n_nodes + 2, feat_size_v] frozen features in the engine dtype (models.py:40-54) */
+    const void* table_v; /* [n_nodes + 2, feat_size_v] frozen features in the engine dtype (models.py:40-54); e4m3 in fp8 mode */
     const void* table_t; /* [n_nodes + 2, feat_size_t] */
     int64_t n_nodes;
     uint64_t* rng_state; /* device [2]: {seed, step}; drives dropout + NFR masking */
+    /* PMGT_DTYPE_FP8 only: the tables are e4m3 bytes, feature value = byte value * table_scale_{v,t} (pmgt_quantize_e4m3) */
+    float table_scale_v;
+    float table_scale_t;
 } pmgt_tensors;
 
 /* One collated batch, exactly what pmgt_collate_fn returns (pmgt/pmgt/datasets.py:186-208). */
@@ -157,7 +165,26 @@ int pmgt_profile_end(pmgt_engine* e, char* buf, int cap);
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
 int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);
 
+/* fp8 mode plumbing: dst[i] = e4m3_rne(clamp(src[i] * inv_scale, +-448)) and back (n % 8 == 0).  The frozen tables are
+ * quantised once by the caller with inv_scale = 448 / max|table|; table_scale = max|table| / 448. */
+int pmgt_quantize_e4m3(const float* src, void* dst, int64_t n, float inv_scale, void* stream);
+int pmgt_dequantize_e4m3(const void* src, float* dst, int64_t n, float scale, void* stream);
+
 /* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
+/* per-row absmax e4m3 quantisation (weights per output channel, activations per token): scale[r] = max|row| / 448 */
+int pmgt_op_quant_rows_e4m3(int src_dtype, const void* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd,
+                            float* scale, void* stream);
+/* C (bf16) = (A8 B8^T) * a_scale(row) * b_row_scale[n] + bias on the fp8 MFMA; a_rows = optional row gather on A */
+int pmgt_op_gemm_nt_f8(const void* A, int64_t lda, const int64_t* a_rows, const float* a_row_scale, float a_scale,
+                       const void* B, int64_t ldb, const float* b_row_scale, void* C, int64_t ldc, int M, int N, int K,
+                       const float* bias, const int* m_dev, void* stream);
+/* weight gradient with an e4m3 Q operand (feature-table rows): out = P^T (Q8 * q_scale), P bf16 */
+int pmgt_op_gemm_tn_f8(const void* P, int64_t ldp, const void* Q8, int64_t ldq, float q_scale, const int64_t* q_rows, int M,
+                       int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream);
+/* fused projection + attention forward with the projection on the fp8 MFMA (d = 256): w8 [4d, d] e4m3, wscale [4d] */
+int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* w8, const float* wscale, const float* bias, const float* mask,
+                                  void* qkvc, void* ctx, int n_seq, int S, int H, int dh, float beta, float drop_p,
+                                  uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream);
 int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
                     int64_t ldc, int M, int N, int K, const float* bias, int epilogue, void* aux, int64_t ldaux,
                     const void* residual, int64_t ldr, float drop_p, uint32_t drop_site, const uint64_t* rng,

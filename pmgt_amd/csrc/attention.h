@@ -45,6 +45,11 @@ struct QkvcAttn {
     DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
     int cls_only_seqs = 0;                        // see AttnArgs
     bool hm = false;                              // write Q|K|V|C head-major (see AttnArgs)
+    // fp8 mode (hidden 256 only): the projection runs on v_mfma_f32_16x16x32_fp8_fp8 -- W8 = e4m3 copy of W quantised per
+    // output channel (value = byte * wscale[n]), x quantised per row inside the kernel (fp8.h contract); the outputs and the
+    // attention stay bf16
+    const void* W8 = nullptr;                     // [4d, d] e4m3, row stride ldw bytes
+    const float* wscale = nullptr;                // [4d]
 };
 bool qkvc_attn_supported(const QkvcAttn& a);
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st);

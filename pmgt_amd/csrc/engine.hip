@@ -14,6 +14,7 @@
 
 #include "../../include/pmgt_capi.h"
 #include "attention.h"
+#include "fp8.h"
 #include "gemm.h"
 #include "loss.h"
 #include "optim.h"
@@ -62,6 +63,7 @@ struct LayerOff {
     // mirror offsets (elements of T); -1 = not mirrored (fp32 reads the master copy)
     int64_t mWqkvc, mWqkvcT, mWo, mWoT, mW1, mW1T, mW2, mW2T;
     int64_t mWqkvcT_hm = -1;     // transposed copy with the 4d index in head-major order (dgrad of a head-major Q|K|V|C)
+    int64_t m8Wqkvc = -1, s8Wqkvc = -1;   // fp8 mode: byte offset of the e4m3 copy / offset of its per-channel scales
 };
 
 }  // namespace pmgt
@@ -77,6 +79,13 @@ struct pmgt_engine {
     std::vector<ParamEntry> entries;
     // mirror
     int64_t mWv, mWt, mWn, mWnT, mirror_elems;
+    // fp8 mode (PMGT_DTYPE_FP8): bf16 engine + e4m3 copies (per-output-channel scales) of the feature-projection and
+    // Q|K|V|C weights, rebuilt every forward by one launch; the frozen tables arrive as e4m3 from the caller
+    bool fp8 = false;
+    int64_t m8Wv = -1, m8Wt = -1, s8Wv = -1, s8Wt = -1, mirror8_bytes = 0, mscale_elems = 0;
+    std::vector<QuantDesc> desc8;
+    QuantDesc* desc8_dev = nullptr;
+    int desc8_rows = 0;
     std::vector<MirrorDesc> desc;
     MirrorDesc* desc_dev = nullptr;
     int mirror_tiles = 0;
@@ -159,7 +168,7 @@ static void build_layout(pmgt_engine* e) {
     e->total = cur;
 
     // ---- mirror layout
-    const bool half = e->cfg.dtype == PMGT_DTYPE_BF16;
+    const bool half = e->cfg.dtype != PMGT_DTYPE_F32;
     int64_t mc = 0;
     int tiles = 0;
     auto add_m = [&](int64_t src, int rows, int cols, bool copy, bool transpose, int64_t* dst, int64_t* dst_t, int64_t* dst_t_hm = nullptr) {
@@ -195,6 +204,23 @@ static void build_layout(pmgt_engine* e) {
     add_m(e->Wn, Fv + Ft, d, half, true, &e->mWn, &e->mWnT);
     e->mirror_elems = mc;
     e->mirror_tiles = tiles;
+    if (e->fp8) {
+        int64_t bc = 0, sc = 0;
+        int rows = 0;
+        auto add_q = [&](int64_t src, int r, int c, int64_t* dst, int64_t* scale) {
+            QuantDesc q;
+            q.src = src; q.dst = bc; q.scale = sc; q.rows = r; q.cols = c; q.row_start = rows;
+            *dst = bc; *scale = sc;
+            bc += align_up((int64_t)r * c, 16);
+            sc += align_up(r, 4);
+            rows += r;
+            e->desc8.push_back(q);
+        };
+        add_q(e->Wv, d, Fv, &e->m8Wv, &e->s8Wv);
+        add_q(e->Wt, d, Ft, &e->m8Wt, &e->s8Wt);
+        for (int l = 0; l < e->L; ++l) add_q(e->layers[l].Wqkvc, 4 * d, d, &e->layers[l].m8Wqkvc, &e->layers[l].s8Wqkvc);
+        e->mirror8_bytes = bc; e->mscale_elems = sc; e->desc8_rows = rows;
+    }
 }
 
 // ---- workspace carving ---------------------------------------------------------------------------
@@ -220,6 +246,10 @@ template <typename T> struct Bufs {
     int64_t* ids;      // [Tseq, S] concatenated node ids
     float* mask;       // [Tseq, S]
     T* mirror;
+    char* mirror8 = nullptr;   // fp8 mode: e4m3 weight copies
+    float* mscale = nullptr;   //           their per-channel scales
+    char* x8 = nullptr;        //           per-row quantised layer input of the unfused Q|K|V|C projection [M, d]
+    float* xscale = nullptr;   //           [M]
     T *E, *emb_pre, *h0;
     hipEvent_t sort_done = nullptr;   // set when the token sort of this step already runs on the side stream
     bool qkvc_hm = false;   // Q|K|V|C (and its gradient) are stored head-major (fused forward + one-wave MFMA backward)
@@ -267,7 +297,7 @@ static int64_t sort_temp_bytes(int M) {      // rocPRIM's size query, cached per
 }
 
 static int64_t tn_slab_elems(int dtype, int M, int N1, int N2) {
-    const int bkm = dtype == PMGT_DTYPE_BF16 ? 64 : 32;
+    const int bkm = dtype != PMGT_DTYPE_F32 ? 64 : 32;
     return (int64_t)gemm_tn_pick_splits(M, N1, N2, bkm) * N1 * N2;
 }
 
@@ -279,6 +309,12 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     b.ids = c.get<int64_t>(M);
     b.mask = c.get<float>(M);
     b.mirror = c.get<T>(e->mirror_elems);
+    if (e->fp8) {
+        b.mirror8 = c.get<char>(e->mirror8_bytes);
+        b.mscale = c.get<float>(e->mscale_elems);
+        b.x8 = c.get<char>(M * d);
+        b.xscale = c.get<float>(M);
+    }
     b.E = c.get<T>(M * 2 * d);
     b.a = c.get<float>(M * 2);
     b.emb_pre = c.get<T>(M * d);
@@ -430,6 +466,14 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
     return 0;
 }
 
+// weight copies of a forward pass: bf16 W / W^T mirror (+ the e4m3 copies of the fp8 mode)
+template <typename T>
+static int build_mirrors(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, hipStream_t st) {
+    RUNP("mirror", build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    if (e->fp8) RUNP("mirror", quant_params_e4m3(t->params, e->desc8_dev, (int)e->desc8.size(), e->desc8_rows, b.mirror8, b.mscale, st));
+    return 0;
+}
+
 // whether encoder_forward takes the fused projection + attention kernel (and, in training, stores Q|K|V|C head-major):
 // a pure function of the configuration, the shape and the debug switches, so a separate backward call can re-derive it
 template <typename T>
@@ -460,7 +504,19 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     const int64_t n_rows = t->n_nodes + 2;
     const bool table_mode = use_table_projection(t, M, ids != nullptr);
     b.e_by_id = table_mode;
-    for (int mod = 0; mod < 2; ++mod) {
+    PMGT_CHECK(!e->fp8 || ids != nullptr, -3, "fp8 mode gathers e4m3 feature rows by node id: pre-gathered feature tensors are not supported");
+    for (int mod = 0; mod < 2 && e->fp8; ++mod) {      // e4m3 table rows x e4m3 weights on the fp8 MFMA
+        GemmF8 g;
+        const int F = mod == 0 ? e->Fv : e->Ft;
+        g.A = mod == 0 ? t->table_v : t->table_t; g.lda = F; g.a_rows = table_mode ? nullptr : ids;
+        g.a_scale = mod == 0 ? t->table_scale_v : t->table_scale_t;
+        g.B = b.mirror8 + (mod == 0 ? e->m8Wv : e->m8Wt); g.ldb = F; g.b_row_scale = b.mscale + (mod == 0 ? e->s8Wv : e->s8Wt);
+        g.C = b.E + mod * d; g.ldc = 2 * d;
+        g.M = table_mode ? (int)n_rows : M; g.N = d; g.K = F;
+        g.bias = P + e->bvt + mod * d;
+        RUNP("fwd.gemm_featproj", gemm_nt_f8(g, st));
+    }
+    for (int mod = 0; mod < 2 && !e->fp8; ++mod) {
         GemmNT g;
         const int F = mod == 0 ? e->Fv : e->Ft;
         if (ids) { g.A = mod == 0 ? t->table_v : t->table_t; g.a_rows = table_mode ? nullptr : ids; }
@@ -506,13 +562,20 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             f.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             f.cls_only_seqs = (shortcut && l == L - 1) ? n_cls_only : 0;
             f.hm = train && !g_no_hm;        // the backward that reads it understands the layout; inference keeps q | k | v | c
+            if (e->fp8) { f.W8 = b.mirror8 + o.m8Wqkvc; f.wscale = b.mscale + o.s8Wqkvc; }
             if (fused_qa_applies<T>(e, Tseq, S, attn_probs != nullptr) && qkvc_attn_supported(f)) {
                 RUNP("fwd.qkvc_attention", qkvc_attn_fwd(f, st));
                 fused = true;
                 b.qkvc_hm = f.hm;
             }
         }
-        if (!fused) {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
+        if (!fused && e->fp8) {   // per-row e4m3 of the layer input, then the fp8 GEMM
+            RUNP("fwd.quant_x", quant_rows_e4m3<T>(hin, d, M, d, b.x8, d, b.xscale, st));
+            GemmF8 g;
+            g.A = b.x8; g.lda = d; g.a_row_scale = b.xscale; g.B = b.mirror8 + o.m8Wqkvc; g.ldb = d; g.b_row_scale = b.mscale + o.s8Wqkvc;
+            g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
+            RUNP("fwd.gemm_qkvc", gemm_nt_f8(g, st));
+        } else if (!fused) {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
             GemmWS g;
             g.A = hin; g.lda = d; g.B = wsel<T>(e, t, b, o.Wqkvc, o.mWqkvc); g.ldb = d;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
@@ -606,7 +669,7 @@ struct SideReduce {
 template <typename T>
 static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
                  int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t main,
-                 float* bias_dst = nullptr, int perm_d = 0, int perm_dh = 0) {
+                 float* bias_dst = nullptr, int perm_d = 0, int perm_dh = 0, float q_f8_scale = 0.f) {
     SideReduce sr(e, main);
     const int slot = b.wg_idx++ & 1;
     float* slab = b.slab + (int64_t)slot * b.slab_elems;
@@ -616,6 +679,7 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
     GemmTN g;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
     g.slab = slab; g.m_dev = m_dev; g.zeros = e->zeros; g.perm_d = perm_d; g.perm_dh = perm_dh;
+    g.q_f8 = q_f8_scale > 0.f; g.q_scale = q_f8_scale;      // fp8 mode: Q = e4m3 feature table
     g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
     g.bias_slab = bias_dst ? bpart : nullptr;          // [splits <= 512][N1]
     RUNP(name, gemm_tn<T>(g, st));
@@ -740,6 +804,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         m.stats = b.emb_stats; m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
         m.part = b.part;
         const bool by_node = b.e_by_id && !g_no_segsum;
+        PMGT_CHECK(!e->fp8 || (feat_v == nullptr && feat_t == nullptr), -3, "fp8 mode: pre-gathered feature tensors are not supported");
+        const float sv8 = e->fp8 ? t->table_scale_v : 0.f, st8 = e->fp8 ? t->table_scale_t : 0.f;     // > 0: the tables are e4m3
         if (by_node) {
             // Table mode: per token only the LayerNorm backward (dF); the segment sums of dF per node id feed the
             // per-node backward of the modality mix, whose dE [N+2, 2d] is the P operand of the weight-gradient GEMM.
@@ -755,8 +821,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             m.phase = 1; m.M = n_rows; m.E = b.E; m.e_rows = nullptr; m.dF = b.bC; m.dF_f32 = true; m.dE = b.bD;
             RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
             RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(n_rows), 6 * d + 4, G + e->ln_g, true, st));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD, 2 * d, (const T*)t->table_v, e->Fv, nullptr, n_rows, n_rows, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD + d, 2 * d, (const T*)t->table_t, e->Ft, nullptr, n_rows, n_rows, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD, 2 * d, (const T*)t->table_v, e->Fv, nullptr, n_rows, n_rows, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt, 0, 0, sv8));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD + d, 2 * d, (const T*)t->table_t, e->Ft, nullptr, n_rows, n_rows, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d, 0, 0, st8));
         } else {
             m.M = M; m.E = b.E; m.e_rows = b.e_by_id ? b.ids : nullptr; m.pre = b.emb_pre;
             m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB;
@@ -764,8 +830,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
             RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
             RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt, 0, 0, sv8));
+            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d, 0, 0, st8));
         }
     }
     RUN(join_side_all<T>(e, b, st));       // the caller's stream sees every gradient
@@ -814,7 +880,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         b.sort_done = e->next_sync();
         PMGT_HIP(hipEventRecord(b.sort_done, e->side));
     }
-    RUNP("mirror", build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUN(build_mirrors<T>(e, t, b, st));
     // Training fast path: the caller does not ask for last_hidden_state, so the last layer's attn-out/FFN blocks
     // only run on the rows the loss reads (compact order: B target CLS, P pair CLS, masked rows).
     const bool sc = train && !g_no_shortcut && o->last_hidden == nullptr;
@@ -845,6 +911,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         NfrDiffArgs a;
         a.pred = b.pred; a.tids = b.nfr_tids; a.count = b.nfr_count; a.cap = cap; a.Fv = e->Fv; a.Ft = e->Ft;
         a.table_v = t->table_v; a.table_t = t->table_t; a.sse_part = b.sse_part;
+        a.tables_f8 = e->fp8; a.scale_v = t->table_scale_v; a.scale_t = t->table_scale_t;
         RUNP("loss.nfr_diff", nfr_diff<T>(a, st));
     }
     RUN(loss_finish(b.gsr_part, B, train ? b.sse_part : nullptr, nfr_diff_parts(cap), b.nfr_count, e->Fv, e->Ft, train,
@@ -878,7 +945,7 @@ static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, con
     if (!m) {   // attention_mask=None -> ones (pmgt/pmgt/modeling_pmgt.py:113-114)
         m = nullptr;
     }
-    RUN(build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUN(build_mirrors<T>(e, t, b, st));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, ids, (const T*)fv, (const T*)ft, m, false, (T*)hidden_states, attn_probs, st));
     if (last_hidden)
         PMGT_HIP(hipMemcpyAsync(last_hidden, b.layer[e->L - 1].hout, (size_t)Tseq * S * e->d * sizeof(T),
@@ -905,7 +972,7 @@ static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* id
     PMGT_HIP(hipMemcpyAsync(b.rng_snap, t->rng_state, 16, hipMemcpyDeviceToDevice, st));
     if (ids) PMGT_HIP(hipMemcpyAsync(b.ids, ids, M * 8, hipMemcpyDeviceToDevice, st));
     PMGT_HIP(hipMemcpyAsync(b.mask, mask, M * 4, hipMemcpyDeviceToDevice, st));
-    RUN(build_mirror<T>(t->params, b.mirror, e->desc_dev, (int)e->desc.size(), e->mirror_tiles, st));
+    RUN(build_mirrors<T>(e, t, b, st));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, ids ? b.ids : nullptr, (const T*)fv, (const T*)ft, b.mask, train, (T*)nullptr,
                            (float*)nullptr, st));
     if (last_hidden)
@@ -941,7 +1008,7 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv
 extern "C" {
 
 const char* pmgt_last_error(void) { return g_err; }
-int pmgt_abi_version(void) { return 1; }
+int pmgt_abi_version(void) { return 2; }
 
 pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     if (!cfg) { set_error("config is NULL"); return nullptr; }
@@ -950,15 +1017,16 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
                   cfg->num_attention_heads);   // pmgt/pmgt/modeling_pmgt.py:381-387
         return nullptr;
     }
-    const int ali = cfg->dtype == PMGT_DTYPE_BF16 ? 8 : 4;
+    const int ali = cfg->dtype == PMGT_DTYPE_FP8 ? 16 : (cfg->dtype == PMGT_DTYPE_BF16 ? 8 : 4);
     if (cfg->hidden_size % ali || cfg->intermediate_size % ali || cfg->feat_size_v % ali || cfg->feat_size_t % ali ||
         cfg->hidden_size > 1024) {
         set_error("HIP path needs hidden/intermediate/feature sizes that are multiples of %d and hidden_size <= 1024", ali);
         return nullptr;
     }
-    if (cfg->dtype != PMGT_DTYPE_F32 && cfg->dtype != PMGT_DTYPE_BF16) { set_error("unknown dtype %d", cfg->dtype); return nullptr; }
+    if (cfg->dtype != PMGT_DTYPE_F32 && cfg->dtype != PMGT_DTYPE_BF16 && cfg->dtype != PMGT_DTYPE_FP8) { set_error("unknown dtype %d", cfg->dtype); return nullptr; }
     pmgt_engine* e = new pmgt_engine();
     e->cfg = *cfg;
+    e->fp8 = cfg->dtype == PMGT_DTYPE_FP8;
     e->d = cfg->hidden_size; e->L = cfg->num_hidden_layers; e->H = cfg->num_attention_heads; e->I = cfg->intermediate_size;
     e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
     build_layout(e);
@@ -976,12 +1044,21 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
             return nullptr;
         }
     }
+    if (!e->desc8.empty()) {
+        if (hipMalloc((void**)&e->desc8_dev, e->desc8.size() * sizeof(QuantDesc)) != hipSuccess ||
+            hipMemcpy(e->desc8_dev, e->desc8.data(), e->desc8.size() * sizeof(QuantDesc), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("pmgt_engine_create: no usable HIP device (hipMalloc/hipMemcpy failed)");
+            delete e;
+            return nullptr;
+        }
+    }
     return e;
 }
 
 void pmgt_engine_destroy(pmgt_engine* e) {
     if (!e) return;
     if (e->desc_dev) (void)hipFree(e->desc_dev);
+    if (e->desc8_dev) (void)hipFree(e->desc8_dev);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     for (auto ev : e->sync_ev) (void)hipEventDestroy(ev);
     delete e;
@@ -1004,7 +1081,7 @@ int pmgt_param_entry(const pmgt_engine* e, int index, char* name, int name_cap, 
 
 int64_t pmgt_workspace_bytes(const pmgt_engine* e, int n_seq, int seq_len, int n_targets, int training) {
     Carver c(nullptr);
-    if (e->cfg.dtype == PMGT_DTYPE_BF16) { Bufs<bf16> b; carve<bf16>(e, c, b, n_seq, seq_len, std::max(n_targets, 1), training != 0); }
+    if (e->cfg.dtype != PMGT_DTYPE_F32) { Bufs<bf16> b; carve<bf16>(e, c, b, n_seq, seq_len, std::max(n_targets, 1), training != 0); }
     else { Bufs<float> b; carve<float>(e, c, b, n_seq, seq_len, std::max(n_targets, 1), training != 0); }
     return c.cur;
 }
@@ -1013,8 +1090,9 @@ int pmgt_pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* 
                        int64_t workspace_bytes, int flags, void* stream) {
     PMGT_CHECK(e && t && b && o && workspace, -2, "pmgt_pretrain_step: NULL argument");
     PMGT_CHECK(t->params && t->table_v && t->table_t && t->rng_state && o->loss && o->logits, -2, "pmgt_pretrain_step: NULL tensor");
+    PMGT_CHECK(!e->fp8 || (t->table_scale_v > 0.f && t->table_scale_t > 0.f), -2, "pmgt_pretrain_step: fp8 mode needs the table scales");
     PMGT_CHECK(!(flags & PMGT_FLAG_BACKWARD) || t->grads, -2, "pmgt_pretrain_step: grads buffer is NULL");
-    if (e->cfg.dtype == PMGT_DTYPE_BF16) return pretrain_step<bf16>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    if (e->cfg.dtype != PMGT_DTYPE_F32) return pretrain_step<bf16>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
     return pretrain_step<float>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 
@@ -1022,7 +1100,7 @@ int pmgt_encode_ids(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, c
                     void* last_hidden, void* hidden_states, float* attn_probs, void* workspace, int64_t workspace_bytes,
                     void* stream) {
     PMGT_CHECK(e && t && ids && workspace && t->params && t->table_v && t->table_t, -2, "pmgt_encode_ids: NULL argument");
-    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+    if (e->cfg.dtype != PMGT_DTYPE_F32)
         return encode<bf16>(e, t, ids, nullptr, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
     return encode<float>(e, t, ids, nullptr, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1031,7 +1109,7 @@ int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v,
                       int n_seq, int seq_len, void* last_hidden, void* hidden_states, float* attn_probs, void* workspace,
                       int64_t workspace_bytes, void* stream) {
     PMGT_CHECK(e && t && feat_v && feat_t && workspace && t->params, -2, "pmgt_encode_feats: NULL argument");
-    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+    if (e->cfg.dtype != PMGT_DTYPE_F32)
         return encode<bf16>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
     return encode<float>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1041,7 +1119,7 @@ int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids,
                       int flags, void* stream) {
     PMGT_CHECK(e && t && workspace && t->params && t->rng_state, -2, "pmgt_encode_train: NULL argument");
     PMGT_CHECK(!ids || (t->table_v && t->table_t), -2, "pmgt_encode_train: feature tables are not set");
-    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+    if (e->cfg.dtype != PMGT_DTYPE_F32)
         return encode_train<bf16>(e, t, ids, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
     return encode_train<float>(e, t, ids, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
@@ -1050,7 +1128,7 @@ int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* feat
                          int n_seq, int seq_len, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     PMGT_CHECK(e && t && workspace && t->params && t->grads, -2, "pmgt_encode_backward: NULL argument");
     PMGT_CHECK(feat_v || (t->table_v && t->table_t), -2, "pmgt_encode_backward: feature tables are not set");
-    if (e->cfg.dtype == PMGT_DTYPE_BF16)
+    if (e->cfg.dtype != PMGT_DTYPE_F32)
         return encode_backward<bf16>(e, t, feat_v, feat_t, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
     return encode_backward<float>(e, t, feat_v, feat_t, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
@@ -1100,11 +1178,11 @@ int pmgt_profile_end(pmgt_engine* e, char* buf, int cap) {
 }
 
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {
-    if (dtype == PMGT_DTYPE_BF16) return cast_f32<bf16>(src, (bf16*)dst, n, (hipStream_t)stream);
+    if (dtype != PMGT_DTYPE_F32) return cast_f32<bf16>(src, (bf16*)dst, n, (hipStream_t)stream);
     return cast_f32<float>(src, (float*)dst, n, (hipStream_t)stream);
 }
 int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream) {
-    if (dtype == PMGT_DTYPE_BF16) return cast_to_f32<bf16>((const bf16*)src, dst, n, (hipStream_t)stream);
+    if (dtype != PMGT_DTYPE_F32) return cast_to_f32<bf16>((const bf16*)src, dst, n, (hipStream_t)stream);
     return cast_to_f32<float>((const float*)src, dst, n, (hipStream_t)stream);
 }
 
@@ -1223,6 +1301,50 @@ int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const 
     a.dctx = dctx; a.dqkvc = dqkvc;
     if (dtype == PMGT_DTYPE_BF16) return attn_bwd<bf16>(a, (hipStream_t)stream);
     return attn_bwd<float>(a, (hipStream_t)stream);
+}
+
+// ---- fp8 mode ---------------------------------------------------------------------------------------
+int pmgt_quantize_e4m3(const float* src, void* dst, int64_t n, float inv_scale, void* stream) {
+    return quant_tensor_e4m3(src, dst, n, inv_scale, (hipStream_t)stream);
+}
+int pmgt_dequantize_e4m3(const void* src, float* dst, int64_t n, float scale, void* stream) {
+    return dequant_tensor_e4m3(src, dst, n, scale, (hipStream_t)stream);
+}
+int pmgt_op_quant_rows_e4m3(int src_dtype, const void* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd, float* scale,
+                            void* stream) {
+    if (src_dtype == PMGT_DTYPE_F32) return quant_rows_e4m3<float>((const float*)src, lds, rows, cols, dst, ldd, scale, (hipStream_t)stream);
+    return quant_rows_e4m3<bf16>((const bf16*)src, lds, rows, cols, dst, ldd, scale, (hipStream_t)stream);
+}
+int pmgt_op_gemm_nt_f8(const void* A, int64_t lda, const int64_t* a_rows, const float* a_row_scale, float a_scale, const void* B,
+                       int64_t ldb, const float* b_row_scale, void* C, int64_t ldc, int M, int N, int K, const float* bias,
+                       const int* m_dev, void* stream) {
+    GemmF8 g;
+    g.A = A; g.lda = lda; g.a_rows = a_rows; g.a_row_scale = a_row_scale; g.a_scale = a_scale; g.B = B; g.ldb = ldb;
+    g.b_row_scale = b_row_scale; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.m_dev = m_dev;
+    return gemm_nt_f8(g, (hipStream_t)stream);
+}
+int pmgt_op_gemm_tn_f8(const void* P, int64_t ldp, const void* Q8, int64_t ldq, float q_scale, const int64_t* q_rows, int M, int N1,
+                       int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream) {
+    GemmTN g;
+    g.P = P; g.ldp = ldp; g.Q = Q8; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2; g.slab = slab; g.m_dev = m_dev;
+    g.q_f8 = true; g.q_scale = q_scale;
+    g.splits = gemm_tn_pick_splits(M, N1, N2, 64);
+    int rc = gemm_tn<bf16>(g, (hipStream_t)stream);
+    if (rc) return rc;
+    return slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, accumulate != 0, (hipStream_t)stream);
+}
+int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* w8, const float* wscale, const float* bias, const float* mask, void* qkvc,
+                                  void* ctx, int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                                  const uint64_t* rng, void* stream) {
+    QkvcAttn f;
+    const int d = H * dh;
+    f.X = x; f.ldx = d; f.W8 = w8; f.wscale = wscale; f.ldw = d; f.bias = bias; f.qkvc = qkvc; f.ldq = 4 * d; f.ctx = ctx; f.ldc = d;
+    f.mask = mask; f.Tseq = n_seq; f.S = S; f.H = H; f.dh = dh; f.beta = beta;
+    f.drop1 = DropCfg{rng, drop_p, site1};
+    f.drop2 = DropCfg{rng, drop_p, site2};
+    PMGT_CHECK(x && w8 && wscale && qkvc && ctx, -2, "pmgt_op_qkvc_attention_fwd_f8: NULL argument");
+    PMGT_CHECK(qkvc_attn_supported(f), -3, "pmgt_op_qkvc_attention_fwd_f8: unsupported shape (needs S = 32, dh = 32, d = 256)");
+    return qkvc_attn_fwd(f, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,260 @@
+// fp8 (OCP e4m3) mode: quantisation kernels and the fp8 MFMA "NT" GEMM (see fp8.h).
+//
+// gemm_nt_f8_kernel: 128 x 128 output tile, 4 waves (2 x 2, 64 x 64 each as 4 x 4 v_mfma_f32_16x16x32_fp8_fp8 tiles),
+// K-step 128 (one 128-byte LDS row per operand row, as in the bf16 tile kernel: half the bytes per k), operands staged
+// global -> registers -> LDS in 16-byte chunks, double-buffered, next tile's loads issued before the MFMAs.  A fragment
+// is 8 bytes (k = 32 kk + 8 q .. + 7): the 16-byte chunk index is XOR-swizzled by (row >> 1) & 7, which puts the 32 lanes
+// of a half-wave (16 rows x 2 k-groups) on 32 distinct 8-byte slots of the 64 banks.  The row gather (feature rows by node
+// id) is the A-operand row index, as in the bf16 path.  Epilogue: acc * sa[m] * sb[n] + bias -> bf16 through an fp32 LDS
+// stage so that every global store is a full 16-byte vector.
+#include "fp8.h"
+
+namespace pmgt {
+
+__device__ __forceinline__ int f8_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void gemm_nt_f8_kernel(GemmF8 g) {
+    constexpr int BM = 128, BN = 128, BK = 128;
+    constexpr int TM = 4, TN = 4, LA = 4, LB = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
+    char* sA = smem;
+    char* sB = smem + 2 * BM * 128;
+
+    const int num_n = (g.N + BN - 1) / BN;
+    const int num_m = (g.M + BM - 1) / BM;
+    const int b = blockIdx.x;
+    const int grp = b / (8 * num_n), within = b % (8 * num_n);
+    const int m_tile = grp * 8 + (within & 7), n_tile = within >> 3;       // N-tiles of one M-tile share an XCD
+    if (m_tile >= num_m) return;
+    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (m0 >= Mlim) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int c = tid & 7, r0 = tid >> 3;
+    const char* arow[LA];
+    const char* brow[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int m = min(m0 + r0 + 32 * i, Mlim - 1);
+        const int64_t row = g.a_rows ? g.a_rows[m] : (int64_t)m;
+        arow[i] = (const char*)g.A + row * g.lda;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int n = min(n0 + r0 + 32 * i, g.N - 1);
+        brow[i] = (const char*)g.B + (int64_t)n * g.ldb;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[LA], rb[LB];
+    auto gload = [&](int k0) {
+        const int k = k0 + c * 16;
+        const bool ok = k < g.K;                       // K % 16 == 0 (host check)
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ra[i] = ok ? *(const u32x4*)(arow[i] + k) : (u32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < LB; ++i) rb[i] = ok ? *(const u32x4*)(brow[i] + k) : (u32x4){0, 0, 0, 0};
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *(u32x4*)(sA + buf * BM * 128 + f8_off(r0 + 32 * i, c)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *(u32x4*)(sB + buf * BN * 128 + f8_off(r0 + 32 * i, c)) = rb[i];
+    };
+
+    const int nk = (g.K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const char* a_base = sA + buf * BM * 128;
+        const char* b_base = sB + buf * BN * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {               // k = 32 kk + 8 q: chunk 2 kk + (q >> 1), half q & 1
+            long fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const long*)(a_base + f8_off(wm * 64 + i * 16 + r, 2 * kk + (q >> 1)) + 8 * (q & 1));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const long*)(b_base + f8_off(wn * 64 + j * 16 + r, 2 * kk + (q >> 1)) + 8 * (q & 1));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+    constexpr int ES = BN + 4;
+    float* stage = (float*)smem;                        // 64 x ES floats
+    bf16* C = (bf16*)g.C;
+    const int er = tid >> 4, ec = (tid & 15) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) stage[(i * 16 + 4 * q + e) * ES + wn * 64 + j * 16 + r] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = er + 16 * it;
+            const int m = m0 + pass * 64 + row;
+            if (m < Mlim) {
+                const float sa = g.a_row_scale ? g.a_row_scale[m] : g.a_scale;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int n = n0 + ec + 4 * h;
+                    if (n < g.N) {                          // N % 4 == 0 (host check)
+                        f32x4 v = *(const f32x4*)(stage + row * ES + ec + 4 * h);
+                        f32x4 sb = {1.f, 1.f, 1.f, 1.f};
+                        if (g.b_row_scale) sb = *(const f32x4*)(g.b_row_scale + n);
+                        v = v * (sb * sa);
+                        if (g.bias) v += *(const f32x4*)(g.bias + n);
+                        store4<bf16>(C + (int64_t)m * g.ldc + n, v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return 0;
+    PMGT_CHECK(g.K > 0 && g.K % 16 == 0 && g.N % 4 == 0, -2, "gemm_nt_f8: K=%d must be a multiple of 16, N=%d of 4", g.K, g.N);
+    PMGT_CHECK(g.lda % 16 == 0 && g.ldb % 16 == 0 && g.ldc % 4 == 0, -2, "gemm_nt_f8: leading dimensions must keep 16-byte rows");
+    PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 8) == 0, -2, "gemm_nt_f8: unaligned operands");
+    PMGT_CHECK((g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0) && (g.b_row_scale == nullptr || ((uintptr_t)g.b_row_scale % 16) == 0), -2,
+               "gemm_nt_f8: bias / scale vectors must be 16-byte aligned");
+    const int num_n = cdiv(g.N, 128), num_m = cdiv(g.M, 128);
+    hipLaunchKernelGGL(gemm_nt_f8_kernel, dim3(8 * num_n * cdiv(num_m, 8)), dim3(256), 0, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// quantisation
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void load8f(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8f<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void load8f<bf16>(const bf16* p, float (&v)[8]) {
+    const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+}
+
+// one wave per row: pass 1 = absmax, pass 2 = scale + convert (the row comes back from L2)
+template <typename T>
+__device__ __forceinline__ void quant_row(const T* src, int cols, char* dst, float* scale_out, int lane) {
+    float m = 0.f;
+    for (int c0 = lane * 8; c0 < cols; c0 += 64 * 8) {
+        float v[8];
+        load8f<T>(src + c0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    }
+    m = wave_max(m);
+    const float inv = m > 0.f ? E4M3_MAX / m : 1.f;
+    if (lane == 0) *scale_out = m > 0.f ? m / E4M3_MAX : 1.f;
+    for (int c0 = lane * 8; c0 < cols; c0 += 64 * 8) {
+        float v[8];
+        load8f<T>(src + c0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * inv, -E4M3_MAX), E4M3_MAX);
+        *(u32x2*)(dst + c0) = pack8_e4m3(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const T* src, int64_t lds, int rows, int cols, char* dst, int64_t ldd, float* scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    quant_row<T>(src + (int64_t)row * lds, cols, dst + (int64_t)row * ldd, scale + row, threadIdx.x & 63);
+}
+
+template <typename T>
+int quant_rows_e4m3(const T* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd, float* scale, hipStream_t st) {
+    if (rows <= 0) return 0;
+    PMGT_CHECK(cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, -2, "quant_rows_e4m3: cols=%d and the leading dimensions must be multiples of 8", cols);
+    PMGT_CHECK(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, -2, "quant_rows_e4m3: unaligned buffers");
+    hipLaunchKernelGGL((quant_rows_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, src, lds, rows, cols, (char*)dst, ldd, scale);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+template int quant_rows_e4m3<float>(const float*, int64_t, int, int, void*, int64_t, float*, hipStream_t);
+template int quant_rows_e4m3<bf16>(const bf16*, int64_t, int, int, void*, int64_t, float*, hipStream_t);
+
+__global__ __launch_bounds__(256) void quant_params_kernel(const float* params, const QuantDesc* desc, int n_desc, int total_rows, char* dst,
+                                                           float* scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total_rows) return;
+    int k = 0;
+    while (k + 1 < n_desc && row >= desc[k + 1].row_start) ++k;
+    const QuantDesc d = desc[k];
+    const int lr = row - d.row_start;
+    quant_row<float>(params + d.src + (int64_t)lr * d.cols, d.cols, dst + d.dst + (int64_t)lr * d.cols, scale + d.scale + lr, threadIdx.x & 63);
+}
+
+int quant_params_e4m3(const float* params, const QuantDesc* desc_dev, int n_desc, int total_rows, void* dst, float* scale, hipStream_t st) {
+    if (total_rows <= 0 || n_desc <= 0) return 0;
+    hipLaunchKernelGGL(quant_params_kernel, dim3(cdiv(total_rows, 4)), dim3(256), 0, st, params, desc_dev, n_desc, total_rows, (char*)dst, scale);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void quant_tensor_kernel(const float* src, char* dst, int64_t n8, float inv) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8f<float>(src + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * inv, -E4M3_MAX), E4M3_MAX);
+        *(u32x2*)(dst + i * 8) = pack8_e4m3(v);
+    }
+}
+__global__ __launch_bounds__(256) void dequant_tensor_kernel(const char* src, float* dst, int64_t n8, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        unpack8_e4m3(*(const u32x2*)(src + i * 8), v);
+        f32x4 a = {v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale}, b = {v[4] * scale, v[5] * scale, v[6] * scale, v[7] * scale};
+        *(f32x4*)(dst + i * 8) = a;
+        *(f32x4*)(dst + i * 8 + 4) = b;
+    }
+}
+
+int quant_tensor_e4m3(const float* src, void* dst, int64_t n, float inv_scale, hipStream_t st) {
+    if (n <= 0) return 0;
+    PMGT_CHECK(n % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, -2, "quant_tensor_e4m3: n=%lld must be a multiple of 8, buffers aligned", (long long)n);
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(quant_tensor_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n8, 256), 4096)), dim3(256), 0, st, src, (char*)dst, n8, inv_scale);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+int dequant_tensor_e4m3(const void* src, float* dst, int64_t n, float scale, hipStream_t st) {
+    if (n <= 0) return 0;
+    PMGT_CHECK(n % 8 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 16) == 0, -2, "dequant_tensor_e4m3: n=%lld must be a multiple of 8, buffers aligned", (long long)n);
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(dequant_tensor_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n8, 256), 4096)), dim3(256), 0, st, (const char*)src, dst, n8, scale);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace pmgt

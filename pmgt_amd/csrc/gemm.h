@@ -54,6 +54,8 @@ struct GemmTN {
     // P's columns are in head-major order (head, matrix, w) of a [4 x perm_d] block structure with head size perm_dh:
     // output row n1 is written to row (matrix * perm_d + head * perm_dh + w) of the slab.  0 = identity.
     int perm_d = 0, perm_dh = 0;
+    bool q_f8 = false;                          // fp8 mode: Q is an e4m3 feature table (ldq in bytes), value = byte * q_scale
+    float q_scale = 1.f;
 };
 void gemm_tn_disable_dma(int on);
 void gemm_tn_disable_big(int on);     // A/B: never use the 256 x 256 weight-gradient tile

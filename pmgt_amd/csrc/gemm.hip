@@ -613,8 +613,12 @@ template <typename T> int gemm_tn_bkm() { return sizeof(T) == 2 ? 64 : 32; }
 template int gemm_tn_bkm<float>();
 template int gemm_tn_bkm<bf16>();
 
-template <typename T>
+// Q8 (fp8 mode, feature-projection weight gradient): the rows of Q are e4m3 bytes of a frozen feature table (value = byte *
+// g.q_scale); a staging chunk is 8 bytes instead of 16 and is widened to bf16 on its way into LDS, so the gather moves
+// half the bytes and the MFMA loop is the bf16 one.
+template <typename T, bool Q8 = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) {
+    static_assert(!Q8 || sizeof(T) == 2, "e4m3 Q operand: bf16 path only");
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BKM = sizeof(T) == 2 ? 64 : 32;    // reduction rows per step
     constexpr int ROWB = 128 * sizeof(T);            // LDS bytes per tile row (128 columns)
@@ -678,8 +682,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
             (void)okm;      // the zero-select for padding rows/columns happens at LDS-store time (sstore), so the
                             // loads stay in flight across the MFMA phase instead of being waited for here
             rp[i] = *(const u32x4*)((const char*)g.P + ((int64_t)mc * g.ldp + cpc) * (int64_t)sizeof(T));
-            rq[i] = *(const u32x4*)((const char*)g.Q + (qidx[i] * g.ldq + cqc) * (int64_t)sizeof(T));
+            if constexpr (Q8) {
+                const u32x2 w = *(const u32x2*)((const char*)g.Q + qidx[i] * g.ldq + cqc);
+                rq[i] = (u32x4){w[0], w[1], 0u, 0u};
+            } else {
+                rq[i] = *(const u32x4*)((const char*)g.Q + (qidx[i] * g.ldq + cqc) * (int64_t)sizeof(T));
+            }
         }
+    };
+    // 8 e4m3 bytes -> 8 bf16 (times the table scale)
+    auto widen = [&](u32x4 w) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], true);
+        const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], true);
+        const float sc = g.q_scale;
+        const bf16x8 o = {(bf16)(a[0] * sc), (bf16)(a[1] * sc), (bf16)(b[0] * sc), (bf16)(b[1] * sc),
+                          (bf16)(c[0] * sc), (bf16)(c[1] * sc), (bf16)(d[0] * sc), (bf16)(d[1] * sc)};
+        return __builtin_bit_cast(u32x4, o);
     };
     auto sstore = [&](int buf, int mb) {
 #pragma unroll
@@ -692,7 +711,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
             const bool okm = mb + row < mend;
             const u32x4 z = {0, 0, 0, 0};
             *(u32x4*)(sP + buf * TILEB + off) = (okm && n1_0 + ch * EPC < g.N1) ? rp[i] : z;
-            *(u32x4*)(sQ + buf * TILEB + off) = (okm && n2_0 + ch * EPC < g.N2) ? rq[i] : z;
+            u32x4 qv = rq[i];
+            if constexpr (Q8) qv = widen(qv);
+            *(u32x4*)(sQ + buf * TILEB + off) = (okm && n2_0 + ch * EPC < g.N2) ? qv : z;
         }
     };
 
@@ -1259,13 +1280,23 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     if (g.N1 <= 0 || g.N2 <= 0) return 0;
     PMGT_CHECK(g.N1 % EPC == 0 && g.N2 % EPC == 0, -2, "gemm_tn: N1=%d N2=%d must be multiples of %d", g.N1, g.N2, EPC);
     PMGT_CHECK(g.ldp % EPC == 0 && g.ldq % EPC == 0, -2, "gemm_tn: leading dims must be multiples of %d", EPC);
-    PMGT_CHECK(((uintptr_t)g.P % 16) == 0 && ((uintptr_t)g.Q % 16) == 0, -2, "gemm_tn: operands must be 16-byte aligned");
+    PMGT_CHECK(((uintptr_t)g.P % 16) == 0 && ((uintptr_t)g.Q % (g.q_f8 ? 8 : 16)) == 0, -2, "gemm_tn: operands must be 16-byte aligned");
     PMGT_CHECK(g.splits >= 1 && g.slab, -2, "gemm_tn: bad splits/slab");
     PMGT_CHECK(g.perm_dh == 0 || (sizeof(T) == 2 && !g_tn_no_dma && g.zeros != nullptr), -2, "gemm_tn: the row permutation needs the LDS-DMA kernel");
     const int bkm = gemm_tn_bkm<T>();
     int chunk = cdiv(cdiv(std::max(g.M, 1), g.splits), bkm) * bkm;
     const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);
     dim3 grid(8 * tiles * cdiv(g.splits, 8));
+    if (g.q_f8) {
+        if constexpr (sizeof(T) == 2) {
+            PMGT_CHECK(g.perm_dh == 0 && ((uintptr_t)g.Q % 8) == 0, -2, "gemm_tn: e4m3 Q operand needs 8-byte rows and no row permutation");
+            hipLaunchKernelGGL((gemm_tn_kernel<T, true>), grid, dim3(256), 0, st, g, chunk);
+            PMGT_LAUNCH_OK();
+            return 0;
+        } else {
+            PMGT_CHECK(false, -2, "gemm_tn: e4m3 Q operand belongs to the fp8 mode (bf16 activations)");
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         if (g.q_rows == nullptr && g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm) &&
             g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm)) {

@@ -29,6 +29,8 @@ struct NfrDiffArgs {
     int cap = 0, Fv = 0, Ft = 0;
     const void* table_v = nullptr;  // [N+2, Fv]
     const void* table_t = nullptr;  // [N+2, Ft]
+    bool tables_f8 = false;         // fp8 mode: the tables are e4m3 bytes, value = byte * scale_{v,t}
+    float scale_v = 1.f, scale_t = 1.f;
     float* sse_part = nullptr;      // [nfr_diff_parts(cap)][2]
 };
 inline int nfr_diff_parts(int cap) { return cdiv(cap, 8); }

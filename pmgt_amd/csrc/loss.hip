@@ -197,7 +197,20 @@ template int gsr_fwd_bwd<bf16>(const GsrArgs&, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // NFR: pred (from the GEMM) -> dpred in place + squared-error partials per modality
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// 4 consecutive table elements as fp32: storage type T, or (F8) e4m3 bytes times the table's scale
+template <typename T, bool F8>
+__device__ __forceinline__ f32x4 table_load4(const void* table, int64_t elem, float scale) {
+    if constexpr (F8) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const int w = *(const int*)((const char*)table + elem);
+        const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+        return (f32x4){lo[0] * scale, lo[1] * scale, hi[0] * scale, hi[1] * scale};
+    } else {
+        return load4<T>((const T*)table + elem);
+    }
+}
+
+template <typename T, bool F8>
 __global__ __launch_bounds__(256) void nfr_diff_kernel(NfrDiffArgs a) {
     __shared__ float red[8];
     const int n = *a.count;
@@ -210,11 +223,11 @@ __global__ __launch_bounds__(256) void nfr_diff_kernel(NfrDiffArgs a) {
         for (int r = r0; r < r1; ++r) {
             const int64_t tid = a.tids[r];
             T* p = (T*)a.pred + (int64_t)r * F;
-            const T* tv = (const T*)a.table_v + tid * a.Fv;
-            const T* tt = (const T*)a.table_t + tid * a.Ft;
             for (int c4 = threadIdx.x * 4; c4 < F; c4 += 1024) {
                 const bool isv = c4 < a.Fv;
-                f32x4 diff = load4<T>(p + c4) - (isv ? load4<T>(tv + c4) : load4<T>(tt + (c4 - a.Fv)));
+                const f32x4 tgt = isv ? table_load4<T, F8>(a.table_v, tid * a.Fv + c4, a.scale_v)
+                                      : table_load4<T, F8>(a.table_t, tid * a.Ft + (c4 - a.Fv), a.scale_t);
+                f32x4 diff = load4<T>(p + c4) - tgt;
                 const float ss = sum4(diff * diff);
                 if (isv) sv += ss; else stx += ss;
                 store4<T>(p + c4, diff * (isv ? cv : ct));
@@ -235,7 +248,12 @@ __global__ __launch_bounds__(256) void nfr_diff_kernel(NfrDiffArgs a) {
 template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st) {
     if (a.cap <= 0) return 0;
     PMGT_CHECK(a.Fv % 4 == 0 && a.Ft % 4 == 0, -2, "nfr_diff: feature sizes must be multiples of 4");
-    hipLaunchKernelGGL((nfr_diff_kernel<T>), dim3(nfr_diff_parts(a.cap)), dim3(256), 0, st, a);
+    if (a.tables_f8) {
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((nfr_diff_kernel<T, true>), dim3(nfr_diff_parts(a.cap)), dim3(256), 0, st, a);
+        else PMGT_CHECK(false, -2, "nfr_diff: e4m3 tables belong to the fp8 mode (bf16 activations)");
+    } else {
+        hipLaunchKernelGGL((nfr_diff_kernel<T, false>), dim3(nfr_diff_parts(a.cap)), dim3(256), 0, st, a);
+    }
     PMGT_LAUNCH_OK();
     return 0;
 }

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "attention.h"
+#include "fp8.h"
 #include "gemm.h"
 
 namespace pmgt {
@@ -383,21 +384,39 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
 // phase, so one's projection overlaps the other's attention.  Every A-tile fragment read now feeds 8 MFMAs instead of
 // 4: half the LDS traffic per row.
 //   wave w = (head uh = w >> 1, matrix pair mh = w & 1: {Q, K} or {V, C});  attention role (head uh, query half w & 1).
-template <int KS> struct QaCfg2 {
+template <int KS, bool F8 = false> struct QaCfg2 {
     static constexpr int K = 32 * KS;
-    static constexpr int ROWB = K * 2;
-    static constexpr int CPR = K / 8;
+    static constexpr int ROWB = F8 ? K : K * 2;               // LDS bytes per row of the x tile (e4m3 in the fp8 mode)
+    static constexpr int CPR = K / 8;                         // 8-element chunks per row (16 B of bf16 in HBM)
     static constexpr int TILEB = 32 * ROWB;
     static constexpr int LPT = 32 * CPR / 256;
     static_assert(LPT * 256 == 32 * CPR, "tile must be a whole number of chunks per thread");
+    static_assert(!F8 || CPR == 32, "fp8 form: one row per 32 lanes (hidden size 256)");
     static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
     static constexpr int QTB = 32 * 512;                      // projection tile: 32 rows x 256 bf16
-    static constexpr int SMEM = 2 * TILEB + QTB + 4 * 64 * 4 + 256 * 4;     // A ring + projection tile + per-wave {rho, madd} + bias
+    // A ring + projection tile + per-wave {rho, madd} + bias (+ fp8: channel scales of W, row scales of the two x tiles)
+    static constexpr int SMEM = 2 * TILEB + QTB + 4 * 64 * 4 + 256 * 4 + (F8 ? 256 * 4 + 2 * 32 * 4 : 0);
 };
 
-template <int KS>
+// max over the 32 consecutive lanes [0, 32) / [32, 64) of a wave, result in every lane (cf. sum_lanes32 in common.h)
+__device__ __forceinline__ float max_lanes32(float v) {
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+    float x = v, y = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return raw_max(x, y);
+}
+
+// F8: same structure, the projection on the fp8 MFMA.  W fragments are 8 bytes (64 VGPRs per wave instead of 128); the x tile
+// is quantised per row (absmax over the 32 lanes that hold the row -> e4m3, fp8.h contract) on its way from the staging
+// registers into LDS, so the fragment reads move half the bytes; the 8-byte chunk index is XOR-swizzled by 2 (row & 15),
+// which spreads the 16 rows x 2 k-groups of a half-wave over 32 distinct 8-byte slots.  acc * rowscale * wscale + bias
+// gives the same bf16 projection tile; everything after it is unchanged.
+template <int KS, bool F8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qkvc_attn_fwd2_kernel(QkvcAttn a) {
-    using C = QaCfg2<KS>;
+    using C = QaCfg2<KS, F8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     char* qt = smem + 2 * C::TILEB;
@@ -417,15 +436,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // local column of this wave's 16-column block cb: matrix 2 mh + (cb >> 1), head uh, half cb & 1
     auto cbase = [&](int cb) { return 64 * (2 * mh + (cb >> 1)) + 32 * uh + 16 * (cb & 1); };
 
-    bf16x8 wf[4][KS];
+    using wfrag_t = std::conditional_t<F8, long, bf16x8>;
+    wfrag_t wf[4][KS];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int n = gcol(cbase(cb) + r);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[cb][ks] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 32 * ks + 8 * q);
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (F8) wf[cb][ks] = *(const long*)((const char*)a.W8 + (int64_t)n * a.ldw + 32 * ks + 8 * q);
+            else wf[cb][ks] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 32 * ks + 8 * q);
+        }
     }
     float* bias_l = wl + 4 * 64;          // bias of the slab's 256 local columns (LDS: 16 VGPRs fewer)
     bias_l[tid] = a.bias ? a.bias[gcol(tid)] : 0.f;
+    float* wscale_l = bias_l + 256;       // fp8: dequantisation scale of the slab's 256 output channels
+    float* rowscale_l = wscale_l + 256;   // fp8: [2 tiles][32 rows]
+    if constexpr (F8) wscale_l[tid] = a.wscale[gcol(tid)];
 
     u32x4 ra[1][C::LPT];
     auto gload = [&](int mt, int set) {
@@ -441,7 +467,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < C::LPT; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / C::CPR, ch = idx % C::CPR;
-            *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
+            if constexpr (F8) {
+                const bf16x8 xv = __builtin_bit_cast(bf16x8, ra[set][i]);
+                float f[8], m = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] = (float)xv[e]; m = raw_max(m, fabsf(f[e])); }
+                m = max_lanes32(m);                       // the 32 lanes of this half-wave hold the row
+                const float inv = m > 0.f ? E4M3_MAX / m : 1.f;
+                if (ch == 0) rowscale_l[buf * 32 + row] = m > 0.f ? m / E4M3_MAX : 1.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * inv, -E4M3_MAX, E4M3_MAX);
+                *(u32x2*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ ((row & 15) << 1)) << 3)) = pack8_e4m3(f);
+            } else {
+                *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
+            }
         }
     };
 
@@ -476,17 +515,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const char* a_base = sA + P * C::TILEB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 fa[2];
+            wfrag_t fa[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 16 * i + r;
-                fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
+                if constexpr (F8) fa[i] = *(const long*)(a_base + row * C::ROWB + (((4 * ks + q) ^ ((row & 15) << 1)) << 3));
+                else fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
             }
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)      // D[n = 4 q + e][m = r]: acc[i][cb][e] = out[16 i + r][cbase(cb) + 4 q + e]
-                    acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {    // D[n = 4 q + e][m = r]: acc[i][cb][e] = out[16 i + r][cbase(cb) + 4 q + e]
+                    if constexpr (F8) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0);
+                    else acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0);
+                }
         }
         QA_STAMP(2);
 #pragma unroll
@@ -494,7 +536,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 const int row = 16 * i + r;
-                const f32x4 v = acc[i][cb] + *(const f32x4*)(bias_l + cbase(cb) + 4 * q);
+                f32x4 v = acc[i][cb];
+                if constexpr (F8) v = v * (*(const f32x4*)(wscale_l + cbase(cb) + 4 * q) * rowscale_l[P * 32 + row]);
+                v += *(const f32x4*)(bias_l + cbase(cb) + 4 * q);
                 bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *(bf16x4*)(qt + qt_addr(row, (cbase(cb) >> 3) + (q >> 1)) + 8 * (q & 1)) = o;
             }
@@ -526,9 +570,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 bool qkvc_attn_supported(const QkvcAttn& a) {
     const int d = a.H * 32;
+    if (a.W8 && !(d == 256 && a.wscale && ((uintptr_t)a.W8 % 8) == 0)) return false;
     return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.H % 2 == 0 && a.Tseq >= 2 && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
            a.ldq % 8 == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0 &&
-           ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.ctx % 8) == 0 && (a.bias == nullptr || ((uintptr_t)a.bias % 16) == 0);
+           ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.ctx % 8) == 0 && (a.bias == nullptr || ((uintptr_t)a.bias % 16) == 0) &&
+           (a.W != nullptr || a.W8 != nullptr);
 }
 
 template <int KS> static int launch_qa(const QkvcAttn& a, hipStream_t st) {
@@ -546,9 +592,9 @@ template <int KS> static int launch_qa(const QkvcAttn& a, hipStream_t st) {
     return 0;
 }
 
-template <int KS> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
-    using C = QaCfg2<KS>;
-    auto kern = qkvc_attn_fwd2_kernel<KS>;
+template <int KS, bool F8 = false> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
+    using C = QaCfg2<KS, F8>;
+    auto kern = qkvc_attn_fwd2_kernel<KS, F8>;
     static bool attr_done = false;
     if (!attr_done) {
         PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
@@ -569,6 +615,7 @@ static bool qa_form1() {
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
     if (a.Tseq <= 0) return 0;
     PMGT_CHECK(qkvc_attn_supported(a), -2, "qkvc_attn_fwd: unsupported shape S=%d dh=%d H=%d", a.S, a.dh, a.H);
+    if (a.W8) return launch_qa2<8, true>(a, st);
     if (qa_form1()) return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
     return a.H * 32 == 256 ? launch_qa2<8>(a, st) : launch_qa2<4>(a, st);
 }

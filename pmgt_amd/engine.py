@@ -32,8 +32,10 @@ class Engine:
         self.lib = _lib.hip()
         self.config = config
         self.dtype_name = dtype
-        self.dtype_code = {"fp32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16}[dtype]
-        self.torch_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[dtype]
+        # "fp8": the bf16 engine with e4m3 feature tables and fp8-MFMA feature / Q|K|V|C projections (include/pmgt_capi.h)
+        self.dtype_code = {"fp32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8": _lib.DTYPE_FP8}[dtype]
+        self.torch_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.bfloat16}[dtype]
+        self.table_scale = (0.0, 0.0)
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         feats = list(config.feat_hidden_sizes)
@@ -102,12 +104,35 @@ class Engine:
 
     def set_tables(self, visual, textual):
         """Frozen feature tables [N+2, F_m] (pmgt/pmgt/models.py:40-54), cast once to the engine dtype."""
-        tabs = []
+        tabs, scales = [], []
         for a in (visual, textual):
             t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
-            tabs.append(t.to(self.device, dtype=self.torch_dtype).contiguous())
+            if self.dtype_name == "fp8":
+                # one scale per table: value = e4m3 byte * (max|table| / 448), quantised once by the library's kernel
+                t = t.to(self.device, dtype=torch.float32).contiguous()
+                amax = float(t.abs().max())
+                scale = np.float32(amax) / np.float32(448.0) if amax > 0 else np.float32(1.0)
+                inv = np.float32(448.0) / np.float32(amax) if amax > 0 else np.float32(1.0)
+                q = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
+                _lib.check(self.lib.pmgt_quantize_e4m3(_ptr(t), _ptr(q), t.numel(), float(inv), _stream()))
+                tabs.append(q)
+                scales.append(float(scale))
+            else:
+                tabs.append(t.to(self.device, dtype=self.torch_dtype).contiguous())
+                scales.append(0.0)
         self.table_v, self.table_t = tabs
+        self.table_scale = tuple(scales)
         self.n_nodes = int(self.table_v.shape[0] - 2)
+
+    def dequantized_tables(self):
+        """fp8 mode: the feature values the kernels see (fp32 [N+2, F_m]) -- what a checker must use as the tables."""
+        assert self.dtype_name == "fp8"
+        out = []
+        for q, sc in zip((self.table_v, self.table_t), self.table_scale):
+            o = torch.empty(q.shape, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.pmgt_dequantize_e4m3(_ptr(q), _ptr(o), q.numel(), sc, _stream()))
+            out.append(o)
+        return out
 
     def cast(self, x: torch.Tensor) -> torch.Tensor:
         """fp32 device tensor -> engine dtype through the library's own cast kernel."""
@@ -121,7 +146,7 @@ class Engine:
         return _lib.TensorsC(self.params.data_ptr(), g.data_ptr(),
                              0 if self.table_v is None else self.table_v.data_ptr(),
                              0 if self.table_t is None else self.table_t.data_ptr(), self.n_nodes,
-                             self.rng_state.data_ptr())
+                             self.rng_state.data_ptr(), self.table_scale[0], self.table_scale[1])
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:

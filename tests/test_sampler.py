@@ -179,4 +179,4 @@ def test_capi_symbols_exported():
         assert hasattr(hip, s), s
     for s in _lib.SAMPLER_SYMBOLS:
         assert hasattr(smp, s), s
-    assert _lib.hip().pmgt_abi_version() == 1
+    assert _lib.hip().pmgt_abi_version() == 2      # 2: pmgt_tensors gained the fp8 table scales
