@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1024,
                     help="target nodes per GPU per step; SURVEY 8(d) lists 32 (author's script), 256 (CLI default), 1024")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="bf16 = BASELINE.json's metric; fp8 = bf16 engine with e4m3 feature tables / fp8-MFMA feature + Q|K|V|C projections (config 5)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--intermediate", type=int, default=0, help="override intermediate size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,6 +159,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     loss_last = trainer.last_loss.item()
+    grad_norm_last = eng.grad_norm().item()
+    if not (np.isfinite(loss_last) and np.isfinite(grad_norm_last)):
+        # a step whose loss or pre-clip gradient norm is not finite does no learning (clip coefficient 0 / NaN parameters):
+        # its time is not a measurement of the training step
+        raise RuntimeError(f"bench: non-finite training state after the timed steps (loss {loss_last}, grad norm {grad_norm_last})")
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -179,6 +185,7 @@ def main():
                                f"dropout {args.dropout}, clip 5.0, AdamW lr 1e-4 wd 1e-2",
                    "parallelism": f"dp{world}", "global_batch": world * B, "seq_len": S},
         "loss_last": round(loss_last, 5),
+        "grad_norm_last": round(grad_norm_last, 5),
         "side_stream_reductions": bool(args.overlap),
         "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count()},
     }
@@ -199,7 +206,7 @@ def main():
         phases = {k: {"launches_per_step": c // nprof, "ms_per_step": round(ms / nprof, 4), "share": round(ms / tot, 4)}
                   for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out["phases"] = phases
-        esz = 2 if args.dtype == "bf16" else 4
+        esz = 4 if args.dtype == "fp32" else 2
         M = 12 * B * S
         dom = next((k for k in phases if phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz) is not None), next(iter(phases)))
         w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz)
@@ -207,7 +214,7 @@ def main():
         avg_s = ms / cnt / 1e3
         if w is not None:
             flops, byts = w
-            peak_t = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            peak_t = MFMA_F32_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
             if flops > 0 and flops / (peak_t * 1e12) >= byts / (HBM_PEAK_GBS * 1e9):
                 ach = flops / avg_s / 1e12
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": peak_t,

@@ -428,7 +428,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nw = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    // wave index as a KNOWN wave-uniform value: every `if` on t / ntq below becomes a scalar branch (a condition derived from
+    // threadIdx.x is divergent to the compiler, which then masks EXEC around the block -- and MFMA ignores EXEC)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int gidx = blockIdx.x * nw + wave;
     const int S = FULL ? NT * 16 : a.S, H = a.H, d = H * DH;
     const bool act = gidx < a.Tseq * H;

@@ -1212,6 +1212,22 @@ int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_
     return slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, accumulate != 0, (hipStream_t)stream);
 }
 
+// weight gradient + bias gradient (column sums of P riding along as ones-MFMAs) + optional head-major row permutation:
+// exactly what the engine's wgrad helper launches for the Q|K|V|C projection
+int pmgt_op_gemm_tn_bias(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, int M, int N1, int N2, float* slab,
+                         float* out, float* bias_slab, float* bias_out, int perm_d, int perm_dh, void* stream) {
+    GemmTN g;
+    g.P = P; g.ldp = ldp; g.Q = Q; g.ldq = ldq; g.M = M; g.N1 = N1; g.N2 = N2; g.slab = slab; g.bias_slab = bias_slab;
+    g.zeros = zero_page(); g.perm_d = perm_d; g.perm_dh = perm_dh;
+    g.splits = gemm_tn_pick_splits(M, N1, N2, dtype != PMGT_DTYPE_F32 ? 64 : 32);
+    PMGT_CHECK(g.splits <= 512, -2, "pmgt_op_gemm_tn_bias: bias_slab holds at most 512 splits");
+    int rc = dtype != PMGT_DTYPE_F32 ? gemm_tn<bf16>(g, (hipStream_t)stream) : gemm_tn<float>(g, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, false, (hipStream_t)stream);
+    if (rc || !bias_slab) return rc;
+    return slab_reduce(bias_slab, g.splits, N1, bias_out, false, (hipStream_t)stream);
+}
+
 int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream) {
     if (dtype == PMGT_DTYPE_BF16) return colsum<bf16>((const bf16*)Y, ldy, M, N, slab, out, false, nullptr, (hipStream_t)stream);
     return colsum<float>((const float*)Y, ldy, M, N, slab, out, false, nullptr, (hipStream_t)stream);

@@ -1058,7 +1058,11 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
     const int n1_0 = (tile / tn2) * 256, n2_0 = (tile % tn2) * 256;
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The wave index must be KNOWN to be wave-uniform (readfirstlane): the bias MFMAs below sit under `(i >> 1) == wn`, and
+    // a condition derived from threadIdx.x is divergent to the compiler, which then guards the block with an EXEC mask
+    // instead of a branch -- MFMA ignores EXEC (every wave summed every fragment into accb) while the v_mov that builds
+    // the ones operand obeys it (uninitialised operand): bias gradients of 1e27 at B = 1024, the clip coefficient 0.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int r = lane & 15, q = lane >> 4;
 

@@ -134,6 +134,38 @@ def test_gemm_tn(dt, M, N1, N2):
     assert rel_err(out, ref2) < (1e-5 if dt == "fp32" else 2e-3)
 
 
+@pytest.mark.parametrize("dt,M,N1,N2,hm", [("fp32", 700, 256, 64, False), ("bf16", 3000, 1024, 256, False), ("bf16", 3000, 1024, 256, True),
+                                           ("bf16", 70016, 1024, 256, False), ("bf16", 70016, 1024, 256, True),      # 256 x 256 tile
+                                           ("bf16", 66000, 512, 512, False), ("bf16", 40000, 256, 1536, False)])
+def test_gemm_tn_bias_sums_and_head_major_rows(dt, M, N1, N2, hm):
+    """The bias gradient rides along in the weight-gradient kernels as MFMAs against a ones fragment, and the Q|K|V|C
+    projection's P operand arrives head-major (rows of the result are permuted back to q | k | v | c): every TN kernel
+    (register-staged, LDS-DMA, 256 x 256 tile) against fp64 column sums / products."""
+    _lib, L = _setup()
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M + N1 + N2)
+    Pm = torch.randn(M, N1, generator=g) + 0.25          # non-zero column means
+    Q = torch.randn(M, N2, generator=g)
+    Pd, Qd = to_dev(Pm, tdt), to_dev(Q, tdt)
+    slab = torch.empty(L.pmgt_op_gemm_tn_slab_elems(code, M, N1, N2), device="cuda")
+    bslab = torch.full((512 * N1,), float("nan"), device="cuda")
+    out = torch.full((N1, N2), float("nan"), device="cuda")
+    bout = torch.full((N1,), float("nan"), device="cuda")
+    d, dh = (N1 // 4, 32) if hm else (0, 0)
+    _lib.check(L.pmgt_op_gemm_tn_bias(code, P(Pd), N1, P(Qd), N2, M, N1, N2, P(slab), P(out), P(bslab), P(bout), d, dh, stream()))
+    ref = rounded(Pm, tdt).T @ rounded(Q, tdt)
+    bref = rounded(Pm, tdt).sum(0)
+    if hm:      # column (head h, matrix m, w) of P -> row m * d + h * dh + w of the result
+        n1 = torch.arange(N1)
+        dst = ((n1 // dh) % 4) * d + (n1 // (4 * dh)) * dh + n1 % dh
+        r2, b2 = torch.empty_like(ref), torch.empty_like(bref)
+        r2[dst], b2[dst] = ref, bref
+        ref, bref = r2, b2
+    assert rel_err(out, ref) < (1e-5 if dt == "fp32" else 2e-3)
+    assert torch.isfinite(bout).all()
+    assert rel_err(bout, bref) < (1e-5 if dt == "fp32" else 2e-3), rel_err(bout, bref)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_colsum(dt):
     _lib, L = _setup()
