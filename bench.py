@@ -148,8 +148,11 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    loss_first = None
     for i in range(args.steps):
-        trainer.train_step(staged[(args.warmup + i) % n_stage])
+        l = trainer.train_step(staged[(args.warmup + i) % n_stage])
+        if i == 0:
+            loss_first = l          # device scalar of the first timed step; read after the timed region
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -184,6 +187,7 @@ def main():
                                f"(context=S tokens incl. target), B={B} targets/GPU/step, 12 sequences/target, "
                                f"dropout {args.dropout}, clip 5.0, AdamW lr 1e-4 wd 1e-2",
                    "parallelism": f"dp{world}", "global_batch": world * B, "seq_len": S},
+        "loss_first": round(loss_first.item(), 5),
         "loss_last": round(loss_last, 5),
         "grad_norm_last": round(grad_norm_last, 5),
         "side_stream_reductions": bool(args.overlap),

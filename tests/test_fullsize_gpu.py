@@ -9,7 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-B = 128          # targets -> 12 * B * 32 = 49 152 tokens (table mode needs >= 2 (N + 2) = 14 508)
+B = 192          # targets -> 12 * B * 32 = 73 728 tokens: table mode needs >= 2 (N + 2) = 14 508, and the 256 x 256
+                 # weight-gradient tile (with its ones-MFMA bias sums and head-major rows) needs >= 65 536 -- at 128 targets
+                 # that kernel never ran under a test, and its bias gradients were garbage at the bench's batch size
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +69,10 @@ def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
     cos = torch.nn.functional.cosine_similarity(fast.grads, plain.grads, dim=0).item()
     assert cos > 0.999, cos
     for name in ("bert.embeddings.feat_linear.0.weight", "bert.encoder.layer.0.attention.self.query.weight",
-                 "bert.encoder.layer.3.output.dense.weight", "nfr_loss.projections.1.weight"):
+                 "bert.encoder.layer.3.output.dense.weight", "nfr_loss.projections.1.weight",
+                 "bert.encoder.layer.0.attention.self.query.bias", "bert.encoder.layer.1.attention.self.key.bias",
+                 "bert.encoder.layer.2.attention.self.value.bias", "bert.encoder.layer.3.attention.self.ctx_attention.bias",
+                 "bert.encoder.layer.1.intermediate.dense.bias", "bert.encoder.layer.2.output.dense.bias"):
         a, b = fast.view(name, grad=True), plain.view(name, grad=True)
         assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.99, name        # bf16 round-off only (the two paths round at different points)
 
@@ -76,7 +81,7 @@ def test_full_size_step_is_reproducible_and_descends(world):
     a, b = engine(world), engine(world)
     oa, ob = step(a, world, want_hidden=False), step(b, world, want_hidden=False)
     assert oa["loss"].item() == ob["loss"].item() and torch.equal(a.grads, b.grads)
-    assert torch.isfinite(a.grads).all()
+    assert torch.isfinite(a.grads).all() and a.grads.abs().max().item() < 1e3          # finite is not enough: 1e27 is finite
     valid = int((world["batch"][0]["node_ids"][:, 1:] != 0).sum())
     assert abs(oa["nfr_count"].item() / valid - 0.16) < 0.02                     # mask ratio of the reference
     losses = []
@@ -85,3 +90,4 @@ def test_full_size_step_is_reproducible_and_descends(world):
         a.optimizer_step(lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
         losses.append(out["loss"].item())
     assert np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
+    assert np.isfinite(a.grad_norm().item()) and a.grad_norm().item() < 1e3            # the clip coefficient was not 0
