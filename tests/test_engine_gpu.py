@@ -367,3 +367,63 @@ def test_head_major_qkvc_layout_is_transparent():
         e = eng.entry(k)
         a, b = res[0][1][e["offset"]: e["offset"] + e["numel"]], res[1][1][e["offset"]: e["offset"] + e["numel"]]
         assert ((a - b).norm() / b.norm()).item() < 1e-2, k      # rows land at the right q | k | v | c positions
+
+
+# ---- C4 / C5 shapes (BASELINE.json configs 4 and 5: d = 512, H = 8 -> head size 64, S = 64) against the oracle ----------------
+def _c4_case(B=4, n=3000, L=2, seed=11):
+    """A graph large enough for the per-token (gather-fused) feature projection: 2 (N + 2) > 12 B S tokens."""
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    from pmgt_amd.graph import synthetic_graph
+    S = 64
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, hidden_size=512, num_attention_heads=8,
+                         num_hidden_layers=L, intermediate_size=512, beta=0.5)
+    graph = synthetic_graph(n, 6 * n, seed=seed)
+    smp = MCNSampler(graph, max_ctx_neigh=S - 1)
+    tgt, pair, num_pairs, labels = smp.batch(np.arange(2, 2 + B), MODE_TRAIN, threads=2, base_seed=seed, counter=0)
+    batch = (tgt, pair, num_pairs, labels)
+    g = torch.Generator().manual_seed(seed)
+    ids = tgt["node_ids"]
+    r1, r2 = torch.rand(B, S - 1, generator=g), torch.rand(B, S - 1, generator=g)
+    repl = torch.randint(2, n + 2, (B * (S - 1),), generator=g)
+    masked, m2, tidx = po.nfr_masking(ids, n, r1, repl, r2)
+    full = torch.full_like(ids, -1)
+    full[:, 1:][m2] = tidx
+    return dict(cfg=cfg, params=po.synth_params(cfg, 5), tables=po.synth_tables(n, cfg["feat_hidden_sizes"], 6), batch=batch,
+                n_nodes=n, inj=(masked.cuda(), full.cuda()), inj_cpu=(masked, m2, tidx))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp8"])
+def test_c4_shapes_match_the_oracle(dtype):
+    """d = 512 / head size 64 / S = 64 take other kernels than the headline shape: cooperative attention, K = 512 tile GEMMs,
+    gather-fused feature projection and its gathered weight gradient (token mode), unfused fp8 Q|K|V|C projection."""
+    case = _c4_case()
+    eng = make_engine(case, dtype=dtype)
+    tables, cfg = case["tables"], dict(case["cfg"])
+    if dtype == "fp8":
+        tables = [po.fake_quant_tensor(t)[0] for t in tables]
+        cfg["fp8"] = True
+    p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items()}
+    ref = po.pretrain_forward(p, cfg, tables, case["batch"], training=True, nfr_inject=case["inj_cpu"])
+    ref["loss"].backward()
+    out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=case["inj"])
+    tol_loss = 1e-4 if dtype == "fp32" else 2e-2
+    np.testing.assert_allclose(out["loss"].item(), ref["loss"].item(), rtol=tol_loss)
+    np.testing.assert_allclose(out["gsr"].item(), ref["gsr"].item(), rtol=tol_loss)
+    np.testing.assert_allclose(out["nfr"].item(), ref["nfr"].item(), rtol=tol_loss)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].detach().numpy(), rtol=0, atol=1e-4 if dtype == "fp32" else 3e-2)
+    worst = (1.0, None)
+    gscale = max(float(p[e["name"]].grad.abs().max()) for e in eng.entries)
+    for e in eng.entries:
+        a, b = eng.view(e["name"], grad=True).reshape(-1).cpu().double(), p[e["name"]].grad.reshape(-1).double()
+        if float(b.abs().max()) < 1e-6 * gscale:      # key.bias: the softmax over keys is invariant to it, its gradient is round-off
+            assert float(a.abs().max()) < 1e-4 * gscale, e["name"]
+            continue
+        if dtype == "fp32":
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) < 2e-3 * scale + 1e-9, e["name"]
+        c = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        worst = min(worst, (c, e["name"]))
+    assert worst[0] > (0.9999 if dtype == "fp32" else 0.97), worst
+    flat_a = torch.cat([eng.view(e["name"], grad=True).reshape(-1) for e in eng.entries]).cpu()
+    flat_b = torch.cat([p[e["name"]].grad.reshape(-1) for e in eng.entries])
+    assert torch.nn.functional.cosine_similarity(flat_a, flat_b, dim=0).item() > (0.99999 if dtype == "fp32" else 0.99)

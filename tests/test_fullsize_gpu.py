@@ -70,11 +70,15 @@ def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
     assert cos > 0.999, cos
     for name in ("bert.embeddings.feat_linear.0.weight", "bert.encoder.layer.0.attention.self.query.weight",
                  "bert.encoder.layer.3.output.dense.weight", "nfr_loss.projections.1.weight",
-                 "bert.encoder.layer.0.attention.self.query.bias", "bert.encoder.layer.1.attention.self.key.bias",
+                 "bert.encoder.layer.0.attention.self.query.bias", "bert.encoder.layer.1.attention.self.ctx_attention.bias",
                  "bert.encoder.layer.2.attention.self.value.bias", "bert.encoder.layer.3.attention.self.ctx_attention.bias",
                  "bert.encoder.layer.1.intermediate.dense.bias", "bert.encoder.layer.2.output.dense.bias"):
         a, b = fast.view(name, grad=True), plain.view(name, grad=True)
-        assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.99, name        # bf16 round-off only (the two paths round at different points)
+        # bf16 round-off only (the two paths round at different points); bias gradients are sums of ~1e-6 entries with
+        # heavy cancellation, hence the wider bound -- the failure this guards against is cos ~ 0 / values of 1e27
+        assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > (0.95 if name.endswith("bias") else 0.99), name
+    for l in range(4):      # the softmax over keys is invariant to the key bias: its gradient is exactly 0 (round-off here), not 1e27
+        assert fast.view(f"bert.encoder.layer.{l}.attention.self.key.bias", grad=True).abs().max().item() < 1e-6
 
 
 def test_full_size_step_is_reproducible_and_descends(world):
