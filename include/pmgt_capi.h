@@ -181,8 +181,9 @@ int pmgt_op_gemm_nt_f8(const void* A, int64_t lda, const int64_t* a_rows, const 
 /* weight gradient with an e4m3 Q operand (feature-table rows): out = P^T (Q8 * q_scale), P bf16 */
 int pmgt_op_gemm_tn_f8(const void* P, int64_t ldp, const void* Q8, int64_t ldq, float q_scale, const int64_t* q_rows, int M,
                        int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream);
-/* fused projection + attention forward with the projection on the fp8 MFMA (d = 256): w8 [4d, d] e4m3, wscale [4d] */
-int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* w8, const float* wscale, const float* bias, const float* mask,
+/* fused projection + attention forward with the projection on the fp8 MFMA (d = 256): w8 [4d, d] e4m3, wscale [4d]; the layer
+ * input either as bf16 x (quantised per row inside the kernel) or, x8 != NULL, as e4m3 rows + one scale per row */
+int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* x8, const float* xscale, const void* w8, const float* wscale, const float* bias, const float* mask,
                                   void* qkvc, void* ctx, int n_seq, int S, int H, int dh, float beta, float drop_p,
                                   uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream);
 int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
@@ -237,6 +238,9 @@ void pmgt_debug_disable_segment_sum(int on);
 /* A/B switch: 1 keeps Q|K|V|C in q | k | v | c column order between the fused forward and the attention backward
  * (default in training: head-major, 4 * dh contiguous elements per (row, head)) */
 void pmgt_debug_disable_head_major(int on);
+/* A/B switch (fp8 mode): 1 = layer inputs are quantised by their consumer (inside the fused projection + attention kernel)
+ * instead of by the kernel that produces them (fused-LayerNorm epilogue of the FFN2 GEMM, embed_mix); bit-identical results */
+void pmgt_debug_disable_producer_quant(int on);
 /* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */
 void pmgt_debug_disable_fused_qkvc_attention(int on);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,

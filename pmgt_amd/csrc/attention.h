@@ -50,6 +50,10 @@ struct QkvcAttn {
     // attention stay bf16
     const void* W8 = nullptr;                     // [4d, d] e4m3, row stride ldw bytes
     const float* wscale = nullptr;                // [4d]
+    // ... and, when the producer of x already quantised it (gemm_ws fused-LayerNorm epilogue, embed_mix): e4m3 rows [Tseq*32, d]
+    // with row stride ldx BYTES and one scale per row; X is then not read
+    const void* X8 = nullptr;
+    const float* xscale = nullptr;
 };
 bool qkvc_attn_supported(const QkvcAttn& a);
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st);

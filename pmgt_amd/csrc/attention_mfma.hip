@@ -61,12 +61,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int c0, int 
 // through the LDS crossbar -- these reductions sit on the dependent chain max -> exp -> sum -> reciprocal.
 // (inline asm on two copies of v: the builtins fold when both operands are the same value; "s_nop 1" covers the
 // VALU-write -> permlane-read hazard, cdna_hip_programming.md T21)
-// v_max_f32 without the canonicalising self-max clang puts in front of fmaxf for values of unknown origin
-__device__ __forceinline__ float raw_max(float a, float b) {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// (raw_max: common.h)
 __device__ __forceinline__ float xchg16(float v, bool is_max) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));

@@ -231,6 +231,23 @@ __device__ __forceinline__ float sum_lanes32(float v) {
     return a + b;
 }
 
+// v_max_f32 without the canonicalising self-max clang adds in front of fmaxf for values of unknown origin
+__device__ __forceinline__ float raw_max(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// max over the 32 consecutive lanes [0, 32) / [32, 64) of a wave, result in every lane (cf. sum_lanes32)
+__device__ __forceinline__ float max_lanes32(float v) {
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
+    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+    float x = v, y = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return raw_max(x, y);
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

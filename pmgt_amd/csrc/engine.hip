@@ -447,6 +447,7 @@ static int g_no_fused_qa = 0;
 static int g_no_hm = 0;
 static int g_no_table_proj = 0;
 static int g_no_segsum = 0;
+static int g_no_producer_quant = 0;
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -535,18 +536,24 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         m.gamma = P + e->ln_g; m.beta = P + e->ln_b; m.eps = e->cfg.layer_norm_eps;
         m.a = b.a; m.stats = b.emb_stats; m.h0 = b.h0;
         m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
+        // fp8 mode: whoever PRODUCES a layer input also writes it as per-row e4m3 (x8 / xscale), so the projection that
+        // consumes it neither re-reads the bf16 row nor quantises it (x8_ok tracks whether the current `hin` has that copy)
+        const bool pq = e->fp8 && !g_no_producer_quant;
         if (table_mode && !g_no_segsum) {
             // the modality mix a0 e_v + a1 e_t depends on the node only: once per node, then one [d] row per token
             T* F_all = b.E + n_rows * 2 * d;                 // fits: (N + 2) * 3d <= M * 2d
             m.phase = 1; m.M = (int)n_rows; m.E = b.E; m.pre = F_all;
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
             m.phase = 2; m.M = M; m.E = F_all; m.e_rows = ids; m.pre = b.emb_pre;
+            if (pq) { m.q8 = b.x8; m.q8_scale = b.xscale; }
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
         } else {
             m.M = M; m.E = b.E; m.e_rows = table_mode ? ids : nullptr; m.pre = b.emb_pre;
+            if (pq) { m.q8 = b.x8; m.q8_scale = b.xscale; }
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
         }
     }
+    bool x8_ok = e->fp8 && !g_no_producer_quant;
     if (hidden_states) PMGT_HIP(hipMemcpyAsync(hidden_states, b.h0, (size_t)M * d * sizeof(T), hipMemcpyDeviceToDevice, st));
     const T* hin = b.h0;
     for (int l = 0; l < L; ++l) {
@@ -563,6 +570,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             f.cls_only_seqs = (shortcut && l == L - 1) ? n_cls_only : 0;
             f.hm = train && !g_no_hm;        // the backward that reads it understands the layout; inference keeps q | k | v | c
             if (e->fp8) { f.W8 = b.mirror8 + o.m8Wqkvc; f.wscale = b.mscale + o.s8Wqkvc; }
+            if (e->fp8 && x8_ok) { f.X8 = b.x8; f.xscale = b.xscale; f.ldx = d; }
             if (fused_qa_applies<T>(e, Tseq, S, attn_probs != nullptr) && qkvc_attn_supported(f)) {
                 RUNP("fwd.qkvc_attention", qkvc_attn_fwd(f, st));
                 fused = true;
@@ -570,7 +578,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             }
         }
         if (!fused && e->fp8) {   // per-row e4m3 of the layer input, then the fp8 GEMM
-            RUNP("fwd.quant_x", quant_rows_e4m3<T>(hin, d, M, d, b.x8, d, b.xscale, st));
+            if (!x8_ok) RUNP("fwd.quant_x", quant_rows_e4m3<T>(hin, d, M, d, b.x8, d, b.xscale, st));
             GemmF8 g;
             g.A = b.x8; g.lda = d; g.a_row_scale = b.xscale; g.B = b.mirror8 + o.m8Wqkvc; g.ldb = d; g.b_row_scale = b.mscale + o.s8Wqkvc;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
@@ -620,6 +628,13 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.drop = dropcfg(t, train, pd, l, SITE_FO);
             g.res = tb.u; g.ldr = d;
             g.ln_out = tb.hout; g.ln_stats = tb.stats2; g.ln_gamma = P + o.ln2g; g.ln_beta = P + o.ln2b; g.ln_eps = e->cfg.layer_norm_eps;
+            x8_ok = false;
+            if constexpr (sizeof(T) == 2) {
+                if (e->fp8 && !g_no_producer_quant && !sc && l + 1 < L && !g_force_tile && gemm_ws_supported(g) && gemm_ws_fuses_ln(g)) {
+                    g.q8 = b.x8; g.q8_scale = b.xscale;      // the next layer's input, quantised where it is produced
+                    x8_ok = true;
+                }
+            }
             RUN(linear<T>(e, "fwd.gemm_ffn2", g, st));
         }
         if (hidden_states)
@@ -1271,6 +1286,7 @@ void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }
 void pmgt_debug_disable_table_projection(int on) { g_no_table_proj = on; }
 void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
 void pmgt_debug_disable_head_major(int on) { g_no_hm = on; }
+void pmgt_debug_disable_producer_quant(int on) { g_no_producer_quant = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
@@ -1349,16 +1365,16 @@ int pmgt_op_gemm_tn_f8(const void* P, int64_t ldp, const void* Q8, int64_t ldq, 
     if (rc) return rc;
     return slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, accumulate != 0, (hipStream_t)stream);
 }
-int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* w8, const float* wscale, const float* bias, const float* mask, void* qkvc,
+int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* x8, const float* xscale, const void* w8, const float* wscale, const float* bias, const float* mask, void* qkvc,
                                   void* ctx, int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
                                   const uint64_t* rng, void* stream) {
     QkvcAttn f;
     const int d = H * dh;
-    f.X = x; f.ldx = d; f.W8 = w8; f.wscale = wscale; f.ldw = d; f.bias = bias; f.qkvc = qkvc; f.ldq = 4 * d; f.ctx = ctx; f.ldc = d;
+    f.X = x; f.X8 = x8; f.xscale = xscale; f.ldx = d; f.W8 = w8; f.wscale = wscale; f.ldw = d; f.bias = bias; f.qkvc = qkvc; f.ldq = 4 * d; f.ctx = ctx; f.ldc = d;
     f.mask = mask; f.Tseq = n_seq; f.S = S; f.H = H; f.dh = dh; f.beta = beta;
     f.drop1 = DropCfg{rng, drop_p, site1};
     f.drop2 = DropCfg{rng, drop_p, site2};
-    PMGT_CHECK(x && w8 && wscale && qkvc && ctx, -2, "pmgt_op_qkvc_attention_fwd_f8: NULL argument");
+    PMGT_CHECK((x || (x8 && xscale)) && w8 && wscale && qkvc && ctx, -2, "pmgt_op_qkvc_attention_fwd_f8: NULL argument");
     PMGT_CHECK(qkvc_attn_supported(f), -3, "pmgt_op_qkvc_attention_fwd_f8: unsupported shape (needs S = 32, dh = 32, d = 256)");
     return qkvc_attn_fwd(f, (hipStream_t)stream);
 }

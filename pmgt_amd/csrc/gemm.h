@@ -34,6 +34,10 @@ struct GemmWS : GemmNT {
     const float* ln_gamma = nullptr;
     const float* ln_beta = nullptr;
     float ln_eps = 1e-12f;
+    // fp8 mode, fused-LayerNorm form only: the LayerNorm output additionally leaves as per-row e4m3 (fp8.h contract) for the
+    // next layer's fp8 Q|K|V|C projection: q8 [M, N] bytes, q8_scale [M]
+    void* q8 = nullptr;
+    float* q8_scale = nullptr;
 };
 bool gemm_ws_supported(const GemmWS& g);
 bool gemm_ws_fuses_ln(const GemmWS& g);     // false: the caller runs LayerNorm as its own launch

@@ -14,6 +14,7 @@
 // placed on the same XCD so their A re-reads hit that XCD's L2.
 #include <type_traits>
 
+#include "fp8.h"
 #include "gemm.h"
 
 namespace pmgt {
@@ -228,17 +229,32 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
                 for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
                 ss = sum_lanes32(ss);
                 const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + g.ln_eps);
+                bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) {
                     if ((tid & 31) == 0) { g.ln_stats[2 * (int64_t)m] = mean; g.ln_stats[2 * (int64_t)m + 1] = rstd; }
                     const f32x4 g0 = *(const f32x4*)(cvec + 256 + ecol), g1 = *(const f32x4*)(cvec + 256 + ecol + 4);
                     const f32x4 b0 = *(const f32x4*)(cvec + 512 + ecol), b1 = *(const f32x4*)(cvec + 512 + ecol + 4);
-                    bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         o[e] = (bf16)((v[e] - mean) * rstd * g0[e] + b0[e]);
                         o[4 + e] = (bf16)((v[4 + e] - mean) * rstd * g1[e] + b1[e]);
                     }
                     *(bf16x8*)(LNO + (int64_t)m * g.ldc + n) = o;
+                }
+                if (g.q8) {      // (uniform) the row as e4m3 for the next layer's fp8 projection; every lane joins the row maximum
+                    float f[8], mx = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)o[e];      // the bf16 values that were stored: the quantisation of the STORED x
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx = raw_max(mx, fabsf(f[e]));
+                    mx = max_lanes32(mx);
+                    const float inv = mx > 0.f ? E4M3_MAX / mx : 1.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * inv, -E4M3_MAX, E4M3_MAX);
+                    if (ok) {
+                        *(u32x2*)((char*)g.q8 + (int64_t)m * g.N + n) = pack8_e4m3(f);
+                        if ((tid & 31) == 0) g.q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
+                    }
                 }
             }
         }

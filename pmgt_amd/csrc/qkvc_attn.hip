@@ -75,12 +75,6 @@ template <int KS> struct QaCfg {
     static constexpr int SMEM = 2 * TILEB + QTB + 8 * 64 * 4; // A ring + projection tile + per-wave {rho[32], madd[32]}
 };
 
-// v_max_f32 without the canonicalising self-max clang adds in front of fmaxf for values of unknown origin
-__device__ __forceinline__ float raw_max(float a, float b) {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
 // reduction over the 4 lanes l, l^16, l^32, l^48 in the VALU (v_permlane16/32_swap, see attention_mfma.hip)
 __device__ __forceinline__ float qred(float v, bool is_max) {
     float a = v, b = v;
@@ -384,7 +378,8 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
 // phase, so one's projection overlaps the other's attention.  Every A-tile fragment read now feeds 8 MFMAs instead of
 // 4: half the LDS traffic per row.
 //   wave w = (head uh = w >> 1, matrix pair mh = w & 1: {Q, K} or {V, C});  attention role (head uh, query half w & 1).
-template <int KS, bool F8 = false> struct QaCfg2 {
+// F8: 0 = bf16, 1 = fp8 projection with x quantised inside the kernel, 2 = fp8 projection on x that arrives as e4m3 rows + scales
+template <int KS, int F8 = 0> struct QaCfg2 {
     static constexpr int K = 32 * KS;
     static constexpr int ROWB = F8 ? K : K * 2;               // LDS bytes per row of the x tile (e4m3 in the fp8 mode)
     static constexpr int CPR = K / 8;                         // 8-element chunks per row (16 B of bf16 in HBM)
@@ -392,29 +387,22 @@ template <int KS, bool F8 = false> struct QaCfg2 {
     static constexpr int LPT = 32 * CPR / 256;
     static_assert(LPT * 256 == 32 * CPR, "tile must be a whole number of chunks per thread");
     static_assert(!F8 || CPR == 32, "fp8 form: one row per 32 lanes (hidden size 256)");
+    static_assert(F8 >= 0 && F8 <= 2, "F8 mode");
     static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
     static constexpr int QTB = 32 * 512;                      // projection tile: 32 rows x 256 bf16
     // A ring + projection tile + per-wave {rho, madd} + bias (+ fp8: channel scales of W, row scales of the two x tiles)
     static constexpr int SMEM = 2 * TILEB + QTB + 4 * 64 * 4 + 256 * 4 + (F8 ? 256 * 4 + 2 * 32 * 4 : 0);
 };
 
-// max over the 32 consecutive lanes [0, 32) / [32, 64) of a wave, result in every lane (cf. sum_lanes32 in common.h)
-__device__ __forceinline__ float max_lanes32(float v) {
-    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
-    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
-    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
-    v = raw_max(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
-    float x = v, y = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return raw_max(x, y);
-}
-
 // F8: same structure, the projection on the fp8 MFMA.  W fragments are 8 bytes (64 VGPRs per wave instead of 128); the x tile
 // is quantised per row (absmax over the 32 lanes that hold the row -> e4m3, fp8.h contract) on its way from the staging
 // registers into LDS, so the fragment reads move half the bytes; the 8-byte chunk index is XOR-swizzled by 2 (row & 15),
 // which spreads the 16 rows x 2 k-groups of a half-wave over 32 distinct 8-byte slots.  acc * rowscale * wscale + bias
-// gives the same bf16 projection tile; everything after it is unchanged.
-template <int KS, bool F8>
+// gives the same bf16 projection tile; everything after it is unchanged.  F8 == 2: the producer of x (the fused-LayerNorm
+// epilogue of gemm_ws / embed_mix, both HBM-bound with the row in 32 lanes) already wrote the e4m3 rows and their scales
+// (bit-identical to what the in-kernel quantisation computes from the bf16 x): the kernel reads half the bytes and its
+// VALU-bound attention phase loses the ~160 instructions of the quantisation.
+template <int KS, int F8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void qkvc_attn_fwd2_kernel(QkvcAttn a) {
     using C = QaCfg2<KS, F8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -436,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // local column of this wave's 16-column block cb: matrix 2 mh + (cb >> 1), head uh, half cb & 1
     auto cbase = [&](int cb) { return 64 * (2 * mh + (cb >> 1)) + 32 * uh + 16 * (cb & 1); };
 
-    using wfrag_t = std::conditional_t<F8, long, bf16x8>;
+    using wfrag_t = std::conditional_t<F8 != 0, long, bf16x8>;
     wfrag_t wf[4][KS];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
@@ -454,20 +442,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (F8) wscale_l[tid] = a.wscale[gcol(tid)];
 
     u32x4 ra[1][C::LPT];
+    float rsc = 1.f;                   // F8 == 2: scale of row (tid & 31) of the tile in flight
     auto gload = [&](int mt, int set) {
 #pragma unroll
         for (int i = 0; i < C::LPT; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / C::CPR, ch = idx % C::CPR;
-            ra[set][i] = *(const u32x4*)((const char*)a.X + ((int64_t)(mt * 32 + row) * a.ldx) * 2 + ch * 16);
+            if constexpr (F8 == 2) {
+                const u32x2 w = *(const u32x2*)((const char*)a.X8 + (int64_t)(mt * 32 + row) * a.ldx + ch * 8);
+                ra[set][i] = (u32x4){w[0], w[1], 0u, 0u};
+            } else {
+                ra[set][i] = *(const u32x4*)((const char*)a.X + ((int64_t)(mt * 32 + row) * a.ldx) * 2 + ch * 16);
+            }
         }
+        if constexpr (F8 == 2) rsc = a.xscale[(int64_t)mt * 32 + (tid & 31)];
     };
     auto sstore = [&](int buf, int set) {
 #pragma unroll
         for (int i = 0; i < C::LPT; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / C::CPR, ch = idx % C::CPR;
-            if constexpr (F8) {
+            if constexpr (F8 == 2) {
+                *(u32x2*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ ((row & 15) << 1)) << 3)) = (u32x2){ra[set][i][0], ra[set][i][1]};
+            } else if constexpr (F8 == 1) {
                 const bf16x8 xv = __builtin_bit_cast(bf16x8, ra[set][i]);
                 float f[8], m = 0.f;
 #pragma unroll
@@ -482,6 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
             }
         }
+        if constexpr (F8 == 2) { if (tid < 32) rowscale_l[buf * 32 + tid] = rsc; }
     };
 
     const QaAttnConst kc = qa_attn_const(a, r, q);
@@ -571,8 +569,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 bool qkvc_attn_supported(const QkvcAttn& a) {
     const int d = a.H * 32;
     if (a.W8 && !(d == 256 && a.wscale && ((uintptr_t)a.W8 % 8) == 0)) return false;
+    if (a.X8 && !(a.W8 && a.xscale && ((uintptr_t)a.X8 % 8) == 0)) return false;
     return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.H % 2 == 0 && a.Tseq >= 2 && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
-           a.ldq % 8 == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0 &&
+           a.ldq % 8 == 0 && a.ldc % 4 == 0 && (a.X8 != nullptr || (a.X != nullptr && ((uintptr_t)a.X % 16) == 0)) && ((uintptr_t)a.W % 16) == 0 &&
            ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.ctx % 8) == 0 && (a.bias == nullptr || ((uintptr_t)a.bias % 16) == 0) &&
            (a.W != nullptr || a.W8 != nullptr);
 }
@@ -592,7 +591,7 @@ template <int KS> static int launch_qa(const QkvcAttn& a, hipStream_t st) {
     return 0;
 }
 
-template <int KS, bool F8 = false> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
+template <int KS, int F8 = 0> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
     using C = QaCfg2<KS, F8>;
     auto kern = qkvc_attn_fwd2_kernel<KS, F8>;
     static bool attr_done = false;
@@ -615,7 +614,8 @@ static bool qa_form1() {
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
     if (a.Tseq <= 0) return 0;
     PMGT_CHECK(qkvc_attn_supported(a), -2, "qkvc_attn_fwd: unsupported shape S=%d dh=%d H=%d", a.S, a.dh, a.H);
-    if (a.W8) return launch_qa2<8, true>(a, st);
+    if (a.W8 && a.X8) return launch_qa2<8, 2>(a, st);
+    if (a.W8) return launch_qa2<8, 1>(a, st);
     if (qa_form1()) return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
     return a.H * 32 == 256 ? launch_qa2<8>(a, st) : launch_qa2<4>(a, st);
 }

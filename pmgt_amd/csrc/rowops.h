@@ -43,6 +43,8 @@ struct EmbedMix {
     void* pre = nullptr;           // [M, d] LayerNorm input (saved)
     float* stats = nullptr;        // [M, 2]
     void* h0 = nullptr;            // [M, d] output
+    void* q8 = nullptr;            // fp8 mode: h0 additionally as per-row e4m3 (fp8.h contract) [M, d] bytes ...
+    float* q8_scale = nullptr;     // ... and its scales [M], for the first layer's fp8 Q|K|V|C projection
     DropCfg drop = {nullptr, 0.f, 0};
     // backward only
     const void* dh0 = nullptr;     // [M, d]

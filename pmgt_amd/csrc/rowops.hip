@@ -2,6 +2,7 @@
 // One wave (64 lanes) owns one row; a lane holds 4-element chunks `lane + 64*i` of the row in
 // registers (d <= 1024), so every row is read once and reduced with wave shuffles.  These kernels
 // are HBM-bound: algorithmic bytes per row are listed in DESIGN.md.
+#include "fp8.h"
 #include "rowops.h"
 
 namespace pmgt {
@@ -257,17 +258,40 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)d + p.eps);
     if (lane == 0) { p.stats[2 * (int64_t)m] = mean; p.stats[2 * (int64_t)m + 1] = rstd; }
     const DropKey dk = make_drop_key(p.drop);
+    f32x4 oq[NCH];
+    float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
+        oq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (ch < nch) {
             f32x4 o = (x[i] - mean) * rstd * *(const f32x4*)(p.gamma + 4 * ch) + *(const f32x4*)(p.beta + 4 * ch);
             if (dk.on) {
-{ float dm[4]; drop_mul4(dk, (uint32_t)m, (uint32_t)ch, dm);
+                float dm[4];
+                drop_mul4(dk, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] *= dm[e]; }
+                for (int e = 0; e < 4; ++e) o[e] *= dm[e];
             }
             store4<T>((T*)p.h0 + (int64_t)m * d + 4 * ch, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oq[i][e] = to_f<T>(from_f<T>(o[e])); mx = fmaxf(mx, fabsf(oq[i][e])); }
+        }
+    }
+    if (p.q8) {      // (uniform) the stored row once more as e4m3 + scale (fp8.h contract)
+        mx = wave_max(mx);
+        const float inv = mx > 0.f ? E4M3_MAX / mx : 1.f;
+        if (lane == 0) p.q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[i][0] * inv, -E4M3_MAX, E4M3_MAX),
+                                                    __builtin_amdgcn_fmed3f(oq[i][1] * inv, -E4M3_MAX, E4M3_MAX), w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[i][2] * inv, -E4M3_MAX, E4M3_MAX),
+                                                    __builtin_amdgcn_fmed3f(oq[i][3] * inv, -E4M3_MAX, E4M3_MAX), w, true);
+                *(int*)((char*)p.q8 + (int64_t)m * d + 4 * ch) = w;
+            }
         }
     }
 }

@@ -164,7 +164,7 @@ def test_fused_qkvc_attention_with_fp8_projection(T, beta, drop):
     rng = torch.tensor([1234, 5], dtype=torch.int64, device="cuda")
     q1 = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
     c1 = torch.full((T, S, d), float("nan"), device="cuda", dtype=torch.bfloat16)
-    _lib.check(L.pmgt_op_qkvc_attention_fwd_f8(P(xd), P(W8), P(ws), P(bd), P(md), P(q1), P(c1), T, S, H, dh, beta, drop, 17, 18,
+    _lib.check(L.pmgt_op_qkvc_attention_fwd_f8(P(xd), None, None, P(W8), P(ws), P(bd), P(md), P(q1), P(c1), T, S, H, dh, beta, drop, 17, 18,
                                                P(rng), stream()))
     assert torch.isfinite(q1.float()).all() and torch.isfinite(c1.float()).all()
     # projection against the emulation (fp64 product of the dequantised operands)
@@ -183,6 +183,11 @@ def test_fused_qkvc_attention_with_fp8_projection(T, beta, drop):
     _lib.check(L.pmgt_op_quant_rows_e4m3(1, P(xd), d, M, d, P(x8), d, P(xs), stream()))
     _lib.check(L.pmgt_op_gemm_nt_f8(P(x8), d, None, P(xs), 1.0, P(W8), d, P(ws), P(q2), 4 * d, M, 4 * d, d, P(bd), None, stream()))
     assert rel_err(q1, q2) < 4e-3 and (q1 != q2).float().mean().item() < 0.02      # same products; fp32 sum order differs
+    # x handed over already quantised (what the engine does: the producer of x writes the e4m3 rows): bit-identical outputs
+    q3, c3 = torch.full_like(q1, float("nan")), torch.full_like(c1, float("nan"))
+    _lib.check(L.pmgt_op_qkvc_attention_fwd_f8(None, P(x8), P(xs), P(W8), P(ws), P(bd), P(md), P(q3), P(c3), T, S, H, dh, beta, drop, 17, 18,
+                                               P(rng), stream()))
+    assert torch.equal(q3, q1) and torch.equal(c3, c1)
     # attention half
     c2 = torch.empty_like(c1)
     _lib.check(L.pmgt_op_attention_fwd(1, P(q1), P(md), P(c2), None, T, S, H, dh, beta, drop, 17, 18, P(rng), stream()))
@@ -246,6 +251,14 @@ def test_fp8_engine_paths_agree_and_train():
     eng = make_engine(case, dtype="fp8")
     base = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
     g0 = eng.grads.clone()
+    # layer inputs quantised by their producer (default) or by their consumer: the same bytes, hence the same step
+    L.pmgt_debug_disable_producer_quant(1)
+    try:
+        eng.rng_state[1] = 0
+        o = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
+    finally:
+        L.pmgt_debug_disable_producer_quant(0)
+    assert o["loss"].item() == base["loss"].item() and torch.equal(eng.grads, g0)
     for switch in (L.pmgt_debug_disable_fused_qkvc_attention, L.pmgt_debug_disable_table_projection, L.pmgt_debug_disable_last_layer_shortcut):
         switch(1)
         try:
