@@ -368,6 +368,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + (int64_t)kt * ROWB),
                                              (lds_void_t*)(st + BM * ROWB + 16 * (BI * wave + j) * ROWB), 16, 0, 0);
     };
+    // one DMA instruction of a stage (piece 0 .. AI - 1: A rows, AI .. PER - 1: B rows)
+    auto issue_piece = [&](int kt, int piece) __attribute__((always_inline)) {
+        char* st = smem + (kt % NST) * STAGE;
+        if (piece < AI)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[piece] + (int64_t)kt * ROWB),
+                                             (lds_void_t*)(st + 16 * (AI * wave + piece) * ROWB), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[piece - AI] + (int64_t)kt * ROWB),
+                                             (lds_void_t*)(st + BM * ROWB + 16 * (BI * wave + piece - AI) * ROWB), 16, 0, 0);
+    };
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -394,6 +404,126 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
 #else
 #define NT_STAMP(k_) do { } while (0)
 #endif
+    if constexpr (BN == 256) {
+        // ---- main loop, rolling-prefetch form (no extra registers).  Per k-step the eight waves read 96 KB of fragments from
+        // LDS (768 cycles of the LDS pipe) and run 1024 cycles of MFMA per SIMD; with all twelve reads of a step issued at its
+        // top, both waves of a SIMD first wait for LDS and then queue for the matrix pipe (stamps: ~2000 cycles per step).
+        // Here the step is four QUADRANTS of 8 MFMAs (A halves A0 = fragments 0..3, A1 = 4..7; B halves B0 = 8, 9, B1 = 10, 11)
+        // walked in snake order, and each half is re-loaded for the NEXT step as soon as its last quadrant has been issued:
+        //     even step:  Q(A0,B0)  Q(A0,B1) | mid |  ld A0'  Q(A1,B1)  ld B1'  Q(A1,B0)  ld B0', A1'
+        //     odd step:   Q(A0,B1)  Q(A0,B0) | mid |  ld A0'  Q(A1,B0)  ld B0'  Q(A1,B1)  ld B1', A1'
+        // so every read is in flight for at least one quadrant (128 matrix-pipe cycles) before its first use and the LDS
+        // traffic is spread over the whole step.  `mid` = lgkmcnt(0) [every read of stage kt has landed] -> vmcnt [own DMAs of
+        // stage kt + 1] -> s_barrier -> DMA of stage kt + 4 into ring slot kt % 4 (free: all waves are past their last read
+        // of stage kt).  One barrier per step as before; prefetch distance 4 on the 4-slot ring.
+        u32x4 t[12];
+        const uint32_t aA0 = lds_base + offa[0], aB0 = lds_base + offb[0];      // offa[i] = offa[0] + 1024 i, offb[j] = offb[0] + 1024 j
+#define NT_LD_A(H, ADDR)                                                                                                  \
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"     \
+                     "ds_read_b128 %3, %4 offset:%8"                                                                       \
+                     : "=&v"(t[4 * (H)]), "=&v"(t[4 * (H) + 1]), "=&v"(t[4 * (H) + 2]), "=&v"(t[4 * (H) + 3])                  \
+                     : "v"(ADDR), "n"(4096 * (H)), "n"(4096 * (H) + 1024), "n"(4096 * (H) + 2048), "n"(4096 * (H) + 3072)     \
+                     : "memory")
+#define NT_LD_B(H, ADDR)                                                                                                  \
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                       \
+                     : "=&v"(t[8 + 2 * (H)]), "=&v"(t[8 + 2 * (H) + 1])                                                     \
+                     : "v"(ADDR), "n"(2048 * (H)), "n"(2048 * (H) + 1024)                                                   \
+                     : "memory")
+#define NT_QUAD(AH, BH)                                                                                                    \
+        do {                                                                                                              \
+            _Pragma("unroll") for (int i_ = 4 * (AH); i_ < 4 * (AH) + 4; ++i_)                                             \
+                _Pragma("unroll") for (int j_ = 2 * (BH); j_ < 2 * (BH) + 2; ++j_)                                         \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i_]),               \
+                                                                          __builtin_bit_cast(bf16x8, t[8 + j_]), acc[i_][j_], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        } while (0)
+        static_assert(PER == 4 && NST == 4, "vmcnt constants below: 4 DMA instructions per wave per stage, 4 ring slots");
+        // (a static s_setprio(1) for the younger half of the workgroup only moves the 300-cycle lag to the other half: the two
+        // waves of a SIMD share one matrix pipe)
+#pragma unroll
+        for (int kt = 0; kt < NST; ++kt)
+            if (kt < nk) issue(kt);
+        NT_STAMP(4);
+        {   // stage 0 landed for everyone, then its twelve reads in the order an odd step leaves them: A0, B0, B1, A1
+            const int younger = min(NST - 1, nk - 1);
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            NT_LD_A(0, aA0); NT_LD_B(0, aB0); NT_LD_B(1, aB0); NT_LD_A(1, aA0);
+        }
+        auto mid = [&](int kt) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+            if (kt + 1 < nk) {
+                const int younger = min(kt + 3, nk - 1) - (kt + 1);      // stages issued so far: 0 .. min(kt + 3, nk - 1)
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            NT_STAMP(0);
+            __builtin_amdgcn_s_barrier();
+            NT_STAMP(1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // The four DMA instructions of stage kt + 4 go out ONE PER QUADRANT after the barrier of step kt (ring slot kt % 4 is
+        // free from there on), the last one in the first half of step kt + 1: issued together right after the barrier they cost
+        // every wave 380-630 cycles (stamps; the address path takes 64 B per clock per CU, i.e. 512 cycles for the 32 KB of a
+        // stage) during which it issues no MFMA.  Every piece of a stage is still issued before the NEXT step's barrier, so the
+        // vmcnt ladder above is unchanged.
+#define NT_DMA(KT, PIECE)                                                 \
+        do {                                                              \
+            if ((KT) + NST < nk) issue_piece((KT) + NST, (PIECE));        \
+            __builtin_amdgcn_sched_barrier(0);                            \
+        } while (0)
+        // two steps per loop iteration, straight-line (nk is even: K % 64 == 0 is a launch condition of this tile) -- with the
+        // even / odd forms under an `if` the accumulators meet in phi nodes and the compiler stops updating them in place
+        for (int kt = 0; kt < nk; kt += 2) {
+            {
+                const uint32_t so = (uint32_t)(((kt + 1) % NST) * STAGE);
+                const uint32_t aA = aA0 + so, aB = aB0 + so;
+                // entry: outstanding reads in issue order A0(4) B0(2) B1(2) A1(4)
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[8]), "+v"(t[9]));
+                NT_QUAD(0, 0);
+                if (kt > 0) NT_DMA(kt - 1, 3);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t[10]), "+v"(t[11]));
+                NT_QUAD(0, 1);
+                mid(kt);
+                NT_DMA(kt, 0);
+                NT_LD_A(0, aA);                          // (kt + 1 < nk always: nk is even)
+                NT_QUAD(1, 1);
+                NT_DMA(kt, 1);
+                NT_LD_B(1, aB);
+                NT_QUAD(1, 0);
+                NT_DMA(kt, 2);
+                NT_LD_B(0, aB); NT_LD_A(1, aA);
+            }
+            {
+                const bool more = kt + 2 < nk;          // (uniform)
+                const uint32_t so = (uint32_t)(((kt + 2) % NST) * STAGE);
+                const uint32_t aA = aA0 + so, aB = aB0 + so;
+                // entry: outstanding reads in issue order A0(4) B1(2) B0(2) A1(4)
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[10]), "+v"(t[11]));
+                NT_QUAD(0, 1);
+                NT_DMA(kt, 3);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t[8]), "+v"(t[9]));
+                NT_QUAD(0, 0);
+                mid(kt + 1);
+                NT_DMA(kt + 1, 0);
+                if (more) NT_LD_A(0, aA);
+                NT_QUAD(1, 0);
+                NT_DMA(kt + 1, 1);
+                if (more) NT_LD_B(0, aB);
+                NT_QUAD(1, 1);
+                NT_DMA(kt + 1, 2);
+                if (more) { NT_LD_B(1, aB); NT_LD_A(1, aA); }
+            }
+        }
+#undef NT_LD_A
+#undef NT_DMA
+#undef NT_LD_B
+#undef NT_QUAD
+    } else {
 #pragma unroll
     for (int kt = 0; kt < NST - 1; ++kt)
         if (kt < nk) issue(kt);
@@ -448,6 +578,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
             // every wave has passed this step's barrier)
             if (i == 3 && kt + NST - 1 < nk) issue(kt + NST - 1);
         }
+    }
     }
     NT_STAMP(3);
     __builtin_amdgcn_s_barrier();       // the ring becomes the staging buffer
@@ -570,7 +701,7 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
             static int narrow = -1;
             if (narrow < 0) { const char* ev = getenv("PMGT_NT_BIG_BN"); narrow = ev ? atoi(ev) : 0; }
             const int nm = cdiv(g.M, 256);
-            if (g.N % 256 == 0 && narrow != 128) {
+            if (g.N % 256 == 0 && g.K % 64 == 0 && narrow != 128) {      // (K % 64: the 256-wide tile walks k-steps in pairs)
                 constexpr int smem = 4 * (256 + 256) * 64;
                 static bool attr_set = false;
                 if (!attr_set) {
