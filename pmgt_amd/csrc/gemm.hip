@@ -408,6 +408,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         // ---- main loop, rolling-prefetch form (no extra registers).  Per k-step the eight waves read 96 KB of fragments from
         // LDS (768 cycles of the LDS pipe) and run 1024 cycles of MFMA per SIMD; with all twelve reads of a step issued at its
         // top, both waves of a SIMD first wait for LDS and then queue for the matrix pipe (stamps: ~2000 cycles per step).
+        // The MFMA operands are SWAPPED (D = W_frag x A_frag^T): acc[i][j][e] = out[16 i + r][16 j + 4 q + e], a lane owns four
+        // CONSECUTIVE output columns of one row -- the epilogue below pairs two such blocks with v_permlane16_swap and stores 16
+        // bytes per lane straight from the registers (or stages them with ds_write_b128 instead of four ds_write_b32).
         // Here the step is four QUADRANTS of 8 MFMAs (A halves A0 = fragments 0..3, A1 = 4..7; B halves B0 = 8, 9, B1 = 10, 11)
         // walked in snake order, and each half is re-loaded for the NEXT step as soon as its last quadrant has been issued:
         //     even step:  Q(A0,B0)  Q(A0,B1) | mid |  ld A0'  Q(A1,B1)  ld B1'  Q(A1,B0)  ld B0', A1'
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         do {                                                                                                              \
             _Pragma("unroll") for (int i_ = 4 * (AH); i_ < 4 * (AH) + 4; ++i_)                                             \
                 _Pragma("unroll") for (int j_ = 2 * (BH); j_ < 2 * (BH) + 2; ++j_)                                         \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i_]),               \
-                                                                          __builtin_bit_cast(bf16x8, t[8 + j_]), acc[i_][j_], 0, 0, 0); \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[8 + j_]),           \
+                                                                          __builtin_bit_cast(bf16x8, t[i_]), acc[i_][j_], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                                            \
         } while (0)
         static_assert(PER == 4 && NST == 4, "vmcnt constants below: 4 DMA instructions per wave per stage, 4 ring slots");
@@ -602,6 +605,58 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
             dst[it] = *(const bf16x8*)(R + (int64_t)m * g.ldr + n0 + ec);
         }
     };
+    constexpr bool SWAPPED = BN == 256;             // accumulator layout of the main loop above (see there)
+    if constexpr (SWAPPED) {
+        if (g.epi == EPI_NONE && !dk.on) {
+            // ---- direct epilogue (bias / residual only: the data-gradient GEMMs): no LDS staging, no barriers.  Blocks (j, j + 1)
+            // of a row are paired with v_permlane16_swap (fp32), after which lane (r, q) owns 8 consecutive columns of row
+            // 16 i + r: one 16-byte residual load and one 16-byte store per lane, 64 contiguous bytes per row and instruction.
+            // The staged form cost 15.5k of a tile's 74k cycles (stamps), with one workgroup per CU nothing overlaps it.
+            const int cb = ((q & 1) << 4) | ((q & 2) << 2);          // q = 0, 1, 2, 3 -> columns 0, 16, 8, 24 of the 32-column pair
+            const int ncol = n0 + wn * 64 + cb;
+            u32x4 rr[8][2];
+            if (R) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = min(m0 + wm * 128 + 16 * i + r, g.M - 1);
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) rr[i][pr] = *(const u32x4*)(R + (int64_t)m * g.ldr + ncol + 32 * pr);
+                }
+            }
+            f32x4 bv[2][2];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                bv[pr][0] = g.bias ? *(const f32x4*)(g.bias + ncol + 32 * pr) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                bv[pr][1] = g.bias ? *(const f32x4*)(g.bias + ncol + 32 * pr + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + 16 * i + r;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    f32x4 a = acc[i][2 * pr], b = acc[i][2 * pr + 1];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+                                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+                    a += bv[pr][0];
+                    b += bv[pr][1];
+                    if (R) {
+                        const bf16x8 rv8 = __builtin_bit_cast(bf16x8, rr[i][pr]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] += (float)rv8[e]; b[e] += (float)rv8[4 + e]; }
+                    }
+                    const bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+                    if (m < g.M) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ncol + 32 * pr) = o;
+                }
+            }
+#ifdef PMGT_TN_PROF
+            NT_STAMP(5);
+            if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
+                for (int k_ = 0; k_ < 6; ++k_) g_nt_prof[blockIdx.x == 0 ? 0 : 1][wave][k_] = pacc[k_];
+#endif
+            return;
+        }
+    }
     if (R) load_res(0, rv[0]);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -610,10 +665,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SWAPPED) {
+                        *(f32x4*)(stage + (ii * 16 + r) * ES + wn * 64 + j * 16 + 4 * q) = acc[(pass & 1) * 4 + ii][j];
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        stage[(ii * 16 + 4 * q + e) * ES + wn * 64 + j * 16 + r] = acc[(pass & 1) * 4 + ii][j][e];
+                        for (int e = 0; e < 4; ++e)
+                            stage[(ii * 16 + 4 * q + e) * ES + wn * 64 + j * 16 + r] = acc[(pass & 1) * 4 + ii][j][e];
+                    }
+                }
         }
         __syncthreads();
 #pragma unroll
