@@ -219,6 +219,8 @@ def main():
         if w is not None:
             flops, byts = w
             peak_t = MFMA_F32_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
+            if args.dtype == "fp8" and dom == "fwd.qkvc_attention":
+                byts = M * d * (1 + 5 * esz) + M * 4        # x arrives as e4m3 rows + one fp32 scale per row; outputs stay bf16
             if flops > 0 and flops / (peak_t * 1e12) >= byts / (HBM_PEAK_GBS * 1e9):
                 ach = flops / avg_s / 1e12
                 out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": peak_t,
@@ -237,7 +239,7 @@ def main():
         try:
             tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
             ph = tr["phases"].get(out["roofline"]["kernel"])
-            if ph and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate:
+            if ph and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16":
                 out["roofline"]["traffic"] = ph["hbm_mb_per_launch"]
                 out["roofline"]["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
         except (OSError, KeyError, ValueError):
