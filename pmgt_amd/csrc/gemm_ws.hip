@@ -228,7 +228,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
                 ss = sum_lanes32(ss);
-                const float rstd = 1.f / sqrtf(ss * (1.f / 256.f) + g.ln_eps);
+                // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequences (~40 VALU instructions per row pass in an epilogue that
+                // in-kernel stamps show VALU-bound: 5.4k / 9.1k cycles per tile on the older / younger wave of a SIMD)
+                const float rstd = __builtin_amdgcn_rsqf(ss * (1.f / 256.f) + g.ln_eps);
                 bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) {
                     if ((tid & 31) == 0) { g.ln_stats[2 * (int64_t)m] = mean; g.ln_stats[2 * (int64_t)m + 1] = rstd; }
