@@ -19,15 +19,25 @@
 
 namespace pmgt {
 
-template <int KS> struct WsCfg {
+// NW = waves per workgroup.  8: one 512-thread workgroup per CU, 64-row tiles, wave w owns 32 output columns.  4: TWO 256-thread
+// workgroups per CU (as qkvc_attn_fwd2_kernel), 32-row tiles, wave w owns 64 output columns (128 VGPRs of W at K = 256): in-kernel
+// stamps show the 8-wave form marching through an MFMA phase (2.8k cycles per tile) and a VALU-bound epilogue phase (9k cycles with
+// the fused LayerNorm) in lockstep between barriers; two workgroups drift out of phase, so one's epilogue overlaps the other's MFMAs.
+template <int KS, int NW = 8> struct WsCfg {
     static constexpr int K = 32 * KS;
+    static constexpr int NT = 64 * NW;                 // threads
+    static constexpr int TR = 8 * NW;                  // tile rows
+    static constexpr int IT = TR / 16;                 // 16-row MFMA tiles per wave
+    static constexpr int JW = 16 / NW;                 // 16-column MFMA tiles per wave
+    static constexpr int PR = NT / 32;                 // rows per epilogue pass (32 lanes per row): 4 passes per tile
     static constexpr int ROWB = K * 2;                 // A tile row bytes
     static constexpr int CPR = K / 8;                  // 16-byte chunks per row
-    static constexpr int TILEB = 64 * ROWB;
-    static constexpr int LPT = 64 * CPR / 512;         // chunks per thread per tile (K >= 64)
-    static_assert(LPT * 512 == 64 * CPR, "tile must be a whole number of chunks per thread");
+    static constexpr int TILEB = TR * ROWB;
+    static constexpr int LPT = TR * CPR / NT;          // chunks per thread per tile (K >= 64)
+    static_assert(LPT * NT == TR * CPR, "tile must be a whole number of chunks per thread");
+    static_assert(NW == 8 || NW == 4, "waves per workgroup");
     static constexpr int ES = 256 + 4;                 // staging row stride (floats)
-    static constexpr int SMEM = 2 * TILEB + 64 * ES * 4 + 3 * 256 * 4;   // A ring + staging + bias/gamma/beta
+    static constexpr int SMEM = 2 * TILEB + TR * ES * 4 + 3 * 256 * 4;   // A ring + staging + bias/gamma/beta
     static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
 };
 
@@ -44,14 +54,14 @@ __device__ unsigned int g_ws_prof[2][8][8];
 #define WS_STAMP(k_) do { } while (0)
 #endif
 
-template <int KS, int MODE>
-__global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
+template <int KS, int MODE, int NW>
+__device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
     constexpr bool HAS_PF = MODE == WS_GELU_GRAD || MODE == WS_RES || MODE == WS_RES_LN;
-    using C = WsCfg<KS>;
+    using C = WsCfg<KS, NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     float* stage = (float*)(smem + 2 * C::TILEB);
-    float* cvec = stage + 64 * C::ES;       // [3][256]: bias, LN gamma, LN beta of this column slab (LDS, so the
+    float* cvec = stage + C::TR * C::ES;       // [3][256]: bias, LN gamma, LN beta of this column slab (LDS, so the
                                             // epilogue never waits on vmcnt for them)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -62,13 +72,13 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
     const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
     const int gx = gridDim.x / ny;
     const int nb = y * 256;
-    const int num_mt = (g.M + 63) / 64;
+    const int num_mt = (g.M + C::TR - 1) / C::TR;
 
-    // ---- resident W fragments: rows n = nb + 32 wave + 16 j + r, k = 32 ks + 8 q
-    bf16x8 wf[2][KS];
+    // ---- resident W fragments: rows n = nb + 16 JW wave + 16 j + r, k = 32 ks + 8 q
+    bf16x8 wf[C::JW][KS];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nb + 32 * wave + 16 * j + r;
+    for (int j = 0; j < C::JW; ++j) {
+        const int n = nb + 16 * C::JW * wave + 16 * j + r;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (n < g.N) wf[j][ks] = *(const bf16x8*)((const bf16*)g.B + (int64_t)n * g.ldb + 32 * ks + 8 * q);
@@ -76,27 +86,27 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
         }
     }
 
-    if (tid < 256) {
+    if (tid < 256) {      // (every thread of the 4-wave form)
         const int n = nb + tid;
         cvec[tid] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
         cvec[256 + tid] = (g.ln_out && n < g.N) ? g.ln_gamma[n] : 0.f;
         cvec[512 + tid] = (g.ln_out && n < g.N) ? g.ln_beta[n] : 0.f;
     }
 
-    u32x4 ra[2][C::LPT];
+    u32x4 ra[NW == 8 ? 2 : 1][C::LPT];
     auto gload = [&](int mt, int set) {
 #pragma unroll
         for (int i = 0; i < C::LPT; ++i) {
-            const int idx = tid + 512 * i;
+            const int idx = tid + C::NT * i;
             const int row = idx / C::CPR, ch = idx % C::CPR;
-            const int m = min(mt * 64 + row, g.M - 1);
+            const int m = min(mt * C::TR + row, g.M - 1);
             ra[set][i] = *(const u32x4*)((const char*)g.A + ((int64_t)m * g.lda) * 2 + ch * 16);
         }
     };
     auto sstore = [&](int buf, int set) {
 #pragma unroll
         for (int i = 0; i < C::LPT; ++i) {
-            const int idx = tid + 512 * i;
+            const int idx = tid + C::NT * i;
             const int row = idx / C::CPR, ch = idx % C::CPR;
             *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
         }
@@ -132,50 +142,61 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
         if constexpr (HAS_PF) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {      // clamped, unconditional loads (values of padding rows are unused)
-                const int m = min(mt * 64 + erow + 16 * ps, g.M - 1), n = min(nb + ecol, g.N - 8);
+                const int m = min(mt * C::TR + erow + C::PR * ps, g.M - 1), n = min(nb + ecol, g.N - 8);
                 pf[ps] = *(const bf16x8*)(PF + (int64_t)m * ldpf + n);
             }
         }
-        sstore(P, P);
-        if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
+        if constexpr (NW == 8) {
+            sstore(P, P);
+            if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
+        }
         WS_STAMP(1);
         __syncthreads();
         WS_STAMP(2);
-        f32x4 acc[4][2];
+        // 4-wave form: ONE tile in flight in registers (the W fragments take 128 of the 256): loaded here, at the start of the
+        // MFMA phase, parked in the other LDS buffer after the second barrier (that buffer was last read in the previous step's
+        // MFMA phase)
+        const bool more4 = NW == 4 && mt + gx < num_mt;
+        if constexpr (NW == 4) { if (more4) gload(mt + gx, 0); }
+        f32x4 acc[C::IT][C::JW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+        for (int i = 0; i < C::IT; ++i)
+#pragma unroll
+            for (int j = 0; j < C::JW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const char* a_base = sA + P * C::TILEB;
+        if constexpr (NW == 4) __builtin_amdgcn_s_setprio(3);      // the MFMA phase of this workgroup over the other one's VALU phase
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 fa[4];
+            bf16x8 fa[C::IT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < C::IT; ++i) {
                 const int row = 16 * i + r;
                 fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], wf[0][ks], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], wf[1][ks], acc[i][1], 0, 0, 0);
-            }
+            for (int i = 0; i < C::IT; ++i)
+#pragma unroll
+                for (int j = 0; j < C::JW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], wf[j][ks], acc[i][j], 0, 0, 0);
         }
         WS_STAMP(3);
-        // ---- stage the 64 x 256 fp32 tile (row = 16 i + 4 q + e, col = 32 wave + 16 j + r)
+        // ---- stage the TR x 256 fp32 tile (row = 16 i + 4 q + e, col = 16 JW wave + 16 j + r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < C::IT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < C::JW; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    stage[(16 * i + 4 * q + e) * C::ES + 32 * wave + 16 * j + r] = acc[i][j][e];
+                    stage[(16 * i + 4 * q + e) * C::ES + 16 * C::JW * wave + 16 * j + r] = acc[i][j][e];
+        if constexpr (NW == 4) __builtin_amdgcn_s_setprio(0);
         WS_STAMP(4);
         __syncthreads();
         WS_STAMP(5);
-        // ---- row-contiguous epilogue: 16 rows per pass, 4 passes
+        if constexpr (NW == 4) { if (more4) sstore(P ^ 1, 0); }
+        // ---- row-contiguous epilogue: PR rows per pass, 4 passes
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int row = erow + 16 * ps;
-            const int m = mt * 64 + row;
+            const int row = erow + C::PR * ps;
+            const int m = mt * C::TR + row;
             const int n = nb + ecol;
             const bool ok = m < g.M && n < g.N;
             float v[8];
@@ -259,6 +280,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
                     }
                 }
             }
+            if constexpr (NW == 4) __builtin_amdgcn_sched_barrier(0);      // one pass at a time: 128 of the 256 VGPRs hold W
         }
         // the next tile's staging writes happen after its first barrier, which every wave reaches only after
         // finishing this epilogue; its A-tile write targets the other LDS buffer.
@@ -266,7 +288,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
 
     int mt = x;
     if (mt < num_mt) gload(mt, 0);
-    if (mt + gx < num_mt) gload(mt + gx, 1);
+    if constexpr (NW == 8) { if (mt + gx < num_mt) gload(mt + gx, 1); }
+    else { if (mt < num_mt) sstore(0, 0); }
     while (mt < num_mt) {
         tile_step(std::integral_constant<int, 0>{}, mt);
         mt += gx;
@@ -279,6 +302,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
         for (int k_ = 0; k_ < 8; ++k_) g_ws_prof[blockIdx.x == 0 ? 0 : 1][wave][k_] = pacc[k_];
 #endif
+}
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(GemmWS g) {
+    gemm_ws_body<KS, MODE, 8>(g);
+}
+template <int KS, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_ws2_kernel(GemmWS g) {
+    gemm_ws_body<KS, MODE, 4>(g);
 }
 
 static int ws_mode(const GemmWS& g) {
@@ -297,15 +329,45 @@ bool gemm_ws_supported(const GemmWS& g) {
 }
 bool gemm_ws_fuses_ln(const GemmWS& g) { return gemm_ws_supported(g) && ws_mode(g) == WS_RES_LN; }
 
+// Which form runs (A/B on one box, c2 shapes, ms per step of the phase, 8-wave -> two 4-wave workgroups):
+//   GELU (ffn1) 0.389 -> 0.362, GELU' (dgrad_ffn2) 0.467 -> 0.438, plain (dgrad_attn_out) 0.250 -> 0.243: VALU-heavy epilogues
+//   with nothing but the A stream to prefetch -- the overlap pays;
+//   residual (dgrad_ffn1) 0.333 -> 0.393, residual + LayerNorm (attn_out, ffn2) 0.58 -> 0.68 / 0.56 -> 0.66: the residual
+//   prefetch and the LayerNorm temporaries do not fit next to 128 VGPRs of W (30 spilled), and one tile in flight per
+//   workgroup instead of two costs memory-level parallelism on launches that are served from the Infinity Cache.
+// PMGT_WS_FORM=1 / 2 forces one form everywhere (the two-workgroup form needs K >= 128: chunks per thread).
+static int ws_form(int mode) {
+    static const int v = [] { const char* e = getenv("PMGT_WS_FORM"); return e ? atoi(e) : 0; }();
+    if (v == 1 || v == 2) return v;
+    return (mode == WS_GELU || mode == WS_GELU_GRAD || mode == WS_PLAIN) ? 2 : 1;
+}
+
 template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st) {
-    using C = WsCfg<KS>;
+    const int ny = cdiv(g.N, 256);
+    if constexpr (KS >= 4) {
+        if (ws_form(MODE) == 2) {
+            using C = WsCfg<KS, 4>;
+            auto kern = gemm_ws2_kernel<KS, MODE>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+                attr_done = true;
+            }
+            const int num_mt = cdiv(g.M, C::TR);
+            const int gx = std::max(8, std::min(512 / ny, num_mt) / 8 * 8);      // two workgroups per CU
+            hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(C::NT), C::SMEM, st, g);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
+    }
+    using C = WsCfg<KS, 8>;
     auto kern = gemm_ws_kernel<KS, MODE>;
     static bool attr_done = false;
     if (!attr_done) {
         PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
         attr_done = true;
     }
-    const int ny = cdiv(g.N, 256), num_mt = cdiv(g.M, 64);
+    const int num_mt = cdiv(g.M, 64);
     int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, ~one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(512), C::SMEM, st, g);
     PMGT_LAUNCH_OK();
