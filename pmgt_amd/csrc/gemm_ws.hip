@@ -318,7 +318,8 @@ static int ws_mode(const GemmWS& g) {
     if (g.epi == EPI_NONE && !g.res && !drop) return WS_PLAIN;
     if (g.epi == EPI_GELU && !g.res && !drop) return WS_GELU;
     if (g.epi == EPI_GELU_GRAD && !g.res && !drop) return WS_GELU_GRAD;
-    if (g.epi == EPI_NONE && g.res) return (g.ln_out && g.N == 256) ? WS_RES_LN : WS_RES;
+    static const bool no_ln = [] { const char* e = getenv("PMGT_WS_NO_LN"); return e && atoi(e) == 1; }();      // A/B: LayerNorm as its own launch
+    if (g.epi == EPI_NONE && g.res) return (g.ln_out && g.N == 256 && !no_ln) ? WS_RES_LN : WS_RES;
     return -1;
 }
 
