@@ -138,8 +138,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
         // epilogue operand (residual, or the saved pre-activation for GELU') of this tile: issued first so it
         // is OLDER than the A prefetch below; the epilogue can then wait for it with a counted vmcnt and leave
         // the prefetch in flight.
+        // (4-wave form with a residual: no prefetch -- 128 of the 256 VGPRs hold W; the operand is loaded in its pass and the
+        // other workgroup of the CU covers the latency)
+        constexpr bool PF_EARLY = HAS_PF && !(NW == 4 && (MODE == WS_RES || MODE == WS_RES_LN));
         bf16x8 pf[4];
-        if constexpr (HAS_PF) {
+        if constexpr (PF_EARLY) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {      // clamped, unconditional loads (values of padding rows are unused)
                 const int m = min(mt * C::TR + erow + C::PR * ps, g.M - 1), n = min(nb + ecol, g.N - 8);
@@ -227,7 +230,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                     for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
                 }
                 if constexpr (MODE == WS_RES || MODE == WS_RES_LN) {
-                    const bf16x8 rv = pf[ps];
+                    bf16x8 rv;
+                    if constexpr (PF_EARLY) rv = pf[ps];
+                    else rv = *(const bf16x8*)(PF + (int64_t)m * ldpf + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                 }
@@ -333,9 +338,10 @@ bool gemm_ws_fuses_ln(const GemmWS& g) { return gemm_ws_supported(g) && ws_mode(
 // Which form runs (A/B on one box, c2 shapes, ms per step of the phase, 8-wave -> two 4-wave workgroups):
 //   GELU (ffn1) 0.389 -> 0.362, GELU' (dgrad_ffn2) 0.467 -> 0.438, plain (dgrad_attn_out) 0.250 -> 0.243: VALU-heavy epilogues
 //   with nothing but the A stream to prefetch -- the overlap pays;
-//   residual (dgrad_ffn1) 0.333 -> 0.393, residual + LayerNorm (attn_out, ffn2) 0.58 -> 0.68 / 0.56 -> 0.66: the residual
-//   prefetch and the LayerNorm temporaries do not fit next to 128 VGPRs of W (30 spilled), and one tile in flight per
-//   workgroup instead of two costs memory-level parallelism on launches that are served from the Infinity Cache.
+//   residual (dgrad_ffn1) 0.333 -> 0.42, residual + LayerNorm (attn_out, ffn2) 0.56 -> 0.60 / 0.54 -> 0.58 (with the
+//   residual loaded in its pass instead of prefetched, so that nothing spills next to the 128 VGPRs of W: 254 VGPRs; with
+//   the prefetch 30 were spilled and the launches took 0.68 / 0.66): these launches are served from the Infinity Cache to
+//   a large part, and one tile in flight per workgroup instead of two costs them memory-level parallelism.
 // PMGT_WS_FORM=1 / 2 forces one form everywhere (the two-workgroup form needs K >= 128: chunks per thread).
 static int ws_form(int mode) {
     static const int v = [] { const char* e = getenv("PMGT_WS_FORM"); return e ? atoi(e) : 0; }();
