@@ -396,8 +396,7 @@ template <int KS, int F8 = 0> struct QaCfg2 {
 
 // F8: same structure, the projection on the fp8 MFMA.  W fragments are 8 bytes (64 VGPRs per wave instead of 128); the x tile
 // is quantised per row (absmax over the 32 lanes that hold the row -> e4m3, fp8.h contract) on its way from the staging
-// registers into LDS, so the fragment reads move half the bytes; the 8-byte chunk index is XOR-swizzled by 2 (row & 15),
-// which spreads the 16 rows x 2 k-groups of a half-wave over 32 distinct 8-byte slots.  acc * rowscale * wscale + bias
+// registers into LDS, so the fragment reads move half the bytes (16-byte chunks XOR-swizzled by row & 15, as the bf16 tile).  acc * rowscale * wscale + bias
 // gives the same bf16 projection tile; everything after it is unchanged.  F8 == 2: the producer of x (the fused-LayerNorm
 // epilogue of gemm_ws / embed_mix, both HBM-bound with the row in 32 lanes) already wrote the e4m3 rows and their scales
 // (bit-identical to what the in-kernel quantisation computes from the bf16 x): the kernel reads half the bytes and its
@@ -424,15 +423,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // local column of this wave's 16-column block cb: matrix 2 mh + (cb >> 1), head uh, half cb & 1
     auto cbase = [&](int cb) { return 64 * (2 * mh + (cb >> 1)) + 32 * uh + 16 * (cb & 1); };
 
-    using wfrag_t = std::conditional_t<F8 != 0, long, bf16x8>;
-    wfrag_t wf[4][KS];
+    // fp8 forms: the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with every scale = 1 (E8M0 0x7f) -- 128 k per
+    // instruction at twice the per-k rate of the non-scaled fp8 / bf16 forms (the only fp8 MFMA of gfx950 that reaches the fp8
+    // peak): 16 instead of 64 MFMAs per wave and step.  A lane holds 32 consecutive k (32 bytes) of its row for both operands
+    // (k = 128 s + 32 q + 0..31), W from HBM once, x from LDS with two 16-byte reads.
+    typedef int i32x8_t __attribute__((ext_vector_type(8)));
+    constexpr int KQ = F8 ? KS / 4 : KS;                 // MFMA k-steps
+    using wfrag_t = std::conditional_t<F8 != 0, i32x8_t, bf16x8>;
+    wfrag_t wf[4][KQ];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int n = gcol(cbase(cb) + r);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if constexpr (F8) wf[cb][ks] = *(const long*)((const char*)a.W8 + (int64_t)n * a.ldw + 32 * ks + 8 * q);
-            else wf[cb][ks] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 32 * ks + 8 * q);
+        for (int ks = 0; ks < KQ; ++ks) {
+            if constexpr (F8) {
+                const u32x4 lo = *(const u32x4*)((const char*)a.W8 + (int64_t)n * a.ldw + 128 * ks + 32 * q);
+                const u32x4 hi = *(const u32x4*)((const char*)a.W8 + (int64_t)n * a.ldw + 128 * ks + 32 * q + 16);
+                wf[cb][ks] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            } else {
+                wf[cb][ks] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 32 * ks + 8 * q);
+            }
         }
     }
     float* bias_l = wl + 4 * 64;          // bias of the slab's 256 local columns (LDS: 16 VGPRs fewer)
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int idx = tid + 256 * i;
             const int row = idx / C::CPR, ch = idx % C::CPR;
             if constexpr (F8 == 2) {
-                *(u32x2*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ ((row & 15) << 1)) << 3)) = (u32x2){ra[set][i][0], ra[set][i][1]};
+                *(u32x2*)(sA + buf * C::TILEB + row * C::ROWB + (((ch >> 1) ^ (row & 15)) << 4) + 8 * (ch & 1)) = (u32x2){ra[set][i][0], ra[set][i][1]};
             } else if constexpr (F8 == 1) {
                 const bf16x8 xv = __builtin_bit_cast(bf16x8, ra[set][i]);
                 float f[8], m = 0.f;
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (ch == 0) rowscale_l[buf * 32 + row] = m > 0.f ? m / E4M3_MAX : 1.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e] * inv, -E4M3_MAX, E4M3_MAX);
-                *(u32x2*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ ((row & 15) << 1)) << 3)) = pack8_e4m3(f);
+                *(u32x2*)(sA + buf * C::TILEB + row * C::ROWB + (((ch >> 1) ^ (row & 15)) << 4) + 8 * (ch & 1)) = pack8_e4m3(f);
             } else {
                 *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
             }
@@ -512,19 +522,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int cb = 0; cb < 4; ++cb) acc[i][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const char* a_base = sA + P * C::TILEB;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KQ; ++ks) {
             wfrag_t fa[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 16 * i + r;
-                if constexpr (F8) fa[i] = *(const long*)(a_base + row * C::ROWB + (((4 * ks + q) ^ ((row & 15) << 1)) << 3));
-                else fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
+                if constexpr (F8) {      // 32 bytes of the row: 16-byte chunks 2 (4 ks + q) and + 1, XOR-swizzled by row & 15
+                    const int c0 = 2 * (4 * ks + q);
+                    const u32x4 lo = *(const u32x4*)(a_base + row * C::ROWB + ((c0 ^ (row & 15)) << 4));
+                    const u32x4 hi = *(const u32x4*)(a_base + row * C::ROWB + (((c0 + 1) ^ (row & 15)) << 4));
+                    fa[i] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                } else {
+                    fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
+                }
             }
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {    // D[n = 4 q + e][m = r]: acc[i][cb][e] = out[16 i + r][cbase(cb) + 4 q + e]
-                    if constexpr (F8) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0);
+                    if constexpr (F8)      // formats 0 / 0 = e4m3 x e4m3; block scales 0x7f = 2^0
+                        acc[i][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
                     else acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][ks], fa[i], acc[i][cb], 0, 0, 0);
                 }
         }

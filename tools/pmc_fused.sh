@@ -2,8 +2,8 @@
 # SQ / LDS counters of the fused projection + attention forward (microbench), one counter group per pass
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/pmc_fused; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters
-  rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python3 $REPO/tools/microbench.py 1024 fused > /dev/null 2> $OUT/$1.err
-  for c in $2; do python3 $REPO/tools/summarize_rocprof.py pmc $OUT/$1 $c 2>/dev/null | grep -E "qkvc_attn_fwd|kernel " | head -3; done
+  rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python3 $REPO/tools/microbench.py 1024 ${MODE:-fused} > /dev/null 2> $OUT/$1.err
+  for c in $2; do python3 $REPO/tools/summarize_rocprof.py pmc $OUT/$1 $c 2>/dev/null | grep -E "${KPAT:-qkvc_attn_fwd}|kernel " | head -3; done
   rm -rf $OUT/$1
 }
 run a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
