@@ -24,7 +24,8 @@ extern "C" {
 #define PMGT_DTYPE_F32 0  /* parity mode: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 #define PMGT_DTYPE_BF16 1 /* perf mode: bf16 activations/weight copies, fp32 accumulate + master weights */
 /* fp8 mode (BASELINE.json config 5): the bf16 engine with OCP e4m3 where the north star names it -- frozen feature tables
- * stored as e4m3 (one scale per table), feature-projection and Q|K|V|C projections on v_mfma_f32_16x16x32_fp8_fp8 with
+ * stored as e4m3 (one scale per table), feature-projection and Q|K|V|C projections on the fp8 MFMA
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) with
  * weights quantised per output channel and activations per row; every other tensor, the attention, the backward GEMMs and
  * the optimizer as in PMGT_DTYPE_BF16. */
 #define PMGT_DTYPE_FP8 2

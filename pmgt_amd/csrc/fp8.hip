@@ -1,17 +1,18 @@
 // fp8 (OCP e4m3) mode: quantisation kernels and the fp8 MFMA "NT" GEMM (see fp8.h).
 //
-// gemm_nt_f8_kernel: 128 x 128 output tile, 4 waves (2 x 2, 64 x 64 each as 4 x 4 v_mfma_f32_16x16x32_fp8_fp8 tiles),
+// gemm_nt_f8_kernel: 128 x 128 output tile, 4 waves (2 x 2, 64 x 64 each as 4 x 4 tiles of the block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: the fp8 MFMA of gfx950 that runs at the fp8 rate),
 // K-step 128 (one 128-byte LDS row per operand row, as in the bf16 tile kernel: half the bytes per k), operands staged
 // global -> registers -> LDS in 16-byte chunks, double-buffered, next tile's loads issued before the MFMAs.  A fragment
-// is 8 bytes (k = 32 kk + 8 q .. + 7): the 16-byte chunk index is XOR-swizzled by (row >> 1) & 7, which puts the 32 lanes
-// of a half-wave (16 rows x 2 k-groups) on 32 distinct 8-byte slots of the 64 banks.  The row gather (feature rows by node
+// is 32 bytes (k = 32 q .. 32 q + 31, two 16-byte reads): the 16-byte chunk index is XOR-swizzled by row & 7, so the 16
+// rows of a quarter-wave read land on 8 distinct chunks x 2 row parities = all 64 banks.  The row gather (feature rows by node
 // id) is the A-operand row index, as in the bf16 path.  Epilogue: acc * sa[m] * sb[n] + bias -> bf16 through an fp32 LDS
 // stage so that every global store is a full 16-byte vector.
 #include "fp8.h"
 
 namespace pmgt {
 
-__device__ __forceinline__ int f8_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int f8_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 __global__ __launch_bounds__(256) void gemm_nt_f8_kernel(GemmF8 g) {
     constexpr int BM = 128, BN = 128, BK = 128;
@@ -78,17 +79,22 @@ __global__ __launch_bounds__(256) void gemm_nt_f8_kernel(GemmF8 g) {
         if (kt + 1 < nk) gload((kt + 1) * BK);
         const char* a_base = sA + buf * BM * 128;
         const char* b_base = sB + buf * BN * 128;
+        {   // one block-scaled MFMA per 16 x 16 tile and 128-k step (unit scales): lane (r, q) holds k = 32 q .. 32 q + 31 of its row
+            typedef int i32x8_t __attribute__((ext_vector_type(8)));
+            i32x8_t fa[TM], fb[TN];
+            auto frag = [&](const char* base, int row) {
+                const u32x4 lo = *(const u32x4*)(base + f8_off(row, 2 * q)), hi = *(const u32x4*)(base + f8_off(row, 2 * q + 1));
+                return (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            };
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {               // k = 32 kk + 8 q: chunk 2 kk + (q >> 1), half q & 1
-            long fa[TM], fb[TN];
+            for (int i = 0; i < TM; ++i) fa[i] = frag(a_base, wm * 64 + i * 16 + r);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const long*)(a_base + f8_off(wm * 64 + i * 16 + r, 2 * kk + (q >> 1)) + 8 * (q & 1));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const long*)(b_base + f8_off(wn * 64 + j * 16 + r, 2 * kk + (q >> 1)) + 8 * (q & 1));
+            for (int j = 0; j < TN; ++j) fb[j] = frag(b_base, wn * 64 + j * 16 + r);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
         if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
