@@ -45,7 +45,7 @@ struct QkvcAttn {
     DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
     int cls_only_seqs = 0;                        // see AttnArgs
     bool hm = false;                              // write Q|K|V|C head-major (see AttnArgs)
-    // fp8 mode (hidden 256 only): the projection runs on v_mfma_f32_16x16x32_fp8_fp8 -- W8 = e4m3 copy of W quantised per
+    // fp8 mode (hidden 256 only): the projection runs on the block-scaled fp8 MFMA (unit scales) -- W8 = e4m3 copy of W quantised per
     // output channel (value = byte * wscale[n]), x quantised per row inside the kernel (fp8.h contract); the outputs and the
     // attention stay bf16
     const void* W8 = nullptr;                     // [4d, d] e4m3, row stride ldw bytes

@@ -1,4 +1,4 @@
-// OCP e4m3 (gfx950: e4m3fn, NOT the MI300 fnuz encoding) pieces of the fp8 mode: quantisation kernels and the fp8 MFMA
+// OCP e4m3 (gfx950: e4m3fn, NOT the MI300 fnuz encoding) pieces of the fp8 mode: quantisation kernels and the fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales)
 // GEMM of the feature projection / Q|K|V|C projection (config C5 of BASELINE.json: "fp8 (e4m3) feature-projection + QKV
 // MFMA path").  Everything else of the fp8 mode is the bf16 engine.
 //
