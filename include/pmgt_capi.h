@@ -198,6 +198,7 @@ int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_
  * the Q|K|V|C projection (perm_d = hidden size, perm_dh = head size; 0 = none) */
 int pmgt_op_gemm_tn_bias(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, int M, int N1, int N2, float* slab,
                          float* out, float* bias_slab, float* bias_out, int perm_d, int perm_dh, void* stream);
+/* column sums of Y [M, N]; slab: ceil(M / 96) * N floats of scratch */
 int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream);
 int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const float* gamma, const float* beta,
                           int M, int d, float eps, float drop_p, uint32_t drop_site, const uint64_t* rng, void* stream);

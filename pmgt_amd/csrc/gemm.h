@@ -70,10 +70,14 @@ template <typename T> int gemm_tn_bkm();
 // dst[i] (+)= sum_s slab[s*n + i]   (n % 4 == 0; the slab is used as scratch and clobbered)
 int slab_reduce(const float* slab, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st);
 
-// Column sums of Y[M,N] (bias gradients): dst[n] (+)= sum_m Y[m,n]; needs slab of cdiv(M,256)*N floats.
+// Column sums of Y[M,N] (bias gradients): dst[n] (+)= sum_m Y[m,n]; needs slab of colsum_slab_elems(M, N) floats.
 template <typename T>
 int colsum(const T* Y, int64_t ldy, int M, int N, float* slab, float* dst, bool accumulate,
            const int* m_dev, hipStream_t st);
-inline int64_t colsum_slab_elems(int M, int N) { return (int64_t)cdiv(M, 256) * N; }
+// rows per block: 96 keeps the position-gradient sums of the bench shape (12 288 rows x 8 192 columns) at 128 row blocks (one
+// slab_reduce level) x 8 column blocks = 1 024 workgroups; with 256 rows per block that launch had 384 workgroups and one
+// load in flight per lane (2.4 TB/s)
+constexpr int COLSUM_ROWS = 96;
+inline int64_t colsum_slab_elems(int M, int N) { return (int64_t)cdiv(M, COLSUM_ROWS) * N; }
 
 }  // namespace pmgt

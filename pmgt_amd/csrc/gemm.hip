@@ -1599,12 +1599,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, in
     const int Mlim = m_dev ? min(M, *m_dev) : M;
     const int cc = threadIdx.x % CC, rl = threadIdx.x / CC;
     const int col = (blockIdx.y * CC + cc) * EPC;
-    const int mb = blockIdx.x * 256, me = min(Mlim, mb + 256);
+    const int mb = blockIdx.x * COLSUM_ROWS, me = min(Mlim, mb + COLSUM_ROWS);
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
     if (col < N) {
-        for (int m = mb + rl; m < me; m += RL) {
+        int m = mb + rl;
+        if constexpr (sizeof(T) == 2) {      // four rows per trip: four independent 16-byte loads in flight per lane
+            for (; m + 3 * RL < me; m += 4 * RL) {
+                const bf16x8 v0 = *(const bf16x8*)(Y + (int64_t)m * ldy + col), v1 = *(const bf16x8*)(Y + (int64_t)(m + RL) * ldy + col);
+                const bf16x8 v2 = *(const bf16x8*)(Y + (int64_t)(m + 2 * RL) * ldy + col), v3 = *(const bf16x8*)(Y + (int64_t)(m + 3 * RL) * ldy + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+            }
+        }
+        for (; m < me; m += RL) {
             if constexpr (sizeof(T) == 2) {
                 bf16x8 v = *(const bf16x8*)(Y + (int64_t)m * ldy + col);
 #pragma unroll
@@ -1636,7 +1645,7 @@ int colsum(const T* Y, int64_t ldy, int M, int N, float* slab, float* dst, bool 
     constexpr int EPC = 16 / sizeof(T);
     PMGT_CHECK(N % EPC == 0 && ldy % EPC == 0 && ((uintptr_t)Y % 16) == 0, -2,
                "colsum: N=%d / ld must be multiples of %d and Y 16-byte aligned", N, EPC);
-    const int rb = std::max(1, cdiv(M, 256));
+    const int rb = std::max(1, cdiv(M, COLSUM_ROWS));
     const int chunks = N / EPC;
     if (chunks <= 32) hipLaunchKernelGGL((colsum_kernel<T, 32>), dim3(rb, cdiv(chunks, 32)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
     else if (chunks <= 64) hipLaunchKernelGGL((colsum_kernel<T, 64>), dim3(rb, cdiv(chunks, 64)), dim3(256), 0, st, Y, ldy, M, N, slab, m_dev);
