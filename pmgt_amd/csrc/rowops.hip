@@ -296,9 +296,73 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     }
 }
 
+// Token phase of the table mode at d = 256 (the bench shape), FOUR rows per wave: the generic kernel above gives a wave one row
+// -- node id -> mixed row F[id] -> LayerNorm -> stores is one dependent chain of two memory round trips, and 32 resident waves
+// per CU keep 32 rows x 1.5 KB in flight (3.3 TB/s measured).  Here the four ids, then the four rows, are loaded back to back
+// before anything is consumed.  Same arithmetic in the same order as embed_mix_fwd_kernel<T, 1, 2> (bit-identical outputs).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tok4_fwd_kernel(EmbedMix p) {
+    constexpr int R = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x * 4 + wave) * R;
+    if (m0 >= p.M) return;
+    constexpr int d = 256;
+    int64_t er[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) er[k] = p.e_rows[min(m0 + k, p.M - 1)];
+    f32x4 x[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[k] = load4<T>((const T*)p.E + er[k] * d + 4 * lane);
+    const DropKey dk = make_drop_key(p.drop);
+    const f32x4 gam = *(const f32x4*)(p.gamma + 4 * lane), bet = *(const f32x4*)(p.beta + 4 * lane);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int m = m0 + k;
+        if (m >= p.M) break;
+        const int s = m % p.S;
+        f32x4 v = x[k] * 1.f + (f32x4){0.f, 0.f, 0.f, 0.f} * 0.f + *(const f32x4*)(p.pos + (int64_t)s * d + 4 * lane) +
+                  *(const f32x4*)(p.role + (s > 0 ? d : 0) + 4 * lane);
+        store4<T>((T*)p.pre + (int64_t)m * d + 4 * lane, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
+        const float mean = wave_sum(sum4(v)) / (float)d;
+        const f32x4 t = v - mean;
+        const float rstd = 1.f / sqrtf(wave_sum(sum4(t * t)) / (float)d + p.eps);
+        if (lane == 0) { p.stats[2 * (int64_t)m] = mean; p.stats[2 * (int64_t)m + 1] = rstd; }
+        f32x4 o = (v - mean) * rstd * gam + bet;
+        if (dk.on) {
+            float dm[4];
+            drop_mul4(dk, (uint32_t)m, (uint32_t)lane, dm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= dm[e];
+        }
+        store4<T>((T*)p.h0 + (int64_t)m * d + 4 * lane, o);
+        if (p.q8) {
+            f32x4 oq;
+            float mx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oq[e] = to_f<T>(from_f<T>(o[e])); mx = fmaxf(mx, fabsf(oq[e])); }
+            mx = wave_max(mx);
+            const float inv = mx > 0.f ? E4M3_MAX / mx : 1.f;
+            if (lane == 0) p.q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[0] * inv, -E4M3_MAX, E4M3_MAX),
+                                                __builtin_amdgcn_fmed3f(oq[1] * inv, -E4M3_MAX, E4M3_MAX), w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[2] * inv, -E4M3_MAX, E4M3_MAX),
+                                                __builtin_amdgcn_fmed3f(oq[3] * inv, -E4M3_MAX, E4M3_MAX), w, true);
+            *(int*)((char*)p.q8 + (int64_t)m * d + 4 * lane) = w;
+        }
+    }
+}
+
 template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st) {
     if (e.M <= 0) return 0;
     PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_fwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
+    if (e.phase == 2 && e.d == 256 && e.e_rows != nullptr && sizeof(T) == 2) {
+        hipLaunchKernelGGL((embed_tok4_fwd_kernel<T>), dim3(cdiv(e.M, 16)), dim3(256), 0, st, e);
+        PMGT_LAUNCH_OK();
+        return 0;
+    }
     dim3 grid(cdiv(e.M, 4)), block(256);
 #define PMGT_EMB_FWD(PH)                                                                                          \
     do {                                                                                                          \
