@@ -43,7 +43,8 @@ def audit(path):
             for lj in lines[i + 1:i + 400]:
                 if RESTORE.search(lj):
                     break
-                n += "v_mfma" in lj
+                # MFMA, s_barrier and s_setprio all ignore EXEC; a barrier under a mask is a hang when the skip is missing
+                n += any(op in lj for op in ("v_mfma", "s_barrier", "s_setprio"))
             if n and not skip:
                 hits.append((func, i + 1, n))
     return hits
@@ -55,7 +56,7 @@ def main():
         outs = list(ex.map(lambda f: isa(f, os.path.join(tmp, f.replace(".hip", ".s"))), FILES))
         for f, o in zip(FILES, outs):
             for func, line, n in audit(o):
-                bad.append(f"{f}: {func} (asm line {line}): {n} v_mfma under an EXEC mask without a skip branch")
+                bad.append(f"{f}: {func} (asm line {line}): {n} EXEC-ignoring instruction(s) (v_mfma / s_barrier / s_setprio) under an EXEC mask without a skip branch")
     for b in bad:
         print(b)
     print(f"audited {len(FILES)} files: {len(bad)} hit(s)")
