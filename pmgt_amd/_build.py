@@ -19,7 +19,11 @@ HIP_SOURCES = ["gemm.hip", "gemm_ws.hip", "fp8.hip", "rowops.hip", "attention.hi
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs (no v_accvgpr_read moves before every VALU
 # use of a result: -7 % VALU instructions in the attention backward, which is VALU-issue-bound)
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# -fno-slp-vectorize: the SLP vectoriser pairs adjacent fp32 adds / multiplies of the epilogues into v_pk_add_f32 / v_pk_mul_f32,
+# which issue no faster than the two scalar instructions they replace on gfx950 and cost v_mov shuffles to build the register
+# pairs (streaming-GEMM LayerNorm epilogue: 485 -> 287 packed + move instructions per tile); the epilogues are VALU-bound:
+# LayerNorm backward 1.09 -> 0.97 ms per step, step 11.00 -> 10.84 ms
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("PMGT_EXTRA_HIP_FLAGS", "").split()
 
 
 def _newer(target, deps):
