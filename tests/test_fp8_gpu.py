@@ -281,3 +281,35 @@ def test_fp8_engine_paths_agree_and_train():
         eng.encode(feats=feats, attention_mask=tgt["attention_mask"].cuda())
     last, _, _ = eng.encode(ids=tgt["node_ids"].cuda(), attention_mask=tgt["attention_mask"].cuda())
     assert torch.isfinite(last.float()).all()
+
+
+@pytest.mark.parametrize("name", ["ncf_mlp", "ncf_neumf"])
+def test_fp8_second_caller_tracks_the_reference(name):
+    """PMGT_NCF (second caller of the encoder boundary: pmgt_encode_train / pmgt_encode_backward under autograd) in fp8 mode
+    against the reference's fp32 goldens: logits and loss to fp8-level tolerances, encoder gradients by direction."""
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.pmgt_ncf import PMGT_NCF
+    c = gu.ncf_case(name)
+    gold = c["gold"]
+    model = PMGT_NCF(user_num=c["users"], item_num=c["n_nodes"], factor_num=c["factor"], num_layers=c["num_layers"],
+                     model=c["model"], config=PMGTConfig(**c["cfg"]), dtype="fp8")
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in list(c["params"].items()) + list(c["head"].items()):
+            sd[k].copy_(v)
+    model.set_features([t.numpy() for t in c["tables"]])
+    model.train()
+    logits = model(c["user"], c["item"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, c["labels"].cuda())
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), gold["loss"], rtol=3e-2)
+    np.testing.assert_allclose(logits.detach().float().cpu().numpy(), gold["logits"], rtol=0, atol=0.1 * np.abs(gold["logits"]).max() + 0.02)
+    flat, ref = [], []
+    for k, p in model.named_parameters():
+        if not p.requires_grad or ("grad/" + k) not in gold.files:
+            continue
+        flat.append(p.grad.detach().float().cpu().reshape(-1))
+        ref.append(torch.from_numpy(gold["grad/" + k].astype(np.float32)).reshape(-1))
+    assert len(flat) > 10
+    cos = torch.nn.functional.cosine_similarity(torch.cat(flat), torch.cat(ref), dim=0).item()
+    assert cos > 0.98, cos
