@@ -456,14 +456,14 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
             RUNP(name, gemm_ws(g, st));
             if (g.ln_out && !gemm_ws_fuses_ln(g))
                 RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
-                                                DropCfg{nullptr, 0.f, 0}, st, g.m_dev));
+                                                DropCfg{nullptr, 0.f, 0}, st, g.m_dev, g.q8, g.q8_scale));
             return 0;
         }
     }
     RUNP(name, gemm_nt<T>(g, st));
     if (g.ln_out)
         RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
-                                        DropCfg{nullptr, 0.f, 0}, st, g.m_dev));
+                                        DropCfg{nullptr, 0.f, 0}, st, g.m_dev, g.q8, g.q8_scale));
     return 0;
 }
 
@@ -630,8 +630,10 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.ln_out = tb.hout; g.ln_stats = tb.stats2; g.ln_gamma = P + o.ln2g; g.ln_beta = P + o.ln2b; g.ln_eps = e->cfg.layer_norm_eps;
             x8_ok = false;
             if constexpr (sizeof(T) == 2) {
-                if (e->fp8 && !g_no_producer_quant && !sc && l + 1 < L && !g_force_tile && gemm_ws_supported(g) && gemm_ws_fuses_ln(g)) {
-                    g.q8 = b.x8; g.q8_scale = b.xscale;      // the next layer's input, quantised where it is produced
+                if (e->fp8 && !g_no_producer_quant && !sc && l + 1 < L) {
+                    // the next layer's input, quantised where it is produced: the fused-LayerNorm epilogue of the streaming GEMM,
+                    // or the LayerNorm launch that follows the tiled GEMM (d = 512 shapes)
+                    g.q8 = b.x8; g.q8_scale = b.xscale;
                     x8_ok = true;
                 }
             }

@@ -8,6 +8,8 @@
 // rows of a quarter-wave read land on 8 distinct chunks x 2 row parities = all 64 banks.  The row gather (feature rows by node
 // id) is the A-operand row index, as in the bf16 path.  Epilogue: acc * sa[m] * sb[n] + bias -> bf16 through an fp32 LDS
 // stage so that every global store is a full 16-byte vector.
+#include <stdlib.h>
+
 #include "fp8.h"
 
 namespace pmgt {
@@ -140,6 +142,165 @@ __global__ __launch_bounds__(256) void gemm_nt_f8_kernel(GemmF8 g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile for the large fp8 GEMMs (the Q|K|V|C projection of the d = 512 shapes: M = 196 608, N = 2 048, K = 512): the
+// structure of gemm_nt_big_kernel (gemm.hip) with e4m3 operands -- 8 waves (2 x 4, 128 x 64 outputs each), 4-slot LDS-DMA ring
+// of 64-byte rows = 64 k per stage (half the DMA and LDS bytes per k of the bf16 tile), counted vmcnt, one barrier per stage,
+// the four DMA instructions of stage kt + 3 spread between the MFMAs of stage kt.  v_mfma_f32_16x16x32_fp8_fp8 with swapped
+// operands (a lane owns four consecutive output columns), 8-byte fragments (k = 32 h + 8 q .. + 7: source chunk 2 h + (q >> 1),
+// XOR-swizzled by (row >> 2) & 3 on the DMA source side: the 32 lanes of a half-wave hit 64 distinct banks); direct epilogue
+// acc * sa[m] * sb[n] + bias -> bf16 from the registers (v_permlane16_swap pairs two 16-column blocks: 16-byte stores).
+// (The block-scaled 16x16x128 MFMA would need 128-byte rows = a 2-slot ring; this tile is bound by its DMA stream first.)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_f8_t;
+typedef __attribute__((address_space(1))) const void gbl_void_f8_t;
+
+__global__ __launch_bounds__(512) void gemm_nt_f8_big_kernel(GemmF8 g) {
+    constexpr int BM = 256, BN = 256, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = 4, AI = 2, BI = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int num_n = g.N / BN;
+    const int num_m = (g.M + BM - 1) / BM;
+    const int b = blockIdx.x;
+    const int grp = b / (8 * num_n), within = b % (8 * num_n);
+    const int m_tile = grp * 8 + (within & 7), n_tile = within >> 3;
+    if (m_tile >= num_m) return;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+
+    const char* asrc[AI];
+    const char* bsrc[BI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int row = 16 * (AI * wave + j) + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = min(m0 + row, g.M - 1);
+        asrc[j] = (const char*)g.A + (int64_t)m * g.lda + ch * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = 16 * (BI * wave + j) + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);
+        bsrc[j] = (const char*)g.B + (int64_t)(n0 + row) * g.ldb + ch * 16;
+    }
+    auto issue_piece = [&](int kt, int piece) __attribute__((always_inline)) {
+        char* st = smem + (kt % NST) * STAGE;
+        if (piece < AI)
+            __builtin_amdgcn_global_load_lds((gbl_void_f8_t*)(asrc[piece] + (int64_t)kt * ROWB),
+                                             (lds_void_f8_t*)(st + 16 * (AI * wave + piece) * ROWB), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gbl_void_f8_t*)(bsrc[piece - AI] + (int64_t)kt * ROWB),
+                                             (lds_void_f8_t*)(st + BM * ROWB + 16 * (BI * wave + piece - AI) * ROWB), 16, 0, 0);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_f8_t*)smem;
+    const int sw = (r >> 2) & 3;
+    uint32_t aA[2], aB[2];      // per k-half h: byte address of this lane's 8-byte fragment in row (wm 128 + r) / (wn 64 + r) of stage 0
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = ((2 * h + (q >> 1)) ^ sw) << 4;
+        aA[h] = lds_base + (uint32_t)((wm * 128 + r) * ROWB + pos + 8 * (q & 1));
+        aB[h] = lds_base + (uint32_t)(BM * ROWB + (wn * 64 + r) * ROWB + pos + 8 * (q & 1));
+    }
+    const int nk = g.K / 64;
+#pragma unroll
+    for (int kt = 0; kt < NST - 1; ++kt)
+        if (kt < nk) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) issue_piece(kt, pc);
+        }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = min(NST - 2, nk - 1 - kt);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t so = (uint32_t)((kt % NST) * STAGE);
+        u32x2 fa[2][8], fb[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            asm volatile(
+                "ds_read_b64 %0, %12\n\t"
+                "ds_read_b64 %1, %12 offset:1024\n\t"
+                "ds_read_b64 %2, %12 offset:2048\n\t"
+                "ds_read_b64 %3, %12 offset:3072\n\t"
+                "ds_read_b64 %4, %13\n\t"
+                "ds_read_b64 %5, %13 offset:1024\n\t"
+                "ds_read_b64 %6, %13 offset:2048\n\t"
+                "ds_read_b64 %7, %13 offset:3072\n\t"
+                "ds_read_b64 %8, %13 offset:4096\n\t"
+                "ds_read_b64 %9, %13 offset:5120\n\t"
+                "ds_read_b64 %10, %13 offset:6144\n\t"
+                "ds_read_b64 %11, %13 offset:7168"
+                : "=&v"(fb[h][0]), "=&v"(fb[h][1]), "=&v"(fb[h][2]), "=&v"(fb[h][3]), "=&v"(fa[h][0]), "=&v"(fa[h][1]), "=&v"(fa[h][2]),
+                  "=&v"(fa[h][3]), "=&v"(fa[h][4]), "=&v"(fa[h][5]), "=&v"(fa[h][6]), "=&v"(fa[h][7])
+                : "v"(aB[h] + so), "v"(aA[h] + so)
+                : "memory");
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // the twelve reads of half 0 have landed when at most the twelve of half 1 are outstanding
+            if (h == 0)
+                asm volatile("s_waitcnt lgkmcnt(12)"
+                             : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]),
+                               "+v"(fa[0][3]), "+v"(fa[0][4]), "+v"(fa[0][5]), "+v"(fa[0][6]), "+v"(fa[0][7]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]),
+                               "+v"(fa[1][3]), "+v"(fa[1][4]), "+v"(fa[1][5]), "+v"(fa[1][6]), "+v"(fa[1][7]));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, fb[h][j]), __builtin_bit_cast(long, fa[h][i]),
+                                                                           acc[i][j], 0, 0, 0);
+                // ring slot (kt + 3) % 4 was last read in stage kt - 1, and every wave is past this stage's barrier
+                if ((i & 3) == 3 && kt + NST - 1 < nk) issue_piece(kt + NST - 1, 2 * h + (i >> 2));
+            }
+        }
+    }
+
+    // ---- direct epilogue: acc[i][j][e] = out[wm 128 + 16 i + r][wn 64 + 16 j + 4 q + e]
+    bf16* Cp = (bf16*)g.C;
+    const int cb = ((q & 1) << 4) | ((q & 2) << 2);          // q = 0, 1, 2, 3 -> columns 0, 16, 8, 24 of the 32-column pair
+    const int ncol = n0 + wn * 64 + cb;
+    f32x4 bv[2][2], sv[2][2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bv[pr][k] = g.bias ? *(const f32x4*)(g.bias + ncol + 32 * pr + 4 * k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sv[pr][k] = g.b_row_scale ? *(const f32x4*)(g.b_row_scale + ncol + 32 * pr + 4 * k) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + 16 * i + r;
+        const float sa = g.a_row_scale ? g.a_row_scale[min(m, g.M - 1)] : g.a_scale;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            f32x4 a = acc[i][2 * pr], c = acc[i][2 * pr + 1];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                         "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+            a = a * (sv[pr][0] * sa) + bv[pr][0];
+            c = c * (sv[pr][1] * sa) + bv[pr][1];
+            const bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)c[0], (bf16)c[1], (bf16)c[2], (bf16)c[3]};
+            if (m < g.M) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ncol + 32 * pr) = o;
+        }
+    }
+}
+
+static bool f8_big_ok(const GemmF8& g) {
+    return g.a_rows == nullptr && g.m_dev == nullptr && g.M >= 4096 && g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128 && g.lda % 16 == 0 &&
+           g.ldb % 16 == 0 && g.ldc % 8 == 0 && ((uintptr_t)g.C % 16) == 0;
+}
+
 int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return 0;
     PMGT_CHECK(g.K > 0 && g.K % 16 == 0 && g.N % 4 == 0, -2, "gemm_nt_f8: K=%d must be a multiple of 16, N=%d of 4", g.K, g.N);
@@ -147,6 +308,18 @@ int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
     PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 8) == 0, -2, "gemm_nt_f8: unaligned operands");
     PMGT_CHECK((g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0) && (g.b_row_scale == nullptr || ((uintptr_t)g.b_row_scale % 16) == 0), -2,
                "gemm_nt_f8: bias / scale vectors must be 16-byte aligned");
+    static const bool no_big = [] { const char* e = getenv("PMGT_F8_NO_BIG"); return e && atoi(e) == 1; }();      // A/B
+    if (f8_big_ok(g) && !no_big) {
+        constexpr int smem = 4 * (256 + 256) * 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_f8_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_f8_big_kernel, dim3(cdiv(cdiv(g.M, 256), 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
+        PMGT_LAUNCH_OK();
+        return 0;
+    }
     const int num_n = cdiv(g.N, 128), num_m = cdiv(g.M, 128);
     hipLaunchKernelGGL(gemm_nt_f8_kernel, dim3(8 * num_n * cdiv(num_m, 8)), dim3(256), 0, st, g);
     PMGT_LAUNCH_OK();

@@ -9,7 +9,8 @@ namespace pmgt {
 // y = dropout(LN(x)); stats[m] = {mean, rstd}.  d % 4 == 0, d <= 1024.  One wave per row.
 template <typename T>
 int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
-           DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr);
+           DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr, void* q8 = nullptr, float* q8_scale = nullptr);
+// (q8 / q8_scale: fp8 mode -- y additionally as per-row e4m3 [M, d] bytes + scales [M], fp8.h contract)
 // dx = LN'(dy * in_mask); optional second output dx_drop = dx * out_mask (gradient of the dropout
 // that fed the residual sum).  Partials go to `part` ([ln_bwd_parts(M)][3][d] floats): dgamma, dbeta and
 // dbias = column sum of dx_drop (or dx): the bias gradient of the dense layer in front of the LayerNorm.

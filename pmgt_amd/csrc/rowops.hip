@@ -17,7 +17,8 @@ __device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + 
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int M, int d, float eps, DropCfg drop, const int* m_dev) {
+                                                     int M, int d, float eps, DropCfg drop, const int* m_dev, char* __restrict__ q8,
+                                                     float* __restrict__ q8_scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
     if (m_dev) M = min(M, *m_dev);
@@ -44,9 +45,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)d + eps);
     if (lane == 0) { stats[2 * (int64_t)m] = mean; stats[2 * (int64_t)m + 1] = rstd; }
     const DropKey dk = make_drop_key(drop);
+    f32x4 oq[NCH];
+    float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
+        oq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (ch < nch) {
             f32x4 g = *(const f32x4*)(gamma + 4 * ch), b = *(const f32x4*)(beta + 4 * ch);
             f32x4 o = (v[i] - mean) * rstd * g + b;
@@ -56,24 +60,44 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
                     for (int e = 0; e < 4; ++e) o[e] *= dm[e]; }
             }
             store4<T>(y + (int64_t)m * d + 4 * ch, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oq[i][e] = to_f<T>(from_f<T>(o[e])); mx = fmaxf(mx, fabsf(oq[i][e])); }
+        }
+    }
+    if (q8) {      // (uniform) fp8 mode: the stored row once more as per-row e4m3 + scale (fp8.h contract) for the next projection
+        mx = wave_max(mx);
+        const float inv = mx > 0.f ? E4M3_MAX / mx : 1.f;
+        if (lane == 0) q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[i][0] * inv, -E4M3_MAX, E4M3_MAX),
+                                                    __builtin_amdgcn_fmed3f(oq[i][1] * inv, -E4M3_MAX, E4M3_MAX), w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[i][2] * inv, -E4M3_MAX, E4M3_MAX),
+                                                    __builtin_amdgcn_fmed3f(oq[i][3] * inv, -E4M3_MAX, E4M3_MAX), w, true);
+                *(int*)(q8 + (int64_t)m * d + 4 * ch) = w;
+            }
         }
     }
 }
 
 template <typename T>
 int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta, int M, int d, float eps,
-           DropCfg out_drop, hipStream_t st, const int* m_dev) {
+           DropCfg out_drop, hipStream_t st, const int* m_dev, void* q8v, float* q8_scale) {
+    char* q8 = (char*)q8v;
     if (M <= 0) return 0;
     PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_fwd: hidden size %d must be a multiple of 4 and <= 1024", d);
     dim3 grid(cdiv(M, 4)), block(256);
-    if (d <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev);
-    else if (d <= 512) hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev);
-    else hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev);
+    if (d <= 256) hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev, q8, q8_scale);
+    else if (d <= 512) hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev, q8, q8_scale);
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), grid, block, 0, st, x, y, stats, gamma, beta, M, d, eps, out_drop, m_dev, q8, q8_scale);
     PMGT_LAUNCH_OK();
     return 0;
 }
-template int ln_fwd<float>(const float*, float*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*);
-template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*);
+template int ln_fwd<float>(const float*, float*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*, void*, float*);
+template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*, void*, float*);
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  64 rows per block (16 per wave); dgamma/dbeta partials per block.

@@ -75,7 +75,8 @@ def _rand_e4m3(shape, g, spread=1.0):
     return q.view(torch.uint8), q.to(torch.float64)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 1536), (77, 40, 48), (1000, 256, 768), (513, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 1536), (77, 40, 48), (1000, 256, 768), (513, 1024, 256),
+                                   (4100, 512, 512), (8192, 2048, 512), (5000, 256, 192)])      # last three: the 256 x 256 LDS-DMA tile
 @pytest.mark.parametrize("gather", [False, True])
 def test_gemm_nt_f8(M, N, K, gather):
     """C = (A8 B8^T) sa sb + bias on v_mfma_f32_16x16x32_fp8_fp8.  Random (asymmetric) e4m3 operands: every product is
