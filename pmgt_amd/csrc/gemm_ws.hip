@@ -1,4 +1,4 @@
-// Weight-stationary streaming GEMM for the d x d layers (bf16, K <= 256, K % 32 == 0).
+// Weight-stationary streaming GEMM for the d x d layers (bf16, K in {64, 128, 256, 512}).
 //
 //   C[M, N] = epi(A[M, K] * W[N, K]^T)   with optional fused LayerNorm over the full row (N == 256)
 //
@@ -36,8 +36,16 @@ template <int KS, int NW = 8> struct WsCfg {
     static constexpr int LPT = TR * CPR / NT;          // chunks per thread per tile (K >= 64)
     static_assert(LPT * NT == TR * CPR, "tile must be a whole number of chunks per thread");
     static_assert(NW == 8 || NW == 4, "waves per workgroup");
+    // K = 512 (KS = 16, the d = 512 shapes): the 256-column slab of W takes 128 VGPRs per lane in the 8-wave form and a 64-row A
+    // tile 64 KB of LDS, so there is ONE LDS buffer and the next tile goes into it by LDS-DMA (no staging registers: a row is
+    // 1 KB = one global_load_lds instruction, the chunk swizzle applied on the source side) right after the second barrier,
+    // when every wave is done with its fragments; the epilogue phase covers its latency
+    static constexpr bool DMA = KS == 16;
+    static constexpr bool ONE = NW == 4 || KS == 16;     // one tile in flight
+    static constexpr int NBUF = KS == 16 ? 1 : 2;
+    static_assert(!(NW == 4 && KS == 16), "two workgroups per CU do not fit at K = 512");
     static constexpr int ES = 256 + 4;                 // staging row stride (floats)
-    static constexpr int SMEM = 2 * TILEB + TR * ES * 4 + 3 * 256 * 4;   // A ring + staging + bias/gamma/beta
+    static constexpr int SMEM = NBUF * TILEB + TR * ES * 4 + 3 * 256 * 4;   // A ring + staging + bias/gamma/beta
     static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
 };
 
@@ -60,7 +68,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
     using C = WsCfg<KS, NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    float* stage = (float*)(smem + 2 * C::TILEB);
+    float* stage = (float*)(smem + C::NBUF * C::TILEB);
     float* cvec = stage + C::TR * C::ES;       // [3][256]: bias, LN gamma, LN beta of this column slab (LDS, so the
                                             // epilogue never waits on vmcnt for them)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,7 +101,19 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
         cvec[512 + tid] = (g.ln_out && n < g.N) ? g.ln_beta[n] : 0.f;
     }
 
-    u32x4 ra[NW == 8 ? 2 : 1][C::LPT];
+    u32x4 ra[C::DMA ? 1 : (C::ONE ? 1 : 2)][C::DMA ? 1 : C::LPT];
+    typedef __attribute__((address_space(3))) void lds_void_ws_t;
+    typedef __attribute__((address_space(1))) const void gbl_void_ws_t;
+    auto dma_tile = [&](int mt) {       // (KS == 16) 64 rows x 1 KB: wave w moves rows 8 w .. 8 w + 7, LDS slot `lane` <- source chunk lane ^ (row & 15)
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 8 * uw + j;
+            const int m = min(mt * C::TR + row, g.M - 1);
+            const char* src = (const char*)g.A + ((int64_t)m * g.lda) * 2 + ((lane ^ (row & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_void_ws_t*)src, (lds_void_ws_t*)(sA + row * C::ROWB), 16, 0, 0);
+        }
+    };
     auto gload = [&](int mt, int set) {
 #pragma unroll
         for (int i = 0; i < C::LPT; ++i) {
@@ -142,14 +162,17 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
         // other workgroup of the CU covers the latency)
         constexpr bool PF_EARLY = HAS_PF && !(NW == 4 && (MODE == WS_RES || MODE == WS_RES_LN));
         bf16x8 pf[4];
-        if constexpr (PF_EARLY) {
+        auto load_pf = [&]() {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {      // clamped, unconditional loads (values of padding rows are unused)
                 const int m = min(mt * C::TR + erow + C::PR * ps, g.M - 1), n = min(nb + ecol, g.N - 8);
                 pf[ps] = *(const bf16x8*)(PF + (int64_t)m * ldpf + n);
             }
-        }
-        if constexpr (NW == 8) {
+        };
+        // (K = 512 form: the barrier below waits for the LDS-DMA of this tile with vmcnt(0), which would expose these loads' latency
+        // too -- they go out after it instead, under the MFMA phase)
+        if constexpr (PF_EARLY && !C::DMA) load_pf();
+        if constexpr (!C::ONE) {
             sstore(P, P);
             if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
         }
@@ -159,14 +182,15 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
         // 4-wave form: ONE tile in flight in registers (the W fragments take 128 of the 256): loaded here, at the start of the
         // MFMA phase, parked in the other LDS buffer after the second barrier (that buffer was last read in the previous step's
         // MFMA phase)
-        const bool more4 = NW == 4 && mt + gx < num_mt;
-        if constexpr (NW == 4) { if (more4) gload(mt + gx, 0); }
+        if constexpr (PF_EARLY && C::DMA) load_pf();
+        const bool more4 = C::ONE && mt + gx < num_mt;
+        if constexpr (C::ONE && !C::DMA) { if (more4) gload(mt + gx, 0); }
         f32x4 acc[C::IT][C::JW];
 #pragma unroll
         for (int i = 0; i < C::IT; ++i)
 #pragma unroll
             for (int j = 0; j < C::JW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const char* a_base = sA + P * C::TILEB;
+        const char* a_base = sA + (C::NBUF == 1 ? 0 : P) * C::TILEB;
         if constexpr (NW == 4) __builtin_amdgcn_s_setprio(3);      // the MFMA phase of this workgroup over the other one's VALU phase
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -194,7 +218,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
         WS_STAMP(4);
         __syncthreads();
         WS_STAMP(5);
-        if constexpr (NW == 4) { if (more4) sstore(P ^ 1, 0); }
+        if constexpr (C::DMA) { if (more4) dma_tile(mt + gx); }
+        else if constexpr (C::ONE) { if (more4) sstore(P ^ 1, 0); }
         // ---- row-contiguous epilogue: PR rows per pass, 4 passes
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -218,7 +243,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                     for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_fast((float)pre[e]); }
                     *(bf16x8*)(AUX + (int64_t)m * g.ldaux + n) = pre;
                 } else if constexpr (MODE == WS_GELU_GRAD) {
-                    const bf16x8 pre = pf[ps];
+                    bf16x8 pre;
+                    if constexpr (PF_EARLY) pre = pf[ps];
+                    else pre = *(const bf16x8*)(PF + (int64_t)m * ldpf + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)pre[e]);
                 }
@@ -292,9 +319,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
     };
 
     int mt = x;
-    if (mt < num_mt) gload(mt, 0);
-    if constexpr (NW == 8) { if (mt + gx < num_mt) gload(mt + gx, 1); }
-    else { if (mt < num_mt) sstore(0, 0); }
+    if constexpr (C::DMA) {
+        if (mt < num_mt) dma_tile(mt);
+    } else {
+        if (mt < num_mt) gload(mt, 0);
+        if constexpr (!C::ONE) { if (mt + gx < num_mt) gload(mt + gx, 1); }
+        else { if (mt < num_mt) sstore(0, 0); }
+    }
     while (mt < num_mt) {
         tile_step(std::integral_constant<int, 0>{}, mt);
         mt += gx;
@@ -329,7 +360,7 @@ static int ws_mode(const GemmWS& g) {
 }
 
 bool gemm_ws_supported(const GemmWS& g) {
-    return ws_mode(g) >= 0 && g.a_rows == nullptr && g.m_dev == nullptr && g.K % 32 == 0 && g.K >= 64 && g.K <= 256 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
+    return ws_mode(g) >= 0 && g.a_rows == nullptr && g.m_dev == nullptr && g.K % 32 == 0 && g.K >= 64 && g.K <= 512 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
            g.M >= 64 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
            (g.aux == nullptr || g.ldaux % 8 == 0);
 }
@@ -351,7 +382,7 @@ static int ws_form(int mode) {
 
 template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st) {
     const int ny = cdiv(g.N, 256);
-    if constexpr (KS >= 4) {
+    if constexpr (KS >= 4 && KS <= 8) {
         if (ws_form(MODE) == 2) {
             using C = WsCfg<KS, 4>;
             auto kern = gemm_ws2_kernel<KS, MODE>;
@@ -398,6 +429,7 @@ int gemm_ws(const GemmWS& g, hipStream_t st) {
     switch (g.K) {
         case 64: return launch_mode<2>(g, st);
         case 128: return launch_mode<4>(g, st);
+        case 512: return launch_mode<16>(g, st);
         default: return launch_mode<8>(g, st);
     }
 }

@@ -373,6 +373,10 @@ def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
     (640, 128, 128, 0, True, 0.0, True),       # d = 128: streaming kernel, LayerNorm unfused
     (500, 64, 64, 1, False, 0.0, False),
     (100, 264, 256, 0, False, 0.0, False),     # N not a multiple of the slab
+    (5000, 512, 512, 0, True, 0.1, True),      # d = 512 (C4 shapes): K = 512 form (one LDS buffer, A tile by LDS-DMA), LayerNorm unfused
+    (3001, 512, 512, 1, False, 0.0, False),    # ... GELU
+    (2000, 512, 512, 2, False, 0.0, False),    # ... GELU'
+    (4096, 2048, 512, 0, False, 0.0, False),   # ... eight column slabs
 ])
 def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, drop, ln):
     """bf16 weight-stationary streaming GEMM (gemm_ws.hip) == tiled kernel (same dropout masks) == torch."""
