@@ -95,8 +95,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rehearsal of the N > 1 control flow on a one-GPU box: PMGT_BENCH_BACKEND=gloo PMGT_BENCH_ONE_DEVICE=1 (every rank
+        # on cuda:0, gradients all-reduced through the host); the driver's runs use the defaults (RCCL, one GPU per rank)
+        backend = os.environ.get("PMGT_BENCH_BACKEND", "nccl")
+        if os.environ.get("PMGT_BENCH_ONE_DEVICE") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     dev = f"cuda:{local}"
 
     from pmgt_amd.configuration_pmgt import PMGTConfig
@@ -201,10 +209,13 @@ def main():
     # ---- per-phase HIP-event timers (separate pass, not part of `value`)
     if rank == 0 and not args.no_phase_profile:
         nprof = 5
+        # rank 0 alone runs this pass: no gradient all-reduce in it (the other ranks are past their last collective)
+        ws, trainer.world_size = trainer.world_size, 1
         eng.profile_begin()
         for i in range(nprof):
             trainer.train_step(staged[i % n_stage])
         prof = eng.profile_end()
+        trainer.world_size = ws
         torch.cuda.synchronize()
         tot = sum(ms for _, ms in prof.values())
         phases = {k: {"launches_per_step": c // nprof, "ms_per_step": round(ms / nprof, 4), "share": round(ms / tot, 4)}
