@@ -258,7 +258,7 @@ def main():
 
     # ---- end-to-end with the live host sampler (optional, reported separately)
     if args.end_to_end and rank == 0:
-        out["end_to_end"] = trainer.run_live(sampler, shard, B, steps=min(args.steps, 10), threads=threads)
+        out["end_to_end"] = trainer.run_live(sampler, shard, B, steps=min(args.steps, 30), threads=threads)
 
     # ---- CPU baseline: the oracle (CPU restatement pinned to the reference) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -104,16 +104,23 @@ class Trainer:
         free_q: "queue.Queue[int]" = queue.Queue()
         ready_q: "queue.Queue" = queue.Queue()
         for i in range(depth):
-            free_q.put(i)
+            free_q.put((i, None))
         n = len(node_ids)
+
+        t_sample = [0.0]
+        t_starved = [0.0]
 
         def producer():
             for step in range(steps):
-                slot = free_q.get()
+                slot, done = free_q.get()
+                if done is not None:
+                    done.synchronize()     # the pinned slot may be refilled once the step that read its copies is done
                 lo = (step * batch_size) % max(n - batch_size, 1)
                 tg = np.resize(node_ids[lo:], batch_size)
+                ts = time.perf_counter()
                 tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, out=slots[slot], threads=threads,
                                                             base_seed=7, counter=step * batch_size)
+                t_sample[0] += time.perf_counter() - ts
                 with torch.cuda.stream(copy_stream):
                     cu = lambda dct: {k: v.to(dev, non_blocking=True) for k, v in dct.items()}
                     b = (cu(tgt), cu(pair), num_pairs.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
@@ -126,18 +133,23 @@ class Trainer:
         t0 = time.perf_counter()
         th.start()
         for _ in range(steps):
+            ts = time.perf_counter()
             slot, b, ev = ready_q.get()
+            t_starved[0] += time.perf_counter() - ts
             torch.cuda.current_stream().wait_event(ev)
             self.train_step(b)
-            ev2 = torch.cuda.Event()
-            ev2.record()
-            ev2.synchronize()          # the pinned slot may be refilled once its copies and step are done
-            free_q.put(slot)
+            for v in list(b[0].values()) + list(b[1].values()) + [b[2], b[3]]:
+                v.record_stream(torch.cuda.current_stream())      # allocated on the copy stream, read on this one
+            done = torch.cuda.Event()
+            done.record()
+            free_q.put((slot, done))       # the launch thread does not wait for the GPU: the producer does, before it refills
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         th.join()
         return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
-                "sampler_threads": threads, "steps": steps}
+                "sampler_threads": threads, "steps": steps, "pipeline_depth": depth,
+                "sampler_ms_per_batch": round(t_sample[0] / steps * 1e3, 3),
+                "launch_thread_idle_ms_per_step": round(t_starved[0] / steps * 1e3, 3)}
 
 
 def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:
