@@ -377,6 +377,8 @@ def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
     (3001, 512, 512, 1, False, 0.0, False),    # ... GELU
     (2000, 512, 512, 2, False, 0.0, False),    # ... GELU'
     (4096, 2048, 512, 0, False, 0.0, False),   # ... eight column slabs
+    (3001, 256, 512, 0, True, 0.1, True),      # FFN2 with I = 2 d: K = 512 form WITH the fused LayerNorm (N = 256), ragged M
+    (2048, 256, 512, 0, True, 0.0, False),     # ... residual only
 ])
 def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, drop, ln):
     """bf16 weight-stationary streaming GEMM (gemm_ws.hip) == tiled kernel (same dropout masks) == torch."""
