@@ -78,3 +78,23 @@ def test_auc_matches_sklearn():
         assert abs(roc_auc_score(y, s) - sk(y, s)) < 1e-12
     with pytest.raises(ValueError):
         roc_auc_score(np.ones(5), rs.rand(5))
+
+
+def test_bench_rank0_phase_pass_issues_no_collective():
+    """bench.py at N > 1: after the timed region only rank 0 runs the per-phase timer pass, so that pass must not enter the
+    gradient all-reduce (its peers are already past their last collective and it would never return).  Trainer.optimizer_step
+    all-reduces iff world_size > 1; the pass has to run with world_size 1 and restore it afterwards."""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    blk = next(n for n in ast.walk(main) if isinstance(n, ast.If) and "no_phase_profile" in ast.unparse(n.test))
+    body = [ast.unparse(s) for s in blk.body]
+    begin = next(i for i, s in enumerate(body) if "profile_begin" in s)
+    end = next(i for i, s in enumerate(body) if "profile_end" in s)
+    assert any(s.replace(" ", "") == "(ws,trainer.world_size)=(trainer.world_size,1)" for s in body[:begin]), body[:begin]
+    assert any(s.replace(" ", "") == "trainer.world_size=ws" for s in body[end:]), body[end:]
+    # and the Trainer really keys the all-reduce on that attribute
+    tsrc = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pmgt_amd", "trainer.py")).read()
+    assert "if self.world_size > 1:\n            allreduce_mean_(eng.grads)" in tsrc
