@@ -264,7 +264,7 @@ def test_segment_sum_wgrad_matches_per_token_wgrad(name, dtype):
         b = res[1][0][e["offset"]: e["offset"] + e["numel"]]
         rel = ((a - b).norm() / b.norm()).item()
         # bf16: the two paths differ by one rounding of the mixed feature in the forward, so every gradient moves by
-        # bf16 noise; against the fp32 engine both are equally close (1.2 % on these tensors, tools/scratch/segcmp.py)
+        # bf16 noise; against the fp32 engine both are equally close (1.2 % on these tensors, a one-off comparison script)
         assert rel < (2e-6 if dtype == "fp32" else 2e-2), (k, rel)
         if dtype == "fp32":
             gu.check_stored(case["gold"], "grad/" + k, a.view(*e["shape"]).cpu().numpy(), 2e-3, 2e-3 * float(b.abs().mean()) + 1e-9)

@@ -1,5 +1,6 @@
-import sys, time, torch, numpy as np
-sys.path.insert(0, "/root/repo")
+"""hipGraph replay vs eager launches of one training step (A/B tool, not a test): python tools/graph_replay_bench.py [B]."""
+import os, sys, time, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmgt_amd.configuration_pmgt import PMGTConfig
 from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
 from pmgt_amd.engine import Engine
