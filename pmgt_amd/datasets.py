@@ -34,6 +34,7 @@ class MCNSampler:
         self.lib = _lib.sampler()
         self.graph = graph
         self.S = max_ctx_neigh + 1
+        self.hops = tuple(int(h) for h in hop_sampling_sizes)
         hops = np.asarray(list(hop_sampling_sizes), dtype=np.int32)
         self.h = self.lib.pmgt_sampler_create(graph.n_nodes, _p(graph.indptr), _p(graph.indices), _p(graph.weights),
                                               _p(hops), len(hops), max_ctx_neigh, max_total_samples, min_neg_samples)
@@ -92,9 +93,53 @@ class MCNSampler:
         return tgt, pair, buf["num_pairs"][:n], buf["labels"][:tot]
 
 
-def get_input_tensor(sampler: MCNSampler, target_node: int) -> Tuple[torch.LongTensor, torch.FloatTensor]:
-    """pmgt/pmgt/datasets.py:64-79 — (LongTensor [S] = [target] + context, FloatTensor [S] mask)."""
+_DEFAULT_SEED = 0
+
+
+def set_seed(seed: int):
+    """np.random.seed analogue (pmgt/utils/base.py:37) for the samplers `get_input_tensor` creates behind a graph:
+    re-seeds the ones that exist and seeds the ones created later."""
+    global _DEFAULT_SEED
+    _DEFAULT_SEED = int(seed)
+    for g in list(_GRAPHS_WITH_SAMPLERS):
+        for smp in g._pmgt_samplers.values():
+            smp.seed(seed)
+
+
+_GRAPHS_WITH_SAMPLERS: list = []
+
+
+def _sampler_for(graph: CSRGraph, hop_sampling_sizes: Sequence[int], max_num_ctx_neigh: int) -> MCNSampler:
+    cache = graph.__dict__.setdefault("_pmgt_samplers", {})
+    key = (tuple(int(h) for h in hop_sampling_sizes), int(max_num_ctx_neigh))
+    smp = cache.get(key)
+    if smp is None:
+        smp = cache[key] = MCNSampler(graph, max_num_ctx_neigh, key[0])
+        smp.seed(_DEFAULT_SEED)
+        if not any(g is graph for g in _GRAPHS_WITH_SAMPLERS):
+            _GRAPHS_WITH_SAMPLERS.append(graph)
+    return smp
+
+
+def get_input_tensor(graph, target_node: int, hop_sampling_sizes: Optional[Sequence[int]] = None,
+                     max_num_ctx_neigh: Optional[int] = None) -> Tuple[torch.LongTensor, torch.FloatTensor]:
+    """pmgt/pmgt/datasets.py:64-79 -- (LongTensor [S] = [target] + context, FloatTensor [S] mask), same four arguments
+    (second caller: pmgt/pmgt_ncf/datasets.py:62).  `graph` is a CSRGraph; the native sampler of that (graph, hop sizes,
+    context length) is created on first use and kept on the graph, so successive calls continue ONE sequential stream as
+    the reference's global np.random does (seed it with `set_seed`).  An MCNSampler may be passed instead of the graph
+    (then the last two arguments are optional and, if given, must agree with it)."""
+    if isinstance(graph, MCNSampler):
+        sampler = graph
+        if max_num_ctx_neigh is not None and max_num_ctx_neigh + 1 != sampler.S:
+            raise ValueError(f"max_num_ctx_neigh={max_num_ctx_neigh} does not match the sampler's context length {sampler.S - 1}")
+        if hop_sampling_sizes is not None and tuple(hop_sampling_sizes) != tuple(sampler.hops):
+            raise ValueError(f"hop_sampling_sizes={list(hop_sampling_sizes)} do not match the sampler's {list(sampler.hops)}")
+    else:
+        if hop_sampling_sizes is None or max_num_ctx_neigh is None:
+            raise TypeError("get_input_tensor(graph, target_node, hop_sampling_sizes, max_num_ctx_neigh)")
+        sampler = _sampler_for(graph, hop_sampling_sizes, max_num_ctx_neigh)
     ids, mask = sampler.context(target_node)
+    assert len(ids) == sampler.S, f"# of context nodes must be {sampler.S - 1}"
     return torch.from_numpy(ids), torch.from_numpy(mask)
 
 

@@ -14,22 +14,23 @@ import numpy as np
 import torch
 
 
+def init_value(name: str, shape, config, generator: torch.Generator) -> torch.Tensor:
+    """The reference's initial distribution of ONE parameter (pmgt/pmgt/modeling_pmgt.py:44-58 under `bert.`;
+    nn.Linear's default under `nfr_loss.`, pmgt/pmgt/models.py:31-54) -- pure torch, no device."""
+    if name.startswith("nfr_loss."):
+        bound = 1.0 / math.sqrt(config.hidden_size)            # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)), bias likewise
+        return (torch.rand(shape, generator=generator) * 2 - 1) * bound
+    if name.endswith("LayerNorm.weight"):
+        return torch.ones(shape)
+    if name.endswith(".bias"):
+        return torch.zeros(shape)
+    return torch.randn(shape, generator=generator) * config.initializer_range
+
+
 def reference_init(engine, seed: int = 0):
     g = torch.Generator().manual_seed(seed)
-    std = engine.config.initializer_range
     for e in engine.entries:
-        name, shape = e["name"], e["shape"]
-        if name.startswith("nfr_loss."):
-            fan_in = engine.config.hidden_size
-            bound = 1.0 / math.sqrt(fan_in)
-            v = (torch.rand(shape, generator=g) * 2 - 1) * bound
-        elif name.endswith("LayerNorm.weight"):
-            v = torch.ones(shape)
-        elif name.endswith(".bias"):
-            v = torch.zeros(shape)
-        else:
-            v = torch.randn(shape, generator=g) * std
-        engine.view(name).copy_(v)
+        engine.view(e["name"]).copy_(init_value(e["name"], e["shape"], engine.config, g))
 
 
 def synthetic_features(n_nodes: int, feat_sizes=(1536, 768), seed: int = 0):

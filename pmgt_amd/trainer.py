@@ -96,60 +96,119 @@ class Trainer:
         return replay
 
     # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
-    def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3):
+    def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3,
+                 stall_timeout_s: float = 120.0):
         eng = self.engine
         dev = eng.device
         copy_stream = torch.cuda.Stream(device=dev)
         slots = [sampler.alloc(batch_size, MODE_TRAIN, pinned=True) for _ in range(depth)]
-        free_q: "queue.Queue[int]" = queue.Queue()
-        ready_q: "queue.Queue" = queue.Queue()
-        for i in range(depth):
-            free_q.put((i, None))
         n = len(node_ids)
-
         t_sample = [0.0]
-        t_starved = [0.0]
 
-        def producer():
-            for step in range(steps):
-                slot, done = free_q.get()
-                if done is not None:
-                    done.synchronize()     # the pinned slot may be refilled once the step that read its copies is done
-                lo = (step * batch_size) % max(n - batch_size, 1)
-                tg = np.resize(node_ids[lo:], batch_size)
-                ts = time.perf_counter()
-                tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, out=slots[slot], threads=threads,
-                                                            base_seed=7, counter=step * batch_size)
-                t_sample[0] += time.perf_counter() - ts
-                with torch.cuda.stream(copy_stream):
-                    cu = lambda dct: {k: v.to(dev, non_blocking=True) for k, v in dct.items()}
-                    b = (cu(tgt), cu(pair), num_pairs.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
-                    ev = torch.cuda.Event()
-                    ev.record(copy_stream)
-                ready_q.put((slot, b, ev))
+        def produce(step, slot, done):
+            if done is not None:
+                done.synchronize()     # the pinned slot may be refilled once the step that read its copies is done
+            lo = (step * batch_size) % max(n - batch_size, 1)
+            tg = np.resize(node_ids[lo:], batch_size)
+            ts = time.perf_counter()
+            tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, out=slots[slot], threads=threads,
+                                                        base_seed=7, counter=step * batch_size)
+            t_sample[0] += time.perf_counter() - ts
+            with torch.cuda.stream(copy_stream):
+                cu = lambda dct: {k: v.to(dev, non_blocking=True) for k, v in dct.items()}
+                b = (cu(tgt), cu(pair), num_pairs.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return b, ev
 
-        th = threading.Thread(target=producer, daemon=True)
+        pipe = ProducerPipeline(produce, steps, depth, stall_timeout_s=stall_timeout_s)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        th.start()
-        for _ in range(steps):
-            ts = time.perf_counter()
-            slot, b, ev = ready_q.get()
-            t_starved[0] += time.perf_counter() - ts
-            torch.cuda.current_stream().wait_event(ev)
-            self.train_step(b)
-            for v in list(b[0].values()) + list(b[1].values()) + [b[2], b[3]]:
-                v.record_stream(torch.cuda.current_stream())      # allocated on the copy stream, read on this one
-            done = torch.cuda.Event()
-            done.record()
-            free_q.put((slot, done))       # the launch thread does not wait for the GPU: the producer does, before it refills
-        torch.cuda.synchronize()
+        pipe.start()
+        try:
+            for slot, (b, ev) in pipe:
+                torch.cuda.current_stream().wait_event(ev)
+                self.train_step(b)
+                for v in list(b[0].values()) + list(b[1].values()) + [b[2], b[3]]:
+                    v.record_stream(torch.cuda.current_stream())      # allocated on the copy stream, read on this one
+                done = torch.cuda.Event()
+                done.record()
+                pipe.release(slot, done)   # the launch thread does not wait for the GPU: the producer does, before it refills
+        finally:
+            torch.cuda.synchronize()
+            pipe.close()
         el = time.perf_counter() - t0
-        th.join()
         return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
                 "sampler_threads": threads, "steps": steps, "pipeline_depth": depth,
                 "sampler_ms_per_batch": round(t_sample[0] / steps * 1e3, 3),
-                "launch_thread_idle_ms_per_step": round(t_starved[0] / steps * 1e3, 3)}
+                "launch_thread_idle_ms_per_step": round(pipe.starved_s / steps * 1e3, 3)}
+
+
+class PipelineError(RuntimeError):
+    """The producer thread of a ProducerPipeline died or stalled; the original exception (if any) is the __cause__."""
+
+
+class ProducerPipeline:
+    """`depth` reusable slots filled by ONE producer thread and drained in order by the calling thread (the host side of
+    `Trainer.run_live`: sampler -> pinned slot -> async copy).  `produce(step, slot, token)` runs on the producer thread;
+    `token` is whatever the consumer passed to `release(slot, token)` when it handed the slot back (None the first time).
+    A producer that raises (sampler ValueError for an isolated / out-of-range node, a failed pin or copy) or stops
+    delivering for `stall_timeout_s` does not leave the consumer blocked: iteration raises PipelineError instead."""
+
+    def __init__(self, produce, steps: int, depth: int, stall_timeout_s: float = 120.0, poll_s: float = 0.2):
+        self.produce, self.steps, self.depth = produce, steps, depth
+        self.stall_timeout_s, self.poll_s = stall_timeout_s, poll_s
+        self.free_q: "queue.Queue" = queue.Queue()
+        self.ready_q: "queue.Queue" = queue.Queue()
+        for i in range(depth):
+            self.free_q.put((i, None))
+        self.starved_s = 0.0
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        try:
+            for step in range(self.steps):
+                while True:                      # a consumer that stopped early must not leave this thread blocked
+                    if self._stop.is_set():
+                        return
+                    try:
+                        slot, token = self.free_q.get(timeout=self.poll_s)
+                        break
+                    except queue.Empty:
+                        continue
+                self.ready_q.put(("item", slot, self.produce(step, slot, token)))
+        except BaseException as exc:             # delivered to the consumer, which re-raises
+            self.ready_q.put(("error", None, exc))
+
+    def start(self):
+        self._th.start()
+
+    def release(self, slot: int, token=None):
+        self.free_q.put((slot, token))
+
+    def close(self):
+        self._stop.set()
+        if self._th.is_alive():
+            self._th.join(timeout=5.0)
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            t0 = time.perf_counter()
+            while True:
+                try:
+                    kind, slot, payload = self.ready_q.get(timeout=self.poll_s)
+                    break
+                except queue.Empty:
+                    waited = time.perf_counter() - t0
+                    if not self._th.is_alive() and self.ready_q.empty():
+                        raise PipelineError("input pipeline: the producer thread exited without delivering a batch")
+                    if waited > self.stall_timeout_s:
+                        raise PipelineError(f"input pipeline: no batch for {waited:.0f} s (producer stalled)")
+            self.starved_s += time.perf_counter() - t0
+            if kind == "error":
+                raise PipelineError(f"input pipeline: producer failed: {payload!r}") from payload
+            yield slot, payload
 
 
 def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:
