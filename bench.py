@@ -51,7 +51,9 @@ def parse():
     ap.add_argument("--no-phase-profile", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="partial-sum reductions on the engine's side stream (A/B; measured neutral)")
     ap.add_argument("--sampler-threads", type=int, default=0)
-    ap.add_argument("--end-to-end", action="store_true", help="also time steps fed by the live host sampler")
+    ap.add_argument("--end-to-end", action="store_true", help="(default on; kept for compatibility) also time steps fed by the live host sampler")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the live-sampler pass")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the B=32 / B=256 extra measurements (N=1 only)")
     return ap.parse_args()
 
 
@@ -85,6 +87,51 @@ def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
         "bwd.embed_mix": (0.0, M * 7 * d * esz),
     }
     return table.get(name)
+
+
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup CPU quota when there is one (a GPU box shows all 256 hardware threads
+    in os.cpu_count() but grants a share of them), else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    try:
+        return float(len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return float(os.cpu_count() or 1)
+
+
+def kernel_sources_sha():
+    """Fingerprint of the HIP sources: profiles/traffic.json is only quoted when it was measured on these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pmgt_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def time_steps(trainer, staged, steps, warmup):
+    for i in range(warmup):
+        trainer.train_step(staged[i % len(staged)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer.train_step(staged[(warmup + i) % len(staged)])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -131,24 +178,35 @@ def main():
     trainer = Trainer(eng, lr=1e-4, weight_decay=1e-2, max_grad_norm=5.0, world_size=world)
     trainer.broadcast_parameters()
 
-    # ---- pre-stage node-context batches in HBM (host MCNSampling, C++ threads)
-    threads = args.sampler_threads or min(os.cpu_count() or 1, 32)
+    # ---- pre-stage node-context batches in HBM (host MCNSampling, C++ worker pool)
+    from pmgt_amd.parallel import shard_indices
+    share = host_cpu_share()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    # sampler workers per rank: this rank's part of the CPU share minus two CPUs for the launch thread and the runtime's
+    threads = args.sampler_threads or int(max(2, min(32, share / max(local_world, 1) - 2)))
     sampler = MCNSampler(graph, max_ctx_neigh=S - 1)
-    perm = np.random.RandomState(0).permutation(nodes) + 2
-    shard = perm[rank::world]
+    # DistributedSampler semantics (what PL injects, pmgt/base_trainer.py:309-322): rank r takes r::W of one seeded permutation
+    shard = shard_indices(nodes, rank, world, seed=0, epoch=0) + 2
+    cu = lambda dct: {k: v.to(dev) for k, v in dct.items()}
+
+    def stage(Bx, count, ctr0=0):
+        out = []
+        for i in range(count):
+            tg = np.resize(shard[(i * Bx) % max(len(shard) - Bx, 1):], Bx) if len(shard) >= Bx else np.resize(shard, Bx)
+            tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, threads=threads, base_seed=rank, counter=ctr0 + i * Bx)
+            out.append((cu(tgt), cu(pair), num_pairs.to(dev), labels.to(dev)))
+        return out
+
     n_stage = min(args.steps + args.warmup, 8)
-    staged = []
-    for i in range(n_stage):
-        tg = np.resize(shard[(i * B) % max(len(shard) - B, 1):], B) if len(shard) >= B else np.resize(shard, B)
-        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, threads=threads, base_seed=rank, counter=i * B)
-        cu = lambda dct: {k: v.to(dev) for k, v in dct.items()}
-        staged.append((cu(tgt), cu(pair), num_pairs.to(dev), labels.to(dev)))
-    # sustained rate of the host sampler alone (what the live pipeline of --end-to-end sees): back-to-back calls into one buffer
+    staged = stage(B, n_stage)
+    # sustained rate of the host sampler alone, as the live pipeline uses it: one warm call (worker pool and staging buffers
+    # exist, pages touched), then back-to-back calls into one buffer
     slot = sampler.alloc(B, MODE_TRAIN)
+    sampler.batch(np.resize(shard, B), MODE_TRAIN, out=slot, threads=threads, base_seed=rank, counter=n_stage * B)
     t0 = time.perf_counter()
     for i in range(4):
         sampler.batch(np.resize(shard[(i * B) % max(len(shard) - B, 1):], B), MODE_TRAIN, out=slot, threads=threads,
-                      base_seed=rank, counter=(n_stage + i) * B)
+                      base_seed=rank, counter=(n_stage + 1 + i) * B)
     sampler_nodes_per_s = 4 * B / max(time.perf_counter() - t0, 1e-9)
     del slot
 
@@ -166,7 +224,7 @@ def main():
     for i in range(args.steps):
         l = trainer.train_step(staged[(args.warmup + i) % n_stage])
         if i == 0:
-            loss_first = l          # device scalar of the first timed step; read after the timed region
+            loss_first = l.clone()  # device scalar of the first timed step (the engine recycles its output buffers); read after the timed region
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -205,23 +263,24 @@ def main():
         "loss_last": round(loss_last, 5),
         "grad_norm_last": round(grad_norm_last, 5),
         "side_stream_reductions": bool(args.overlap),
-        "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count()},
+        "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count(),
+                         "cpu_share": round(share, 1)},
+        "allreduce": ("per-bucket, overlapped with the backward pass" if world > 1 else None),
     }
 
     flops_node = train_flops_per_node(d, I, L, S)
     out["train_gflop_per_node"] = round(flops_node / 1e9, 3)
     out["mfma_util_vs_bf16_dense_peak"] = round(value / world * flops_node / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
 
-    # ---- per-phase HIP-event timers (separate pass, not part of `value`)
-    if rank == 0 and not args.no_phase_profile:
+    # ---- per-phase HIP-event timers (separate pass, not part of `value`).  EVERY rank runs it, collectives included: the
+    # control flow of all ranks is identical from init to destroy (only rank 0 prints), so no rank can be left alone in a
+    # collective or tear the process group down while a peer still uses it.
+    if not args.no_phase_profile:
         nprof = 5
-        # rank 0 alone runs this pass: no gradient all-reduce in it (the other ranks are past their last collective)
-        ws, trainer.world_size = trainer.world_size, 1
         eng.profile_begin()
         for i in range(nprof):
             trainer.train_step(staged[i % n_stage])
         prof = eng.profile_end()
-        trainer.world_size = ws
         torch.cuda.synchronize()
         tot = sum(ms for _, ms in prof.values())
         phases = {k: {"launches_per_step": c // nprof, "ms_per_step": round(ms / nprof, 4), "share": round(ms / tot, 4)}
@@ -252,19 +311,54 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them
     # in separate passes, tools/gpu_profile.sh); the committed summary of the last such run is quoted when it is for
     # this workload, else traffic stays null.
-    if rank == 0 and "roofline" in out:
+    if "roofline" in out:
         try:
             tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
             ph = tr["phases"].get(out["roofline"]["kernel"])
-            if ph and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16":
+            fresh = tr.get("kernel_sources_sha") == kernel_sources_sha()       # measured on THESE kernels, else it is stale: null
+            if ph and fresh and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16":
                 out["roofline"]["traffic"] = ph["hbm_mb_per_launch"]
                 out["roofline"]["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
         except (OSError, KeyError, ValueError):
             pass
 
-    # ---- end-to-end with the live host sampler (optional, reported separately)
-    if args.end_to_end and rank == 0:
-        out["end_to_end"] = trainer.run_live(sampler, shard, B, steps=min(args.steps, 30), threads=threads)
+    # ---- batch sizes of the reference's own entry points (N = 1): B=32 = scripts/run_pmgt.sh:11, B=256 = the CLI default
+    # (train.py:33-38); eager launches and, where capture works, the whole step replayed as ONE hipGraph
+    if world == 1 and not args.no_batch_sweep:
+        sweep = {}
+        for Bx in (32, 256):
+            if Bx == B:
+                continue
+            st_x = stage(Bx, 4, ctr0=10 ** 6)
+            ms = time_steps(trainer, st_x, steps=30, warmup=5) * 1e3
+            ent = {"nodes_per_s": round(Bx / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+            try:
+                replay = trainer.capture_step(st_x[0])
+                for _ in range(3):
+                    replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    replay()
+                torch.cuda.synchronize()
+                gms = (time.perf_counter() - t0) / 30 * 1e3
+                ent["hipgraph_replay"] = {"nodes_per_s": round(Bx / gms * 1e3, 1), "ms_per_step": round(gms, 4)}
+            except Exception as exc:                      # capture is an optimisation, never a reason to lose the bench line
+                ent["hipgraph_replay"] = {"error": repr(exc)[:200]}
+            sweep[str(Bx)] = ent
+        out["batch_sweep"] = sweep
+
+    # ---- end to end with the live host sampler (threaded C++ MCNSampling -> pinned slots -> side-stream H2D): the rate a
+    # training job sees; `value` above is the pre-staged rate the metric is defined on.  Every rank runs it (symmetric).
+    if not args.no_end_to_end:
+        e2e = trainer.run_live(sampler, shard, B, steps=min(args.steps, 30), threads=threads)
+        if world > 1:
+            tt = torch.tensor([e2e["ms_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e2e["ms_per_step"] = round(tt.item(), 3)
+            e2e["nodes_per_s"] = round(world * B / tt.item() * 1e3, 1)
+        e2e["vs_prestaged"] = round(e2e["nodes_per_s"] / value, 4)
+        out["end_to_end"] = e2e
 
     # ---- CPU baseline: the oracle (CPU restatement pinned to the reference) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -273,12 +367,14 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()                      # nobody tears the group down while a peer is still inside a collective
         dist.destroy_process_group()
 
 
 def cpu_baseline(cfg, graph, S, dropout):
     """Times the CPU oracle (oracle/pmgt_oracle.py, checked against the reference's golden vectors) on the
-    host cores: fp32, all threads, same shapes, B=16 targets per step (192 sequences), fwd+bwd+clip+AdamW."""
+    host cores: fp32, up to 16 threads, same shapes, B=8 targets per step (96 sequences), fwd+bwd+clip+AdamW."""
     from oracle import pmgt_oracle as po
     from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
     cores = min(os.cpu_count() or 1, 16)     # more threads only slow these small ops down (oversubscription)

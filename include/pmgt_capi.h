@@ -156,6 +156,17 @@ typedef struct pmgt_adam {
 } pmgt_adam;
 int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* a, void* stream);
 
+/* Gradient-ready notification for the data-parallel exchange (replaces DDP's autograd hooks + buckets,
+ * pmgt/base_trainer.py:309-322 -> pl.Trainer(gpus=N)): during a backward pass the engine calls cb(user, offset, numel) on
+ * the CALLING host thread right after it has enqueued the last launch that writes grads[offset, offset + numel) -- i.e.
+ * work the callee enqueues on `stream` (an event record, an all-reduce that waits for that event) is ordered after those
+ * writes and overlaps the rest of the backward pass.  Buckets arrive in backward order and tile the flat buffer exactly
+ * once per backward call: NFR head (pmgt_pretrain_step only; pmgt_encode_backward produces no gradient for it and its
+ * buckets tile the `bert.*` range), encoder layers L-1 .. 0, embeddings.  cb = NULL switches it off.  With the
+ * side-stream reductions on (pmgt_engine_set_overlap) one bucket covering the whole buffer is reported at the end. */
+typedef void (*pmgt_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
+void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, void* user);
+
 /* Per-phase timers (what the reference lacks entirely): between begin and end every group of
  * kernel launches is bracketed by HIP events on its stream; end() waits for them and writes one
  * "name count total_ms" line per phase into buf.  Off by default. */

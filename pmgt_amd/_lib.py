@@ -43,6 +43,8 @@ class AdamC(C.Structure):
 
 
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8 = 0, 1, 2
+# void (*pmgt_grad_ready_fn)(void* user, int64_t offset, int64_t numel)  (include/pmgt_capi.h)
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 FLAG_TRAINING, FLAG_BACKWARD, FLAG_ACCUMULATE = 1, 2, 4
 EPI_NONE, EPI_GELU, EPI_GELU_GRAD = 0, 1, 2
 
@@ -55,6 +57,7 @@ HIP_SYMBOLS = [
     "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd", "pmgt_debug_force_valu_attention", "pmgt_debug_force_tile_gemm", "pmgt_debug_enable_nt_dma", "pmgt_engine_set_overlap", "pmgt_op_qkvc_attention_fwd", "pmgt_debug_disable_fused_qkvc_attention", "pmgt_debug_disable_table_projection", "pmgt_debug_disable_segment_sum", "pmgt_debug_disable_head_major", "pmgt_debug_disable_coop_attention_bwd", "pmgt_debug_disable_last_layer_shortcut", "pmgt_op_linear",
     "pmgt_quantize_e4m3", "pmgt_dequantize_e4m3", "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8",
     "pmgt_op_qkvc_attention_fwd_f8", "pmgt_op_gemm_tn_bias", "pmgt_debug_disable_producer_quant",
+    "pmgt_engine_set_grad_ready_callback",
 ]
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
@@ -129,6 +132,8 @@ def hip():
     L.pmgt_debug_disable_table_projection.restype = None
     L.pmgt_debug_disable_fused_qkvc_attention.argtypes = [i]
     L.pmgt_debug_disable_fused_qkvc_attention.restype = None
+    L.pmgt_engine_set_grad_ready_callback.argtypes = [vp, GRAD_READY_FN, vp]
+    L.pmgt_engine_set_grad_ready_callback.restype = None
     L.pmgt_engine_set_overlap.argtypes = [vp, i]
     L.pmgt_engine_set_overlap.restype = None
     L.pmgt_debug_enable_nt_dma.argtypes = [i]

@@ -97,6 +97,11 @@ struct pmgt_engine {
     std::vector<hipEvent_t> sync_ev;
     size_t sync_next = 0;
     bool overlap = false;     // partial-sum reductions on the side stream (see SideReduce): measured neutral, opt-in
+    // data-parallel exchange: called when a contiguous range of the flat gradient buffer is final in stream order
+    pmgt_grad_ready_fn grad_cb = nullptr;
+    void* grad_cb_user = nullptr;
+    bool grad_cb_fine() const { return grad_cb != nullptr && !(overlap && side != nullptr); }
+    void grad_ready(int64_t off, int64_t numel) const { if (grad_cb && numel > 0) grad_cb(grad_cb_user, off, numel); }
     hipEvent_t next_sync() {
         if (sync_ev.empty()) {
             sync_ev.resize(64);
@@ -737,7 +742,7 @@ static inline int join_side_all(const pmgt_engine* e, Bufs<T>& b, hipStream_t ma
 template <typename T>
 static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st,
                             bool shortcut = false, bool train = true, const T* feat_v = nullptr, const T* feat_t = nullptr,
-                            int n_cls_only = 0) {
+                            int n_cls_only = 0, bool whole_buffer = false) {
     const int d = e->d, I = e->I, L = e->L, H = e->H;
     const int M = Tseq * S;
     const float* P = t->params;
@@ -806,6 +811,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
         RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc,
                      b.qkvc_hm ? d : 0, b.qkvc_hm ? e->dh : 0));
+        // every gradient of layer l is final in stream order: let the data-parallel exchange of this bucket start now
+        if (e->grad_cb_fine()) e->grad_ready(o.Wqkvc, (l + 1 < L ? e->layers[l + 1].Wqkvc : e->Wn) - o.Wqkvc);
         {   // d hin = dqkvc Wqkvc + residual branch
             GemmNT g;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + (b.qkvc_hm ? o.mWqkvcT_hm : o.mWqkvcT); g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
@@ -852,6 +859,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
     }
     RUN(join_side_all<T>(e, b, st));       // the caller's stream sees every gradient
+    if (e->grad_cb_fine()) e->grad_ready(0, L > 0 ? e->layers[0].Wqkvc : e->Wn);         // embeddings bucket
+    else if (e->grad_cb) e->grad_ready(0, whole_buffer ? e->total : e->Wn);            // side-stream reductions: one bucket
     return 0;
 }
 
@@ -938,12 +947,13 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     if (bwd) {
         const int msp = std::max(256, cap / 5);
         RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hN, d, nrows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st, t->grads + e->bn));
+        if (e->grad_cb_fine()) e->grad_ready(e->Wn, e->total - e->Wn);          // NFR head bucket
         GemmNT g;
         g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.M = cap; g.N = d; g.K = F; g.m_dev = b.nfr_count;
         g.C = sc ? dhL + (int64_t)(B + Pn) * d : b.dq; g.ldc = d;      // compacted: the masked rows ARE rows B+P.. of dhL
         RUNP("bwd.dgrad_nfr", gemm_nt<T>(g, st));
         if (!sc) RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
-        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc, true, (const T*)nullptr, (const T*)nullptr, B + Pn));
+        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc, true, (const T*)nullptr, (const T*)nullptr, B + Pn, true));
     }
     if (train) RUN(advance_rng(t->rng_state, st));
     return 0;
@@ -1290,6 +1300,9 @@ void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
 void pmgt_debug_disable_head_major(int on) { g_no_hm = on; }
 void pmgt_debug_disable_producer_quant(int on) { g_no_producer_quant = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
+void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, void* user) {
+    if (e) { e->grad_cb = cb; e->grad_cb_user = user; }
+}
 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,

@@ -154,6 +154,35 @@ class Engine:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _workspace_bytes(self, n_seq: int, S: int, B: int, training: bool) -> int:
+        key = (n_seq, S, B, bool(training))
+        cache = self.__dict__.setdefault("_ws_bytes", {})
+        if key not in cache:
+            cache[key] = int(self.lib.pmgt_workspace_bytes(self.h, n_seq, S, B, 1 if training else 0))
+        return cache[key]
+
+    OUTPUT_RING = 4
+
+    def _outputs(self, B: int, P: int, S: int, want_hidden: bool):
+        """Output tensors of pretrain_step from a ring of OUTPUT_RING persistent sets per shape (no allocator call and no
+        memset launch on the step's critical path): what a call returns stays valid until OUTPUT_RING - 1 further calls
+        with the same shape have been made -- clone a result that must live longer."""
+        key = (B, P, S, bool(want_hidden))
+        rings = self.__dict__.setdefault("_out_rings", {})
+        ring = rings.get(key)
+        if ring is None:
+            if len(rings) > 16:          # ragged last batches etc.: do not grow without bound
+                rings.clear()
+            d = self.config.hidden_size
+            ring = rings[key] = dict(next=0, sets=[(
+                torch.empty(3, dtype=torch.float32, device=self.device),
+                torch.empty(P, dtype=torch.float32, device=self.device),
+                torch.empty(B, S, d, dtype=self.torch_dtype, device=self.device) if want_hidden else None,
+                torch.zeros(1, dtype=torch.int32, device=self.device)) for _ in range(self.OUTPUT_RING)])
+        out = ring["sets"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % self.OUTPUT_RING
+        return out
+
     # ---- PMGT.forward (+ backward) ---------------------------------------------------------------
     def pretrain_step(self, batch, training: bool, backward: bool = False, accumulate: bool = False,
                       nfr_inject=None, random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16,
@@ -165,11 +194,10 @@ class Engine:
         B, S = ids.shape
         P = int(pair["node_ids"].shape[0])
         n_seq = B + P + (B if training else 0)
-        ws = self._workspace(self.lib.pmgt_workspace_bytes(self.h, n_seq, S, B, 1 if training else 0))
-        loss = torch.empty(3, dtype=torch.float32, device=self.device)
-        logits = torch.empty(P, dtype=torch.float32, device=self.device)
-        hidden = torch.empty(B, S, self.config.hidden_size, dtype=self.torch_dtype, device=self.device) if want_hidden else None
-        count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = self._workspace(self._workspace_bytes(n_seq, S, B, training))
+        loss, logits, hidden, count = self._outputs(B, P, S, want_hidden)
+        if not training:
+            count.zero_()                # only the training path writes the number of masked rows
         keep = [ids, tgt["attention_mask"].contiguous(), pair["node_ids"].contiguous(),
                 pair["attention_mask"].contiguous(), num_pairs.contiguous(), labels.to(torch.float32).contiguous()]
         bc = _lib.BatchC(B, P, S, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
@@ -184,6 +212,7 @@ class Engine:
         tc = self._tensors(grad_buffer)
         _lib.check(self.lib.pmgt_pretrain_step(self.h, C.byref(tc), C.byref(bc), C.byref(oc), _ptr(ws), ws.numel(),
                                                flags, _stream()))
+        self._raise_hook_error()
         return dict(loss=loss[0], gsr=loss[1], nfr=loss[2], losses=loss, logits=logits, last_hidden_state=hidden,
                     nfr_count=count)
 
@@ -246,6 +275,7 @@ class Engine:
         ws = state["ws"]
         _lib.check(self.lib.pmgt_encode_backward(self.h, C.byref(tc), _ptr(state["fv"]), _ptr(state["ft"]), _ptr(d_last),
                                                  state["n_seq"], state["S"], _ptr(ws), ws.numel(), flags, _stream()))
+        self._raise_hook_error()
 
     # ---- clip + AdamW ----------------------------------------------------------------------------------
     def optimizer_step(self, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
@@ -257,6 +287,27 @@ class Engine:
                         self.opt_step.data_ptr(), self.opt_scalars.data_ptr(), self.opt_scratch.data_ptr())
         tc = self._tensors()
         _lib.check(self.lib.pmgt_optimizer_step(self.h, C.byref(tc), C.byref(ac), _stream()))
+
+    def set_grad_ready_hook(self, fn=None):
+        """fn(offset, numel) is called on the launching thread, in stream order, as soon as grads[offset: offset + numel]
+        is final during a backward pass (buckets: NFR head, layers L-1 .. 0, embeddings); None removes the hook.
+        An exception raised by `fn` is re-raised by the pretrain_step / encode_backward call that triggered it."""
+        self._hook_error = None
+        if fn is None:
+            self._grad_cb = _lib.GRAD_READY_FN(0)
+        else:
+            def _cb(_user, off, numel):
+                try:
+                    fn(int(off), int(numel))
+                except BaseException as exc:         # never unwind through the C frames
+                    self._hook_error = exc
+            self._grad_cb = _lib.GRAD_READY_FN(_cb)            # keep the thunk alive as long as the engine holds its address
+        self.lib.pmgt_engine_set_grad_ready_callback(self.h, self._grad_cb, None)
+
+    def _raise_hook_error(self):
+        err, self._hook_error = getattr(self, "_hook_error", None), None
+        if err is not None:
+            raise err
 
     def set_overlap(self, on: bool):
         """Partial-sum reductions of the backward pass on the engine's side stream (default) or on the caller's stream."""

@@ -79,10 +79,74 @@ def save_checkpoint(model, path: str, prefix: str = "net.", **extra):
     torch.save({"state_dict": to_reference_state_dict(model, prefix), **extra}, path)
 
 
+class _Opaque(dict):
+    """Stand-in for any class a checkpoint pickles that is not plain data (Lightning's AttributeDict / AttrDict
+    hyper-parameters, callback state objects, ...): keeps items and attributes, runs none of the original code."""
+
+    def __init__(self, *args, **kwargs):
+        dict.__init__(self)
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        elif isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):
+            self.__dict__.update(state[1])
+
+    def __reduce__(self):                       # never re-pickled as the original class
+        return (dict, (dict(self),))
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    """Restricted unpickler for checkpoints written by the reference's Lightning run (pmgt/base_trainer.py:291-298:
+    ModelCheckpoint -> {"state_dict", "hyper_parameters", "callbacks", "optimizer_states", ...}).  torch's
+    weights_only loader refuses such a file because `hyper_parameters` is an AttributeDict / AttrDict; this one resolves
+    ONLY tensor / container reconstruction globals and maps every other global to an inert placeholder, so a real checkpoint
+    loads without pytorch_lightning installed and without executing code from the file."""
+
+    _ALLOWED = {
+        ("collections", "OrderedDict"), ("collections", "defaultdict"), ("copyreg", "_reconstructor"), ("builtins", "dict"),
+        ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "object"),
+        ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+        ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+        ("torch._utils", "_rebuild_parameter_with_state"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+        ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+        ("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+            return getattr(torch, name)
+        return _Opaque
+
+
+class _TolerantPickle:            # the `pickle_module` interface torch.load asks for
+    Unpickler = _TolerantUnpickler
+    __name__ = "pmgt_amd.io._TolerantPickle"
+
+    @staticmethod
+    def load(f, **kw):
+        return _TolerantUnpickler(f, **kw).load()
+
+
+def read_checkpoint(path) -> dict:
+    """A checkpoint file as plain data.  First torch's weights_only loader (enough for checkpoints written by
+    `save_checkpoint`); a file it refuses because it pickles non-tensor classes -- a real Lightning checkpoint of the
+    reference -- goes through the restricted tolerant unpickler above (still no code from the file is executed)."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError:
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_TolerantPickle)
+
+
 def load_checkpoint(model, path_or_dict, prefix: str = "net.", strict: bool = True):
-    """Accepts a Lightning checkpoint ({"state_dict": {"net.…": …}}), a bare state_dict with or without the
-    prefix, or a path to either; copies the weights into the engine's flat buffer and re-uploads the tables."""
-    ck = torch.load(path_or_dict, map_location="cpu", weights_only=True) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+    """Accepts a Lightning checkpoint ({"state_dict": {"net.…": …}, "hyper_parameters": …, "callbacks": …,
+    "optimizer_states": …}), a bare state_dict with or without the prefix, or a path to either; copies the weights into the
+    engine's flat buffer and re-uploads the tables."""
+    ck = read_checkpoint(path_or_dict) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
     sd = ck.get("state_dict", ck)
     if any(k.startswith(prefix) for k in sd):
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}

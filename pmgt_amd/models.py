@@ -168,15 +168,17 @@ class PMGT(PMGTPretrainedModel):
         out = eng.pretrain_step(batch, training=self.training, backward=want_grad, nfr_inject=nfr_inject,
                                 random_node_ratio=self.random_node_ratio, mask_node_ratio=self.mask_node_ratio,
                                 grad_buffer=scratch)
-        loss = out["loss"]
+        # the engine hands out its outputs from a small ring of persistent buffers: this module surface returns copies, so a
+        # caller may keep the results of many steps (e.g. a validation epoch's list of outputs) like the reference's
+        loss, logits = out["loss"].clone(), out["logits"].clone()
         if want_grad:
             names = [n for n, p in self.named_parameters() if p.requires_grad]
             params = [p for _, p in self.named_parameters() if p.requires_grad]
             loss = _PretrainLoss.apply(loss, scratch, [self._engine_name(n) for n in names], eng, *params)
         last = out["last_hidden_state"].float()
         if not return_dict:
-            return (loss, out["logits"], last, None) + tuple(v for v in (hidden, attn) if v is not None)
-        return PMGTForPreTrainingOutput(loss=loss, prediction_logits=out["logits"], last_hidden_state=last,
+            return (loss, logits, last, None) + tuple(v for v in (hidden, attn) if v is not None)
+        return PMGTForPreTrainingOutput(loss=loss, prediction_logits=logits, last_hidden_state=last,
                                         pooler_output=None, hidden_states=hidden, attentions=attn)
 
     @staticmethod

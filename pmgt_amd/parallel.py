@@ -33,6 +33,52 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+class BucketedAllReduce:
+    """The overlapped form of the exchange (DDP's bucketed overlap, pmgt/base_trainer.py:309-322):
+    `bucket_ready(offset, numel)` is the engine's gradient-ready hook -- it is called in stream order as soon as a
+    contiguous range of the flat gradient buffer is final (NFR head, layers L-1 .. 0, embeddings) and starts an
+    ASYNCHRONOUS all-reduce of that slice.  On RCCL the collective runs on the process group's own stream, ordered after
+    the launches enqueued so far, next to the rest of the backward pass; `wait()` orders the caller's stream after all of
+    them (no host block on RCCL) and returns the number of elements exchanged so the caller can check coverage."""
+
+    def __init__(self, flat: torch.Tensor):
+        self.flat = flat
+        self.enabled = True
+        self._pending = []
+        self._elems = 0
+
+    def bucket_ready(self, offset: int, numel: int):
+        if not self.enabled:
+            return
+        import torch.distributed as dist
+        sl = self.flat[offset: offset + numel]
+        avg = dist.get_backend() == "nccl"
+        work = dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((work, sl, avg))
+        self._elems += numel
+
+    def wait(self) -> int:
+        ws = world()[1]
+        for work, sl, avg in self._pending:
+            work.wait()
+            if not avg:
+                sl.div_(ws)
+        n, self._elems = self._elems, 0
+        self._pending.clear()
+        return n
+
+
+def gather_predictions(preds: np.ndarray, labels: np.ndarray):
+    """Validation across ranks (the reference logs a per-rank AUC, pmgt/pmgt/trainer.py:182-195 without
+    sync_dist; here every rank gets the predictions / labels of ALL shards, rank order, so one AUC is reported)."""
+    import torch.distributed as dist
+    if world()[1] == 1:
+        return preds, labels
+    parts = [None] * world()[1]
+    dist.all_gather_object(parts, (np.asarray(preds), np.asarray(labels)))
+    return np.concatenate([p for p, _ in parts]), np.concatenate([l for _, l in parts])
+
+
 def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
     import torch.distributed as dist
     if world()[1] > 1:

@@ -20,13 +20,13 @@ import numpy as np
 import torch
 
 from .datasets import MODE_EVAL, MODE_INFERENCE, MODE_TRAIN
-from .parallel import allreduce_mean_, broadcast_
+from .parallel import BucketedAllReduce, allreduce_mean_, broadcast_, gather_predictions, world
 
 
 class Trainer:
     def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
-                 random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16):
+                 random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True):
         self.engine = engine
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
@@ -35,6 +35,12 @@ class Trainer:
         self.random_node_ratio, self.mask_node_ratio = random_node_ratio, mask_node_ratio
         self.last_loss = None
         self._micro = 0
+        # world_size > 1: per-bucket all-reduce started from the engine's gradient-ready hook while the backward pass of
+        # the earlier layers is still running (overlap_allreduce=False: ONE blocking all-reduce after the backward pass)
+        self._exchange = None
+        if world_size > 1 and overlap_allreduce:
+            self._exchange = BucketedAllReduce(engine.grads)
+            engine.set_grad_ready_hook(self._exchange.bucket_ready)
 
     def broadcast_parameters(self, src: int = 0):
         """DDP constructor semantics: every replica starts from rank `src`'s parameters."""
@@ -42,7 +48,10 @@ class Trainer:
             broadcast_(self.engine.params, src=src)
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
-        """loss = net(*batch)[0] with gradients left in engine.grads (pmgt/pmgt/trainer.py:156-160)."""
+        """loss = net(*batch)[0] with gradients left in engine.grads (pmgt/pmgt/trainer.py:156-160).  The returned device
+        scalar lives in the engine's output ring (valid for the next Engine.OUTPUT_RING - 1 steps; clone it to keep it)."""
+        if self._exchange is not None:      # gradients are exchanged once per optimizer step: on the last micro-batch
+            self._exchange.enabled = self.world_size > 1 and self._micro == self.accum - 1
         out = self.engine.pretrain_step(batch, training=True, backward=True, accumulate=self._micro > 0,
                                         random_node_ratio=self.random_node_ratio, mask_node_ratio=self.mask_node_ratio,
                                         want_hidden=False)
@@ -51,10 +60,14 @@ class Trainer:
 
     def optimizer_step(self):
         eng = self.engine
+        if self.world_size > 1:
+            done = self._exchange.wait() if self._exchange is not None else 0
+            if done == 0:
+                allreduce_mean_(eng.grads)
+            elif done != eng.n_params:
+                raise RuntimeError(f"gradient exchange covered {done} of {eng.n_params} elements")
         if self.accum > 1:
             eng.grads.div_(self.accum)
-        if self.world_size > 1:
-            allreduce_mean_(eng.grads)
         eng.optimizer_step(lr=self.lr, weight_decay=self.weight_decay, betas=self.betas, eps=self.eps,
                            max_grad_norm=self.max_grad_norm)
 
@@ -235,21 +248,36 @@ def roc_auc_score(labels: np.ndarray, scores: np.ndarray) -> float:
 
 
 @torch.no_grad()
-def evaluate(engine, sampler, node_ids: np.ndarray, batch_size: int = 256, threads: int = 8, seed: int = 0):
+def evaluate(engine, sampler, node_ids: np.ndarray, batch_size: int = 256, threads: int = 8, seed: int = 0,
+             distributed: bool = False):
     """Validation pass (pmgt/pmgt/trainer.py:162-195): eval-mode forward with 1 positive + 1 negative
-    per target, sigmoid(logits) vs labels -> {'loss/val', 'val/auc'}."""
-    preds, labs, losses = [], [], []
-    for lo in range(0, len(node_ids), batch_size):
-        tg = node_ids[lo: lo + batch_size]
-        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_EVAL, threads=threads, base_seed=seed, counter=lo)
+    per target, sigmoid(logits) vs labels -> {'loss/val', 'val/auc'}.  `loss/val` is the mean of the per-batch losses
+    (what `self.log("loss/val", ...)` aggregates over an epoch, weighted by batch size).  distributed=True under an
+    initialised process group: rank r evaluates node_ids[r::W] and the predictions of all ranks are gathered, so every
+    rank reports the same AUC over the whole validation set (the reference's AUC is per rank: no sync_dist)."""
+    node_ids = np.asarray(node_ids)
+    rank, ws = world() if distributed else (0, 1)
+    mine = node_ids[rank::ws]
+    preds, labs = [np.empty(0, np.float32)], [np.empty(0, np.float32)]
+    loss_sum = 0.0
+    for lo in range(0, len(mine), batch_size):
+        tg = mine[lo: lo + batch_size]
+        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_EVAL, threads=threads, base_seed=seed, counter=rank + ws * lo)
         cu = lambda d: {k: v.to(engine.device) for k, v in d.items()}
         out = engine.pretrain_step((cu(tgt), cu(pair), num_pairs.to(engine.device), labels.to(engine.device)),
                                    training=False, want_hidden=False)
         preds.append(torch.sigmoid(out["logits"]).cpu().numpy())
         labs.append(labels.numpy())
-        losses.append(out["loss"].item() * len(tg))
+        loss_sum += out["loss"].item() * len(tg)
     preds, labs = np.concatenate(preds), np.concatenate(labs)
-    return {"loss/val": float(np.sum(losses) / len(node_ids)), "val/auc": roc_auc_score(labs, preds)}
+    n_total = len(mine)
+    if ws > 1:
+        import torch.distributed as dist
+        preds, labs = gather_predictions(preds, labs)
+        parts = [None] * ws
+        dist.all_gather_object(parts, (loss_sum, n_total))
+        loss_sum, n_total = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    return {"loss/val": float(loss_sum / max(n_total, 1)), "val/auc": roc_auc_score(labs, preds)}
 
 
 @torch.no_grad()

@@ -1,0 +1,169 @@
+"""Full-size steps against the CPU ORACLE (not against the engine itself): the engine-level wiring that only large
+batches reach -- table-mode projection, fused projection + attention, head-major Q|K|V|C, 256 x 256 weight-gradient and
+data-gradient tiles (M >= 65 536 tokens), last-layer shortcut, sorted segment sums -- checked on one step of
+
+  * C2: 7 252 nodes / 88 606 edges, L4 H8 d256 S32, B = 192 targets (73 728 tokens), fp32 and bf16 engines;
+  * C3: 10 834 nodes / 38 252 edges, same model, bf16 (measured: even at average degree 7 the 656 draws of a 3-hop
+    sample reach >= 31 distinct neighbours, so no context of this graph is padded), and the same node count as disjoint
+    22-node islands, where EVERY context is padded and masked (10 of 32 positions);
+  * C4 / C5: 10^6 nodes (feature rows beyond the 2 GiB offset), L = 6 H8 d512 S64, bf16 and fp8, B = 4;
+
+with dropout 0 and injected NFR draws (torch's RNG stream cannot be matched on the device).  Tolerances: fp32 -- loss
+rtol 1e-4 (north_star), gradients 2e-3 of the tensor's scale; bf16 / fp8 -- loss rtol 2e-2 and per-tensor gradient
+cosine >= 0.99, where a BIAS gradient (a sum of ~1e5 signed terms that cancels to ~1e-6) may instead agree to 2 % of the
+scale of its own layer's weight gradient: that is the noise floor bf16 activations put under such a sum, and it still
+rejects a wrong sum by orders of magnitude (the round-1 bias bug produced 1e27)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pmgt_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def islands_graph(n, size, seed):
+    """n nodes in disjoint rings (with chords) of `size` < S nodes: a node can never collect S - 1 distinct context
+    neighbours, so EVERY context is right-padded with 0 and masked (pmgt/pmgt/datasets.py:46-51,56-61)."""
+    from pmgt_amd.graph import CSRGraph
+    rs = np.random.RandomState(seed)
+    edges = []
+    for lo in range(0, n - n % size, size):
+        hi = lo + size if lo + 2 * size <= n else n            # the last island takes the remainder
+        m = hi - lo
+        ring = np.stack([np.arange(m), (np.arange(m) + 1) % m], 1) + lo
+        chord = np.stack([np.arange(0, m - 5, 3), np.arange(0, m - 5, 3) + 5], 1) + lo
+        edges += [ring, chord]
+        if hi == n:
+            break
+    e = np.concatenate(edges).astype(np.int64)
+    return CSRGraph.from_edge_list(n, e + 2, 0.2 + rs.rand(len(e)))
+
+
+def make_case(n, e, cfgkw, S, B, seed, tables=None, islands=0):
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    from pmgt_amd.graph import synthetic_graph
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, beta=0.5, **cfgkw)
+    graph = islands_graph(n, islands, seed) if islands else synthetic_graph(n, e, seed=seed)
+    smp = MCNSampler(graph, max_ctx_neigh=S - 1)
+    rs = np.random.RandomState(seed)
+    targets = rs.choice(n, B, replace=False).astype(np.int64) + 2
+    batch = smp.batch(targets, MODE_TRAIN, threads=4, base_seed=seed, counter=0)
+    ids = batch[0]["node_ids"]
+    g = torch.Generator().manual_seed(seed)
+    r1, r2 = torch.rand(B, S - 1, generator=g), torch.rand(B, S - 1, generator=g)
+    repl = torch.randint(2, n + 2, (B * (S - 1),), generator=g)
+    masked, m2, tidx = po.nfr_masking(ids, n, r1, repl, r2)
+    full = torch.full_like(ids, -1)
+    full[:, 1:][m2] = tidx
+    return dict(cfg=cfg, params=po.synth_params(cfg, seed + 1), n=n, batch=batch, inj=(masked.cuda(), full.cuda()),
+                inj_cpu=(masked, m2, tidx), pad_share=float((batch[1]["attention_mask"] == 0).float().mean()))
+
+
+def dev_batch(batch):
+    tgt, pair, num_pairs, labels = batch
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}
+    return cu(tgt), cu(pair), num_pairs.cuda(), labels.cuda()
+
+
+def run_engine(case, dtype, tables):
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.engine import Engine
+    kw = {k: v for k, v in case["cfg"].items() if k != "fp8"}
+    eng = Engine(PMGTConfig(**kw), dtype=dtype, seed=0)
+    eng.load_params(case["params"])
+    eng.set_tables(tables[0], tables[1])
+    out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=case["inj"], want_hidden=False)
+    torch.cuda.synchronize()
+    return eng, out
+
+
+def run_oracle(case, tables, fp8=False):
+    cfg = dict(case["cfg"])
+    if fp8:
+        cfg["fp8"] = True
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items()}
+    ref = po.pretrain_forward(p, cfg, tables, case["batch"], training=True, nfr_inject=case["inj_cpu"])
+    ref["loss"].backward()
+    return p, ref
+
+
+def compare(eng, out, p, ref, dtype):
+    tol = 1e-4 if dtype == "fp32" else 2e-2
+    for k in ("loss", "gsr", "nfr"):
+        np.testing.assert_allclose(out[k].item(), ref[k].item(), rtol=tol, err_msg=k)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].detach().numpy(), rtol=0, atol=2e-4 if dtype == "fp32" else 3e-2)
+    grads = {e["name"]: eng.view(e["name"], grad=True).detach().cpu().double().flatten() for e in eng.entries}
+    want = {k: v.grad.double().flatten() for k, v in p.items()}
+    gscale = max(float(v.abs().max()) for v in want.values())
+    assert all(torch.isfinite(v).all() for v in grads.values()) and max(float(v.abs().max()) for v in grads.values()) < 10 * gscale
+    bad = []
+    for name, a in grads.items():
+        b = want[name]
+        if ".key.bias" in name:          # the softmax over keys is invariant to the key bias: exactly 0 in exact arithmetic
+            assert float(a.abs().max()) < 1e-4 * gscale and float(b.abs().max()) < 1e-4 * gscale, name
+            continue
+        err = float((a - b).abs().max())
+        if dtype == "fp32":
+            if err > 2e-3 * float(b.abs().max()) + 1e-9:
+                bad.append((name, err, float(b.abs().max())))
+            continue
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        if cos >= 0.99:
+            continue
+        sibling = name[:-4] + "weight"
+        if name.endswith(".bias") and sibling in want and err <= 2e-2 * float(want[sibling].abs().max()):
+            continue                     # cancellation-dominated sum: within the bf16 noise floor of its own layer
+        bad.append((name, cos, err, float(b.abs().max())))
+    assert not bad, bad
+    flat_a, flat_b = torch.cat([grads[e["name"]] for e in eng.entries]), torch.cat([want[e["name"]] for e in eng.entries])
+    assert torch.nn.functional.cosine_similarity(flat_a, flat_b, dim=0).item() > (0.999999 if dtype == "fp32" else 0.999)
+
+
+C2 = dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256)
+
+
+@pytest.mark.parametrize("graph,dtype", [("c2", "bf16"), ("c2", "fp32"), ("c3", "bf16"), ("c3_islands", "bf16"), ("c3_islands", "fp32")])
+def test_full_size_step_matches_the_oracle(graph, dtype):
+    n, e = {"c2": (7252, 88606), "c3": (10834, 38252), "c3_islands": (10834, 0)}[graph]
+    case = make_case(n, e, C2, S=32, B=192, seed={"c2": 21, "c3": 22, "c3_islands": 23}[graph], islands=22 if graph == "c3_islands" else 0)
+    assert 12 * 192 * 32 >= 65536 and 2 * (n + 2) <= 12 * 192 * 32              # big tiles and the table-mode projection are reached
+    if graph == "c3_islands":
+        assert case["pad_share"] > 0.25, case["pad_share"]                      # every context ends in padded, masked positions
+    tables = po.synth_tables(n, case["cfg"]["feat_hidden_sizes"], 9)
+    eng, out = run_engine(case, dtype, [t.numpy() for t in tables])
+    p, ref = run_oracle(case, tables)
+    compare(eng, out, p, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_million_node_tables_l6_d512_s64_match_the_oracle(dtype):
+    """C4 / C5 shapes at their real node count: the engine gathers rows of [10^6 + 2, 1536] / [.., 768] tables (row offsets
+    past 2 GiB in the gather-fused projection and in the gathered weight gradient); the oracle sees the same rows through a
+    compact table (ids remapped in order of first use -- the model only looks rows up by id)."""
+    n, S, B = 1_000_000, 64, 4
+    case = make_case(n, 3_000_000, dict(hidden_size=512, num_attention_heads=8, num_hidden_layers=6, intermediate_size=512), S, B, seed=31)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    tabs = []
+    for f in case["cfg"]["feat_hidden_sizes"]:
+        t = torch.randn(n + 2, f, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16).float()   # bf16-representable
+        t[:2] = 0
+        tabs.append(t)
+    assert tabs[0].numel() * 2 > 2 ** 31                                        # bf16 rows beyond the 2 GiB byte offset
+    eng, out = run_engine(case, dtype, tabs)
+    tabs_seen = eng.dequantized_tables() if dtype == "fp8" else tabs             # fp8: the e4m3 values the kernels read
+    # compact tables for the oracle: every id the step touches, 0 and 1 kept in place
+    tgt, pair, num_pairs, labels = case["batch"]
+    masked, m2, tidx = case["inj_cpu"]
+    used = torch.unique(torch.cat([tgt["node_ids"].flatten(), pair["node_ids"].flatten(), masked.flatten(), tidx.flatten(),
+                                   torch.tensor([0, 1])]))
+    assert int(used.max()) > 700_000                                            # rows far beyond 2 GiB are really in the batch
+    remap = torch.full((n + 2,), -1, dtype=torch.int64)
+    remap[used] = torch.arange(len(used))
+    assert remap[0] == 0 and remap[1] == 1
+    small = [t[used.cuda()].cpu() for t in tabs_seen]
+    rm = lambda d: {"node_ids": remap[d["node_ids"]], "attention_mask": d["attention_mask"]}
+    case_o = dict(case, batch=(rm(tgt), rm(pair), num_pairs, labels), inj_cpu=(remap[masked], m2, remap[tidx]))
+    p, ref = run_oracle(case_o, small, fp8=dtype == "fp8")
+    compare(eng, out, p, ref, dtype)

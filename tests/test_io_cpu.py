@@ -91,3 +91,71 @@ def test_load_node_init_emb_remap_and_normalise(tmp_path):
     np.testing.assert_allclose(got, sk_normalize(exp), rtol=1e-6, atol=1e-7)
     raw = pio.load_node_init_emb(str(tmp_path / "item_encoder"), str(tmp_path / "node_encoder"), str(tmp_path / "emb.npy"), normalize=False)
     np.testing.assert_array_equal(raw[[0, 2, 3]], emb[[0, 1, 2]])
+
+
+def test_lightning_shaped_checkpoint_loads_without_lightning(tmp_path):
+    """A checkpoint as the reference's run writes it (pmgt/base_trainer.py:291-298 ModelCheckpoint + save_hyperparameters,
+    :146 `self.net`): state_dict under `net.`, hyper_parameters as a pytorch_lightning AttributeDict, callbacks, optimizer
+    states.  pytorch_lightning is NOT installed here, and torch's weights_only loader refuses the AttributeDict global: the
+    file must still load, as plain data, without executing anything from it."""
+    import pickle
+    import sys
+    import types
+
+    import torch
+
+    from pmgt_amd import io as pio
+
+    # build the checkpoint with a stand-in for pytorch_lightning.utilities.parsing.AttributeDict, then make it unimportable
+    names = ["pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing"]
+    mods = {n: types.ModuleType(n) for n in names}
+
+    class AttributeDict(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    class Boom:                                      # an arbitrary object whose unpickling would run code
+        def __reduce__(self):
+            return (exec, ("raise SystemExit('code from the checkpoint ran')",))
+
+    AttributeDict.__module__ = names[2]
+    AttributeDict.__qualname__ = "AttributeDict"
+    mods[names[2]].AttributeDict = AttributeDict
+    sys.modules.update(mods)
+    try:
+        sd = {"net.bert.embeddings.position_embeddings.weight": torch.arange(12.0).view(3, 4),
+              "net.bert.embeddings.position_ids": torch.arange(3)[None],
+              "net.nfr_loss.projections.0.bias": torch.ones(5)}
+        ck = {"epoch": 3, "global_step": 120, "pytorch-lightning_version": "1.5.4", "state_dict": sd,
+              "hyper_parameters": AttributeDict(lr=1e-4, hidden_size=32, dataset_name="TG", nested=AttributeDict(a=1)),
+              "callbacks": {"ModelCheckpoint": {"best_model_score": torch.tensor(0.81), "best_model_path": "/x/y.ckpt",
+                                                "monitor": "val/auc"}, "evil": Boom()},
+              "optimizer_states": [{"state": {0: {"step": 120, "exp_avg": torch.zeros(3, 4)}},
+                                    "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999), "params": [0]}]}],
+              "lr_schedulers": []}
+        path = tmp_path / "last.ckpt"
+        torch.save(ck, path)
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu", weights_only=True)             # why the plain safe loader is not enough
+    got = pio.read_checkpoint(str(path))
+    assert got["epoch"] == 3 and got["pytorch-lightning_version"] == "1.5.4"
+    assert torch.equal(got["state_dict"]["net.bert.embeddings.position_embeddings.weight"], sd["net.bert.embeddings.position_embeddings.weight"])
+    assert got["state_dict"]["net.bert.embeddings.position_ids"].dtype == torch.int64
+    assert dict(got["hyper_parameters"])["hidden_size"] == 32 and dict(got["hyper_parameters"]["nested"]) == {"a": 1}
+    assert float(got["callbacks"]["ModelCheckpoint"]["best_model_score"]) == pytest.approx(0.81)
+    assert got["optimizer_states"][0]["param_groups"][0]["betas"] == (0.9, 0.999)
+    assert type(got["callbacks"]["evil"]).__name__ == "_Opaque"              # inert placeholder: exec() was never resolved
+
+    class Sink:                                        # load_checkpoint strips the `net.` prefix and hands over the weights
+        def load_state_dict(self, state, strict=True):
+            self.state = state
+            return "ok"
+    sink = Sink()
+    assert pio.load_checkpoint(sink, str(path)) == "ok"
+    assert set(sink.state) == {k[4:] for k in sd}

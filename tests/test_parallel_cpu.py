@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pmgt_amd.parallel import allreduce_mean_, broadcast_, shard_indices
+from pmgt_amd.parallel import BucketedAllReduce, allreduce_mean_, broadcast_, gather_predictions, shard_indices
 from pmgt_amd.trainer import roc_auc_score
 
 
@@ -43,6 +43,21 @@ def _worker(rank, world, port, out_dir):
             allreduce_mean_(grad)
             w -= 0.1 * grad
         torch.save(w, os.path.join(out_dir, f"w{rank}.pt"))
+        # the overlapped form: buckets reported in backward order (head, layers L-1..0, embeddings) tile the flat buffer;
+        # after wait() it holds exactly what ONE flat all-reduce gives, on every rank
+        flat = torch.arange(1000, dtype=torch.float32).mul_(0.37 * (rank + 1)).sin_()
+        want = allreduce_mean_(flat.clone())
+        ex = BucketedAllReduce(flat)
+        bounds = [0, 130, 400, 670, 900, 1000]
+        for lo, hi in reversed(list(zip(bounds[:-1], bounds[1:]))):
+            ex.bucket_ready(lo, hi - lo)
+        assert ex.wait() == 1000 and torch.equal(flat, want)
+        ex.enabled = False                       # micro-batches before the last one of an accumulation window: no exchange
+        ex.bucket_ready(0, 1000)
+        assert ex.wait() == 0
+        # validation gather: every rank sees all shards in rank order
+        p, l = gather_predictions(np.full(3 + rank, 0.25 * (rank + 1), np.float32), np.full(3 + rank, float(rank), np.float32))
+        assert p.tolist() == [0.25] * 3 + [0.5] * 4 and l.tolist() == [0.0] * 3 + [1.0] * 4
     finally:
         dist.destroy_process_group()
 
@@ -80,21 +95,24 @@ def test_auc_matches_sklearn():
         roc_auc_score(np.ones(5), rs.rand(5))
 
 
-def test_bench_rank0_phase_pass_issues_no_collective():
-    """bench.py at N > 1: after the timed region only rank 0 runs the per-phase timer pass, so that pass must not enter the
-    gradient all-reduce (its peers are already past their last collective and it would never return).  Trainer.optimizer_step
-    all-reduces iff world_size > 1; the pass has to run with world_size 1 and restore it afterwards."""
+def test_bench_control_flow_is_symmetric_across_ranks():
+    """bench.py at N > 1: every rank must execute the same sequence of GPU steps and collectives from init to destroy
+    (round 1 let rank 0 alone run a profile pass while its peers destroyed the process group: a hang / abort on RCCL).
+    Statically: nothing that launches steps or collectives sits under a rank-dependent condition, the teardown is
+    barrier -> destroy, and the staging shard comes from shard_indices (DistributedSampler semantics)."""
     import ast
-    import os
     src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py")).read()
     tree = ast.parse(src)
     main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
-    blk = next(n for n in ast.walk(main) if isinstance(n, ast.If) and "no_phase_profile" in ast.unparse(n.test))
-    body = [ast.unparse(s) for s in blk.body]
-    begin = next(i for i, s in enumerate(body) if "profile_begin" in s)
-    end = next(i for i, s in enumerate(body) if "profile_end" in s)
-    assert any(s.replace(" ", "") == "(ws,trainer.world_size)=(trainer.world_size,1)" for s in body[:begin]), body[:begin]
-    assert any(s.replace(" ", "") == "trainer.world_size=ws" for s in body[end:]), body[end:]
-    # and the Trainer really keys the all-reduce on that attribute
-    tsrc = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pmgt_amd", "trainer.py")).read()
-    assert "if self.world_size > 1:\n            allreduce_mean_(eng.grads)" in tsrc
+    collective_or_step = ("train_step", "run_live", "profile_begin", "profile_end", "all_reduce", "barrier(", "broadcast",
+                          "time_steps", "capture_step", "destroy_process_group")
+    for node in ast.walk(main):
+        if isinstance(node, ast.If) and "rank" in ast.unparse(node.test) and "world" not in ast.unparse(node.test):
+            body = "\n".join(ast.unparse(b) for b in node.body + node.orelse)
+            assert not any(k in body for k in collective_or_step), ast.unparse(node)[:300]
+    tail = ast.unparse(main.body[-1])
+    assert tail.index("dist.barrier()") < tail.index("dist.destroy_process_group()"), tail
+    assert "shard_indices(nodes, rank, world" in src and "RandomState(0).permutation" not in src
+    # the rank-0-only blocks are the print and the CPU baseline
+    r0 = [ast.unparse(n) for n in ast.walk(main) if isinstance(n, ast.If) and ast.unparse(n.test).startswith("rank == 0")]
+    assert all(("print(" in b or "cpu_baseline" in b) for b in r0), r0

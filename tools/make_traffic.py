@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the committed PMC summaries of one profile set.
 
-Usage: tools/make_traffic.py profiles/r01/<tag>    (reads <tag>_pmc_fetch_size.txt and <tag>_pmc_write_size.txt)
+Usage: tools/make_traffic.py profiles/rNN/<tag> [kernel_sources_sha]   (reads <tag>_pmc_fetch_size.txt and <tag>_pmc_write_size.txt;
+the fingerprint defaults to the current sources: run it on the tree the counters were measured on)
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (counters in KiB; gfx950 tallies 128-B read requests at 64 B,
 /opt/skills/guides/MI355X_MICROARCH.md).  bench.py quotes the entry of its dominant phase as `roofline.traffic`."""
@@ -40,8 +41,12 @@ def main():
         mb = (2.0 * fetch[kf] + write[kw]) * 1024.0 / 1e6
         phases[ph] = {"kernel": kf, "fetch_size_kib": round(fetch[kf], 1), "write_size_kib": round(write[kw], 1),
                       "hbm_mb_per_launch": round(mb, 1)}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_sha
     out = {
         "workload": "c2", "batch": 1024,
+        # fingerprint of pmgt_amd/csrc at measurement time: bench.py nulls `traffic` when the kernels have changed since
+        "kernel_sources_sha": sys.argv[2] if len(sys.argv) > 2 else kernel_sources_sha(),
         "source": f"{prefix}_pmc_fetch_size.txt + {os.path.basename(prefix)}_pmc_write_size.txt "
                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
         "correction": "HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE; counters in KiB",
