@@ -73,9 +73,15 @@ template <typename T, int DH> __device__ __forceinline__ void axpy_row(float* re
     }
 }
 
+// stride (floats) of the [key][query] score matrices: odd, >= the number of queries.  Groups of 128 lanes serve
+// 64 < S <= 100 (max_position_embeddings of the reference, pmgt/pmgt/configuration_pmgt.py:23) with stride 101, which
+// keeps S = 100 / head size 32 / fp32 inside the 160 KiB of a CU (stride 129 would not).
+template <int GS> struct ScoreStride { static constexpr int V = GS == 128 ? 101 : GS + 1; };
+static inline int score_stride(int gs) { return gs == 128 ? 101 : gs + 1; }
+
 static inline size_t attn_group_bytes(int S, int dh, int gs, int esize, bool bwd) {
     size_t tiles = (size_t)(bwd ? 5 : 3) * S * dh * esize;
-    size_t sc = (size_t)2 * S * (gs + 1) * 4;
+    size_t sc = (size_t)2 * S * score_stride(gs) * 4;
     size_t misc = (size_t)2 * gs * 4;
     return (tiles + sc + misc + 15) / 16 * 16;
 }
@@ -85,7 +91,7 @@ static inline size_t attn_group_bytes(int S, int dh, int gs, int esize, bool bwd
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DH, int GS>
 __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
-    constexpr int CH = ChunkT<T>::CH, RS = DH * (int)sizeof(T), NCHK = DH / CH;
+    constexpr int CH = ChunkT<T>::CH, RS = DH * (int)sizeof(T), NCHK = DH / CH, ST = ScoreStride<GS>::V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ng = blockDim.x / GS;
     const int grp = threadIdx.x / GS, li = threadIdx.x % GS;
@@ -98,8 +104,8 @@ __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
     char* sV = sK + S * RS;
     char* sC = sV + S * RS;
     float* sc1 = (float*)(sC + S * RS);
-    float* sc2 = sc1 + S * (GS + 1);
-    float* rho = sc2 + S * (GS + 1);
+    float* sc2 = sc1 + S * ST;
+    float* rho = sc2 + S * ST;
     float* madd = rho + GS;
     const T* X = (const T*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
 
@@ -137,17 +143,17 @@ __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
             const float d2 = dot_row<T, DH>(q, sK + j * RS);
             const float s1 = 1.f - d1 / (rho_i * rho[j]) + (j == li ? 1.f : 0.f) + madd[j];
             const float s2 = d2 / sq + madd[j];
-            sc1[j * (GS + 1) + li] = s1;
-            sc2[j * (GS + 1) + li] = s2;
+            sc1[j * ST + li] = s1;
+            sc2[j * ST + li] = s2;
             mx1 = fmaxf(mx1, s1);
             mx2 = fmaxf(mx2, s2);
         }
         float sum1 = 0.f, sum2 = 0.f;
         for (int j = 0; j < S; ++j) {
-            const float e1 = expf(sc1[j * (GS + 1) + li] - mx1);
-            const float e2 = expf(sc2[j * (GS + 1) + li] - mx2);
-            sc1[j * (GS + 1) + li] = e1;
-            sc2[j * (GS + 1) + li] = e2;
+            const float e1 = expf(sc1[j * ST + li] - mx1);
+            const float e2 = expf(sc2[j * ST + li] - mx2);
+            sc1[j * ST + li] = e1;
+            sc2[j * ST + li] = e2;
             sum1 += e1;
             sum2 += e2;
         }
@@ -159,7 +165,7 @@ __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
         const uint64_t pbase = (((uint64_t)t * H + h) * S + li) * S;
         const uint32_t prow = (uint32_t)(((uint64_t)t * H + h) * S + li);
         for (int j = 0; j < S; ++j) {
-            float p1 = sc1[j * (GS + 1) + li] * w1, p2 = sc2[j * (GS + 1) + li] * w2;
+            float p1 = sc1[j * ST + li] * w1, p2 = sc2[j * ST + li] * w2;
             if (k1.on) { p1 *= drop_mul1(k1, prow, (uint32_t)j); p2 *= drop_mul1(k2, prow, (uint32_t)j); }
             const float p = p1 + p2;
             if (a.probs) a.probs[pbase + j] = p;
@@ -174,7 +180,7 @@ __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DH, int GS>
 __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
-    constexpr int CH = ChunkT<T>::CH, RS = DH * (int)sizeof(T), NCHK = DH / CH;
+    constexpr int CH = ChunkT<T>::CH, RS = DH * (int)sizeof(T), NCHK = DH / CH, ST = ScoreStride<GS>::V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ng = blockDim.x / GS;
     const int grp = threadIdx.x / GS, li = threadIdx.x % GS;
@@ -189,8 +195,8 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
     char* sQ = sC + S * RS;
     char* sO = sQ + S * RS;                       // dO tile
     float* A1 = (float*)(sO + S * RS);            // [key][query], stride GS + 1
-    float* A2 = A1 + S * (GS + 1);
-    float* rho = A2 + S * (GS + 1);
+    float* A2 = A1 + S * ST;
+    float* rho = A2 + S * ST;
     float* madd = rho + GS;
     const T* X = (const T*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
     const T* DO = (const T*)a.dctx + (int64_t)t * S * d + h * DH;
@@ -236,24 +242,24 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
                 const float d2 = dot_row<T, DH>(q, sK + j * RS);
                 const float s1 = 1.f - d1 / (rho_i * rho[j]) + (j == li ? 1.f : 0.f) + madd[j];
                 const float s2 = d2 / sq + madd[j];
-                A1[j * (GS + 1) + li] = s1;
-                A2[j * (GS + 1) + li] = s2;
+                A1[j * ST + li] = s1;
+                A2[j * ST + li] = s2;
                 mx1 = fmaxf(mx1, s1);
                 mx2 = fmaxf(mx2, s2);
             }
             float sum1 = 0.f, sum2 = 0.f;
             for (int j = 0; j < S; ++j) {
-                const float e1 = expf(A1[j * (GS + 1) + li] - mx1);
-                const float e2 = expf(A2[j * (GS + 1) + li] - mx2);
-                A1[j * (GS + 1) + li] = e1;
-                A2[j * (GS + 1) + li] = e2;
+                const float e1 = expf(A1[j * ST + li] - mx1);
+                const float e2 = expf(A2[j * ST + li] - mx2);
+                A1[j * ST + li] = e1;
+                A2[j * ST + li] = e2;
                 sum1 += e1;
                 sum2 += e2;
             }
             const float i1 = 1.f / sum1, i2 = 1.f / sum2;
             for (int j = 0; j < S; ++j) {
-                A1[j * (GS + 1) + li] *= i1;
-                A2[j * (GS + 1) + li] *= i2;
+                A1[j * ST + li] *= i1;
+                A2[j * ST + li] *= i2;
             }
         }
     }
@@ -267,7 +273,7 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
 #pragma unroll
         for (int e = 0; e < DH; ++e) dv[e] = 0.f;
         for (int i = 0; i < S; ++i) {
-            float p1 = beta * A1[j * (GS + 1) + i], p2 = omb * A2[j * (GS + 1) + i];
+            float p1 = beta * A1[j * ST + i], p2 = omb * A2[j * ST + i];
             if (k1.on) { p1 *= drop_mul1(k1, (uint32_t)(hbase + i), (uint32_t)j); p2 *= drop_mul1(k2, (uint32_t)(hbase + i), (uint32_t)j); }
             axpy_row<T, DH>(dv, p1 + p2, sO + i * RS);
         }
@@ -288,8 +294,8 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
             const float dp = dot_row<T, DH>(doi, sV + j * RS);
             float g1 = beta * dp, g2 = omb * dp;
             if (k1.on) { g1 *= drop_mul1(k1, (uint32_t)(hbase + i), (uint32_t)j); g2 *= drop_mul1(k2, (uint32_t)(hbase + i), (uint32_t)j); }
-            rd1 = fmaf(A1[j * (GS + 1) + i], g1, rd1);
-            rd2 = fmaf(A2[j * (GS + 1) + i], g2, rd2);
+            rd1 = fmaf(A1[j * ST + i], g1, rd1);
+            rd2 = fmaf(A2[j * ST + i], g2, rd2);
         }
         float dq[DH];
 #pragma unroll
@@ -298,10 +304,10 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
             const float dp = dot_row<T, DH>(doi, sV + j * RS);
             float g1 = beta * dp, g2 = omb * dp;
             if (k1.on) { g1 *= drop_mul1(k1, (uint32_t)(hbase + i), (uint32_t)j); g2 *= drop_mul1(k2, (uint32_t)(hbase + i), (uint32_t)j); }
-            const float ds1 = A1[j * (GS + 1) + i] * (g1 - rd1);
-            const float ds2 = A2[j * (GS + 1) + i] * (g2 - rd2);
-            A1[j * (GS + 1) + i] = ds1;
-            A2[j * (GS + 1) + i] = ds2;
+            const float ds1 = A1[j * ST + i] * (g1 - rd1);
+            const float ds2 = A2[j * ST + i] * (g2 - rd2);
+            A1[j * ST + i] = ds1;
+            A2[j * ST + i] = ds2;
             axpy_row<T, DH>(dq, ds2 / sq, sK + j * RS);
             axpy_row<T, DH>(dch, -ds1 / rho[j], sC + j * RS);     // dN_ij * c_hat_j
         }
@@ -315,9 +321,9 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
         float dk[DH];
 #pragma unroll
         for (int e = 0; e < DH; ++e) dk[e] = 0.f;
-        for (int i = 0; i < S; ++i) axpy_row<T, DH>(dk, A2[j * (GS + 1) + i] / sq, sQ + i * RS);
+        for (int i = 0; i < S; ++i) axpy_row<T, DH>(dk, A2[j * ST + i] / sq, sQ + i * RS);
         store_row<T, DH>(DX + (int64_t)j * 4 * d + d, dk);
-        for (int i = 0; i < S; ++i) axpy_row<T, DH>(dch, -A1[j * (GS + 1) + i] / rho[i], sC + i * RS);
+        for (int i = 0; i < S; ++i) axpy_row<T, DH>(dch, -A1[j * ST + i] / rho[i], sC + i * RS);
         // through c_hat = c / |c|:  dc = (dch - (dch . c_hat) c_hat) / |c|
         float cc[DH];
         load_row<T, DH>(X + (int64_t)j * 4 * d + 3 * d, cc);
@@ -356,7 +362,8 @@ template <typename T, int DH, int GS> static int launch(const AttnArgs& a, bool 
 template <typename T, int DH> static int launch_gs(const AttnArgs& a, bool bwd, hipStream_t st) {
     if (a.S <= 16) return launch<T, DH, 16>(a, bwd, st);
     if (a.S <= 32) return launch<T, DH, 32>(a, bwd, st);
-    return launch<T, DH, 64>(a, bwd, st);
+    if (a.S <= 64) return launch<T, DH, 64>(a, bwd, st);
+    return launch<T, DH, 128>(a, bwd, st);       // 64 < S <= 100: two waves per (sequence, head), one query row per lane
 }
 
 static int g_force_valu = 0;
@@ -368,8 +375,9 @@ template <typename T> static int dispatch(const AttnArgs& a, bool bwd, hipStream
     if constexpr (sizeof(T) == 2) {
         if (!g_force_valu && attn_mfma_supported(a)) return attn_mfma(a, bwd, st);   // bf16 perf path
     }
-    PMGT_CHECK(a.S >= 1 && a.S <= 64, -3,
-               "attention: sequence length %d not supported by the HIP path yet (1..64; the reference allows <= 100)", a.S);
+    PMGT_CHECK(a.S >= 1 && a.S <= 100, -3,
+               "attention: sequence length %d exceeds the reference's max_position_embeddings default of 100 "
+               "(pmgt/pmgt/configuration_pmgt.py:23)", a.S);
     switch (a.dh) {
         case 16: return launch_gs<T, 16>(a, bwd, st);
         case 32: return launch_gs<T, 32>(a, bwd, st);

@@ -40,7 +40,8 @@ class Engine:
         torch.cuda.set_device(self.device)
         feats = list(config.feat_hidden_sizes)
         if len(feats) != 2:
-            raise ValueError("the HIP path implements the reference's two modalities (visual, textual)")
+            raise ValueError(f"feat_hidden_sizes={feats}: the HIP path implements exactly the two modalities the reference's "
+                             "trainer builds (visual, textual; pmgt/pmgt/trainer.py:114-125) -- see INTEGRATION.md, limits")
         self.cfg_c = _lib.PMGTConfigC(
             config.hidden_size, config.num_hidden_layers, config.num_attention_heads, config.intermediate_size,
             feats[0], feats[1], config.max_position_embeddings, config.layer_norm_eps, config.beta,

@@ -427,3 +427,65 @@ def test_c4_shapes_match_the_oracle(dtype):
     flat_a = torch.cat([eng.view(e["name"], grad=True).reshape(-1) for e in eng.entries]).cpu()
     flat_b = torch.cat([p[e["name"]].grad.reshape(-1) for e in eng.entries])
     assert torch.nn.functional.cosine_similarity(flat_a, flat_b, dim=0).item() > (0.99999 if dtype == "fp32" else 0.99)
+
+
+# ---- sequence lengths 65 .. 100: the reference allows S <= max_position_embeddings = 100 (configuration_pmgt.py:23,
+#      modeling_pmgt.py:189-193); the MFMA kernels stop at 64, above that the one-row-per-lane kernel runs 128-lane groups ----------
+def _long_case(S, cfgkw, B=3, n=500, seed=41):
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    from pmgt_amd.graph import synthetic_graph
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, beta=0.3, **cfgkw)
+    graph = synthetic_graph(n, 20 * n, seed=seed)              # dense enough for > 64 distinct context neighbours ...
+    smp = MCNSampler(graph, max_ctx_neigh=S - 1, hop_sampling_sizes=(32, 8, 4))
+    batch = smp.batch(np.arange(2, 2 + B), MODE_TRAIN, threads=2, base_seed=seed, counter=0)
+    batch[0]["attention_mask"][0, S - 7:] = 0                  # ... and a few padded keys on top (they must be masked out)
+    batch[0]["node_ids"][0, S - 7:] = 0
+    ids = batch[0]["node_ids"]
+    g = torch.Generator().manual_seed(seed)
+    r1, r2 = torch.rand(B, S - 1, generator=g), torch.rand(B, S - 1, generator=g)
+    repl = torch.randint(2, n + 2, (B * (S - 1),), generator=g)
+    masked, m2, tidx = po.nfr_masking(ids, n, r1, repl, r2)
+    full = torch.full_like(ids, -1)
+    full[:, 1:][m2] = tidx
+    return dict(cfg=cfg, params=po.synth_params(cfg, seed), tables=po.synth_tables(n, cfg["feat_hidden_sizes"], seed + 1), batch=batch,
+                n_nodes=n, inj=(masked.cuda(), full.cuda()), inj_cpu=(masked, m2, tidx))
+
+
+@pytest.mark.parametrize("S,dtype,cfgkw", [
+    (100, "fp32", dict(hidden_size=64, num_attention_heads=2, num_hidden_layers=2, intermediate_size=64)),      # head size 32
+    (80, "fp32", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64)),       # head size 16
+    (100, "bf16", dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=2, intermediate_size=256)),    # headline model, S = 100
+    (65, "bf16", dict(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, intermediate_size=128)),     # head size 64, first length past the MFMA path
+])
+def test_sequence_lengths_up_to_max_position_embeddings(S, dtype, cfgkw):
+    case = _long_case(S, cfgkw)
+    assert int(case["batch"][1]["attention_mask"].sum(1).max()) == S          # full-length contexts are really in the batch
+    eng = make_engine(case, dtype=dtype)
+    p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items()}
+    ref = po.pretrain_forward(p, case["cfg"], case["tables"], case["batch"], training=True, nfr_inject=case["inj_cpu"])
+    ref["loss"].backward()
+    out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=case["inj"])
+    tol = 1e-4 if dtype == "fp32" else 2e-2
+    np.testing.assert_allclose(out["loss"].item(), ref["loss"].item(), rtol=tol)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].detach().numpy(), rtol=0, atol=1e-4 if dtype == "fp32" else 3e-2)
+    np.testing.assert_allclose(out["last_hidden_state"].float().cpu().numpy(), ref["last_hidden_state"].detach().numpy(), rtol=0,
+                               atol=2e-4 if dtype == "fp32" else 8e-2)
+    flat_a = torch.cat([eng.view(e["name"], grad=True).reshape(-1) for e in eng.entries]).cpu().double()
+    flat_b = torch.cat([p[e["name"]].grad.reshape(-1) for e in eng.entries]).double()
+    if dtype == "fp32":
+        assert float((flat_a - flat_b).abs().max()) < 2e-3 * float(flat_b.abs().max())
+    assert torch.nn.functional.cosine_similarity(flat_a, flat_b, dim=0).item() > (0.99999 if dtype == "fp32" else 0.99)
+    # inference entry with attention probabilities at S = 100 (rows sum to 1, padded keys get 0)
+    tgt = case["batch"][0]
+    last, hs, pr = eng.encode(ids=tgt["node_ids"].cuda(), attention_mask=tgt["attention_mask"].cuda(), output_attentions=True)
+    assert pr.shape[-2:] == (S, S)
+    np.testing.assert_allclose(pr.sum(-1).cpu().numpy(), 1.0, atol=1e-3 if dtype == "fp32" else 2e-2)
+    assert float(pr[:, 0, :, :, S - 7:].abs().max()) == 0.0
+
+
+def test_sequence_length_past_max_position_embeddings_is_refused():
+    case = _long_case(16, dict(hidden_size=64, num_attention_heads=2, num_hidden_layers=1, intermediate_size=64))
+    eng = make_engine(case, dtype="fp32")
+    ids = torch.randint(2, 100, (2, 101)).cuda()
+    with pytest.raises(Exception, match="max_position_embeddings"):
+        eng.encode(ids=ids)
