@@ -254,6 +254,8 @@ void pmgt_debug_disable_head_major(int on);
 /* A/B switch (fp8 mode): 1 = layer inputs are quantised by their consumer (inside the fused projection + attention kernel)
  * instead of by the kernel that produces them (fused-LayerNorm epilogue of the FFN2 GEMM, embed_mix); bit-identical results */
 void pmgt_debug_disable_producer_quant(int on);
+/* A/B switch: 1 keeps the attention backward and the Q|K|V|C weight gradient as two kernels */
+void pmgt_debug_disable_fused_attention_backward(int on);
 /* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */
 void pmgt_debug_disable_fused_qkvc_attention(int on);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,
@@ -262,6 +264,15 @@ int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* 
 int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq,
                           int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
                           const uint64_t* rng, void* stream);
+/* Attention backward fused with the weight / bias gradient of the Q|K|V|C projection (bf16, S = 32, head size 32, hidden 128 or
+ * 256; replaces pmgt_op_attention_bwd + the [M, 4d]^T [M, d] weight-gradient GEMM, i.e. autograd through
+ * pmgt/pmgt/modeling_pmgt.py:429-433 and :435-526).  x = the layer input [n_seq * 32, d]; dqkvc as pmgt_op_attention_bwd;
+ * slab [parts][4d * d] / bias_slab [parts][4d] (parts = pmgt_op_attention_bwd_wgrad_parts(H)) receive per-workgroup partial
+ * sums in q | k | v | c row order, to be added up by the caller.  head_major = the column layout of qkvc / dqkvc. */
+int pmgt_op_attention_bwd_wgrad_parts(int H);
+int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void* dctx, const void* x, void* dqkvc, float* slab,
+                                float* bias_slab, int n_seq, int H, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                                const uint64_t* rng, int head_major, void* stream);
 
 /* ---- host MCNSampling (libpmgt_sampler.so; pure host code, no HIP) --------------------------------
  * Replaces _sample_context_neigh / get_input_tensor / PMGTDataset.__getitem__ / pmgt_collate_fn

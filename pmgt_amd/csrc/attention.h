@@ -32,6 +32,19 @@ template <typename T> int attn_fwd(const AttnArgs& a, hipStream_t st);
 template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
 
 
+// Attention backward fused with the Q|K|V|C weight gradient (attention_mfma.hip): bf16, S = 32, head size 32, hidden 256 / 128.
+// One launch replaces attn_bwd + the Q|K|V|C gemm_tn: dQ|dK|dV|dC still go to HBM once (the data gradient reads them), the
+// weight / bias gradients leave as `parts` = attn_bwd_wgrad_parts(H) partial slabs [parts][4d, d] / [parts][4d] for slab_reduce.
+struct AttnBwdWg {
+    AttnArgs a;                                    // qkvc, dctx, dqkvc, mask, Tseq, S, H, dh, beta, dropout, hm (cls_only_seqs must be 0)
+    const void* x = nullptr; int64_t ldx = 0;      // [Tseq*32, d] the layer input the projection was applied to
+    float* slab = nullptr;                         // [parts][4d * d]
+    float* bias_slab = nullptr;                    // [parts][4d] or NULL
+};
+int attn_bwd_wgrad_parts(int H);
+bool attn_bwd_wgrad_supported(const AttnBwdWg& w);
+int attn_bwd_wgrad(const AttnBwdWg& w, hipStream_t st);
+
 // Fused Q|K|V|C projection + attention forward (qkvc_attn.hip): bf16, S = 32, head size 32, hidden 256 or 128.
 struct QkvcAttn {
     const void* X = nullptr; int64_t ldx = 0;     // [Tseq*32, d] layer input

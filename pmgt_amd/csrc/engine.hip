@@ -355,6 +355,7 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     int64_t slab = 0;
     const int dt = e->cfg.dtype;
     slab = std::max(slab, tn_slab_elems(dt, (int)M, 4 * d, d));
+    slab = std::max(slab, (int64_t)attn_bwd_wgrad_parts(e->H) * 4 * d * d);          // fused attention backward + weight gradient
     slab = std::max(slab, tn_slab_elems(dt, (int)M, d, d));
     slab = std::max(slab, tn_slab_elems(dt, (int)M, I, d));
     slab = std::max(slab, tn_slab_elems(dt, (int)M, d, I));
@@ -453,6 +454,7 @@ static int g_no_hm = 0;
 static int g_no_table_proj = 0;
 static int g_no_segsum = 0;
 static int g_no_producer_quant = 0;
+static int g_no_fused_abw = 1;      // first form (8 waves: 4 attention + 4 GEMM) is correct but slower than the two kernels: opt-in until the 16-wave form lands
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -799,6 +801,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             PMGT_HIP(hipMemsetAsync(b.bD, 0, (size_t)M * d * sizeof(T), st));
             RUN(scatter_rows<T>(gD, b.need_rows, b.need_cnt, Mt, d, b.bD, st));
         }
+        bool fused_bw = false;
         {
             AttnArgs a;
             a.qkvc = lb.qkvc; a.mask = b.mask; a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
@@ -807,10 +810,35 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.dctx = b.bD; a.dqkvc = b.big;
             a.cls_only_seqs = sc ? n_cls_only : 0;       // their dctx is non-zero at row 0 only (scatter_rows above)
             a.hm = b.qkvc_hm;
-            RUNP("bwd.attention", attn_bwd<T>(a, st));
+            if constexpr (sizeof(T) == 2) {
+                // headline shape: attention backward and the Q|K|V|C weight gradient in ONE launch (attention waves + GEMM waves per
+                // CU): dQ|dK|dV|dC are not re-read for the weight gradient, and its partial sums shrink from one slab per M-split to
+                // one [128, d] block per workgroup
+                AttnBwdWg w;
+                w.a = a; w.x = hin; w.ldx = d;
+                const int parts = attn_bwd_wgrad_parts(H);
+                SideReduce sr(e, st);
+                const int slot = b.wg_idx & 1;
+                w.slab = b.slab + (int64_t)slot * b.slab_elems;
+                w.bias_slab = b.part_side + (int64_t)slot * b.part_side_elems;
+                if (!g_no_fused_abw && !g_force_tile && !attn_valu_forced() && (int64_t)parts * 4 * d * d <= b.slab_elems &&
+                    (int64_t)parts * 4 * d <= b.part_side_elems && attn_bwd_wgrad_supported(w)) {
+                    ++b.wg_idx;
+                    RUN(sr.acquire(b.wg_done[slot]));
+                    RUNP("bwd.attention_wgrad", attn_bwd_wgrad(w, st));
+                    hipStream_t rs = st;
+                    RUN(sr.begin(&rs));
+                    RUNP("bwd.slab_reduce", slab_reduce(w.slab, parts, (int64_t)4 * d * d, G + o.Wqkvc, acc, rs));
+                    RUNP("bwd.slab_reduce", slab_reduce(w.bias_slab, parts, 4 * d, G + o.bqkvc, acc, rs));
+                    RUN(sr.end(b.wg_done[slot]));
+                    fused_bw = true;
+                }
+            }
+            if (!fused_bw) RUNP("bwd.attention", attn_bwd<T>(a, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc,
-                     b.qkvc_hm ? d : 0, b.qkvc_hm ? e->dh : 0));
+        if (!fused_bw)
+            RUN(wgrad<T>("bwd.wgrad_qkvc", e, b, b.big, 4 * d, hin, d, nullptr, M, M, 4 * d, d, G + o.Wqkvc, acc, nullptr, st, G + o.bqkvc,
+                         b.qkvc_hm ? d : 0, b.qkvc_hm ? e->dh : 0));
         // every gradient of layer l is final in stream order: let the data-parallel exchange of this bucket start now
         if (e->grad_cb_fine()) e->grad_ready(o.Wqkvc, (l + 1 < L ? e->layers[l + 1].Wqkvc : e->Wn) - o.Wqkvc);
         {   // d hin = dqkvc Wqkvc + residual branch
@@ -1299,6 +1327,7 @@ void pmgt_debug_disable_table_projection(int on) { g_no_table_proj = on; }
 void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
 void pmgt_debug_disable_head_major(int on) { g_no_hm = on; }
 void pmgt_debug_disable_producer_quant(int on) { g_no_producer_quant = on; }
+void pmgt_debug_disable_fused_attention_backward(int on) { g_no_fused_abw = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, void* user) {
     if (e) { e->grad_cb = cb; e->grad_cb_user = user; }
@@ -1348,6 +1377,18 @@ int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const 
     a.dctx = dctx; a.dqkvc = dqkvc;
     if (dtype == PMGT_DTYPE_BF16) return attn_bwd<bf16>(a, (hipStream_t)stream);
     return attn_bwd<float>(a, (hipStream_t)stream);
+}
+
+int pmgt_op_attention_bwd_wgrad_parts(int H) { return attn_bwd_wgrad_parts(H); }
+int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void* dctx, const void* x, void* dqkvc, float* slab,
+                                float* bias_slab, int n_seq, int H, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                                const uint64_t* rng, int head_major, void* stream) {
+    AttnBwdWg w;
+    w.a = mk_attn(qkvc, mask, n_seq, 32, H, 32, beta, drop_p, site1, site2, rng);
+    w.a.dctx = dctx; w.a.dqkvc = dqkvc; w.a.hm = head_major != 0;
+    w.x = x; w.ldx = (int64_t)H * 32; w.slab = slab; w.bias_slab = bias_slab;
+    PMGT_CHECK(attn_bwd_wgrad_supported(w), -3, "pmgt_op_attention_bwd_wgrad: unsupported shape (needs bf16, S = 32, dh = 32, d in {128, 256}, n_seq >= 2)");
+    return attn_bwd_wgrad(w, (hipStream_t)stream);
 }
 
 // ---- fp8 mode ---------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's full shapes (C2: 7 252-node graph, L4 H8 d256 S32) through size-independent properties:
 the goldens pin the arithmetic on small cases; here the same engine runs a real-size batch and must (a) agree with
 itself when every fast path is switched off (per-token projection, separate GEMM + attention kernels, tiled GEMMs, all
-tokens through the last layer, q|k|v|c column order), (b) be bit-reproducible run to run, (c) mask the reference's
+tokens through the last layer, q|k|v|c column order, attention backward and Q|K|V|C weight gradient as two kernels), (b) be bit-reproducible run to run, (c) mask the reference's
 share of tokens, (d) take a descending optimisation step."""
 import numpy as np
 import pytest
@@ -51,7 +51,8 @@ def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
     fast = engine(world)
     o_fast = step(fast, world, want_hidden=False)
     switches = [L.pmgt_debug_disable_table_projection, L.pmgt_debug_disable_fused_qkvc_attention, L.pmgt_debug_disable_head_major,
-                L.pmgt_debug_disable_last_layer_shortcut, L.pmgt_debug_force_tile_gemm, L.pmgt_debug_disable_segment_sum]
+                L.pmgt_debug_disable_last_layer_shortcut, L.pmgt_debug_force_tile_gemm, L.pmgt_debug_disable_segment_sum,
+                L.pmgt_debug_disable_fused_attention_backward]
     for f in switches:
         f(1)
     try:

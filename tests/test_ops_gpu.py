@@ -268,6 +268,67 @@ def _attn_ref(qkvc, mask, H, beta):
     return (w @ v).permute(0, 2, 1, 3).reshape(T, S, d), w
 
 
+def _to_head_major(t, H, dh):
+    """[..., 4d] in q | k | v | c column order -> head-major (h, matrix, w)."""
+    lead = t.shape[:-1]
+    return t.reshape(*lead, 4, H, dh).transpose(-3, -2).reshape(*lead, 4 * H * dh).contiguous()
+
+
+def _from_head_major(t, H, dh):
+    lead = t.shape[:-1]
+    return t.reshape(*lead, H, 4, dh).transpose(-3, -2).reshape(*lead, 4 * H * dh).contiguous()
+
+
+@pytest.mark.parametrize("T,H,hm,p", [(7, 8, 1, 0.0), (64, 8, 1, 0.0), (9, 4, 1, 0.0), (6, 8, 0, 0.0), (700, 8, 1, 0.0), (23, 8, 1, 0.2),
+                                      (2, 4, 0, 0.2)])
+def test_attention_backward_fused_with_qkvc_weight_gradient(T, H, hm, p):
+    """attn_bwd_wgrad_kernel (attention waves + GEMM waves in one workgroup): dQ|dK|dV|dC against autograd through the fp64
+    restatement of pmgt/pmgt/modeling_pmgt.py:435-526 (p = 0) or against the unfused MFMA backward with the same dropout masks
+    (p > 0); dW / db partials against dQKVC^T x and column sums of the bf16 dQKVC the kernel itself stored.  Odd sequence counts
+    (half-empty last step), more steps than one per workgroup (T = 700), both column layouts, both hidden sizes."""
+    _lib, L = _setup()
+    S, dh, beta = 32, 32, 0.5
+    d = H * dh
+    g = torch.Generator().manual_seed(T * 10 + H)
+    qkvc = torch.randn(T, S, 4 * d, generator=g)
+    dctx = torch.randn(T, S, d, generator=g)
+    xin = torch.randn(T, S, d, generator=g)
+    mask = torch.ones(T, S)
+    for t in range(T):
+        mask[t, 1 + (t * 7) % S:] = 0
+    mask[0] = 1
+    qd, dod, xd, md = to_dev(qkvc, torch.bfloat16), to_dev(dctx, torch.bfloat16), to_dev(xin, torch.bfloat16), mask.cuda()
+    q_in = _to_head_major(qd, H, dh) if hm else qd
+    parts = L.pmgt_op_attention_bwd_wgrad_parts(H)
+    rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+    dx = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    slab = torch.full((parts, 4 * d, d), float("nan"), device="cuda")
+    bslab = torch.full((parts, 4 * d), float("nan"), device="cuda")
+    _lib.check(L.pmgt_op_attention_bwd_wgrad(P(q_in), P(md), P(dod), P(xd), P(dx), P(slab), P(bslab), T, H, beta, p, 11, 12, P(rng), hm,
+                                             stream()))
+    torch.cuda.synchronize()
+    got = _from_head_major(dx, H, dh) if hm else dx
+    assert torch.isfinite(got.float()).all() and torch.isfinite(slab).all() and torch.isfinite(bslab).all()
+    if p == 0.0:
+        xr = rounded(qkvc, torch.bfloat16).requires_grad_(True)
+        ref, _ = _attn_ref(xr, mask.double(), H, beta)
+        ref.backward(rounded(dctx, torch.bfloat16))
+        assert rel_err(got, xr.grad) < 2e-2
+    # the unfused one-wave MFMA backward on the same inputs (same dropout masks: same (seed, step, site, row, column) hash)
+    dx2 = torch.empty_like(dx)
+    L.pmgt_debug_disable_coop_attention_bwd(1)
+    _lib.check(L.pmgt_op_attention_bwd(1, P(qd), P(md), P(dod), P(dx2), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+    L.pmgt_debug_disable_coop_attention_bwd(0)
+    assert rel_err(got, dx2) < 2e-2
+    assert ((got.float() == 0) == (dx2.float() == 0)).float().mean() > 0.995
+    # weight / bias gradient: exactly the sums of what the kernel stored (fp32 accumulation of bf16 products), q | k | v | c rows
+    G = got.double().reshape(T * S, 4 * d).cpu()
+    X = xd.double().reshape(T * S, d).cpu()
+    dW, db = slab.double().sum(0).cpu(), bslab.double().sum(0).cpu()
+    assert rel_err(dW, G.T @ X) < 1e-4
+    assert float((db - G.sum(0)).abs().max()) < 1e-4 * float(G.abs().sum(0).max())
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "bf16-wave"])     # bf16-wave: the one-wave-per-(sequence, head) backward
 @pytest.mark.parametrize("T,S,H,dh,beta", [(5, 16, 4, 16, 0.5), (7, 32, 8, 32, 0.5), (3, 6, 2, 64, 0.3), (2, 64, 2, 64, 0.5),
                                            (4, 32, 1, 128, 1.0), (6, 20, 4, 32, 0.0), (9, 33, 2, 32, 0.7), (5, 48, 3, 64, 0.5),
