@@ -1248,26 +1248,34 @@ template <int DH> static int launch_nt(const AttnArgs& a, bool bwd, hipStream_t 
 //
 // The unfused pair is VALU-bound (attention backward: ~1 100 VALU instructions per (sequence, head), matrix pipe 6 % busy)
 // followed by memory/MFMA-bound (weight gradient: re-reads the 4U of dQ|dK|dV|dC the attention just wrote, plus x, and
-// pushes 256 MB of split-K partial slabs through HBM per layer).  Here one 512-thread workgroup per CU owns ONE head
-// (128 columns of Q|K|V|C) and walks over pairs of sequences with its waves in two ROLES (wave-uniform, scalar branches):
-//   * waves 0-3 (one per SIMD): attention backward of the step's two (sequence, head) pairs, two cooperating waves per
-//     pair as in attn_bwd_coop_kernel (query tile `it`, then key tile `it`), written for a short VALU chain (log2-domain
-//     scores, predicated dropout, 8-byte swizzled image writes read back with ds_read_b64_tr_b16).  Their dQ|dK|dV|dC rows
-//     go into a swizzled LDS tile instead of HBM;
-//   * waves 4-7 (the other wave of each SIMD): the matrix pipe's customers.  They stream the step's x rows into LDS by
-//     LDS-DMA (no staging registers), accumulate dW_head[128, d] += dQKVC_tile^T x_tile of the PREVIOUS step in 128
-//     accumulator registers for the whole life of the workgroup (+ the bias gradient as one more MFMA against an all-ones
-//     operand), and copy that tile to HBM with 16-byte row-contiguous stores.
-// One SIMD thus always holds a VALU-bound and an MFMA-bound wave, which is what lets the two pipes overlap; the weight
-// gradient leaves the kernel as ONE [128, d] partial per workgroup (32 partials per head instead of the 256 MB of slabs).
-// Three raw s_barriers per step order the hand-offs (tiles / images of a pair; the dQKVC tile and the x tile are double
-// buffered between the roles); every LDS access of the DMA-issuing waves is inline asm with counted waits, because the
-// compiler puts s_waitcnt vmcnt(0) in front of any LDS read it can see while an LDS-DMA is in flight.
+// pushes 256 MB of split-K partial slabs through HBM per layer).  Here one 1024-thread workgroup per CU owns ONE head
+// (128 columns of Q|K|V|C) and walks over pairs of sequences with its sixteen waves in two ROLES (wave-uniform, scalar branches):
+//   * waves 0-7 (two per SIMD): attention backward of the step's two (sequence, head) pairs, FOUR waves per pair:
+//     (query / key tile it) x (softmax branch br: 1 = the cosine "diversity" branch, 2 = the scaled dot-product branch).
+//     A branch wave computes its own scores, softmax, dropout mask and softmax backward; the only things the two branches
+//     share are dP = dO V^T (each computes it: two MFMAs) and the mixed probabilities, which meet as two images that the
+//     dV product accumulates one after the other.  They touch HBM only for the 32 mask values of their sequence: Q|K|V|C
+//     and dO rows arrive in LDS tiles (below), dQ|dK|dV|dC leave through an LDS tile.  Written for a short VALU chain
+//     (log2-domain scores, predicated dropout, 8-byte swizzled image writes read back with ds_read_b64_tr_b16; C^ = C / |C|
+//     is never materialised: the inverse norms are folded into dS1 on its way into the two products that consume it);
+//   * waves 8-15 (the other two waves of each SIMD): the matrix pipe's customers and the workgroup's DMA engine.  Per step
+//     they request the NEXT step's rows of Q|K|V|C (256 contiguous bytes per row and head in the head-major layout), dO and x
+//     by LDS-DMA (no staging registers), accumulate dW_head[128, d] += dQKVC_tile^T x_tile of the PREVIOUS step in 64
+//     accumulator registers each for the whole life of the workgroup (+ the bias gradient as one more MFMA against an
+//     all-ones operand), and copy that tile to HBM with 16-byte row-contiguous stores.
+// Why sixteen waves: a wave alone on its SIMD issues one VALU instruction per 4 cycles, two waves together one per 2 -- the
+// first form of this kernel (4 + 4 waves) spent 5 800 cycles per step in its attention role with the vector ALU half idle.
+// Why the attention waves load nothing themselves: 16 waves leave 128 VGPRs per wave, a register prefetch of the next step's
+// fragments does not fit next to the working set, and a spilled register's reload waits with vmcnt(0) -- for the prefetch.
+// The weight gradient leaves the kernel as ONE [128, d] partial per workgroup (32 partials per head instead of 256 MB of
+// slabs).  Three raw s_barriers per step order the hand-offs; every LDS access of the DMA-issuing waves is inline asm with its
+// own waits, because the compiler puts s_waitcnt vmcnt(0) in front of any LDS read it can see while an LDS-DMA is in flight.
+// LDS (d = 256): x tiles 2 x 32 KB | Q|K|V|C-in / dQKVC-out ring 4 x 16 KB | dO tiles 2 x 4 KB | images + norms 2 x 8.25 KB.
 // =================================================================================================
 #ifdef PMGT_ABW_PROF
 // cycles per interval of a step (work / barrier wait alternating: w1 b1 w2 b2 w3 b0), summed over the steps of workgroup 0:
-// [role: 0 = attention wave 0, 1 = GEMM wave 4][interval]; slot 7 = steps
-__device__ unsigned long long g_abw_prof[2][8];
+// [wave][interval]; slot 7 = steps
+__device__ unsigned long long g_abw_prof[16][8];
 #define ABW_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc[k_] += n_ - plast; plast = n_; } while (0)
 #else
 #define ABW_STAMP(k_) do { } while (0)
@@ -1277,19 +1285,21 @@ template <int KT> struct AbwCfg {
     static constexpr int D = 16 * KT;                 // hidden size (256 or 128)
     static constexpr int XROW = D * 2;                // bytes per row of x
     static constexpr int XB = 64 * XROW;              // x tile: the two sequences of a step
-    static constexpr int GB = 64 * 256;               // dQ|dK|dV|dC tile of one head for the two sequences
-    static constexpr int SCR = 4 * 2048 + 3 * 2048 + 256;   // per pair: Q, K, dO, C^ tiles | dS1, P, dS2 images | rho, madd
-    static constexpr int G0 = 2 * XB, S0 = G0 + 2 * GB, SMEM = S0 + 2 * SCR;
-    static constexpr int KH = KT / 2;                 // 16-column k tiles per GEMM wave
+    static constexpr int GB = 64 * 256;               // Q|K|V|C (in) or dQ|dK|dV|dC (out) tile of one head for the two sequences
+    static constexpr int OB = 64 * 64;                // dO tile
+    static constexpr int SCR = 4 * 2048 + 256;        // per pair: dS1, dS2, P1, P2 images | rho, madd
+    // ring of four 16 KB tiles: step i reads in-tile (2 i) & 3 ... out-tile (2 i + 1) & 3
+    static constexpr int G0 = 2 * XB, O0 = G0 + 4 * GB, S0 = O0 + 2 * OB, SMEM = S0 + 2 * SCR;
+    static constexpr int KQ = KT / 4;                 // 16-column k tiles per GEMM wave
 };
 
 // swizzles (all at the granularity the reads and writes share, so they are transparent to the transposing reads):
-//   x / dQKVC tiles: 16-byte chunk c of row -> c ^ abw_f(row), abw_f = 2 * (bits 0, 1, 3 of the row): the 8 rows x 2 chunks one
-//   ds_read_b64_tr_b16 half-wave touches land on 16 different chunk slots, and "+4 rows" stays a plain address offset;
-//   32 x 32 tiles of a pair (64-byte rows): 16-byte chunk c -> c ^ abw_kt(row); images: 8-byte slot s -> s ^ ((row >> 1) & 7)
+//   x / Q|K|V|C / dQKVC tiles: 16-byte chunk c of row -> c ^ abw_f(row), abw_f = 2 * (bits 0, 1, 3 of the row): the 8 rows x 2
+//   chunks one ds_read_b64_tr_b16 half-wave touches land on 16 different chunk slots, and "+4 rows" stays a plain address offset;
+//   dO tile (64-byte rows): 16-byte chunk c -> c ^ abw_kt(row); images: 8-byte slot s -> s ^ ((row >> 1) & 7)
 __device__ __forceinline__ int abw_f(int row) { return 2 * ((row & 3) | ((row >> 1) & 4)); }
 __device__ __forceinline__ int abw_kt(int row) { return ((row >> 1) ^ (row >> 3)) & 3; }
-__device__ __forceinline__ int abw_tile_addr(int row, int byte_col) {      // byte_col multiple of 8
+__device__ __forceinline__ int abw_o_addr(int row, int byte_col) {         // byte_col multiple of 8, 64-byte rows
     return row * 64 + ((((byte_col >> 4) ^ abw_kt(row))) << 4) + (byte_col & 15);
 }
 __device__ __forceinline__ int abw_img_addr(int row, int slot) { return row * 64 + ((slot ^ ((row >> 1) & 7)) << 3); }
@@ -1297,12 +1307,20 @@ __device__ __forceinline__ int abw_g_addr(int row, int byte_col) {         // by
     return row * 256 + (((byte_col >> 4) ^ abw_f(row)) << 4) + (byte_col & 15);
 }
 
-// transposing fragment reads of the swizzled 32 x 32 tiles / images (cf. tr_frag / img_frag)
-template <bool PERM> __device__ __forceinline__ bf16x8 abw_tr_tile(const char* tile, int c0, int r, int q) {
+// transposing fragment reads: element e of lane (r, q) = tile[krow(q, e)][column c0 + r of the 32-column block at byte column mb]
+//   PERM: krow = 16 (e >> 2) + 4 q + (e & 3) (matches an accumulator tile used as the other operand); else krow = 8 q + e
+template <bool PERM> __device__ __forceinline__ bf16x8 abw_tr_g(const char* tile, int mb, int c0, int r, int q) {
     const int row_lo = PERM ? (4 * q + (r >> 2)) : (8 * q + (r >> 2)), row_hi = row_lo + (PERM ? 16 : 4);
+    const int colb = mb + (c0 + 4 * (r & 3)) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + abw_g_addr(row_lo, colb)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + abw_g_addr(row_hi, colb)));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 abw_tr_o(const char* tile, int c0, int r, int q) {        // dO tile, natural k order
+    const int row_lo = 8 * q + (r >> 2), row_hi = row_lo + 4;
     const int colb = (c0 + 4 * (r & 3)) * 2;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + abw_tile_addr(row_lo, colb)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + abw_tile_addr(row_hi, colb)));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + abw_o_addr(row_lo, colb)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + abw_o_addr(row_hi, colb)));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8 abw_tr_img(const char* img, int c0, int r, int q) {      // element e = img[8 q + e][c0 + r]
@@ -1312,239 +1330,210 @@ __device__ __forceinline__ bf16x8 abw_tr_img(const char* img, int c0, int r, int
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-struct AbwFrags {          // everything one attention wave reads from HBM for one (sequence, head): 36 VGPRs
-    bf16x8 fq, fo, fk[2], fv[2], fc[2];
-    float mv;
-};
-
-template <int IT>
-__device__ __forceinline__ void abw_load(AbwFrags& f, const AttnArgs& a, int t, int h, int r, int q, int lane) {
-    const int d = a.H * 32;
-    const int64_t ld = 4 * (int64_t)d;
-    const int hoff = a.hm ? 4 * h * 32 : h * 32, ms = a.hm ? 32 : d;
-    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * 32 * ld + hoff + 8 * q;
-    const bf16* DO = (const bf16*)a.dctx + (int64_t)t * 32 * d + h * 32 + 8 * q;
-    const int x = 16 * IT + r;
-    f.fq = *(const bf16x8*)(X + x * ld);
-    f.fo = *(const bf16x8*)(DO + (int64_t)x * d);
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        const bf16* row = X + (16 * jt + r) * ld;
-        f.fk[jt] = *(const bf16x8*)(row + ms);
-        f.fv[jt] = *(const bf16x8*)(row + 2 * ms);
-        f.fc[jt] = *(const bf16x8*)(row + 3 * ms);
-    }
-    // the RAW mask value: any arithmetic on it here would make the compiler wait (vmcnt(0)) for every load above right away
-    f.mv = a.mask ? a.mask[(int64_t)t * 32 + (lane & 31)] : 1.f;
-}
-
-// One step of an attention wave: pair (sequence t, head h), query / key tile IT.  `scr` = the pair's LDS scratch,
-// `grow` = byte address of row 0 of the pair inside the step's dQ|dK|dV|dC tile.  `bar` = the workgroup barrier.
-// `n` / `tn`: the NEXT step's fragments are requested right after the last use of this step's (the score MFMAs): issued before the
-// first use of `f`, the compiler's conservative s_waitcnt vmcnt(0) at that use would wait for them too (measured: 4 900 of a
-// step's 9 400 cycles).
-template <int IT, typename Bar>
-__device__ __forceinline__ void abw_attention(const AbwFrags& f, AbwFrags& n, int tn, const AttnArgs& a, const DropKey& k1, const DropKey& k2,
-                                              bool act, int t, int h, char* scr, char* grow, int r, int q, int lane, Bar bar) {
+// One step of an attention wave: pair = rows [0, 32) of `gin` (Q|K|V|C, 256-byte rows) / `oin` (dO, 64-byte rows), query / key
+// tile IT, softmax branch BR; results into `gout`; `scr` = the pair's images and norms; `mraw` = raw mask value of key (lane & 31);
+// `bar(k)` = the workgroup barrier.
+template <int IT, int BR, typename Bar>
+__device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& kd, bool act, float mraw, int t, int h, const char* gin,
+                                              const char* oin, char* gout, char* scr, int r, int q, int lane, Bar bar) {
     constexpr float L2E = 1.4426950408889634f;
-    char* tQ = scr;
-    char* tK = scr + 2048;
-    char* tO = scr + 4096;
-    char* tC = scr + 6144;
-    char* iS1 = scr + 8192;
-    char* iP = scr + 10240;
-    char* iS2 = scr + 12288;
-    float* rho = (float*)(scr + 14336);
+    constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
+    char* iS = scr + (BR == 1 ? 0 : 2048);               // dS1 (rows scaled by 1 / |c_i|) | dS2
+    char* iP1 = scr + 4096;
+    char* iP2 = scr + 6144;
+    float* rho = (float*)(scr + 8192);
     float* madd = rho + 32;
     const int x = 16 * IT + r;
-    // ---- I1: own rows -> tiles, inverse norms, mask term (log2 domain, shifted by its maximum over the keys)
-    float ss = 0.f;
+    // ---- I1: fragments from the tiles; branch 1: inverse norms of C and the mask term (log2 domain, shifted by its maximum)
+    bf16x8 fown, kc[2], fv[2], fo;      // own Q rows (branch 2) | K or C rows of all keys | V rows of all keys | own dO rows
+    if (BR == 2) fown = *(const bf16x8*)(gin + abw_g_addr(x, 16 * q));
+    fo = *(const bf16x8*)(oin + abw_o_addr(x, 16 * q));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bf16x2_t c2 = {f.fc[IT][2 * e], f.fc[IT][2 * e + 1]};
-        ss = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, ss, false);
+    for (int jt = 0; jt < 2; ++jt) {
+        kc[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, (BR == 1 ? 192 : 64) + 16 * q));
+        fv[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, 128 + 16 * q));
     }
-    ss = red_q<2>(ss, false);
-    const float rho_x = act ? __builtin_amdgcn_rsqf(ss) : 0.f;
-    if (q == 0) rho[x] = rho_x;
-    {
-        const float mv = (1.f - f.mv) * -10000.f;
+    float ss = 0.f, rho_x = 0.f;
+    if (BR == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16x2_t c2 = {kc[IT][2 * e], kc[IT][2 * e + 1]};
+            ss = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, ss, false);
+        }
+        ss = red_q<2>(ss, false);
+        rho_x = act ? __builtin_amdgcn_rsqf(ss) : 0.f;
+        if (q == 0) rho[x] = rho_x;
+        // the mask term sits with the cosine wave: the dot-product wave reads one fragment more, and the in-kernel stamps showed its
+        // first interval at 1 340 cycles against 770 here with the mask term over there
+        const float mv = (1.f - mraw) * -10000.f;
         float mm = mv;
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x121, 0xf, 0xf, false)));
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x122, 0xf, 0xf, false)));
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x124, 0xf, 0xf, false)));
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x128, 0xf, 0xf, false)));
         mm = red_q<2>(mm, true);
-        if ((lane >> 4) == IT) madd[lane & 31] = (mv - mm) * L2E;      // each wave of the pair writes 16 of the 32 entries
+        if ((lane >> 4) == IT) madd[lane & 31] = (mv - mm) * L2E;      // each tile's cosine wave writes 16 of the 32 entries
     }
-    {
-        const int off = abw_tile_addr(x, 16 * q);
-        *(bf16x8*)(tQ + off) = f.fq;
-        *(bf16x8*)(tK + off) = f.fk[IT];
-        *(bf16x8*)(tO + off) = f.fo;
-        bf16x8 ch;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ch[e] = (bf16)((float)f.fc[IT][e] * rho_x);
-        *(bf16x8*)(tC + off) = ch;
-    }
-    bar(0);
-    // ---- I2: first half, query tile IT: scores (transposed: key on (q, e), query on r), both softmaxes and their backward
-    f32x4 a1[2], a2[2], dp[2];
+    // scores (transposed: key on (q, e), query on r) do not depend on the other waves: start the matrix pipe before the barrier
+    f32x4 sc[2], dp[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
-        if (jt == IT) {
+        if (BR == 1 && jt == IT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) z1[e] = (4 * q + e == r) ? -ss : 0.f;      // "+ I": |c_i|^2 rho_i^2 = 1 on the diagonal
         }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        a1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fc[jt], f.fc[IT], z1, 0, 0, 0);
-        a2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fk[jt], f.fq, z, 0, 0, 0);
-        dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fv[jt], f.fo, z, 0, 0, 0);
+        sc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[jt], BR == 1 ? kc[IT] : fown, z1, 0, 0, 0);
+        dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fo, z, 0, 0, 0);
     }
-    abw_load<IT>(n, a, tn, h, r, q, lane);
+    bar(0);
+    // ---- I2: first half, query tile IT: this branch's softmax and its backward
+    f32x4 rj[2];
     {
-        const float rl = rho_x * L2E;
-        constexpr float isql = 0.17677669529663687f * L2E;
-        float m2 = -INFINITY;
+        const float fac = BR == 1 ? -rho_x * L2E : ISQ * L2E;
+        float mx = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            const f32x4 rj = *(const f32x4*)(rho + 16 * jt + 4 * q);
             const f32x4 mj = *(const f32x4*)(madd + 16 * jt + 4 * q);
+            rj[jt] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (BR == 1) rj[jt] = *(const f32x4*)(rho + 16 * jt + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a1[jt][e] = fmaf(-a1[jt][e], rl * rj[e], mj[e]);
-                a2[jt][e] = fmaf(a2[jt][e], isql, mj[e]);
-                m2 = raw_max(m2, a2[jt][e]);
+                sc[jt][e] = fmaf(sc[jt][e], BR == 1 ? fac * rj[jt][e] : fac, mj[e]);
+                if (BR == 2) mx = raw_max(mx, sc[jt][e]);      // the cosine branch is bounded (-cos + I <= 2): no row maximum
             }
         }
-        m2 = red_q<2>(m2, true);
-        float s1 = 0.f, s2 = 0.f;
+        if (BR == 2) mx = red_q<2>(mx, true);
+        float sum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a1[jt][e] = __builtin_amdgcn_exp2f(a1[jt][e]);
-                a2[jt][e] = __builtin_amdgcn_exp2f(a2[jt][e] - m2);
-                s1 += a1[jt][e];
-                s2 += a2[jt][e];
+                sc[jt][e] = __builtin_amdgcn_exp2f(BR == 2 ? sc[jt][e] - mx : sc[jt][e]);
+                sum += sc[jt][e];
             }
-        s1 = red_q<2>(s1, false);
-        s2 = red_q<2>(s2, false);
-        const float i1 = act ? __builtin_amdgcn_rcpf(s1) : 0.f, i2 = act ? __builtin_amdgcn_rcpf(s2) : 0.f;
+        sum = red_q<2>(sum, false);
+        const float inv = act ? __builtin_amdgcn_rcpf(sum) : 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) { a1[jt] *= i1; a2[jt] *= i2; }
+        for (int jt = 0; jt < 2; ++jt) sc[jt] *= inv;
     }
     {
-        const float cb = a.beta * k1.scale, co = (1.f - a.beta) * k2.scale;      // branch weight x dropout scale
+        const float cw = (BR == 1 ? a.beta : 1.f - a.beta) * kd.scale;      // branch weight x dropout scale
         const uint32_t hrow = (uint32_t)((((uint64_t)t * a.H + h) * 32) + x);
-        float rd1 = 0.f, rd2 = 0.f;
-        f32x4 g1[2], g2[2], pm[2];
+        float rd = 0.f;
+        f32x4 gr[2], pm[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            bool kp1[4] = {true, true, true, true}, kp2[4] = {true, true, true, true};
-            if (k1.on) {
-                drop_keep4(k1, hrow, (uint32_t)(4 * jt + q), kp1);
-                drop_keep4(k2, hrow, (uint32_t)(4 * jt + q), kp2);
-            }
+            bool kp[4] = {true, true, true, true};
+            if (kd.on) drop_keep4(kd, hrow, (uint32_t)(4 * jt + q), kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x1 = kp1[e] ? cb * dp[jt][e] : 0.f, x2 = kp2[e] ? co * dp[jt][e] : 0.f;
-                g1[jt][e] = x1;
-                g2[jt][e] = x2;
-                pm[jt][e] = fmaf(cb, kp1[e] ? a1[jt][e] : 0.f, kp2[e] ? co * a2[jt][e] : 0.f);
-                rd1 = fmaf(a1[jt][e], x1, rd1);
-                rd2 = fmaf(a2[jt][e], x2, rd2);
+                gr[jt][e] = kp[e] ? cw * dp[jt][e] : 0.f;
+                pm[jt][e] = kp[e] ? cw * sc[jt][e] : 0.f;
+                rd = fmaf(sc[jt][e], gr[jt][e], rd);
             }
         }
-        rd1 = red_q<2>(rd1, false);
-        rd2 = red_q<2>(rd2, false);
+        rd = red_q<2>(rd, false);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a1[jt][e] = a1[jt][e] * (g1[jt][e] - rd1);     // dS1
-                a2[jt][e] = a2[jt][e] * (g2[jt][e] - rd2);     // dS2
-            }
+            for (int e = 0; e < 4; ++e) sc[jt][e] = sc[jt][e] * (gr[jt][e] - rd);      // dS of this branch
             const int ia = abw_img_addr(x, 4 * jt + q);          // images are [query i][key j]: 4 consecutive keys = one 8-byte write
-            *(bf16x4*)(iS1 + ia) = pack4(a1[jt]);
-            *(bf16x4*)(iP + ia) = pack4(pm[jt]);
-            *(bf16x4*)(iS2 + ia) = pack4(a2[jt]);
+            // dS1 meets C^_i = C_i / |c_i| in the second half (sum over queries i): the image rows carry the 1 / |c_i|
+            *(bf16x4*)(iS + ia) = pack4(BR == 1 ? sc[jt] * rho_x : sc[jt]);
+            *(bf16x4*)((BR == 1 ? iP1 : iP2) + ia) = pack4(pm[jt]);
+            if (BR == 1) sc[jt] *= rj[jt];                       // ... and C^_j in the first half (sum over keys j): 1 / |c_j| per key
         }
     }
-    // dQ^T and the accumulator-operand half of dC^T for this query tile
+    // branch 2: dQ^T; branch 1: the accumulator-operand half of dC^T -- both for this query tile
     f32x4 dch[2];
     {
-        const bf16x8 b2 = pack_col<2>(a2, 0), b1 = pack_col<2>(a1, 0);
+        const bf16x8 bs = pack_col<2>(sc, 0);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_tile<true>(tK, 16 * ct, r, q), b2, z, 0, 0, 0);
-            dch[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_tile<true>(tC, 16 * ct, r, q), b1, z, 0, 0, 0);
-            *(bf16x4*)(grow + abw_g_addr(x, (16 * ct + 4 * q) * 2)) = pack4(dq * 0.17677669529663687f);      // dQ block: columns 0..31
+            if (BR == 2) {
+                const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(gin, 64, 16 * ct, r, q), bs, z, 0, 0, 0);     // K block
+                *(bf16x4*)(gout + abw_g_addr(x, (16 * ct + 4 * q) * 2)) = pack4(dq * ISQ);      // dQ block: columns 0..31
+            } else {
+                dch[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(gin, 192, 16 * ct, r, q), bs, z, 0, 0, 0);          // C block
+            }
         }
     }
     bar(2);
-    // ---- I3: second half, key tile IT (x is the key index now)
+    // ---- I3: second half, key tile IT (x is the key index now).  dV^T = dO^T (P1 + P2) is split between the two branch waves
+    // (16 columns each): the cosine wave also has dC, the dot-product wave dK.
     {
-        const bf16x8 bt = abw_tr_img(iS1, 16 * IT, r, q), bp = abw_tr_img(iP, 16 * IT, r, q), bs = abw_tr_img(iS2, 16 * IT, r, q);
+        constexpr int CV = BR == 1 ? 0 : 1;
+        const bf16x8 bp1 = abw_tr_img(iP1, 16 * IT, r, q), bp2 = abw_tr_img(iP2, 16 * IT, r, q);
+        const bf16x8 ao = abw_tr_o(oin, 16 * CV, r, q);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp1, z, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp2, dv, 0, 0, 0);                      // P = P1 + P2 meets in the accumulator
+        *(bf16x4*)(gout + abw_g_addr(x, 128 + (16 * CV + 4 * q) * 2)) = pack4(dv);              // dV block
+    }
+    if (BR == 2) {
+        const bf16x8 bs = abw_tr_img(iS, 16 * IT, r, q);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<false>(gin, 0, 16 * ct, r, q), bs, z, 0, 0, 0);         // Q block
+            *(bf16x4*)(gout + abw_g_addr(x, 64 + (16 * ct + 4 * q) * 2)) = pack4(dk * ISQ);       // dK block
+        }
+    } else {
+        const bf16x8 bt = abw_tr_img(iS, 16 * IT, r, q);
         float dt = 0.f;
         f32x4 chv[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_tile<false>(tC, 16 * ct, r, q), bt, dch[ct], 0, 0, 0);
-            const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_tile<false>(tO, 16 * ct, r, q), bp, z, 0, 0, 0);
-            const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_tile<false>(tQ, 16 * ct, r, q), bs, z, 0, 0, 0);
+            const f32x4 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<false>(gin, 192, 16 * ct, r, q), bt, dch[ct], 0, 0, 0);
             const int gc = (16 * ct + 4 * q) * 2;
-            *(bf16x4*)(grow + abw_g_addr(x, 64 + gc)) = pack4(dk * 0.17677669529663687f);       // dK block
-            *(bf16x4*)(grow + abw_g_addr(x, 128 + gc)) = pack4(dv);                             // dV block
             dch[ct] = -dc;           // dN = -dS1
-            chv[ct] = load4<bf16>((const bf16*)(tC + abw_tile_addr(x, gc)));
+            chv[ct] = load4<bf16>((const bf16*)(gin + abw_g_addr(x, 192 + gc))) * rho_x;        // C^_x
             dt += (dch[ct][0] * chv[ct][0] + dch[ct][1] * chv[ct][1]) + (dch[ct][2] * chv[ct][2] + dch[ct][3] * chv[ct][3]);
         }
         dt = red_q<2>(dt, false);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-            *(bf16x4*)(grow + abw_g_addr(x, 192 + (16 * ct + 4 * q) * 2)) = pack4((dch[ct] - chv[ct] * dt) * rho_x);    // dC block
+            *(bf16x4*)(gout + abw_g_addr(x, 192 + (16 * ct + 4 * q) * 2)) = pack4((dch[ct] - chv[ct] * dt) * rho_x);    // dC block
     }
     bar(4);
 }
 
 // ---- GEMM-wave LDS access (inline asm: see the header) ----------------------------------------------------------------
-// eight transposing 8-byte reads = four bf16x8 fragments (lo rows / hi rows = +`hi` bytes), then wait
-__device__ __forceinline__ void abw_read4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t hi, bf16x8 (&out)[4]) {
+// four fragments by transposing 8-byte reads (lo rows, hi rows = + HI bytes), one wait at the end
+template <int HI>
+__device__ __forceinline__ void abw_read_frags(const uint32_t (&ad)[4], bf16x8 (&fr)[4]) {
     u32x2 t[8];
     asm volatile(
         "ds_read_b64_tr_b16 %0, %8\n\t"
-        "ds_read_b64_tr_b16 %1, %12\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
         "ds_read_b64_tr_b16 %2, %9\n\t"
-        "ds_read_b64_tr_b16 %3, %13\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
         "ds_read_b64_tr_b16 %4, %10\n\t"
-        "ds_read_b64_tr_b16 %5, %14\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
         "ds_read_b64_tr_b16 %6, %11\n\t"
-        "ds_read_b64_tr_b16 %7, %15\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%12\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a0 + hi), "v"(a1 + hi), "v"(a2 + hi), "v"(a3 + hi)
+        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "n"(HI)
         : "memory");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = __builtin_bit_cast(bf16x8, (u32x4){t[2 * i][0], t[2 * i][1], t[2 * i + 1][0], t[2 * i + 1][1]});
+    for (int i = 0; i < 4; ++i) fr[i] = __builtin_bit_cast(bf16x8, (u32x4){t[2 * i][0], t[2 * i][1], t[2 * i + 1][0], t[2 * i + 1][1]});
 }
-__device__ __forceinline__ void abw_read128x4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, u32x4 (&out)[4]) {
+__device__ __forceinline__ void abw_read128x2(uint32_t a0, uint32_t a1, u32x4 (&out)[2]) {
     asm volatile(
-        "ds_read_b128 %0, %4\n\t"
-        "ds_read_b128 %1, %5\n\t"
-        "ds_read_b128 %2, %6\n\t"
-        "ds_read_b128 %3, %7\n\t"
+        "ds_read_b128 %0, %2\n\t"
+        "ds_read_b128 %1, %3\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "=&v"(out[0]), "=&v"(out[1])
+        : "v"(a0), "v"(a1)
         : "memory");
 }
 
 template <int KT>
-__global__ __launch_bounds__(512) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
+__global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     using C = AbwCfg<KT>;
     constexpr int D = C::D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1557,7 +1546,9 @@ __global__ __launch_bounds__(512) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     const int npair = (a.Tseq + 1) / 2;
     const int nsteps = xs < npair ? (npair - xs + gx - 1) / gx : 0;
     const int M = a.Tseq * 32;
-    // both roles run nsteps + 1 iterations of three barriers; LDS visibility = every wave waits for its own LDS operations first
+    // Iterations i = 0 .. nsteps + 1, three barriers each.  Iteration i: DMA of the inputs of step i (GEMM waves), attention of
+    // step i - 1 (attention waves), weight-gradient products + copy-out of step i - 2 (GEMM waves).
+    // LDS visibility = every wave waits for its own LDS operations before the barrier.
 #ifdef PMGT_ABW_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long plast = __builtin_readcyclecounter();
@@ -1566,133 +1557,166 @@ __global__ __launch_bounds__(512) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
 #else
     auto bar = [](int) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
 #endif
+    // A SIMD holds waves {k, k + 4, k + 8, k + 12}; issue arbitration is oldest-first, and the per-wave stamps showed the younger wave
+    // of each role (4-7, 12-15) taking 40 % longer per interval than its older twin -- at every barrier the workgroup waited for it.
+    // Static priority for the younger half evens the two out (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
+    if (wave & 4) __builtin_amdgcn_s_setprio(1);
+    // tile ring: step s reads its inputs from ring slot (2 s) & 3 and writes its results to slot (2 s + 1) & 3
+    auto in_tile = [](int s) { return C::G0 + ((2 * s) & 3) * C::GB; };
+    auto out_tile = [](int s) { return C::G0 + ((2 * s + 1) & 3) * C::GB; };
 
-    if (wave < 4) {
+    if (wave < 8) {
         // ================================ attention role ================================
-        const int ul = wave >> 1, it = wave & 1;
+        // waves w and w + 4 share a SIMD: same (tile, branch), the two pairs of the step
+        const int ul = wave >> 2, it = (wave >> 1) & 1, br = wave & 1;         // br = 0: cosine branch (BR 1), 1: dot-product branch (BR 2)
         char* scr = smem + C::S0 + ul * C::SCR;
-        const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
-        auto seq_of = [&](int i) { return 2 * (xs + i * gx) + ul; };
-        AbwFrags f;
-        {
-            const int t0 = min(seq_of(0), a.Tseq - 1);
-            if (it == 0) abw_load<0>(f, a, t0, h, r, q, lane); else abw_load<1>(f, a, t0, h, r, q, lane);
-        }
-        for (int i = 0; i <= nsteps; ++i) {
-            if (i < nsteps) {
-                const int t = seq_of(i);
+        const DropKey kd = make_drop_key(br == 0 ? a.drop1 : a.drop2);
+        auto seq_of = [&](int s) { return 2 * (xs + s * gx) + ul; };
+        const int role = 2 * it + br;
+        auto mask_of = [&](int s) {      // raw mask value of key (lane & 31) of this wave's sequence in step s (clamped: unused past the end)
+            const int t = min(seq_of(s), a.Tseq - 1);
+            return a.mask ? a.mask[(int64_t)t * 32 + (lane & 31)] : 1.f;
+        };
+        float mnext = mask_of(0);
+        for (int i = 0; i <= nsteps + 1; ++i) {
+            const int s = i - 1;
+            if (s >= 0 && s < nsteps) {
+                const int t = seq_of(s);
                 const bool act = t < a.Tseq;
-                char* grow = smem + C::G0 + (i & 1) * C::GB + ul * (32 * 256);
-                AbwFrags n;
-                const int tn = min(seq_of(i + 1), a.Tseq - 1);      // next step's rows (clamped: an unused prefetch at the end)
-                if (it == 0) abw_attention<0>(f, n, tn, a, k1, k2, act, min(t, a.Tseq - 1), h, scr, grow, r, q, lane, bar);
-                else abw_attention<1>(f, n, tn, a, k1, k2, act, min(t, a.Tseq - 1), h, scr, grow, r, q, lane, bar);
-                f = n;
+                const int tc = min(t, a.Tseq - 1);
+                const char* gin = smem + in_tile(s) + ul * (32 * 256);
+                char* gout = smem + out_tile(s) + ul * (32 * 256);
+                const char* oin = smem + C::O0 + (s & 1) * C::OB + ul * (32 * 64);
+                const float mraw = mnext;
+                mnext = mask_of(s + 1);
+                if (role == 0) abw_attention<0, 1>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
+                else if (role == 1) abw_attention<0, 2>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
+                else if (role == 2) abw_attention<1, 1>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
+                else abw_attention<1, 2>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
             } else {
                 bar(0); bar(2); bar(4);
             }
         }
 #ifdef PMGT_ABW_PROF
-        if (blockIdx.x == 0 && wave == 0 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_abw_prof[0][k_] = pacc[k_]; g_abw_prof[0][7] = (unsigned long long)nsteps; }
+        if (blockIdx.x == 0 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_abw_prof[wave][k_] = pacc[k_]; g_abw_prof[wave][7] = (unsigned long long)nsteps; }
 #endif
         return;
     }
     // ==================================== GEMM role ====================================
-    const int g = wave - 4, gn = g & 1, gk = g >> 1;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int g = wave - 8, gn = g & 1, gk = g >> 1;                 // n tiles 4 gn .. 4 gn + 3, k tiles KQ gk .. KQ gk + KQ - 1
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef __attribute__((address_space(1))) const void gbl_void_t;
-    f32x4 acc[4][C::KH], accb[4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    f32x4 acc[4][C::KQ], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < C::KH; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+        for (int j = 0; j < C::KQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // per-lane pieces of the fragment addresses (row part and swizzle key of the "lo" rows; "hi" rows = + 4 rows)
     const int frow = 8 * q + (r >> 2), fkey = abw_f(frow), fsub = (r & 3) >> 1, fhalf = 8 * (r & 1);
     const int hoff = a.hm ? 4 * h * 32 : h * 32, ms = a.hm ? 32 : D;
-    // Schedule of iteration i (tile i - 1 = what the attention waves finished in the previous iteration):
-    //   I1: first 32 rows of tile i - 1 into the accumulators | I2: request the x rows of step i (LDS-DMA, they are consumed from
-    //   I1 of the next iteration on) and copy tile i - 1 to HBM | I3: the other 32 rows; wait for everything this wave has in flight
-    //   before the closing barrier, which publishes the x tile to the other GEMM waves.
-    auto kstep = [&](int ip, int ks) {
-        const uint32_t gb = lds0 + C::G0 + (ip & 1) * C::GB, xb = lds0 + (ip & 1) * C::XB;
-        // A fragments: dQKVC^T, n tiles 4 gn .. 4 gn + 3 (A[n][k = row]); B fragments: x, k tiles KH gk .. (B[k = row][n = x column])
-        bf16x8 fa[4], fb[2][4];
-        uint32_t ad[4];
+    // lane parts of the DMA source addresses (see the DMA block): x rows (lane / LPR = row inside the instruction, lane % LPR = LDS chunk
+    // slot) and Q|K|V|C rows (lane >> 4, lane & 15)
+    constexpr int LPRX = 64 / (1024 / C::XROW);
+    const uint32_t dx_chunk = (uint32_t)((lane % LPRX) ^ abw_f(lane / LPRX)), dx_row = (uint32_t)(lane / LPRX) * (uint32_t)w.ldx * 2u;
+    const uint32_t dq_chunk = (uint32_t)((lane & 15) ^ abw_f(lane >> 4)), dq_row = (uint32_t)(lane >> 4) * 4u * (uint32_t)D * 2u;
+    auto kstep = [&](int s, int ks) {
+        const uint32_t gb = lds0 + out_tile(s), xb = lds0 + (s & 1) * C::XB;
+        // A fragments: dQKVC^T, n tiles 4 gn .. 4 gn + 3 (A[n][k = row]); B fragments: x, this wave's k tiles (B[k = row][n = x column])
+        bf16x8 fa[4], fb[4];
+        uint32_t aa[4], ab[4];
+        int fr_ = frow, fk_ = fkey ^ fsub;        // (fsub is bit 0 of the chunk index, fkey has bit 0 clear)
+        asm volatile("" : "+v"(fr_), "+v"(fk_));    // opaque: the eight addresses below are recomputed here, not kept in VGPRs across the loop
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) ad[nt] = gb + (32 * ks + frow) * 256 + ((((2 * (4 * gn + nt) + fsub)) ^ fkey) << 4) + fhalf;
-        abw_read4(ad[0], ad[1], ad[2], ad[3], 4 * 256, fa);
-        auto read_b = [&](int k4, bf16x8 (&dst)[4]) {
-            uint32_t bd[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bd[u] = xb + (32 * ks + frow) * C::XROW + ((((2 * (C::KH * gk + k4 + u) + fsub)) ^ fkey) << 4) + fhalf;
-            abw_read4(bd[0], bd[1], bd[2], bd[3], 4 * C::XROW, dst);
-        };
-        read_b(0, fb[0]);
-#pragma unroll
-        for (int k4 = 0; k4 < C::KH; k4 += 4) {
-            const int cur = (k4 >> 2) & 1;
-            if (k4 + 4 < C::KH) read_b(k4 + 4, fb[cur ^ 1]);      // the next four B fragments travel under this group's 16 MFMAs
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[nt][k4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[cur][u], acc[nt][k4 + u], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            aa[u] = gb + (32 * ks + fr_) * 256 + (((2 * (4 * gn + u)) ^ fk_) << 4) + fhalf;
+            ab[u] = xb + (32 * ks + fr_) * C::XROW + (((2 * (C::KQ * gk + (u % C::KQ))) ^ fk_) << 4) + fhalf;
         }
-        if (gk == 0) {      // (wave-uniform) bias gradient = column sums of the tile: one more product against all-ones
+        abw_read_frags<4 * 256>(aa, fa);
+        abw_read_frags<4 * C::XROW>(ab, fb);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], ones, accb[nt], 0, 0, 0);
-        }
+        for (int u = 0; u < C::KQ; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
+        // bias gradient = column sums of the tile: one more product against all-ones; this wave sums n tile 4 gn + (gk & 3)
+        const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+        const bf16x8 fsel = (gk & 3) == 0 ? fa[0] : ((gk & 3) == 1 ? fa[1] : ((gk & 3) == 2 ? fa[2] : fa[3]));
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fsel, ones, accb, 0, 0, 0);
     };
-    for (int i = 0; i <= nsteps; ++i) {
-        if (i >= 1) kstep(i - 1, 0);
+    for (int i = 0; i <= nsteps + 1; ++i) {
+        const int sg = i - 2;                     // the step whose results are consumed in this iteration
+        if (sg >= 0) kstep(sg, 0);
         bar(0);
 #ifndef PMGT_ABW_NO_DMA
-        if (i < nsteps) {      // the x rows of step i -> LDS (wave g moves rows 16 g .. 16 g + 15, two rows per 1 KB instruction at d = 256)
-            const int m0 = 64 * (xs + i * gx);
-            char* xb = smem + (i & 1) * C::XB;
-            constexpr int RPI = 1024 / C::XROW;          // rows per DMA instruction: 2 (d = 256) or 4 (d = 128)
-            constexpr int LPR = 64 / RPI;                // lanes per row
+        {
+            // LDS-DMA of this iteration: 52 (d = 256) one-KB instructions, fixed shares per GEMM wave, straight-line code:
+            //   x rows of step i - 1 (RPI rows per instruction; x is only needed when that step's results are consumed, one iteration
+            //   from now, so it travels one iteration behind the attention inputs and two x tiles suffice): wave g takes rows 8 g ..;
+            //   Q|K|V|C rows of the head for step i, 4 rows per instruction: wave g takes rows 8 g .. 8 g + 7;
+            //   dO rows of step i, 16 per instruction: waves 0 - 3.
+            // Per-lane address = two loop-invariant registers XOR / plus wave-uniform terms (the swizzle key of a row splits into a
+            // lane part and a row-block part): ~4 VALU instructions per DMA instead of ~12 -- the vector ALU belongs to the attention waves.
+            const int m0 = 64 * (xs + i * gx), m0x = m0 - 64 * gx;
+            constexpr int RPI = 1024 / C::XROW, LPR = 64 / RPI;
+            if (i >= 1 && i - 1 < nsteps) {
+                char* xb = smem + ((i - 1) & 1) * C::XB;
 #pragma unroll
-            for (int j = 0; j < 16 / RPI; ++j) {
-                const int row0 = 16 * g + RPI * j;
-                const int row = row0 + lane / LPR;
-                const int m = min(m0 + row, M - 1);
-                const char* src = (const char*)w.x + ((int64_t)m * w.ldx) * 2 + (((lane % LPR) ^ abw_f(row)) << 4);
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xb + row0 * C::XROW), 16, 0, 0);
+                for (int j = 0; j < 8 / RPI; ++j) {
+                    const int row0 = 8 * g + RPI * j;                            // (uniform) rows row0 .. row0 + RPI - 1, lane -> row0 + lane / LPR
+                    const int mrow = min(m0x + row0, M - RPI);                    // (uniform) whole instruction clamped into the tensor
+                    // abw_f(row0 + lane / LPR) = abw_f(row0) ^ abw_f(lane / LPR): row0 is a multiple of RPI, lane / LPR < RPI <= 4 (bits 0, 1)
+                    const uint32_t off = (uint32_t)mrow * (uint32_t)w.ldx * 2u + dx_row + ((dx_chunk ^ (uint32_t)abw_f(row0)) << 4);
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)w.x + (size_t)off), (lds_void_t*)(xb + row0 * C::XROW), 16, 0, 0);
+                }
+            }
+            if (i < nsteps) {
+                char* gt = smem + in_tile(i);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row0 = 8 * g + 4 * j;
+                    const int mrow = min(m0 + row0, M - 4);
+                    const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);          // source chunk of the head's 256 bytes
+                    const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
+                    const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
+                }
+                if (g < 4) {
+                    const int row0 = 16 * g, row = row0 + (lane >> 2), c = (lane & 3) ^ abw_kt(row);
+                    const uint32_t m = (uint32_t)min(m0 + row, M - 1);
+                    const char* src = (const char*)a.dctx + (size_t)((m * (uint32_t)D + (uint32_t)(h * 32 + c * 8)) * 2u);
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + C::O0 + (i & 1) * C::OB + row0 * 64), 16, 0, 0);
+                }
             }
         }
 #endif
 #ifndef PMGT_ABW_NO_COPY
-        if (i >= 1) {          // copy the finished dQ|dK|dV|dC tile to HBM: 64 rows x 16 chunks of 16 bytes, 4 per lane
-            const int ip = i - 1;
-            const uint32_t gb = lds0 + C::G0 + (ip & 1) * C::GB;
-            u32x4 v[4];
-            uint32_t ad[4];
+        if (sg >= 0) {          // copy the finished dQ|dK|dV|dC tile to HBM: 64 rows x 16 chunks of 16 bytes, 2 per lane
+            const uint32_t gb = lds0 + out_tile(sg);
+            u32x4 v[2];
+            uint32_t ad[2];
+            int lc = lane;
+            asm volatile("" : "+v"(lc));
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int idx = 64 * (4 * p + g) + lane, row = idx >> 4, c = idx & 15;
+            for (int p = 0; p < 2; ++p) {
+                const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
                 ad[p] = gb + row * 256 + ((c ^ abw_f(row)) << 4);
             }
-            abw_read128x4(ad[0], ad[1], ad[2], ad[3], v);
+            abw_read128x2(ad[0], ad[1], v);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int idx = 64 * (4 * p + g) + lane, row = idx >> 4, c = idx & 15;
-                const int m = 64 * (xs + ip * gx) + row;
-                if (m < M) *(u32x4*)((bf16*)a.dqkvc + (int64_t)m * 4 * D + hoff + (c >> 2) * ms + (c & 3) * 8) = v[p];
+            for (int p = 0; p < 2; ++p) {
+                const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
+                const int m = 64 * (xs + sg * gx) + row;
+                if (m < M) *(u32x4*)((char*)a.dqkvc + (size_t)(((uint32_t)m * 4u * D + (uint32_t)(hoff + (c >> 2) * ms + (c & 3) * 8)) * 2u)) = v[p];
             }
         }
 #endif
         bar(2);
-        if (i >= 1) kstep(i - 1, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the x tile has landed (and its stores have left)
+        if (sg >= 0) kstep(sg, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMAs have landed (and its stores have left)
         bar(4);
     }
 #ifdef PMGT_ABW_PROF
-    if (blockIdx.x == 0 && wave == 4 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_abw_prof[1][k_] = pacc[k_]; g_abw_prof[1][7] = (unsigned long long)nsteps; }
+    if (blockIdx.x == 0 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_abw_prof[wave][k_] = pacc[k_]; g_abw_prof[wave][7] = (unsigned long long)nsteps; }
 #endif
     // ---- the workgroup's partial of dW_head (and db_head): rows of W_qkvc = matrix * d + head * 32 + w
     float* slab = w.slab + (int64_t)xs * 4 * D * D;
@@ -1701,13 +1725,15 @@ __global__ __launch_bounds__(512) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         const int n = 4 * gn + nt;                              // 16-row block of the head's 128 rows: matrix n >> 1, half n & 1
         const int wrow = (n >> 1) * D + h * 32 + 16 * (n & 1) + 4 * q;
 #pragma unroll
-        for (int j = 0; j < C::KH; ++j)
+        for (int j = 0; j < C::KQ; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) slab[(int64_t)(wrow + e) * D + 16 * (C::KH * gk + j) + r] = acc[nt][j][e];
-        if (gk == 0 && r == 0 && w.bias_slab) {
+            for (int e = 0; e < 4; ++e) slab[(int64_t)(wrow + e) * D + 16 * (C::KQ * gk + j) + r] = acc[nt][j][e];
+    }
+    if (r == 0 && w.bias_slab) {
+        const int n = 4 * gn + (gk & 3);
+        const int wrow = (n >> 1) * D + h * 32 + 16 * (n & 1) + 4 * q;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w.bias_slab[(int64_t)xs * 4 * D + wrow + e] = accb[nt][e];
-        }
+        for (int e = 0; e < 4; ++e) w.bias_slab[(int64_t)xs * 4 * D + wrow + e] = accb[e];
     }
 }
 
@@ -1716,6 +1742,7 @@ int attn_bwd_wgrad_parts(int H) { return std::max(8, (256 / std::max(H, 1)) / 8 
 bool attn_bwd_wgrad_supported(const AttnBwdWg& w) {
     const AttnArgs& a = w.a;
     const int d = a.H * 32;
+    if ((int64_t)a.Tseq * 32 * 4 * d * 2 >= (int64_t)1 << 32) return false;      // 32-bit byte offsets inside Q|K|V|C (the saddr addressing form)
     return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.Tseq >= 2 && a.cls_only_seqs == 0 && w.x != nullptr && w.ldx % 8 == 0 &&
            w.slab != nullptr && a.qkvc != nullptr && a.dctx != nullptr && a.dqkvc != nullptr && ((uintptr_t)w.x % 16) == 0 &&
            ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.dctx % 16) == 0 && ((uintptr_t)a.dqkvc % 16) == 0;
@@ -1730,7 +1757,7 @@ template <int KT> static int launch_abw(const AttnBwdWg& w, hipStream_t st) {
         attr_done = true;
     }
     const int gx = attn_bwd_wgrad_parts(w.a.H);
-    hipLaunchKernelGGL(kern, dim3(gx * w.a.H), dim3(512), C::SMEM, st, w);
+    hipLaunchKernelGGL(kern, dim3(gx * w.a.H), dim3(1024), C::SMEM, st, w);
     PMGT_LAUNCH_OK();
     return 0;
 }

@@ -454,7 +454,7 @@ static int g_no_hm = 0;
 static int g_no_table_proj = 0;
 static int g_no_segsum = 0;
 static int g_no_producer_quant = 0;
-static int g_no_fused_abw = 1;      // first form (8 waves: 4 attention + 4 GEMM) is correct but slower than the two kernels: opt-in until the 16-wave form lands
+static int g_no_fused_abw = 0;
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
@@ -1086,6 +1086,10 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
     build_layout(e);
     e->zeros = zero_page();
+    {
+        const char* fa = getenv("PMGT_FUSED_ABW");        // A/B: 1 = attention backward fused with the Q|K|V|C weight gradient
+        if (fa) g_no_fused_abw = atoi(fa) == 1 ? 0 : 1;
+    }
     {
         const char* ev = getenv("PMGT_OVERLAP");
         e->overlap = ev && atoi(ev) == 1;

@@ -30,10 +30,11 @@ for _ in range(5):
 ev[1].record(); torch.cuda.synchronize()
 print("us per launch", ev[0].elapsed_time(ev[1]) / 15 * 1e3)
 if hasattr(L, "pmgt_debug_abw_prof_read"):
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 128)()
     L.pmgt_debug_abw_prof_read(out)
-    a = np.array(list(out), dtype=np.float64).reshape(2, 8)
-    for role, name in enumerate(("attention wave 0", "GEMM wave 4")):
+    a = np.array(list(out), dtype=np.float64).reshape(16, 8)
+    names = [f"attention wave {w} (pair {w >> 2}, tile {(w >> 1) & 1}, {'cosine' if w % 2 == 0 else 'dot'})" for w in range(8)] + [f"GEMM wave {w}" for w in range(8, 16)]
+    for role, name in enumerate(names):
         n = max(a[role, 7], 1)
         print(name, "steps", int(n), "cycles/step:", " ".join(f"{lbl}={a[role, k] / n:.0f}" for k, lbl in enumerate(("w1", "b1", "w2", "b2", "w3", "b0"))),
               "total", f"{a[role, :6].sum() / n:.0f}")
