@@ -254,6 +254,9 @@ void pmgt_debug_disable_head_major(int on);
 /* A/B switch (fp8 mode): 1 = layer inputs are quantised by their consumer (inside the fused projection + attention kernel)
  * instead of by the kernel that produces them (fused-LayerNorm epilogue of the FFN2 GEMM, embed_mix); bit-identical results */
 void pmgt_debug_disable_producer_quant(int on);
+/* A/B switch: 1 sums every set of partial sums of the backward pass (weight-gradient slabs, bias and LayerNorm partials) with a
+ * launch of its own right after its producer, instead of one batched launch per gradient bucket */
+void pmgt_debug_disable_deferred_reductions(int on);
 /* A/B switch: 1 keeps the attention backward and the Q|K|V|C weight gradient as two kernels */
 void pmgt_debug_disable_fused_attention_backward(int on);
 /* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */

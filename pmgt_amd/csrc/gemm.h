@@ -69,6 +69,9 @@ template <typename T> int gemm_tn_bkm();
 
 // dst[i] (+)= sum_s slab[s*n + i]   (n % 4 == 0; the slab is used as scratch and clobbered)
 int slab_reduce(const float* slab, int splits, int64_t n, float* dst, bool accumulate, hipStream_t st);
+// the same for several (slab, destination) pairs in one launch (two when a job has more than 128 slabs); see gemm.hip
+struct ReduceJob { const float* src; float* dst; int64_t n; int rows; bool acc; };
+int multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t st);
 
 // Column sums of Y[M,N] (bias gradients): dst[n] (+)= sum_m Y[m,n]; needs slab of colsum_slab_elems(M, N) floats.
 template <typename T>

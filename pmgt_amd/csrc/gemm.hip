@@ -1590,6 +1590,82 @@ int slab_reduce(const float* slab_c, int splits, int64_t n, float* dst, bool acc
     return 0;
 }
 
+// Several slab reductions in one launch (two when a job has more than 128 slabs): the backward pass produces ~10 sets of partial
+// sums per layer (weight-gradient slabs, bias slabs, LayerNorm partials), and a launch per set costs more in launch latency and
+// serialisation than in bytes -- 40 launches per step took 0.43 ms at every batch size.  Same arithmetic per element as
+// slab_reduce (fixed order: bit-reproducible), jobs packed into the grid through cumulative block counts.
+struct MultiReduceArgs {
+    struct J { float* src; float* dst; int64_t n, row_step; int nrows, group, final, acc, cb; } j[8];
+    int blk0[9];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void multi_reduce_kernel(MultiReduceArgs a) {
+    __shared__ f32x4 red[256];
+    int k = 0;
+    while (k + 1 < a.njobs && (int)blockIdx.x >= a.blk0[k + 1]) ++k;       // (uniform)
+    const MultiReduceArgs::J& jb = a.j[k];
+    const int lb = blockIdx.x - a.blk0[k];
+    const int cbk = lb % jb.cb, grp = lb / jb.cb;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i4 = ((int64_t)cbk * 64 + c) * 4;
+    const int r0 = grp * jb.group, r1 = min(jb.nrows, r0 + jb.group);
+    const int64_t rs = jb.n;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (i4 < jb.n) {
+        int r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            s0 += *(const f32x4*)(jb.src + (int64_t)r * jb.row_step * rs + i4);
+            s1 += *(const f32x4*)(jb.src + (int64_t)(r + 4) * jb.row_step * rs + i4);
+        }
+        if (r < r1) s0 += *(const f32x4*)(jb.src + (int64_t)r * jb.row_step * rs + i4);
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && i4 < jb.n) {
+        f32x4 t = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+        if (jb.final) {
+            if (jb.acc) t += *(const f32x4*)(jb.dst + i4);
+            *(f32x4*)(jb.dst + i4) = t;
+        } else {
+            *(f32x4*)(jb.src + (int64_t)r0 * jb.row_step * rs + i4) = t;
+        }
+    }
+}
+
+int multi_reduce(const ReduceJob* jobs, int njobs, hipStream_t st) {
+    constexpr int G = 128;
+    for (int base = 0; base < njobs; base += 8) {
+        const int nj = std::min(8, njobs - base);
+        for (int level = 0; level < 2; ++level) {
+            MultiReduceArgs a;
+            int cnt = 0, blocks = 0;
+            for (int q = 0; q < nj; ++q) {
+                const ReduceJob& rj = jobs[base + q];
+                if (rj.n <= 0 || rj.rows <= 0) continue;
+                PMGT_CHECK(rj.n % 4 == 0 && ((uintptr_t)rj.src % 16) == 0 && ((uintptr_t)rj.dst % 16) == 0, -2, "multi_reduce: unaligned job");
+                const bool two = rj.rows > G;
+                if (level == 0 && !two) continue;
+                MultiReduceArgs::J& d = a.j[cnt];
+                d.src = const_cast<float*>(rj.src); d.dst = rj.dst; d.n = rj.n;
+                d.cb = (int)cdiv64(rj.n / 4, 64);
+                if (level == 0) { d.nrows = rj.rows; d.group = G; d.row_step = 1; d.final = 0; d.acc = 0; }
+                else {
+                    d.nrows = two ? cdiv(rj.rows, G) : rj.rows; d.group = d.nrows; d.row_step = two ? G : 1; d.final = 1; d.acc = rj.acc ? 1 : 0;
+                }
+                a.blk0[cnt] = blocks;
+                blocks += d.cb * (level == 0 ? cdiv(rj.rows, G) : 1);
+                ++cnt;
+            }
+            if (cnt == 0) continue;
+            a.blk0[cnt] = blocks;
+            a.njobs = cnt;
+            hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+            PMGT_LAUNCH_OK();
+        }
+    }
+    return 0;
+}
+
 // Column sums: a block owns 256 rows x (CC chunk-columns of 16 bytes); thread = (chunk, row lane).
 template <typename T, int CC>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, int64_t ldy, int M, int N,
