@@ -72,6 +72,9 @@ def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
         # fused projection + attention: reads x (1U), writes Q|K|V|C (4U, kept for the backward) and ctx (1U)
         "fwd.qkvc_attention": (g(M, 4 * d, d) + 6.0 * M * S * d, M * 6 * d * esz),
         "bwd.attention": (16.0 * M * S * d, M * 9 * d * esz),
+        # attention backward fused with the Q|K|V|C weight gradient: reads Q|K|V|C (4U), dctx (1U), x (1U), writes dQ|dK|dV|dC (4U);
+        # it runs on L - 1 layers (the last one takes the CLS-only shortcut through the two separate kernels): M of ONE launch
+        "bwd.attention_wgrad": (16.0 * M * S * d + g(M, 4 * d, d), M * 10 * d * esz),
         "bwd.dgrad_ffn2": (g(M, I, d), M * (d + 2 * I) * esz),
         "bwd.dgrad_ffn1": (g(M, d, I), M * (I + 2 * d) * esz),
         "bwd.dgrad_attn_out": (g(M, d, d), M * 2 * d * esz),

@@ -201,7 +201,11 @@ struct WorkerPool {
 struct pmgt_sampler {
     int64_t n_nodes = 0;
     std::vector<int64_t> indptr, indices;
-    std::vector<double> cdf;          // per-edge: normalised cumulative softmax of the row
+    std::vector<double> cdf;          // per-edge: normalised cumulative softmax of the row (build-time only: moved into `edge`)
+    // One 16-byte record per edge -- {cdf, guide, neighbour} -- so that a draw touches ONE run of the row instead of three arrays
+    // (the hop-3 sources are 128 random rows per context: the sampler is bound by their cache misses, not by arithmetic)
+    struct Edge { double cdf; int32_t guide; int32_t nbr; };
+    std::vector<Edge> edge;
     // guide[b + k] = first index i of the row with cdf[i] > k / deg: the exact searchsorted(cdf, u, 'right') of a draw
     // u in [k / deg, (k + 1) / deg) is found by scanning forward from there (1-2 compares instead of a binary search)
     std::vector<int32_t> guide;
@@ -244,11 +248,17 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
     for (int k = 1; k <= depth; ++k) {
         const int size = s->hops[k - 1];
         sc.nxt.clear();
-        for (int64_t node : sc.cur) {
+        const size_t ncur = sc.cur.size();
+        for (size_t ci = 0; ci < ncur; ++ci) {
+            const int64_t node = sc.cur[ci];
+            if (ci + 2 < ncur) {      // the rows of the next sources are known: start their cache misses now
+                const int64_t nb = s->indptr[sc.cur[ci + 2]];
+                __builtin_prefetch(&s->edge[nb]);
+                __builtin_prefetch(&s->edge[nb] + 4);
+            }
             const int64_t b = s->indptr[node], dg = s->indptr[node + 1] - b;
             if (dg <= 0) { set_err("node %lld has no neighbours (the reference raises here)", (long long)node); return -3; }
-            const double* cdf = s->cdf.data() + b;
-            const int32_t* guide = s->guide.data() + b;
+            const pmgt_sampler::Edge* row = s->edge.data() + b;
             const double dgd = (double)dg;
             for (int r = 0; r < size; ++r) {
                 const double u = sc.rng.next_double();
@@ -256,9 +266,9 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
                 int64_t k = (int64_t)(u * dgd);
                 if (k >= dg) k = dg - 1;
                 if ((double)k / dgd > u) --k;                  // u * dg may round up across a bucket edge
-                int64_t idx = guide[k];
-                while (idx < dg && cdf[idx] <= u) ++idx;
-                sc.nxt.push_back(s->indices[b + (idx < dg ? idx : dg - 1)]);
+                int64_t idx = row[k].guide;
+                while (idx < dg && row[idx].cdf <= u) ++idx;
+                sc.nxt.push_back(row[idx < dg ? idx : dg - 1].nbr);
             }
         }
         // Counter(sampled[k]) in first-appearance order
@@ -289,9 +299,11 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
     sc.order.resize(sc.scores.size());
     for (size_t i = 0; i < sc.scores.size(); ++i) sc.order[i] = (int32_t)i;
     const auto& scv = sc.scores;
-    std::partial_sort(sc.order.begin(), sc.order.begin() + num, sc.order.end(), [&scv](int32_t a, int32_t b) {
-        return scv[a].second > scv[b].second || (scv[a].second == scv[b].second && a < b);
-    });
+    // (strict total order: the first `num` of the full sort are the `num` smallest under it, in any selection algorithm --
+    // nth_element + a sort of the prefix is linear in the candidates instead of n log k)
+    auto before = [&scv](int32_t a, int32_t b) { return scv[a].second > scv[b].second || (scv[a].second == scv[b].second && a < b); };
+    if ((size_t)num < sc.order.size()) std::nth_element(sc.order.begin(), sc.order.begin() + num, sc.order.end(), before);
+    std::sort(sc.order.begin(), sc.order.begin() + num, before);
     ids[0] = target;
     for (int i = 0; i < s->max_ctx; ++i) ids[1 + i] = i < num ? sc.scores[sc.order[i]].first : 0;
     for (int i = 0; i < S; ++i) mask[i] = i <= num ? 1.f : 0.f;
@@ -398,6 +410,10 @@ pmgt_sampler* pmgt_sampler_create(int64_t n_nodes, const int64_t* indptr, const 
             s->guide[b + k] = (int32_t)(std::upper_bound(s->cdf.data() + b, s->cdf.data() + b + dg, (double)k / (double)dg) - (s->cdf.data() + b));
         std::sort(s->sorted_idx.begin() + b, s->sorted_idx.begin() + b + dg);
     }
+    s->edge.resize(nnz);
+    for (int64_t i = 0; i < nnz; ++i) s->edge[i] = pmgt_sampler::Edge{s->cdf[i], s->guide[i], (int32_t)s->indices[i]};
+    std::vector<double>().swap(s->cdf);
+    std::vector<int32_t>().swap(s->guide);
     s->main.rng.seed(0);
     return s;
 }

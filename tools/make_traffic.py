@@ -14,6 +14,7 @@ import sys
 PHASE_KERNELS = {           # bench.py phase name -> substring of the kernel that dominates it
     "fwd.qkvc_attention": "qkvc_attn_fwd",
     "bwd.attention": "attn_bwd_mfma_kernel",
+    "bwd.attention_wgrad": "attn_bwd_wgrad_kernel",
     "bwd.dgrad_qkvc": "gemm_nt_big_kernel",
     "bwd.wgrad_qkvc": "gemm_tn_big_kernel",
     "bwd.layernorm": "ln_bwd_kernel",
