@@ -129,15 +129,16 @@ double pairwise_sum(const double* a, int64_t n) {
 
 struct Scratch {     // per-thread sampling state
     MT19937 rng;
-    std::vector<int32_t> cnt, cnt_ver, sc_idx, sc_ver;   // dense per-node stamps
+    struct Stamp { int32_t cnt, cnt_ver, sc_idx, sc_ver; };      // one 16-byte record per node: a visit touches one cache line
+    std::vector<Stamp> st;                                          // dense per-node stamps
     int32_t ver = 0;
     std::vector<int64_t> cur, nxt, hop_order;
     std::vector<std::pair<int64_t, int64_t>> scores;      // (node, score) in first-scored order
     std::vector<int64_t> perm;
-    std::vector<int32_t> order;
+    std::vector<int32_t> order, hist;
     void ensure(int64_t n) {
-        if ((int64_t)cnt.size() < n) {
-            cnt.assign(n, 0); cnt_ver.assign(n, 0); sc_idx.assign(n, 0); sc_ver.assign(n, 0);
+        if ((int64_t)st.size() < n) {
+            st.assign(n, Stamp{0, 0, 0, 0});
             ver = 0;
         }
     }
@@ -243,12 +244,13 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
     sc.ensure(s->n_nodes + 2);
     sc.scores.clear();
     sc.cur.assign(1, target);
-    if (++sc.ver == INT32_MAX) { std::fill(sc.sc_ver.begin(), sc.sc_ver.end(), 0); std::fill(sc.cnt_ver.begin(), sc.cnt_ver.end(), 0); sc.ver = 1; }
+    if (++sc.ver == INT32_MAX) { for (auto& e : sc.st) { e.sc_ver = 0; e.cnt_ver = 0; } sc.ver = 1; }
     const int32_t score_ver = sc.ver;
     for (int k = 1; k <= depth; ++k) {
         const int size = s->hops[k - 1];
-        sc.nxt.clear();
         const size_t ncur = sc.cur.size();
+        sc.nxt.resize(ncur * (size_t)size);
+        int64_t* wr = sc.nxt.data();
         for (size_t ci = 0; ci < ncur; ++ci) {
             const int64_t node = sc.cur[ci];
             if (ci + 2 < ncur) {      // the rows of the next sources are known: start their cache misses now
@@ -260,15 +262,26 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
             if (dg <= 0) { set_err("node %lld has no neighbours (the reference raises here)", (long long)node); return -3; }
             const pmgt_sampler::Edge* row = s->edge.data() + b;
             const double dgd = (double)dg;
-            for (int r = 0; r < size; ++r) {
-                const double u = sc.rng.next_double();
-                // searchsorted(cdf, u, side='right') = first index with cdf[i] > u
-                int64_t k = (int64_t)(u * dgd);
-                if (k >= dg) k = dg - 1;
-                if ((double)k / dgd > u) --k;                  // u * dg may round up across a bucket edge
-                int64_t idx = row[k].guide;
-                while (idx < dg && row[idx].cdf <= u) ++idx;
-                sc.nxt.push_back(row[idx < dg ? idx : dg - 1].nbr);
+            // the draws of one source row: uniforms first (the generator's block refill stays out of the search loop), then the
+            // searches write straight into the output array (sized once per hop)
+            double us[64];
+            const int nd = size < 64 ? size : 64;
+            for (int r0 = 0; r0 < size; r0 += nd) {
+                const int nb_ = size - r0 < nd ? size - r0 : nd;
+                for (int r = 0; r < nb_; ++r) us[r] = sc.rng.next_double();
+                for (int r = 0; r < nb_; ++r) {
+                    const double u = us[r];
+                    // searchsorted(cdf, u, side='right') = first index with cdf[i] > u.  cdf[dg - 1] is exactly 1 > u, so the scan
+                    // needs no bound; its first steps are arithmetic, not branches (their count is random: every one mispredicted)
+                    int64_t k = (int64_t)(u * dgd);
+                    k = k < dg ? k : dg - 1;
+                    int64_t idx = row[k].guide;
+                    idx += row[idx].cdf <= u;
+                    idx += row[idx].cdf <= u;
+                    idx += row[idx].cdf <= u;
+                    while (row[idx].cdf <= u) ++idx;
+                    *wr++ = row[idx].nbr;
+                }
             }
         }
         // Counter(sampled[k]) in first-appearance order
@@ -276,18 +289,20 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
         const int32_t cv = sc.ver;
         sc.hop_order.clear();
         for (int64_t v : sc.nxt) {
-            if (sc.cnt_ver[v] != cv) { sc.cnt_ver[v] = cv; sc.cnt[v] = 0; sc.hop_order.push_back(v); }
-            ++sc.cnt[v];
+            Scratch::Stamp& e = sc.st[v];
+            if (e.cnt_ver != cv) { e.cnt_ver = cv; e.cnt = 0; sc.hop_order.push_back(v); }
+            ++e.cnt;
         }
         const int64_t w = depth - k + 1;
         for (int64_t v : sc.hop_order) {
             if (v == target) continue;
-            if (sc.sc_ver[v] != score_ver) {
-                sc.sc_ver[v] = score_ver;
-                sc.sc_idx[v] = (int32_t)sc.scores.size();
+            Scratch::Stamp& e = sc.st[v];
+            if (e.sc_ver != score_ver) {
+                e.sc_ver = score_ver;
+                e.sc_idx = (int32_t)sc.scores.size();
                 sc.scores.emplace_back(v, 0);
             }
-            sc.scores[sc.sc_idx[v]].second += (int64_t)sc.cnt[v] * w;
+            sc.scores[e.sc_idx].second += (int64_t)e.cnt * w;
         }
         sc.cur.swap(sc.nxt);
     }
@@ -296,14 +311,31 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
     // Only the first max_ctx entries are read, so select them with the strict order (score desc, position asc) instead of
     // sorting everything (same result, n log k instead of n log n).
     const int num = (int)std::min<int64_t>((int64_t)sc.scores.size(), s->max_ctx);
-    sc.order.resize(sc.scores.size());
-    for (size_t i = 0; i < sc.scores.size(); ++i) sc.order[i] = (int32_t)i;
-    const auto& scv = sc.scores;
-    // (strict total order: the first `num` of the full sort are the `num` smallest under it, in any selection algorithm --
-    // nth_element + a sort of the prefix is linear in the candidates instead of n log k)
-    auto before = [&scv](int32_t a, int32_t b) { return scv[a].second > scv[b].second || (scv[a].second == scv[b].second && a < b); };
-    if ((size_t)num < sc.order.size()) std::nth_element(sc.order.begin(), sc.order.begin() + num, sc.order.end(), before);
-    std::sort(sc.order.begin(), sc.order.begin() + num, before);
+    // Scores are small integers (frequency x hop weight, at most sum_k hops-product x weight), so the strict order
+    // (score descending, first-scored position ascending) is a counting sort: histogram, threshold score, then one pass that
+    // drops every candidate into its bucket in position order -- linear in the candidates, no comparisons.
+    int64_t smax = 0;
+    for (const auto& pr : sc.scores) smax = pr.second > smax ? pr.second : smax;
+    sc.hist.assign((size_t)smax + 2, 0);
+    for (const auto& pr : sc.scores) ++sc.hist[(size_t)pr.second];
+    // first output slot of each score value, highest score first; `thr` = the lowest score that still gets slots
+    int64_t thr = smax;
+    {
+        int32_t run = 0;
+        for (int64_t v = smax; v >= 0; --v) {
+            const int32_t c = sc.hist[(size_t)v];
+            sc.hist[(size_t)v] = run;
+            if (run < num) thr = v;
+            run += c;
+        }
+    }
+    sc.order.resize((size_t)num);
+    for (size_t i = 0; i < sc.scores.size(); ++i) {
+        const int64_t v = sc.scores[i].second;
+        if (v < thr) continue;
+        const int32_t slot = sc.hist[(size_t)v]++;
+        if (slot < num) sc.order[(size_t)slot] = (int32_t)i;
+    }
     ids[0] = target;
     for (int i = 0; i < s->max_ctx; ++i) ids[1 + i] = i < num ? sc.scores[sc.order[i]].first : 0;
     for (int i = 0; i < S; ++i) mask[i] = i <= num ? 1.f : 0.f;
@@ -411,7 +443,14 @@ pmgt_sampler* pmgt_sampler_create(int64_t n_nodes, const int64_t* indptr, const 
         std::sort(s->sorted_idx.begin() + b, s->sorted_idx.begin() + b + dg);
     }
     s->edge.resize(nnz);
-    for (int64_t i = 0; i < nnz; ++i) s->edge[i] = pmgt_sampler::Edge{s->cdf[i], s->guide[i], (int32_t)s->indices[i]};
+    // guide SHIFTED by one bucket: a draw u computes k = floor(u * deg) in floating point, which may come out one too large when
+    // u * deg rounds up across a bucket edge; starting the forward scan at the guide of bucket k - 1 is right for both cases
+    // (the answer of bucket k is never before it) and saves the exact k / deg > u check -- a division per draw
+    for (int64_t v = 0; v < n_nodes + 2; ++v) {
+        const int64_t b = indptr[v], dg = indptr[v + 1] - b;
+        for (int64_t k = 0; k < dg; ++k)
+            s->edge[b + k] = pmgt_sampler::Edge{s->cdf[b + k], s->guide[b + (k > 0 ? k - 1 : 0)], (int32_t)s->indices[b + k]};
+    }
     std::vector<double>().swap(s->cdf);
     std::vector<int32_t>().swap(s->guide);
     s->main.rng.seed(0);
