@@ -136,10 +136,13 @@ class Trainer:
 
         pipe = ProducerPipeline(produce, steps, depth, stall_timeout_s=stall_timeout_s)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t_start = time.perf_counter()
+        t0 = None
         pipe.start()
         try:
             for slot, (b, ev) in pipe:
+                if t0 is None:
+                    t0 = time.perf_counter()       # sustained rate: the clock starts when the first batch is there (the fill is reported)
                 torch.cuda.current_stream().wait_event(ev)
                 self.train_step(b)
                 for v in list(b[0].values()) + list(b[1].values()) + [b[2], b[3]]:
@@ -152,6 +155,7 @@ class Trainer:
             pipe.close()
         el = time.perf_counter() - t0
         return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+                "pipeline_fill_ms": round((t0 - t_start) * 1e3, 3),
                 "sampler_threads": threads, "steps": steps, "pipeline_depth": depth,
                 "sampler_ms_per_batch": round(t_sample[0] / steps * 1e3, 3),
                 "launch_thread_idle_ms_per_step": round(pipe.starved_s / steps * 1e3, 3)}
