@@ -989,20 +989,27 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     carve<T>(e, c, b, Tseq, S, B, train);
     PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
     const int64_t bs = (int64_t)B * S, ps = (int64_t)Pn * S;
-    PMGT_HIP(hipMemcpyAsync(b.ids, bt->tgt_ids, bs * 8, hipMemcpyDeviceToDevice, st));
-    PMGT_HIP(hipMemcpyAsync(b.mask, bt->tgt_mask, bs * 4, hipMemcpyDeviceToDevice, st));
-    PMGT_HIP(hipMemcpyAsync(b.ids + bs, bt->pair_ids, ps * 8, hipMemcpyDeviceToDevice, st));
-    PMGT_HIP(hipMemcpyAsync(b.mask + bs, bt->pair_mask, ps * 4, hipMemcpyDeviceToDevice, st));
+    {   // the collated batch -> the step's [Tseq, S] id / mask arrays, one launch
+        CopyJob cj[8];
+        int nc = 0;
+        cj[nc++] = CopyJob{bt->tgt_ids, b.ids, bs * 8};
+        cj[nc++] = CopyJob{bt->tgt_mask, b.mask, bs * 4};
+        cj[nc++] = CopyJob{bt->pair_ids, b.ids + bs, ps * 8};
+        cj[nc++] = CopyJob{bt->pair_mask, b.mask + bs, ps * 4};
+        if (train) {
+            cj[nc++] = CopyJob{bt->tgt_mask, b.mask + bs + ps, bs * 4};                      // models.py:153-156: the masked copy keeps the mask
+            if (bt->nfr_masked_ids) {
+                PMGT_CHECK(bt->nfr_targets, -2, "nfr_targets must accompany nfr_masked_ids");
+                cj[nc++] = CopyJob{bt->nfr_masked_ids, b.ids + bs + ps, bs * 8};
+                cj[nc++] = CopyJob{bt->nfr_targets, b.nfr_tgt, bs * 8};
+            }
+        }
+        RUN(multi_copy(cj, nc, st));
+    }
     if (train) {
-        if (bt->nfr_masked_ids) {
-            PMGT_CHECK(bt->nfr_targets, -2, "nfr_targets must accompany nfr_masked_ids");
-            PMGT_HIP(hipMemcpyAsync(b.ids + bs + ps, bt->nfr_masked_ids, bs * 8, hipMemcpyDeviceToDevice, st));
-            PMGT_HIP(hipMemcpyAsync(b.nfr_tgt, bt->nfr_targets, bs * 8, hipMemcpyDeviceToDevice, st));
-        } else {
+        if (!bt->nfr_masked_ids)
             RUN(nfr_generate(bt->tgt_ids, B, S, (int)t->n_nodes, bt->random_node_ratio, bt->mask_node_ratio, t->rng_state,
                              b.ids + bs + ps, b.nfr_tgt, st));
-        }
-        PMGT_HIP(hipMemcpyAsync(b.mask + bs + ps, bt->tgt_mask, bs * 4, hipMemcpyDeviceToDevice, st));   // models.py:153-156
         RUN(nfr_compact(b.nfr_tgt, B, S, B + Pn, b.nfr_rows, b.nfr_tids, b.nfr_count, st));
     }
     // Table mode backward needs the tokens ordered by node id; the ids are final here, so the (latency-bound, many small
@@ -1051,9 +1058,8 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         RUNP("loss.nfr_diff", nfr_diff<T>(a, st));
     }
     RUN(loss_finish(b.gsr_part, B, train ? b.sse_part : nullptr, nfr_diff_parts(cap), b.nfr_count, e->Fv, e->Ft, train,
-                    o->loss, st));
+                    o->loss, st, train ? o->nfr_count : nullptr));
     if (o->last_hidden) PMGT_HIP(hipMemcpyAsync(o->last_hidden, hL, (size_t)bs * d * sizeof(T), hipMemcpyDeviceToDevice, st));
-    if (o->nfr_count && train) PMGT_HIP(hipMemcpyAsync(o->nfr_count, b.nfr_count, 4, hipMemcpyDeviceToDevice, st));
     if (bwd) {
         const int msp = std::max(256, cap / 5);
         RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hN, d, nrows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st, t->grads + e->bn));

@@ -4,6 +4,8 @@
 
 namespace pmgt {
 
+struct CopyJob { const void* src; void* dst; int64_t bytes; };
+int multi_copy(const CopyJob* jobs, int njobs, hipStream_t st);      // <= 8 device-to-device copies (4-byte granularity) in one launch
 int pair_offsets(const int64_t* num_pairs, int B, int* off, hipStream_t st);
 int nfr_generate(const int64_t* ids, int B, int S, int n_nodes, float random_ratio, float mask_ratio,
                  const uint64_t* rng, int64_t* masked_ids, int64_t* tgt_full, hipStream_t st);
@@ -41,6 +43,6 @@ int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, i
 int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
                     hipStream_t st);
 int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
-                bool with_nfr, float* out, hipStream_t st);
+                bool with_nfr, float* out, hipStream_t st, int* count_out = nullptr);
 
 }  // namespace pmgt

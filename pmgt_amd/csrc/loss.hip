@@ -33,6 +33,42 @@ __global__ __launch_bounds__(1024) void pair_offsets_kernel(const int64_t* __res
     if (tid == 1023) off[B] = part[1023];
 }
 
+// Several small device-to-device copies in ONE launch (the collated batch -> the workspace layout of a step: ids and masks of the
+// target, pair and masked sequences): six hipMemcpyAsync calls cost ~6 us each on the step's critical path at small batch sizes.
+struct MultiCopyArgs {
+    struct J { const uint32_t* src; uint32_t* dst; int64_t n4; } j[8];
+    int blk0[9];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a) {
+    int k = 0;
+    while (k + 1 < a.njobs && (int)blockIdx.x >= a.blk0[k + 1]) ++k;       // (uniform)
+    const MultiCopyArgs::J& jb = a.j[k];
+    const int64_t i0 = ((int64_t)(blockIdx.x - a.blk0[k]) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i0 + e < jb.n4) jb.dst[i0 + e] = jb.src[i0 + e];
+}
+int multi_copy(const CopyJob* jobs, int njobs, hipStream_t st) {
+    MultiCopyArgs a;
+    int cnt = 0, blocks = 0;
+    for (int q = 0; q < njobs; ++q) {
+        if (jobs[q].bytes <= 0) continue;
+        PMGT_CHECK(cnt < 8 && jobs[q].bytes % 4 == 0 && ((uintptr_t)jobs[q].src % 4) == 0 && ((uintptr_t)jobs[q].dst % 4) == 0, -2,
+                   "multi_copy: at most 8 jobs of 4-byte granularity");
+        a.j[cnt].src = (const uint32_t*)jobs[q].src; a.j[cnt].dst = (uint32_t*)jobs[q].dst; a.j[cnt].n4 = jobs[q].bytes / 4;
+        a.blk0[cnt] = blocks;
+        blocks += (int)cdiv64(a.j[cnt].n4, 1024);
+        ++cnt;
+    }
+    if (cnt == 0) return 0;
+    a.blk0[cnt] = blocks;
+    a.njobs = cnt;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(blocks), dim3(256), 0, st, a);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
 int pair_offsets(const int64_t* num_pairs, int B, int* off, hipStream_t st) {
     hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), 0, st, num_pairs, B, off);
     PMGT_LAUNCH_OK();
@@ -310,7 +346,7 @@ int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr
 __global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ gsr_part, int B,
                                                          const float* __restrict__ sse_part, int nparts,
                                                          const int* __restrict__ count, int Fv, int Ft, int with_nfr,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, int* __restrict__ count_out) {
     const int lane = threadIdx.x;
     float g = 0.f, sv = 0.f, stx = 0.f;
     for (int i = lane; i < B; i += 64) g += gsr_part[i];
@@ -324,13 +360,16 @@ __global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict
         stx = wave_sum(stx);
         nfr = 0.5f * (sv / ((float)n * (float)Fv) + stx / ((float)n * (float)Ft));
     }
-    if (lane == 0) { out[0] = g + nfr; out[1] = g; out[2] = nfr; }
+    if (lane == 0) {
+        out[0] = g + nfr; out[1] = g; out[2] = nfr;
+        if (count_out && with_nfr) *count_out = *count;      // the caller's copy of the masked-row count (was a 4-byte memcpy launch)
+    }
 }
 
 int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
-                bool with_nfr, float* out, hipStream_t st) {
+                bool with_nfr, float* out, hipStream_t st, int* count_out) {
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, gsr_part, B, sse_part, nparts, count, Fv, Ft,
-                       with_nfr ? 1 : 0, out);
+                       with_nfr ? 1 : 0, out, count_out);
     PMGT_LAUNCH_OK();
     return 0;
 }
