@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-phase-profile", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="partial-sum reductions on the engine's side stream (A/B; measured neutral)")
     ap.add_argument("--sampler-threads", type=int, default=0)
-    ap.add_argument("--end-to-end", action="store_true", help="(default on; kept for compatibility) also time steps fed by the live host sampler")
+    ap.add_argument("--end-to-end", action="store_true", help="N = 1: on by default; N > 1: also time steps fed by the live host sampler on every rank")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the live-sampler pass")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the B=32 / B=256 extra measurements (N=1 only)")
     return ap.parse_args()
@@ -322,6 +322,9 @@ def main():
             if ph and fresh and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16":
                 out["roofline"]["traffic"] = ph["hbm_mb_per_launch"]
                 out["roofline"]["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
+                if "matrix_pipe_busy" in ph:        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the same profile set
+                    out["roofline"]["matrix_pipe_busy"] = ph["matrix_pipe_busy"]
+                    out["roofline"]["valu_per_mfma"] = ph.get("valu_per_mfma")
         except (OSError, KeyError, ValueError):
             pass
 
@@ -353,7 +356,9 @@ def main():
 
     # ---- end to end with the live host sampler (threaded C++ MCNSampling -> pinned slots -> side-stream H2D): the rate a
     # training job sees; `value` above is the pre-staged rate the metric is defined on.  Every rank runs it (symmetric).
-    if not args.no_end_to_end:
+    # (at N > 1 only on request: the data-parallel numbers the driver collects are the pre-staged `value`; the multi-rank live pipeline
+    # has only been rehearsed over gloo on one GPU)
+    if not args.no_end_to_end and (world == 1 or args.end_to_end):
         e2e = trainer.run_live(sampler, shard, B, steps=min(args.steps, 30), threads=threads)
         if world > 1:
             tt = torch.tensor([e2e["ms_per_step"]], device=dev, dtype=torch.float64)

@@ -173,4 +173,4 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["loss_last"])
-    assert "phases" in out and "end_to_end" in out and "cpu_baseline" not in out
+    assert "phases" in out and "cpu_baseline" not in out and "end_to_end" not in out       # the live pipeline is an N = 1 (or opt-in) pass

@@ -42,6 +42,19 @@ def main():
         mb = (2.0 * fetch[kf] + write[kw]) * 1024.0 / 1e6
         phases[ph] = {"kernel": kf, "fetch_size_kib": round(fetch[kf], 1), "write_size_kib": round(write[kw], 1),
                       "hbm_mb_per_launch": round(mb, 1)}
+        # matrix-pipe occupancy of the same kernel, when the SQ passes of the profile set exist:
+        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), and VALU instructions per MFMA
+        try:
+            busy, cu = parse(prefix + "_pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt"), parse(prefix + "_pmc_SQ_BUSY_CU_CYCLES.txt")
+            valu, mfma = parse(prefix + "_pmc_SQ_INSTS_VALU.txt"), parse(prefix + "_pmc_SQ_INSTS_MFMA.txt")
+            kb = next((k for k in busy if sub in k), None)
+            if kb is not None and cu.get(kb, 0) > 0:
+                phases[ph]["matrix_pipe_busy"] = round(busy[kb] / (4.0 * cu[kb]), 4)
+            kv = next((k for k in valu if sub in k), None)
+            if kv is not None and mfma.get(kv, 0) > 0:
+                phases[ph]["valu_per_mfma"] = round(valu[kv] / mfma[kv], 1)
+        except OSError:
+            pass
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_sources_sha
     out = {
