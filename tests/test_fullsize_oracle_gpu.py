@@ -167,3 +167,15 @@ def test_million_node_tables_l6_d512_s64_match_the_oracle(dtype):
     case_o = dict(case, batch=(rm(tgt), rm(pair), num_pairs, labels), inj_cpu=(remap[masked], m2, remap[tidx]))
     p, ref = run_oracle(case_o, small, fp8=dtype == "fp8")
     compare(eng, out, p, ref, dtype)
+
+
+def test_hidden_128_context_32_takes_the_fused_kernels_and_matches_the_oracle():
+    """d = 128 / H = 4 (head size 32) / S = 32: the other hidden size of the fused projection + attention forward and of the fused
+    attention backward + weight gradient (KT = 8 instantiation), through the whole engine (3 layers: two fused backward launches,
+    the last layer on the CLS-only shortcut), odd number of sequences per step included (B = 7 -> 84 sequences... 7 * 12)."""
+    case = make_case(600, 6000, dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=3, intermediate_size=128), S=32, B=7, seed=41)
+    tables = po.synth_tables(600, case["cfg"]["feat_hidden_sizes"], 9)
+    for dtype in ("bf16", "fp32"):
+        eng, out = run_engine(case, dtype, [t.numpy() for t in tables])
+        p, ref = run_oracle(case, tables)
+        compare(eng, out, p, ref, dtype)
