@@ -84,29 +84,6 @@ __device__ __forceinline__ void store_row32(bf16* row_c0, f32x4 v0, f32x4 v1, in
     if (pred) *(u32x4*)(row_c0 + cb) = (u32x4){ax, ay, bx, by};
 }
 
-// ---- wave64 reductions ------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// reductions inside aligned lane groups of G lanes (G = 16, 32 or 64)
-template <int G> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <int G> __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // ---- dropout RNG --------------------------------------------------------------------------------
 // Counter-based: keep(element) = hash(seed, step, site, element index) >= p * 2^32.  Nothing is
 // stored; backward kernels regenerate the same mask from the same (seed, step, site, index).
@@ -246,6 +223,40 @@ __device__ __forceinline__ float max_lanes32(float v) {
     float x = v, y = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return raw_max(x, y);
+}
+
+// ---- wave64 reductions ------------------------------------------------------------------------
+// Result in every lane, bit-identical across the lanes (every stage pairs lane i with a partner p(i), p an involution, and both
+// compute a + b): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror as DPP modifiers of the add itself, then
+// v_permlane16_swap / v_permlane32_swap for the neighbouring 16-lane row and the other half.  ~12 VALU instructions and no LDS
+// round trip; the ds_bpermute butterfly this replaces cost six dependent LDS latencies and ~45 instructions per value (the
+// LayerNorm backward spent a quarter of its issue slots in it).
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = a + b;
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+template <int CTRL> __device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = dpp_max<0xB1>(v);
+    v = dpp_max<0x4E>(v);
+    v = dpp_max<0x141>(v);
+    v = dpp_max<0x140>(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = fmaxf(a, b);
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }

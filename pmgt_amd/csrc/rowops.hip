@@ -100,7 +100,7 @@ template int ln_fwd<float>(const float*, float*, float*, const float*, const flo
 template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*, int, int, float, DropCfg, hipStream_t, const int*, void*, float*);
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm backward.  64 rows per block (16 per wave); dgamma/dbeta partials per block.
+// LayerNorm backward.  64 rows per block (16 per wave, two at a time); dgamma/dbeta partials per block.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = d >> 2;
+    const float inv_d = 1.f / (float)d;
     const DropKey ik = make_drop_key(in_drop), ok = make_drop_key(out_drop);
     f32x4 gam[NCH], dgam[NCH], dbet[NCH], dbia[NCH];
 #pragma unroll
@@ -119,23 +120,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         gam[i] = ch < nch ? *(const f32x4*)(gamma + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
         dgam[i] = dbet[i] = dbia[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int it = 0; it < rpb / 4; ++it) {
-        const int m = blockIdx.x * rpb + it * 4 + wave;
-        if (m >= M) break;
-        const float mean = stats[2 * (int64_t)m], rstd = stats[2 * (int64_t)m + 1];
+    // one row of the wave: dx, and the row's terms of the three column sums (rows are taken in increasing order, so the sums
+    // do not depend on how many rows are in flight)
+    auto row = [&](int m, const f32x4 (&dyl)[NCH], const f32x4 (&xl)[NCH], float mean, float rstd) __attribute__((always_inline)) {
         f32x4 g[NCH], xh[NCH];
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                f32x4 dyv = load4<T>(dy + (int64_t)m * d + 4 * ch);
+                f32x4 dyv = dyl[i];
                 if (ik.on) {
 { float dm[4]; drop_mul4(ik, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
                 }
-                xh[i] = (load4<T>(x + (int64_t)m * d + 4 * ch) - mean) * rstd;
+                xh[i] = (xl[i] - mean) * rstd;
                 g[i] = dyv * gam[i];
                 dgam[i] += dyv * xh[i];
                 dbet[i] += dyv;
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 g[i] = xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        sg = wave_sum(sg) / (float)d;
-        sgx = wave_sum(sgx) / (float)d;
+        sg = wave_sum(sg) * inv_d;
+        sgx = wave_sum(sgx) * inv_d;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
@@ -165,6 +165,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 for (int e = 0; e < 4; ++e) dbia[i][e] += to_f<T>(from_f<T>(o[e]));   // column sum of what the GEMMs will read
             }
         }
+    };
+    // TWO rows of the wave in flight (their loads are issued before the first row's reductions): with one, the 32 waves of a
+    // CU keep 32 KB of reads in flight, short of what the HBM latency needs at full rate
+    for (int it = 0; it < rpb / 4; it += 2) {
+        const int m0 = blockIdx.x * rpb + it * 4 + wave;
+        if (m0 >= M) break;
+        const bool two = it + 1 < rpb / 4 && m0 + 4 < M;      // (wave-uniform)
+        const int m1 = two ? m0 + 4 : m0;
+        f32x4 dy0[NCH], x0[NCH], dy1[NCH], x1[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = min(lane + 64 * i, nch - 1);      // unconditional loads (a predicate here serialises them); row() ignores the extras
+            dy0[i] = load4<T>(dy + (int64_t)m0 * d + 4 * ch);
+            x0[i] = load4<T>(x + (int64_t)m0 * d + 4 * ch);
+            dy1[i] = load4<T>(dy + (int64_t)m1 * d + 4 * ch);
+            x1[i] = load4<T>(x + (int64_t)m1 * d + 4 * ch);
+        }
+        const float mean0 = stats[2 * (int64_t)m0], rstd0 = stats[2 * (int64_t)m0 + 1];
+        const float mean1 = stats[2 * (int64_t)m1], rstd1 = stats[2 * (int64_t)m1 + 1];
+        row(m0, dy0, x0, mean0, rstd0);
+        if (two) row(m1, dy1, x1, mean1, rstd1);
     }
     // cross-wave reduction of the partials, one wave at a time into LDS
     for (int w = 0; w < 4; ++w) {
@@ -412,6 +433,7 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
     __shared__ float red[6 * 1024 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = p.d, nch = d >> 2;
+    const float inv_d = 1.f / (float)d;
     const DropKey ik = make_drop_key(p.drop);
     f32x4 gam[NCH], dgam[NCH], dbet[NCH], dw0v[NCH], dw0t[NCH], dw1v[NCH], dw1t[NCH];
     f32x4 w0v[NCH], w0t[NCH], w1v[NCH], w1t[NCH];
@@ -458,8 +480,8 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
                     g[i] = xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
-            sg = wave_sum(sg) / (float)d;
-            sgx = wave_sum(sgx) / (float)d;
+            sg = wave_sum(sg) * inv_d;
+            sgx = wave_sum(sgx) * inv_d;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + 64 * i;
