@@ -62,6 +62,29 @@ __device__ unsigned long long g_qa_blk[1024][4];
 #define QA_PROF_FLUSH do { } while (0)
 #endif
 
+#ifdef PMGT_QA_PROF
+// role-split kernel: cycles per interval of workgroup 0, [wave][interval]; [wave][7] = iterations
+__device__ unsigned int g_qa3_prof[16][8];
+#define QA3_PROF_DECL unsigned int pacc3[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long plast3 = __builtin_readcyclecounter();
+#define QA3_STAMP(k)                                                   \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter();  \
+        pacc3[k] += (unsigned int)(now_ - plast3);                     \
+        plast3 = now_;                                                 \
+    } while (0)
+#define QA3_PROF_FLUSH                                                                              \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && lane == 0) {                                                         \
+            for (int k_ = 0; k_ < 7; ++k_) g_qa3_prof[wave][k_] = pacc3[k_];                        \
+            g_qa3_prof[wave][7] = (unsigned int)NI;                                                 \
+        }                                                                                           \
+    } while (0)
+#else
+#define QA3_PROF_DECL
+#define QA3_STAMP(k) do { } while (0)
+#define QA3_PROF_FLUSH do { } while (0)
+#endif
+
 template <int KS> struct QaCfg {
     static constexpr int K = 32 * KS;
     static constexpr int ROWB = K * 2;
@@ -75,7 +98,10 @@ template <int KS> struct QaCfg {
     static constexpr int SMEM = 2 * TILEB + QTB + 8 * 64 * 4; // A ring + projection tile + per-wave {rho[32], madd[32]}
 };
 
-// reduction over the 4 lanes l, l^16, l^32, l^48 in the VALU (v_permlane16/32_swap, see attention_mfma.hip)
+// reduction over the 4 lanes l, l^16, l^32, l^48 on the LDS crossbar (ds_swizzle xor 16 inside the 32-lane halves, ds_bpermute for
+// l ^ 32): two LDS-port instructions and two VALU instructions.  The v_permlane16/32_swap form cost 8 VALU instructions (each swap needs
+// two copies of the value) plus two s_nop; the kernels here are VALU-issue-bound and run this six times per attention problem.
+#ifdef PMGT_QRED_PERMLANE
 __device__ __forceinline__ float qred(float v, bool is_max) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -84,11 +110,23 @@ __device__ __forceinline__ float qred(float v, bool is_max) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return is_max ? raw_max(a, b) : a + b;
 }
+#else
+__device__ __forceinline__ float qred(float v, bool is_max) {
+    float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));      // lane ^ 16
+    v = is_max ? raw_max(v, o) : v + o;
+    o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((threadIdx.x & 63) ^ 32) << 2, __builtin_bit_cast(int, v)));
+    return is_max ? raw_max(v, o) : v + o;
+}
+#endif
 
 // byte address of 16-byte chunk `ch` (0..31) of row `row` inside the swizzled projection tile
 __device__ __forceinline__ int qt_addr(int row, int ch) { return row * 512 + ((ch ^ (row & 15)) << 4); }
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+#ifndef PMGT_QA_MIDPOS
+#define PMGT_QA_MIDPOS 0
+#endif
 
 // max over the whole wave (every lane gets it): DPP row rotations + the two permlane swaps
 __device__ __forceinline__ float qa_wave_max(float v) {
@@ -115,9 +153,14 @@ struct QaAttnConst {
     bool dg[4];                 // lane-constant: key 4 q + e is the query r (diagonal of a 16 x 16 block)
 };
 
-__device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* qt, int R0, int uh, int it, int t, int h, int H,
-                                            const float* mask, float* rho, float* madd, bf16* ctx_row, bool act, int r, int q,
-                                            int lane) {
+// `mv` = additive mask term of key (lane & 31), (1 - mask) * -10000 (0 for an inactive tile), loaded by the caller -- the role-split kernel
+// fetches it one problem ahead; `mid()` runs between the softmax and the P V half (that kernel's workgroup barrier; empty otherwise).
+// IT >= 0: the query half as a compile-time constant (the diagonal term and the operand selects below fold away)
+template <int IT = -1, typename Mid>
+__device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* qt, int R0, int uh, int it_rt, int t, int h, int H,
+                                            bool has_mask, float mv, float* rho, float* madd, bf16* ctx_row, bool act, int r, int q,
+                                            int lane, Mid&& mid) {
+    const int it = IT >= 0 ? IT : it_rt;
     constexpr float L2E = 1.4426950408889634f;
     auto blk = [&](int mtx) { return 4 * (2 * mtx + uh) + q; };
     bf16x8 fq, fk[2], fc[2];
@@ -137,9 +180,7 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
         rho_own[jt] = __builtin_amdgcn_rsqf(ss[jt]);     // 1 / |c_row|
         if (q == 0) rho[16 * jt + r] = rho_own[jt];
     }
-    const bool has_mask = mask != nullptr;               // (uniform)
-    if (has_mask) {
-        const float mv = act ? (1.f - mask[(int64_t)t * 32 + (lane & 31)]) * -10000.f : 0.f;
+    if (has_mask) {                                      // (uniform)
         const float mm = qa_wave_max(mv);
         if (lane < 32) madd[lane] = (mv - mm) * L2E;
     }
@@ -171,6 +212,9 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
         }
     }
     m2 = qred(m2, true);
+#if PMGT_QA_MIDPOS == 2
+    mid();
+#endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -181,9 +225,15 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
             s1 += a1[jt][e];
             s2 += a2[jt][e];
         }
+#if PMGT_QA_MIDPOS == 1
+    mid();
+#endif
     s1 = qred(s1, false);
     s2 = qred(s2, false);
     const float c1 = kc.c_beta * __builtin_amdgcn_rcpf(s1), c2 = kc.c_omb * __builtin_amdgcn_rcpf(s2);
+#if PMGT_QA_MIDPOS == 0
+    mid();
+#endif
     // mix + dropout -> P^T, packed as the B operand (k slot e of lane (r, q): key 16 (e >> 2) + 4 q + (e & 3))
     bf16x8 pb;
     const int i = 16 * it + r;
@@ -213,7 +263,11 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
         o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, z, 0, 0, 0);
     }
     // one 16-byte store per lane: the 64 bytes of this (row, head) leave as one run (common.h: store_row32)
+#ifdef PMGT_QA3_NO_CTX
+    store_row32(ctx_row, o[0], o[1], q, act && t < 0);
+#else
     store_row32(ctx_row, o[0], o[1], q, act);
+#endif
 }
 
 __device__ __forceinline__ QaAttnConst qa_attn_const(const QkvcAttn& a, int r, int q) {
@@ -348,8 +402,9 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
         const int t = 2 * mt + us;
         const bool act = t < a.Tseq;
         if (it == 1 && t < a.cls_only_seqs) return;      // (wave-uniform) only query row 0 of this sequence is ever read
-        qa_attention(kc, qt, 32 * us, uh, it, min(t, a.Tseq - 1), h, a.H, a.mask, rho, madd,
-                     CTX + ((int64_t)min(t, a.Tseq - 1) * 32 + 16 * it + r) * a.ldc + h * 32, act, r, q, lane);
+        const float mv = (a.mask && act) ? (1.f - a.mask[(int64_t)t * 32 + (lane & 31)]) * -10000.f : 0.f;
+        qa_attention(kc, qt, 32 * us, uh, it, min(t, a.Tseq - 1), h, a.H, a.mask != nullptr, mv, rho, madd,
+                     CTX + ((int64_t)min(t, a.Tseq - 1) * 32 + 16 * it + r) * a.ldc + h * 32, act, r, q, lane, [] {});
         QA_STAMP(6);
         // The next tile_step's first barrier orders this phase's LDS reads before the next projection-tile
         // writes (which come after that step's second barrier anyway).
@@ -572,8 +627,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- (b) attention of (sequence mt, head h, queries 16 it .. 16 it + 15)
         const int t = mt;
         if (it == 1 && t < a.cls_only_seqs) return;      // (wave-uniform) only query row 0 of this sequence is ever read
-        qa_attention(kc, qt, 0, uh, it, t, h, a.H, a.mask, rho, madd, CTX + ((int64_t)t * 32 + 16 * it + r) * a.ldc + h * 32, true, r, q,
-                     lane);
+        const float mv = a.mask ? (1.f - a.mask[(int64_t)t * 32 + (lane & 31)]) * -10000.f : 0.f;
+        qa_attention(kc, qt, 0, uh, it, t, h, a.H, a.mask != nullptr, mv, rho, madd, CTX + ((int64_t)t * 32 + 16 * it + r) * a.ldc + h * 32, true, r, q,
+                     lane, [] {});
         QA_STAMP(6);
     };
 
@@ -581,6 +637,254 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (mt < num_mt) { gload(mt, 0); sstore(0, 0); }
     for (int P = 0; mt < num_mt; mt += gx, P ^= 1) tile_step(P, mt);
     QA_PROF_FLUSH;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Role-split form (bf16).  Stamps of the two-workgroup form above (tools/prof/qa_prof.py): a wave marches through
+// projection (1580 cycles for its 64 MFMAs) -> bias / projection-tile writes (1050) -> copy-out (660) -> attention (2470 - 2760, ~390
+// dependent VALU instructions) in sequence, 6200 - 6700 cycles per (sequence, slab) with TWO waves per SIMD: the matrix pipe is busy a
+// quarter of the time and the VALU issues one instruction per ~6 cycles -- there are not enough waves to fill either, and there cannot
+// be more while every wave holds 128 VGPRs of W.  Here ONE 16-wave workgroup per CU splits the roles (as attn_bwd_wgrad_kernel does):
+//   waves 0-7  GEMM role: wave g keeps the W rows of 32 output columns (matrix g >> 1, head g & 1 of the slab; 64 VGPRs), streams the
+//              x tiles in by LDS-DMA (a 4-slot ring, three tiles ahead), per step 32 MFMAs (the 32 x 32 block of the sequence's
+//              projection) -> + bias -> bf16 -> projection-tile ring in LDS; it also copies the previous step's tile to HBM;
+//   waves 8-15 attention role: group (w >> 2) & 1 takes the even / odd steps, wave = (head uh, query half it); a problem spans TWO
+//              iterations (softmax half | barrier | P V half), so each SIMD always holds two GEMM waves feeding the matrix pipe and two
+//              attention waves in different halves feeding the VALU.
+// One s_barrier per iteration; iteration i: GEMM projects step i, copies out step i - 1; attention runs the first half of step i - 1
+// (group (i - 1) & 1) and the second half of step i - 2 (the other group).  Projection tile s lives in ring slot s & 3 from iteration s
+// (written) to s + 2 (last read); x tile s is DMA'd during iteration s - 3 into the slot x tile s - 4 left at the end of iteration s - 4.
+// ------------------------------------------------------------------------------------------------
+template <int KS> struct QaCfg3 {
+    static constexpr int K = 32 * KS, ROWB = K * 2, CPR = K / 8;
+    static constexpr int XT = 32 * ROWB, QTB = 32 * 512;              // x tile, projection tile (32 rows x 256 bf16)
+    static constexpr int RPI = 1024 / ROWB, LPR = 64 / RPI;           // rows per 1-KB DMA instruction, lanes per row
+    static constexpr int NDMA = XT / 1024 / 8;                        // DMA instructions per GEMM wave and tile
+    static_assert(NDMA >= 1 && NDMA * 8 * 1024 == XT && CPR >= 16, "x tile = whole 1-KB instructions per GEMM wave, >= 16 chunks per row");
+    static constexpr int X0 = 0, Q0 = 4 * XT, WL0 = Q0 + 4 * QTB, MK0 = WL0 + 8 * 64 * 4, SMEM = MK0 + 8 * 128;      // + mask rows of 8 steps
+};
+
+typedef __attribute__((address_space(3))) void qa_lds_void_t;
+typedef __attribute__((address_space(1))) const void qa_gbl_void_t;
+
+template <int KS>
+__global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
+    using C = QaCfg3<KS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int d = a.H * 32, ny = a.H / 2;
+    const int b = blockIdx.x;
+    const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
+    const int gx = gridDim.x / ny;
+    const int nsteps = x < a.Tseq ? (a.Tseq - x + gx - 1) / gx : 0;       // sequences x, x + gx, ... (uniform over the workgroup)
+    const int NI = nsteps + 2;
+    auto gcol = [&](int c) { return (c >> 6) * d + (2 * y + ((c >> 5) & 1)) * 32 + (c & 31); };
+    auto ocol = [&](int c) { return a.hm ? ((2 * y + ((c >> 5) & 1)) * 4 + (c >> 6)) * 32 + (c & 31) : gcol(c); };
+    QA3_PROF_DECL
+    // LDS operations of this wave done, then the workgroup barrier (no vmcnt wait: the DMA ring stays in flight across it)
+    auto bar = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        QA3_STAMP(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        QA3_STAMP(1);
+    };
+
+    if (wave >= 8) {
+        // ================================ attention role ================================
+        const int aw = wave - 8, grp = aw >> 2, uh = (aw >> 1) & 1, it = aw & 1;
+        const int h = 2 * y + uh;
+        const QaAttnConst kc = qa_attn_const(a, r, q);
+        float* rho = (float*)(smem + C::WL0) + aw * 64;
+        float* madd = rho + 32;
+        bf16* CTX = (bf16*)a.ctx;
+        const bool has_mask = a.mask != nullptr;
+        // The mask row of a step arrives in LDS with its x tile (GEMM wave 0's DMA): these waves issue no vector-memory LOAD at all, so nothing
+        // ever makes them wait on vmcnt -- a global load of the mask value, even one problem ahead, put an s_waitcnt vmcnt(0) at the top of
+        // every problem, which waited for the previous problem's context STORE to be acknowledged (65 us of a 390 us launch).
+        __builtin_amdgcn_s_barrier();                     // the GEMM role's "x(0) has landed" barrier
+        int nb = 0;
+        for (; nb < 1 + grp; ++nb) bar();                 // the iterations before this group's first tile exists
+        for (int s = grp; s < nsteps; s += 2, nb += 2) {
+            const int t = x + s * gx;
+            const float mv = has_mask ? (1.f - *(const float*)(smem + C::MK0 + (s & 7) * 128 + (lane & 31) * 4)) * -10000.f : 0.f;
+            const char* qt = smem + C::Q0 + (s & 3) * C::QTB;
+            if (it == 1 && t < a.cls_only_seqs) {         // (wave-uniform) only query row 0 of this sequence is ever read
+                bar();
+            } else {
+                bf16* crow = CTX + ((int64_t)t * 32 + 16 * it + r) * a.ldc + h * 32;
+                if (it == 0) qa_attention<0>(kc, qt, 0, uh, 0, t, h, a.H, has_mask, mv, rho, madd, crow, true, r, q, lane, bar);
+                else qa_attention<1>(kc, qt, 0, uh, 1, t, h, a.H, has_mask, mv, rho, madd, crow, true, r, q, lane, bar);
+            }
+            QA3_STAMP(2);
+            bar();
+        }
+        for (; nb < NI; ++nb) bar();
+        QA3_PROF_FLUSH;
+        return;
+    }
+    // ==================================== GEMM role ====================================
+    // The kernel is VALU-issue-bound (one wave-instruction per 4 cycles and SIMD, all 16 waves counted: ~2500 issue cycles per iteration
+    // against 1024 of the matrix pipe), so this role spends as few vector instructions as it can: every per-lane address is a loop-invariant
+    // register plus an IMMEDIATE ring-slot offset (the loop is unrolled over the four slots) or a scalar base (global side), and the bias is
+    // the C operand of the first MFMA of each accumulator.
+    __builtin_amdgcn_s_setprio(2);         // the matrix pipe is the unit to keep fed: its waves win the issue arbitration
+    const int g = wave;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(qa_lds_void_t*)smem;
+    // v_mfma_f32_32x32x16_bf16, operands swapped (A = W rows = output columns, B = x rows): the 32 x 32 block of a wave is ONE
+    // accumulator tile, 16 instructions per step instead of 32 of the 16x16x32 form -- an MFMA holds the SIMD's vector issue for 8 cycles
+    // whatever its shape, and vector issue is what this kernel runs out of.  Lane l: A row / B column l & 31, k = 16 kk + 8 (l >> 5) .. + 7;
+    // D register v = 4 g4 + e: output column 32 g + 8 g4 + 4 (l >> 5) + e of x row l & 31.
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int KK = 2 * KS;
+    const int l31 = lane & 31, lh = lane >> 5;
+    bf16x8 wf[KK];
+    {
+        const int n = gcol(32 * g + l31);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) wf[kk] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 16 * kk + 8 * lh);
+    }
+    // The bias enters as one more MFMA (k slots 0, 1 of an extra k-step: bias split into bf16 hi + lo against ones; every other slot of the A
+    // fragment is zero): 8 VGPRs instead of the 16 a C-operand copy of it would hold, and no VALU adds in the epilogue.  |bias - (hi + lo)| <=
+    // 2^-17 |bias|.
+    bf16x8 wb = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if (a.bias && lh == 0) {
+        const float bf = a.bias[gcol(32 * g + l31)];
+        const bf16 hi = (bf16)bf;
+        wb[0] = hi;
+        wb[1] = (bf16)(bf - (float)hi);
+    }
+    const bf16 one_ = (bf16)1.f;
+    const bf16x8 ones = {one_, one_, one_, one_, one_, one_, one_, one_};
+
+    // x tile by LDS-DMA: instruction j of wave g covers rows (NDMA g + j) RPI ..; lane -> row + lane / LPR, LDS chunk slot lane % LPR, which
+    // holds global chunk slot ^ (row & 15) (the XOR swizzle of the fragment reads below).  (row0 + lane / LPR) & 15 = (row0 & 15) ^ (lane / LPR):
+    // row0 is a multiple of RPI.
+    uint32_t dma_off[C::NDMA];
+#pragma unroll
+    for (int j = 0; j < C::NDMA; ++j) {
+        const int row0 = (C::NDMA * g + j) * C::RPI, row = row0 + lane / C::LPR;
+        dma_off[j] = (uint32_t)row * (uint32_t)a.ldx * 2u + (uint32_t)(((lane % C::LPR) ^ (row & 15)) << 4);
+    }
+    const bool mask_dma = g == 0 && a.mask != nullptr;                  // (wave-uniform) wave 0 also brings the step's 128-byte mask row
+    const int ND = C::NDMA + (mask_dma ? 1 : 0);                        // vector-memory loads of this wave per step
+    auto dma_x = [&](int s, int slot) __attribute__((always_inline)) {
+        const char* src = (const char*)a.X + (size_t)((uint32_t)(x + s * gx) * 32u * (uint32_t)a.ldx * 2u);      // (scalar)
+        char* dst = smem + C::X0 + slot * C::XT;
+#pragma unroll
+        for (int j = 0; j < C::NDMA; ++j)
+            __builtin_amdgcn_global_load_lds((qa_gbl_void_t*)(src + (size_t)dma_off[j]), (qa_lds_void_t*)(dst + (C::NDMA * g + j) * C::RPI * C::ROWB), 16, 0, 0);
+        if (mask_dma) {
+            const char* msrc = (const char*)a.mask + (size_t)(x + s * gx) * 128;
+            if (lane < 8)
+                __builtin_amdgcn_global_load_lds((qa_gbl_void_t*)(msrc + lane * 16), (qa_lds_void_t*)(smem + C::MK0 + (s & 7) * 128), 16, 0, 0);
+        }
+    };
+    // s_waitcnt vmcnt(n), n <= 10, as an immediate
+    auto wait_vm = [](int n) __attribute__((always_inline)) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        }
+    };
+    // fragment reads of an x tile: row l & 31, chunk (2 kk + (l >> 5)) ^ (row & 15): bits 5.. of the chunk's byte offset are the k-step,
+    // so the 2 KS addresses of a tile are ONE register XOR a constant (+ the slot as the instruction's offset)
+    const uint32_t fr0 = (uint32_t)(l31 * C::ROWB + (((lh ^ (l31 & 1)) << 4) | ((l31 & 15) >> 1 << 5)));      // bits 5.. 5 + log2(KK) - 1 hold (row & 15) >> 1 only
+    // projection-tile addresses.  Writes: row l & 31, columns 32 g + 8 g4 + 4 (l >> 5) .. + 3 = chunk 4 g + g4, half l >> 5.
+    // Copy-out reads: row 16 p + 2 g + (lane >> 5), chunk lane & 31 -> 16 bytes to Q|K|V|C row t * 32 + row, column ocol(8 chunk).
+    uint32_t qw[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) qw[g4] = lds0 + C::Q0 + (uint32_t)(l31 * 512 + (((4 * g + g4) ^ (l31 & 15)) << 4) + 8 * lh);
+    const int co_row = 2 * g + (lane >> 5);
+    const uint32_t co_lds = lds0 + C::Q0 + (uint32_t)(co_row * 512 + (((lane & 31) ^ (co_row & 15)) << 4));
+    const uint32_t co_glb = ((uint32_t)co_row * (uint32_t)a.ldq + (uint32_t)ocol(8 * (lane & 31))) * 2u;
+
+    if (0 < nsteps) dma_x(0, 0);
+    if (1 < nsteps) dma_x(1, 1);
+    if (2 < nsteps) dma_x(2, 2);
+    // x(0) has landed for this wave (W / bias loads are older than the DMAs and drain first), then for everyone
+    wait_vm(max(0, min(2, nsteps - 1)) * ND);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // one iteration; SL = i & 3 as a compile-time constant
+    auto iteration = [&](auto SLc, int i) __attribute__((always_inline)) {
+        constexpr int SL = decltype(SLc)::value, SLP = (SL + 3) & 3;        // ring slots of step i and of step i - 1 (= of x(i + 3))
+        QA3_STAMP(2);
+        // ---- (1) projection tile of step i - 1 -> HBM (first: its stores have drained by the vmcnt wait at the end of the iteration)
+        if (i >= 1 && i - 1 < nsteps) {
+            char* dst = (char*)a.qkvc + (size_t)((uint32_t)(x + (i - 1) * gx) * 32u * (uint32_t)a.ldq * 2u);      // (scalar)
+            u32x4 v[2];
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(co_lds), "n"(SLP * C::QTB), "n"(SLP * C::QTB + 16 * 512) : "memory");
+#ifndef PMGT_QA3_NO_COPY
+            *(u32x4*)(dst + (size_t)co_glb) = v[0];
+            *(u32x4*)(dst + (size_t)(16u * (uint32_t)a.ldq * 2u) + (size_t)co_glb) = v[1];
+#else
+            if (a.Tseq < 0) { *(u32x4*)(dst + (size_t)co_glb) = v[0]; *(u32x4*)(dst + (size_t)(16u * (uint32_t)a.ldq * 2u) + (size_t)co_glb) = v[1]; }
+#endif
+        }
+        QA3_STAMP(3);
+        // ---- (2) the ring slot x(i - 1) left at the last barrier takes x(i + 3)
+        if (i + 3 < nsteps) dma_x(i + 3, SLP);
+        // ---- (3) projection of step i
+        if (i < nsteps) {
+            f32x16 acc;
+            u32x4 fa[2];
+            auto rd = [&](int kk) __attribute__((always_inline)) {
+                const uint32_t ad = (fr0 ^ (uint32_t)(kk << 5)) + (lds0 + C::X0);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fa[kk & 1]) : "v"(ad), "n"(SL * C::XT) : "memory");
+            };
+            rd(0);
+            {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, ones, z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) {
+                    rd(kk + 1);
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[kk & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[kk & 1]));
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], __builtin_bit_cast(bf16x8, fa[kk & 1]), acc, 0, 0, 0);
+            }
+            QA3_STAMP(4);
+            // bf16, into projection-tile slot SL (8 bytes per lane and column group)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const bf16x4 o = {(bf16)acc[4 * g4], (bf16)acc[4 * g4 + 1], (bf16)acc[4 * g4 + 2], (bf16)acc[4 * g4 + 3]};
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(qw[g4]), "v"(__builtin_bit_cast(u32x2, o)), "n"(SL * C::QTB) : "memory");
+            }
+        }
+        QA3_STAMP(5);
+        // ---- (4) x(i + 1) has landed for this wave.  vmcnt counts loads and stores alike and retires them in issue order; issued after
+        // x(i + 1)'s DMA: [2 stores, x(i + 2)] in iteration i - 1 and [2 stores, x(i + 3)] in this one.
+        if (i + 1 < nsteps) {
+            const int younger = min(i + 3, nsteps - 1) - (i + 1);
+            wait_vm(younger * ND + ((younger >= 2 && i >= 2) ? 4 : 0));
+        }
+        bar();
+    };
+    for (int i = 0; i < NI; i += 4) {
+        iteration(std::integral_constant<int, 0>{}, i);
+        if (i + 1 < NI) iteration(std::integral_constant<int, 1>{}, i + 1);
+        if (i + 2 < NI) iteration(std::integral_constant<int, 2>{}, i + 2);
+        if (i + 3 < NI) iteration(std::integral_constant<int, 3>{}, i + 3);
+    }
+    QA3_PROF_FLUSH;
 }
 
 bool qkvc_attn_supported(const QkvcAttn& a) {
@@ -623,17 +927,40 @@ template <int KS, int F8 = 0> static int launch_qa2(const QkvcAttn& a, hipStream
     return 0;
 }
 
-static bool qa_form1() {
-    static const bool v = [] { const char* e = getenv("PMGT_QA_FORM"); return e && atoi(e) == 1; }();
+template <int KS> static int launch_qa3(const QkvcAttn& a, hipStream_t st) {
+    using C = QaCfg3<KS>;
+    auto kern = qkvc_attn_fwd3_kernel<KS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+        attr_done = true;
+    }
+    const int ny = a.H / 2;
+    const int gx = std::max(8, std::min(256 / ny, a.Tseq) / 8 * 8);       // one 16-wave workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(1024), C::SMEM, st, a);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// 1 = the 8-wave two-sequence form, 2 = two 4-wave workgroups per CU, 3 (default) = the role-split 16-wave form
+static int qa_form() {
+    static const int v = [] { const char* e = getenv("PMGT_QA_FORM"); const int f = e ? atoi(e) : 3; return f >= 1 && f <= 3 ? f : 3; }();
     return v;
 }
+// the role-split form addresses x and Q|K|V|C with 32-bit byte offsets
+static bool qa3_ok(const QkvcAttn& a) {
+    const int d = a.H * 32;
+    return (int64_t)a.Tseq * 32 * a.ldx * 2 < ((int64_t)1 << 32) && (int64_t)a.Tseq * 32 * a.ldq * 2 < ((int64_t)1 << 32) && (d == 256 || d == 128);
+}
+
 
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
     if (a.Tseq <= 0) return 0;
     PMGT_CHECK(qkvc_attn_supported(a), -2, "qkvc_attn_fwd: unsupported shape S=%d dh=%d H=%d", a.S, a.dh, a.H);
     if (a.W8 && a.X8) return launch_qa2<8, 2>(a, st);
     if (a.W8) return launch_qa2<8, 1>(a, st);
-    if (qa_form1()) return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
+    if (qa_form() == 1) return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
+    if (qa_form() == 3 && qa3_ok(a)) return a.H * 32 == 256 ? launch_qa3<8>(a, st) : launch_qa3<4>(a, st);
     return a.H * 32 == 256 ? launch_qa2<8>(a, st) : launch_qa2<4>(a, st);
 }
 
@@ -642,6 +969,9 @@ int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
 #ifdef PMGT_QA_PROF
 extern "C" int pmgt_debug_qa_prof_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_qa_prof), sizeof(pmgt::g_qa_prof));
+}
+extern "C" int pmgt_debug_qa3_prof_read(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_qa3_prof), sizeof(pmgt::g_qa3_prof));
 }
 extern "C" int pmgt_debug_qa_blk_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_qa_blk), sizeof(pmgt::g_qa_blk));

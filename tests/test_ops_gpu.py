@@ -521,8 +521,12 @@ def test_fused_qkvc_attention_matches_the_two_kernel_path(T, H, beta, drop):
     M = T * S
     _lib.check(L.pmgt_op_linear(1, P(xd), d, P(Wd), d, P(q2), 4 * d, M, 4 * d, d, P(bd), 0, None, 0, None, 0, 0.0, 0, None,
                                 None, None, None, None, 1e-12, stream()))
-    _lib.check(L.pmgt_op_attention_fwd(1, P(q2), P(md), P(c2), None, T, S, H, dh, beta, drop, 17, 18, P(rng), stream()))
-    assert torch.equal(q1, q2)                           # same products, same accumulation order, same rounding
+    # (the attention kernel runs on the fused kernel's own Q|K|V|C, so that the two contexts compare on identical inputs)
+    _lib.check(L.pmgt_op_attention_fwd(1, P(q1), P(md), P(c2), None, T, S, H, dh, beta, drop, 17, 18, P(rng), stream()))
+    # Same products; the fused kernel accumulates 16 k per MFMA (32x32x16) from the bias upwards, the streaming GEMM 32 k per MFMA with
+    # the bias added last: fp32 round-off apart before the bf16 rounding, i.e. equal except for single-ulp flips on a few per cent of elements
+    dq = (q1.float() - q2.float()).abs()
+    assert (dq <= 2 ** -7 * q2.float().abs().clamp_min(2 ** -6)).all() and (dq > 0).float().mean().item() < 0.05
     # The fused kernel evaluates the softmaxes in the log2 domain and folds normalisation, beta and the dropout scale into
     # one factor, so the two paths differ by fp32 round-off BEFORE P is rounded to bf16: single-ulp flips of P and ctx
     # (bf16 eps = 3.9e-3) are expected; a different dropout mask or a wrong score would be orders of magnitude larger.

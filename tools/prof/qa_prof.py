@@ -23,6 +23,19 @@ for k in range(9):
 ev[1].record()
 torch.cuda.synchronize()
 print("last launch: %.1f us" % (ev[0].elapsed_time(ev[1]) * 1e3))
+if hasattr(C.CDLL(_lib._build.hip_lib_path()), "pmgt_debug_qa3_prof_read") and os.environ.get("PMGT_QA_FORM", "3") == "3":
+    # role-split form: workgroup 0, [wave][interval]: 0 = work that ends at a barrier (incl. the vmcnt / lgkmcnt waits), 1 = barrier wait,
+    # GEMM waves: 2 = loop top, 3 = copy-out, 4 = DMA issue + fragment reads + MFMAs, 5 = bias / projection-tile writes;
+    # attention waves: 2 = second half of a problem (the first half ends at the mid barrier: interval 0)
+    raw3 = C.CDLL(_lib._build.hip_lib_path())
+    b3 = np.zeros((16, 8), dtype=np.uint32)
+    raw3.pmgt_debug_qa3_prof_read.argtypes = [C.c_void_p]
+    assert raw3.pmgt_debug_qa3_prof_read(b3.ctypes.data) == 0
+    for w in range(16):
+        n = max(1, int(b3[w, 7]))
+        per = b3[w, :7].astype(np.float64) / n
+        print(f"  wave {w:2d} ({'GEMM' if w < 8 else 'attn'}): iterations {n} total/iter {per.sum():7.0f} | " + " | ".join(f"[{k}] {per[k]:6.0f}" for k in range(7)))
+    sys.exit(0)
 buf = np.zeros((2, 8, 8), dtype=np.uint32)
 raw = C.CDLL(_lib._build.hip_lib_path())
 raw.pmgt_debug_qa_prof_read.argtypes = [C.c_void_p]
