@@ -1712,7 +1712,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
 #endif
         bar(2);
         if (sg >= 0) kstep(sg, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMAs have landed (and its stores have left)
+        // This wave's DMAs have landed.  vmcnt retires loads and stores in issue order, and the two copy-out stores of a FULL tile
+        // (no store instruction skipped by an all-false row predicate) were issued after the DMAs: they may stay in flight -- waiting for
+        // their acknowledgement as well put a store round trip on every iteration's critical path.
+#ifndef PMGT_ABW_WAIT_STORES
+        if (sg >= 0 && 64 * (xs + sg * gx) + 64 <= M) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar(4);
     }
 #ifdef PMGT_ABW_PROF

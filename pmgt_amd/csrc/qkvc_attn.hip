@@ -101,32 +101,18 @@ template <int KS> struct QaCfg {
 // reduction over the 4 lanes l, l^16, l^32, l^48 on the LDS crossbar (ds_swizzle xor 16 inside the 32-lane halves, ds_bpermute for
 // l ^ 32): two LDS-port instructions and two VALU instructions.  The v_permlane16/32_swap form cost 8 VALU instructions (each swap needs
 // two copies of the value) plus two s_nop; the kernels here are VALU-issue-bound and run this six times per attention problem.
-#ifdef PMGT_QRED_PERMLANE
-__device__ __forceinline__ float qred(float v, bool is_max) {
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    v = is_max ? raw_max(a, b) : a + b;
-    a = v; b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return is_max ? raw_max(a, b) : a + b;
-}
-#else
 __device__ __forceinline__ float qred(float v, bool is_max) {
     float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));      // lane ^ 16
     v = is_max ? raw_max(v, o) : v + o;
     o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((threadIdx.x & 63) ^ 32) << 2, __builtin_bit_cast(int, v)));
     return is_max ? raw_max(v, o) : v + o;
 }
-#endif
 
 // byte address of 16-byte chunk `ch` (0..31) of row `row` inside the swizzled projection tile
 __device__ __forceinline__ int qt_addr(int row, int ch) { return row * 512 + ((ch ^ (row & 15)) << 4); }
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-#ifndef PMGT_QA_MIDPOS
-#define PMGT_QA_MIDPOS 0
-#endif
 
 // max over the whole wave (every lane gets it): DPP row rotations + the two permlane swaps
 __device__ __forceinline__ float qa_wave_max(float v) {
@@ -212,9 +198,6 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
         }
     }
     m2 = qred(m2, true);
-#if PMGT_QA_MIDPOS == 2
-    mid();
-#endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -225,15 +208,10 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
             s1 += a1[jt][e];
             s2 += a2[jt][e];
         }
-#if PMGT_QA_MIDPOS == 1
-    mid();
-#endif
     s1 = qred(s1, false);
     s2 = qred(s2, false);
     const float c1 = kc.c_beta * __builtin_amdgcn_rcpf(s1), c2 = kc.c_omb * __builtin_amdgcn_rcpf(s2);
-#if PMGT_QA_MIDPOS == 0
     mid();
-#endif
     // mix + dropout -> P^T, packed as the B operand (k slot e of lane (r, q): key 16 (e >> 2) + 4 q + (e & 3))
     bf16x8 pb;
     const int i = 16 * it + r;
@@ -730,7 +708,7 @@ __global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
     // against 1024 of the matrix pipe), so this role spends as few vector instructions as it can: every per-lane address is a loop-invariant
     // register plus an IMMEDIATE ring-slot offset (the loop is unrolled over the four slots) or a scalar base (global side), and the bias is
     // the C operand of the first MFMA of each accumulator.
-    __builtin_amdgcn_s_setprio(2);         // the matrix pipe is the unit to keep fed: its waves win the issue arbitration
+    __builtin_amdgcn_s_setprio(2);         // the matrix pipe's waves first (measured neutral against 0 / attention-first: the kernel is bound by issue THROUGHPUT)
     const int g = wave;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(qa_lds_void_t*)smem;
     // v_mfma_f32_32x32x16_bf16, operands swapped (A = W rows = output columns, B = x rows): the 32 x 32 block of a wave is ONE
