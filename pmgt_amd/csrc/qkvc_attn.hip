@@ -689,7 +689,11 @@ __global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
             const int t = x + s * gx;
             const float mv = has_mask ? (1.f - *(const float*)(smem + C::MK0 + (s & 7) * 128 + (lane & 31) * 4)) * -10000.f : 0.f;
             const char* qt = smem + C::Q0 + (s & 3) * C::QTB;
+#ifdef PMGT_QA3_NO_ATTN
+            if (t >= 0) {                                 // (ablation build: the attention waves only keep the barriers)
+#else
             if (it == 1 && t < a.cls_only_seqs) {         // (wave-uniform) only query row 0 of this sequence is ever read
+#endif
                 bar();
             } else {
                 bf16* crow = CTX + ((int64_t)t * 32 + 16 * it + r) * a.ldc + h * 32;

@@ -40,7 +40,7 @@ def run(L, n):
     ev[0].record()
     for k in range(n):
         s = sets[k % NS]
-        rc = L.pmgt_op_attention_bwd_wgrad(P(s["q"]), P(mask), P(s["do"]), P(s["x"]), P(dx), P(slab), P(bslab), T, H, 0.5, 0.1, 11, 12, P(rng), 1, st)
+        rc = L.pmgt_op_attention_bwd_wgrad(P(s["q"]), P(mask), P(s["do"]), P(s["x"]), P(dx), P(slab), P(bslab), T, H, 0.5, float(os.environ.get("QA_AB_DROP", "0.1")), 11, 12, P(rng), 1, st)
         assert rc == 0, rc
     ev[1].record()
     torch.cuda.synchronize()

@@ -44,7 +44,7 @@ def run(L, n):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for k in range(n):
-        rc = L.pmgt_op_qkvc_attention_fwd(P(xs[k % NS]), P(W), P(bias), None if os.environ.get("QA_AB_NOMASK") else P(mask), P(qk), P(ctx), T, S, H, dh, 0.5, 0.1, 1, 2, P(rng), st)
+        rc = L.pmgt_op_qkvc_attention_fwd(P(xs[k % NS]), P(W), P(bias), None if os.environ.get("QA_AB_NOMASK") else P(mask), P(qk), P(ctx), T, S, H, dh, 0.5, float(os.environ.get("QA_AB_DROP", "0.1")), 1, 2, P(rng), st)
         assert rc == 0, rc
     ev[1].record()
     torch.cuda.synchronize()
