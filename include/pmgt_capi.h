@@ -257,6 +257,10 @@ void pmgt_debug_disable_producer_quant(int on);
 /* A/B switch: 1 sums every set of partial sums of the backward pass (weight-gradient slabs, bias and LayerNorm partials) with a
  * launch of its own right after its producer, instead of one batched launch per gradient bucket */
 void pmgt_debug_disable_deferred_reductions(int on);
+/* A/B switch: 1 makes every LayerNorm site store its input for the backward pass; by default the sites whose LayerNorm runs in the
+ * epilogue of the streaming GEMM (bf16, hidden size 256) do not, and their backward takes the normalised row from the LayerNorm
+ * OUTPUT: x^ = (y - beta) / gamma */
+void pmgt_debug_disable_layernorm_from_output(int on);
 /* A/B switch: 1 keeps the attention backward and the Q|K|V|C weight gradient as two kernels */
 void pmgt_debug_disable_fused_attention_backward(int on);
 /* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */

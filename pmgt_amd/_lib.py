@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd", "pmgt_debug_force_valu_attention", "pmgt_debug_force_tile_gemm", "pmgt_debug_enable_nt_dma", "pmgt_engine_set_overlap", "pmgt_op_qkvc_attention_fwd", "pmgt_debug_disable_fused_qkvc_attention", "pmgt_debug_disable_table_projection", "pmgt_debug_disable_segment_sum", "pmgt_debug_disable_head_major", "pmgt_debug_disable_coop_attention_bwd", "pmgt_debug_disable_last_layer_shortcut", "pmgt_op_linear",
     "pmgt_quantize_e4m3", "pmgt_dequantize_e4m3", "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8",
     "pmgt_op_qkvc_attention_fwd_f8", "pmgt_op_gemm_tn_bias", "pmgt_debug_disable_producer_quant",
-    "pmgt_engine_set_grad_ready_callback", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts", "pmgt_debug_disable_fused_attention_backward", "pmgt_debug_disable_deferred_reductions",
+    "pmgt_engine_set_grad_ready_callback", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts", "pmgt_debug_disable_fused_attention_backward", "pmgt_debug_disable_deferred_reductions", "pmgt_debug_disable_layernorm_from_output",
 ]
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
@@ -148,6 +148,8 @@ def hip():
     L.pmgt_op_attention_bwd_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, f, f, u32, u32, vp, i, vp]
     L.pmgt_op_attention_bwd_wgrad_parts.argtypes = [i]
     L.pmgt_debug_disable_fused_attention_backward.argtypes = [i]
+    L.pmgt_debug_disable_layernorm_from_output.argtypes = [i]
+    L.pmgt_debug_disable_layernorm_from_output.restype = None
     L.pmgt_debug_disable_deferred_reductions.argtypes = [i]
     L.pmgt_debug_disable_deferred_reductions.restype = None
     L.pmgt_debug_disable_fused_attention_backward.restype = None

@@ -244,6 +244,9 @@ struct Carver {
 template <typename T> struct LayerBufs {
     T *qkvc, *ctx, *ao_pre, *u, *ff_pre, *g, *fo_pre, *hout;
     float *stats1, *stats2;
+    // set by the forward pass: the fused-LayerNorm GEMM of that site did not store its pre-LayerNorm sum (ao_pre / fo_pre hold nothing) and
+    // the backward takes x^ from the LayerNorm output (u / hout) instead
+    bool ln1_from_y = false, ln2_from_y = false;
 };
 
 template <typename T> struct Bufs {
@@ -468,11 +471,20 @@ static int g_no_table_proj = 0;
 static int g_no_segsum = 0;
 static int g_no_producer_quant = 0;
 static int g_no_fused_abw = 0;
+static int g_no_ln_from_y = 0;       // 1: every LayerNorm site stores its input (pre-LayerNorm sum) for the backward pass
+
+// whether linear() will run `g` as a streaming GEMM with the LayerNorm in its epilogue (then the pre-LayerNorm sum need not be stored)
+template <typename T>
+static inline bool linear_fuses_ln(const GemmWS& g) {
+    if constexpr (sizeof(T) == 2) return !g_force_tile && g.ln_out != nullptr && gemm_ws_supported(g) && gemm_ws_fuses_ln(g);
+    return false;
+}
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (!g_force_tile && gemm_ws_supported(g)) {
+            PMGT_CHECK(!g.skip_c || gemm_ws_fuses_ln(g), -2, "linear: skip_c needs the fused-LayerNorm form");
             RUNP(name, gemm_ws(g, st));
             if (g.ln_out && !gemm_ws_fuses_ln(g))
                 RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
@@ -480,6 +492,7 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
             return 0;
         }
     }
+    PMGT_CHECK(!g.skip_c, -2, "linear: skip_c needs the fused-LayerNorm form");
     RUNP(name, gemm_nt<T>(g, st));
     if (g.ln_out)
         RUNP("fwd.layernorm", ln_fwd<T>((const T*)g.C, (T*)g.ln_out, g.ln_stats, g.ln_gamma, g.ln_beta, g.M, g.N, g.ln_eps,
@@ -632,6 +645,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.drop = dropcfg(t, train, pd, l, SITE_AO);
             g.res = hin; g.ldr = d; g.res_gather = sc;
             g.ln_out = tb.u; g.ln_stats = tb.stats1; g.ln_gamma = P + o.ln1g; g.ln_beta = P + o.ln1b; g.ln_eps = e->cfg.layer_norm_eps;
+            g.skip_c = tb.ln1_from_y = !g_no_ln_from_y && linear_fuses_ln<T>(g);
             RUN(linear<T>(e, "fwd.gemm_attn_out", g, st));
         }
         {   // BertIntermediate: gelu(dense(u))
@@ -657,6 +671,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
                     x8_ok = true;
                 }
             }
+            g.skip_c = tb.ln2_from_y = !g_no_ln_from_y && linear_fuses_ln<T>(g);
             RUN(linear<T>(e, "fwd.gemm_ffn2", g, st));
         }
         if (hidden_states)
@@ -773,12 +788,12 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
 // LayerNorm backward + the reduction of its dgamma | dbeta | dbias partials
 template <typename T>
 static int ln_bwd_reduce(const pmgt_engine* e, Bufs<T>& b, const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop,
-                         int Mt, int d, DropCfg out_drop, const int* mdev, float* dst, bool acc, hipStream_t main) {
+                         int Mt, int d, DropCfg out_drop, const int* mdev, float* dst, bool acc, hipStream_t main, const float* beta_y = nullptr) {
     if (b.defer) {
         hipStream_t st = main;
         float* part = nullptr;
         RUN(take_partials<T>(e, b, (int64_t)ln_bwd_parts(Mt) * 3 * d, &part, main));
-        RUNP("bwd.layernorm", ln_bwd<T>(dy, x, stats, gamma, dx, dx_drop, part, Mt, d, DropCfg{nullptr, 0.f, 0}, out_drop, main, mdev));
+        RUNP("bwd.layernorm", ln_bwd<T>(dy, x, stats, gamma, dx, dx_drop, part, Mt, d, DropCfg{nullptr, 0.f, 0}, out_drop, main, mdev, beta_y));
         RUN(queue_reduce<T>(e, b, part, ln_bwd_parts(Mt), 3 * d, dst, acc, main));
         return 0;
     }
@@ -787,7 +802,7 @@ static int ln_bwd_reduce(const pmgt_engine* e, Bufs<T>& b, const T* dy, const T*
     float* part = b.ln_part + (int64_t)slot * b.ln_part_elems;
     RUN(sr.acquire(b.ln_done[slot]));
     hipStream_t st = main;
-    RUNP("bwd.layernorm", ln_bwd<T>(dy, x, stats, gamma, dx, dx_drop, part, Mt, d, DropCfg{nullptr, 0.f, 0}, out_drop, st, mdev));
+    RUNP("bwd.layernorm", ln_bwd<T>(dy, x, stats, gamma, dx, dx_drop, part, Mt, d, DropCfg{nullptr, 0.f, 0}, out_drop, st, mdev, beta_y));
     RUN(sr.begin(&st));
     RUNP("bwd.slab_reduce", slab_reduce(part, ln_bwd_parts(Mt), 3 * d, dst, acc, st));
     RUN(sr.end(b.ln_done[slot]));
@@ -833,8 +848,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         T* gD = sc ? b.c_bD : b.bD;
         T* gbig = sc ? b.c_big : b.big;
         // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
-        RUN(ln_bwd_reduce<T>(e, b, gA, tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d, dropcfg(t, train, pd, l, SITE_FO),
-                             mdev, G + o.ln2g, acc, st));                                              // dgamma | dbeta | db2
+        RUN(ln_bwd_reduce<T>(e, b, gA, tb.ln2_from_y ? tb.hout : tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d,
+                             dropcfg(t, train, pd, l, SITE_FO), mdev, G + o.ln2g, acc, st, tb.ln2_from_y ? P + o.ln2b : nullptr));                                              // dgamma | dbeta | db2
         const T* dY2 = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
@@ -851,8 +866,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
         }
         // LN1 backward
-        RUN(ln_bwd_reduce<T>(e, b, gD, tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d, dropcfg(t, train, pd, l, SITE_AO),
-                             mdev, G + o.ln1g, acc, st));                                              // dgamma | dbeta | dbo
+        RUN(ln_bwd_reduce<T>(e, b, gD, tb.ln1_from_y ? tb.u : tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d,
+                             dropcfg(t, train, pd, l, SITE_AO), mdev, G + o.ln1g, acc, st, tb.ln1_from_y ? P + o.ln1b : nullptr));                                              // dgamma | dbeta | dbo
         const T* dYo = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
         {   // dctx = dYo Wo
@@ -1421,6 +1436,7 @@ void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
 void pmgt_debug_disable_head_major(int on) { g_no_hm = on; }
 void pmgt_debug_disable_producer_quant(int on) { g_no_producer_quant = on; }
 void pmgt_debug_disable_fused_attention_backward(int on) { g_no_fused_abw = on; }
+void pmgt_debug_disable_layernorm_from_output(int on) { g_no_ln_from_y = on; }
 void pmgt_debug_disable_deferred_reductions(int on) { g_no_defer_reduce = on; }
 void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
 void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, void* user) {

@@ -38,6 +38,8 @@ struct GemmWS : GemmNT {
     // next layer's fp8 Q|K|V|C projection: q8 [M, N] bytes, q8_scale [M]
     void* q8 = nullptr;
     float* q8_scale = nullptr;
+    // fused-LayerNorm form only: do not store C, the pre-LayerNorm sum (the LayerNorm backward then takes x^ from the OUTPUT: rowops.h)
+    bool skip_c = false;
 };
 bool gemm_ws_supported(const GemmWS& g);
 bool gemm_ws_fuses_ln(const GemmWS& g);     // false: the caller runs LayerNorm as its own launch

@@ -266,7 +266,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
-                *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
+                if (!(MODE == WS_RES_LN && g.skip_c)) *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;

@@ -14,9 +14,12 @@ int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta
 // dx = LN'(dy * in_mask); optional second output dx_drop = dx * out_mask (gradient of the dropout
 // that fed the residual sum).  Partials go to `part` ([ln_bwd_parts(M)][3][d] floats): dgamma, dbeta and
 // dbias = column sum of dx_drop (or dx): the bias gradient of the dense layer in front of the LayerNorm.
+// `beta_y` != NULL: `x` is the LayerNorm OUTPUT y (what the next sublayer reads anyway) and x^ = (y - beta) / gamma -- the forward
+// pass then never stores the pre-LayerNorm sum (1U of HBM writes per LayerNorm).  Only rstd of `stats` is read; a channel with
+// gamma == 0 gets x^ = 0 (its output is constant).
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
-           int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr);
+           int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr, const float* beta_y = nullptr);
 // rows per workgroup (measured at M = 393k: 64 -> 189 us, 128 -> 192 us, 256 -> 198 us incl. the partial reduction)
 __host__ __device__ inline int ln_bwd_rows(int M) { (void)M; return 64; }
 inline int ln_bwd_parts(int M) { return cdiv(M, ln_bwd_rows(M)); }

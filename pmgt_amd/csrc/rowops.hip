@@ -102,11 +102,12 @@ template int ln_fwd<bf16>(const bf16*, bf16*, float*, const float*, const float*
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  64 rows per block (16 per wave, two at a time); dgamma/dbeta partials per block.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NCH>
+template <typename T, int NCH, bool FROMY = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
-                                                     int M, int d, DropCfg in_drop, DropCfg out_drop, const int* m_dev, int rpb) {
+                                                     int M, int d, DropCfg in_drop, DropCfg out_drop, const int* m_dev, int rpb,
+                                                     const float* __restrict__ beta_y = nullptr) {
     __shared__ float red[3 * 1024];
     if (m_dev) M = min(M, *m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,11 +115,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const float inv_d = 1.f / (float)d;
     const DropKey ik = make_drop_key(in_drop), ok = make_drop_key(out_drop);
     f32x4 gam[NCH], dgam[NCH], dbet[NCH], dbia[NCH];
+    f32x4 bety[FROMY ? NCH : 1], igam[FROMY ? NCH : 1];      // FROMY: x^ = (y - beta) * (1 / gamma)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         gam[i] = ch < nch ? *(const f32x4*)(gamma + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
         dgam[i] = dbet[i] = dbia[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (FROMY) {
+            bety[i] = ch < nch ? *(const f32x4*)(beta_y + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) igam[i][e] = gam[i][e] != 0.f ? 1.f / gam[i][e] : 0.f;
+        }
     }
     // one row of the wave: dx, and the row's terms of the three column sums (rows are taken in increasing order, so the sums
     // do not depend on how many rows are in flight)
@@ -135,7 +142,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
                 }
-                xh[i] = (xl[i] - mean) * rstd;
+                if constexpr (FROMY) xh[i] = (xl[i] - bety[i]) * igam[i];
+                else xh[i] = (xl[i] - mean) * rstd;
                 g[i] = dyv * gam[i];
                 dgam[i] += dyv * xh[i];
                 dbet[i] += dyv;
@@ -210,18 +218,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part, int M,
-           int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev) {
+           int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev, const float* beta_y) {
     if (M <= 0) return 0;
     PMGT_CHECK(d % 4 == 0 && d <= 1024, -2, "ln_bwd: hidden size %d must be a multiple of 4 and <= 1024", d);
     dim3 grid(ln_bwd_parts(M)), block(256);
-    if (d <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, ln_bwd_rows(M));
-    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, ln_bwd_rows(M));
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, ln_bwd_rows(M));
+    const int rpb = ln_bwd_rows(M);
+#define PMGT_LNB(NCH_)                                                                                                                     \
+    do {                                                                                                                                   \
+        if (beta_y) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH_, true>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, rpb, beta_y); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<T, NCH_, false>), grid, block, 0, st, dy, x, stats, gamma, dx, dx_drop, part, M, d, in_drop, out_drop, m_dev, rpb, beta_y);       \
+    } while (0)
+    if (d <= 256) PMGT_LNB(1);
+    else if (d <= 512) PMGT_LNB(2);
+    else PMGT_LNB(4);
+#undef PMGT_LNB
     PMGT_LAUNCH_OK();
     return 0;
 }
-template int ln_bwd<float>(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*);
-template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, bf16*, bf16*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*);
+template int ln_bwd<float>(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*, const float*);
+template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, bf16*, bf16*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*, const float*);
 
 // ------------------------------------------------------------------------------------------------
 // Embedding mix forward: a = softmax(Wa tanh([e_v;e_t]) + ba); x = a0 e_v + a1 e_t + pos[s] + role[s>0];

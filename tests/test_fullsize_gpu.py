@@ -52,7 +52,8 @@ def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
     o_fast = step(fast, world, want_hidden=False)
     switches = [L.pmgt_debug_disable_table_projection, L.pmgt_debug_disable_fused_qkvc_attention, L.pmgt_debug_disable_head_major,
                 L.pmgt_debug_disable_last_layer_shortcut, L.pmgt_debug_force_tile_gemm, L.pmgt_debug_disable_segment_sum,
-                L.pmgt_debug_disable_fused_attention_backward, L.pmgt_debug_disable_deferred_reductions]
+                L.pmgt_debug_disable_fused_attention_backward, L.pmgt_debug_disable_deferred_reductions,
+                L.pmgt_debug_disable_layernorm_from_output]
     for f in switches:
         f(1)
     try:
