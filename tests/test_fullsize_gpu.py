@@ -83,6 +83,41 @@ def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
         assert fast.view(f"bert.encoder.layer.{l}.attention.self.key.bias", grad=True).abs().max().item() < 1e-6
 
 
+def test_layernorm_backward_from_the_layernorm_output_matches_the_stored_input_form(world):
+    """Where the LayerNorm runs in the streaming GEMM's epilogue, the forward does not store the pre-LayerNorm sum and the backward takes
+    x^ = (y - beta) / gamma from the LayerNorm output (rowops.h).  Same forward values exactly (the switch only drops a store); gradients
+    equal up to the bf16 round-off of the two carriers of x^ -- with gamma away from 1 and beta away from 0, so that neither drops out."""
+    from pmgt_amd import _lib
+    L = _lib.hip()
+
+    def run(stored):
+        L.pmgt_debug_disable_layernorm_from_output(1 if stored else 0)
+        try:
+            eng = engine(world)
+            g = torch.Generator().manual_seed(11)
+            for l in range(4):
+                for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
+                    w = eng.view(f"bert.encoder.layer.{l}.{ln}.weight")
+                    w.copy_((0.6 + 0.8 * torch.rand(w.shape, generator=g)).to(w.device))
+                    bb = eng.view(f"bert.encoder.layer.{l}.{ln}.bias")
+                    bb.copy_((0.3 * torch.randn(bb.shape, generator=g)).to(bb.device))
+            return eng, step(eng, world, want_hidden=False)
+        finally:
+            L.pmgt_debug_disable_layernorm_from_output(0)
+
+    ey, oy = run(False)
+    es, os_ = run(True)
+    assert oy["loss"].item() == os_["loss"].item() and torch.equal(oy["logits"], os_["logits"])
+    cos = torch.nn.functional.cosine_similarity(ey.grads, es.grads, dim=0).item()
+    assert cos > 0.9999, cos
+    for l in (0, 2):
+        for name in (f"bert.encoder.layer.{l}.attention.output.LayerNorm.weight", f"bert.encoder.layer.{l}.output.LayerNorm.weight",
+                     f"bert.encoder.layer.{l}.output.LayerNorm.bias", f"bert.encoder.layer.{l}.intermediate.dense.weight"):
+            a, b = ey.view(name, grad=True), es.view(name, grad=True)
+            assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.999, name
+            assert (a - b).norm().item() <= 3e-2 * b.norm().item(), name
+
+
 def test_full_size_step_is_reproducible_and_descends(world):
     a, b = engine(world), engine(world)
     oa, ob = step(a, world, want_hidden=False), step(b, world, want_hidden=False)
