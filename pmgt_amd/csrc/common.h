@@ -181,10 +181,21 @@ __device__ __forceinline__ float erfc_abs_fast(float ax) {
     return __builtin_amdgcn_exp2f(-(p * a));
 }
 __device__ __forceinline__ float gelu_fast(float x) { return fmaf(-0.5f * fabsf(x), erfc_abs_fast(fabsf(x)), fmaxf(x, 0.f)); }
+// gelu'(x) = Phi(x) + x phi(x).  gelu' - 1/2 is odd: t P(t^2) on t = clamp(x, -4, 4) / 4, eight coefficients (tools/fit_gelu.py, grad mode):
+// |error| <= 2.7e-4 everywhere (the clamp included: gelu'(+-4) is within 5e-4 of its limit) -- a tenth of the bf16 rounding of the product it
+// enters.  11 VALU operations and no transcendental; the erfc / exp form it replaces took 18 with two (the GELU' epilogue of the streaming
+// GEMM is vector-issue-bound: 143 us per launch against 111 us for the residual epilogue with the same bytes).
 __device__ __forceinline__ float gelu_fast_grad(float x) {
-    const float hc = 0.5f * erfc_abs_fast(fabsf(x));
-    const float cdf = x > 0.f ? 1.f - hc : hc;
-    return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f), cdf);
+    const float t = __builtin_amdgcn_fmed3f(x, -4.f, 4.f) * 0.25f, t2 = t * t;
+    float p = -1.763080788e+01f;
+    p = fmaf(p, t2, 8.145783234e+01f);
+    p = fmaf(p, t2, -1.613120728e+02f);
+    p = fmaf(p, t2, 1.802627869e+02f);
+    p = fmaf(p, t2, -1.259512939e+02f);
+    p = fmaf(p, t2, 5.725682831e+01f);
+    p = fmaf(p, t2, -1.676991463e+01f);
+    p = fmaf(p, t2, 3.186886549e+00f);
+    return fmaf(p, t, 0.5f);
 }
 template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
     if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
