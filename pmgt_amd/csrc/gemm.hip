@@ -378,6 +378,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
     // one DMA instruction of a stage (piece 0 .. AI - 1: A rows, AI .. PER - 1: B rows)
     auto issue_piece = [&](int kt, int piece) __attribute__((always_inline)) {
         char* st = smem + (kt % NST) * STAGE;
+#ifdef PMGT_NT_NO_A
+        if (piece < AI && g.M > 0) return;      // (ablation builds: the A / the W stream is not fetched; results are garbage)
+#endif
+#ifdef PMGT_NT_NO_W
+        if (piece >= AI && g.M > 0) return;
+#endif
         if (piece < AI)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[piece] + (int64_t)kt * ROWB),
                                              (lds_void_t*)(st + 16 * (AI * wave + piece) * ROWB), 16, 0, 0);
