@@ -223,12 +223,19 @@ __device__ __forceinline__ void probs_T2(const bf16x8 (&fq)[NT][KD], const bf16x
 
 // A operand / B operand fragment of an [i][j] bf16 image (row stride LDB bytes) whose k index runs down the ROWS:
 // element e of lane (r, q) = img[k0 + 8 q + e][c0 + r]  (ds_read_b64_tr_b16, as tr_frag<., false> does for the tiles)
+// Byte offset of the 8-byte chunk at byte column `colb` of image row `row`.  64-byte rows (S = 32): sixteen lanes of a ds_write_b64 group hold
+// sixteen consecutive rows of ONE chunk column -- 64-byte strides, i.e. two bank pairs for all of them (8-way: SQ_LDS_BANK_CONFLICT / IDX_ACTIVE
+// = 0.75 for this kernel); the chunk index is XORed with (row >> 1) & 7, which spreads rows of equal parity over the eight chunk positions.
+template <int LDB> __device__ __forceinline__ int img_off(int row, int colb) {
+    if constexpr (LDB == 64) return row * 64 + ((((colb >> 3) ^ (row >> 1)) & 7) << 3) + (colb & 7);
+    else return row * LDB + colb;
+}
 template <int LDB>
 __device__ __forceinline__ bf16x8 img_frag(const char* img, int k0, int c0, int r, int q) {
     const int row_lo = k0 + 8 * q + (r >> 2), row_hi = row_lo + 4;
     const int colb = (c0 + 4 * (r & 3)) * 2;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + row_lo * LDB + colb));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + row_hi * LDB + colb));
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + img_off<LDB>(row_lo, colb)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + img_off<LDB>(row_hi, colb)));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x4 pack4(const f32x4& v) { return (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
@@ -597,14 +604,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         if (it >= ntq) {        // no gradient through these queries: zero rows in the three images (a1 / a2 are set to 0)
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                *(bf16x4*)(iS1 + i * LDI + (16 * jt + 4 * q) * 2) = z4;
+                *(bf16x4*)(iS1 + img_off<LDI>(i, (16 * jt + 4 * q) * 2)) = z4;
                 a1[jt][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 a2[jt][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if constexpr (SM::ALIAS) {
                     pmr[jt][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 } else {
-                    *(bf16x4*)(iP + i * LDI + (16 * jt + 4 * q) * 2) = z4;
-                    *(bf16x4*)(iS2 + i * LDI + (16 * jt + 4 * q) * 2) = z4;
+                    *(bf16x4*)(iP + img_off<LDI>(i, (16 * jt + 4 * q) * 2)) = z4;
+                    *(bf16x4*)(iS2 + img_off<LDI>(i, (16 * jt + 4 * q) * 2)) = z4;
                 }
             }
             continue;
@@ -637,12 +644,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
                 a1[jt][it][e] = a1[jt][it][e] * (g1[jt][e] - rd1);     // dS1; a == 0 on padding -> ds == 0
                 a2[jt][it][e] = a2[jt][it][e] * (g2[jt][e] - rd2);     // dS2
             }
-            *(bf16x4*)(iS1 + i * LDI + (16 * jt + 4 * q) * 2) = pack4(a1[jt][it]);
+            *(bf16x4*)(iS1 + img_off<LDI>(i, (16 * jt + 4 * q) * 2)) = pack4(a1[jt][it]);
             if constexpr (SM::ALIAS) {
                 pmr[jt][it] = pm[jt];
             } else {
-                *(bf16x4*)(iP + i * LDI + (16 * jt + 4 * q) * 2) = pack4(pm[jt]);
-                *(bf16x4*)(iS2 + i * LDI + (16 * jt + 4 * q) * 2) = pack4(a2[jt][it]);
+                *(bf16x4*)(iP + img_off<LDI>(i, (16 * jt + 4 * q) * 2)) = pack4(pm[jt]);
+                *(bf16x4*)(iS2 + img_off<LDI>(i, (16 * jt + 4 * q) * 2)) = pack4(a2[jt][it]);
             }
         }
     }
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
         for (int it = 0; it < NT; ++it)
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                const int off = (16 * it + r) * LDI + (16 * jt + 4 * q) * 2;
+                const int off = img_off<LDI>(16 * it + r, (16 * jt + 4 * q) * 2);
                 *(bf16x4*)(iP + off) = pack4(pmr[jt][it]);
                 *(bf16x4*)(iS2 + off) = pack4(a2[jt][it]);
             }
