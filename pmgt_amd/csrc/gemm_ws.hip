@@ -266,6 +266,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
+#ifdef PMGT_WS_ABL_NO_C
+                if (g.M < 0)
+#endif
                 if (!(MODE == WS_RES_LN && g.skip_c)) *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
             } else {
 #pragma unroll
@@ -286,7 +289,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                 const float rstd = __builtin_amdgcn_rsqf(ss * (1.f / 256.f) + g.ln_eps);
                 bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) {
-                    if ((tid & 31) == 0) { g.ln_stats[2 * (int64_t)m] = mean; g.ln_stats[2 * (int64_t)m + 1] = rstd; }
+#ifdef PMGT_WS_ABL_NO_STATS
+                    if (g.M < 0)
+#endif
+                    if ((tid & 31) == 0) *(float2*)(g.ln_stats + 2 * (int64_t)m) = make_float2(mean, rstd);      // one 8-byte store (two store instructions cost this epilogue 3 %)
                     const f32x4 g0 = *(const f32x4*)(cvec + 256 + ecol), g1 = *(const f32x4*)(cvec + 256 + ecol + 4);
                     const f32x4 b0 = *(const f32x4*)(cvec + 512 + ecol), b1 = *(const f32x4*)(cvec + 512 + ecol + 4);
 #pragma unroll
@@ -294,6 +300,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                         o[e] = (bf16)((v[e] - mean) * rstd * g0[e] + b0[e]);
                         o[4 + e] = (bf16)((v[4 + e] - mean) * rstd * g1[e] + b1[e]);
                     }
+#ifdef PMGT_WS_ABL_NO_LNO
+                    if (g.M < 0)
+#endif
                     *(bf16x8*)(LNO + (int64_t)m * g.ldc + n) = o;
                 }
                 if (g.q8) {      // (uniform) the row as e4m3 for the next layer's fp8 projection; every lane joins the row maximum
