@@ -8,7 +8,10 @@ AdamW.  Inputs (sampled node-context batches, feature tables) are resident in HB
 region.  Workload at N=1: BASELINE.json configs[1] — VG-sized synthetic item graph (7 252 nodes /
 88 606 edges), L=4 H=8 d=256 I=256 S=32, bf16, B=1024 targets/GPU/step, dropout 0.1, lr 1e-4, wd 1e-2, clip 5.0.
 
-Prints ONE JSON line (rank 0).  Launch N > 1 with torch.distributed.run (one process per GPU).
+Prints ONE JSON line (rank 0).  N > 1: one process per GPU -- either launched by torch.distributed.run (the driver's
+form: WORLD_SIZE / RANK / LOCAL_RANK in the environment, `--gpus` must equal WORLD_SIZE), or `python bench.py --gpus N` alone:
+with WORLD_SIZE unset this process starts the N ranks itself (torch.distributed.run as a child, before anything here touches
+the GPU) and exits with their status -- what `pl.Trainer(gpus=N)` does for the reference (pmgt/base_trainer.py:309-322).
 """
 import argparse
 import json
@@ -54,7 +57,43 @@ def parse():
     ap.add_argument("--end-to-end", action="store_true", help="N = 1: on by default; N > 1: also time steps fed by the live host sampler on every rank")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the live-sampler pass")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the B=32 / B=256 extra measurements (N=1 only)")
+    ap.add_argument("--buckets", default="layer", choices=["layer", "two", "one"],
+                    help="N > 1: gradient all-reduce per engine bucket (NFR head, each layer, embeddings), as two collectives "
+                         "(head + encoder layers | embeddings), or as one after the backward pass")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher check that needs no GPU: the ranks rendezvous over gloo, all-reduce their ranks and rank 0 prints "
+                         "a line with n_gpus = world and value = null")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N rank processes (torch.distributed.run, rendezvous on
+    127.0.0.1) running this same command line and return their exit status.  Called before any GPU call of this process: the
+    parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_launch(world, rank):
+    """No GPU: proves the launch path (rank environment, rendezvous, a collective, symmetric teardown, one line from rank 0)."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "PMGT pre-train nodes/sec", "value": None, "unit": "target nodes/s", "n_gpus": world,
+                          "rehearsal": "launch only (gloo, no GPU)", "rank_sum": t.item()}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
@@ -139,9 +178,16 @@ def time_steps(trainer, staged, steps, warmup):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line "
+                 f"for a different GPU count than was asked for")
+    if args.rehearse_launch:
+        return rehearse_launch(world, rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -178,7 +224,7 @@ def main():
     reference_init(eng, seed=0)
     eng.set_tables(vis, txt)
     del vis, txt
-    trainer = Trainer(eng, lr=1e-4, weight_decay=1e-2, max_grad_norm=5.0, world_size=world)
+    trainer = Trainer(eng, lr=1e-4, weight_decay=1e-2, max_grad_norm=5.0, world_size=world, buckets=args.buckets)
     trainer.broadcast_parameters()
 
     # ---- pre-stage node-context batches in HBM (host MCNSampling, C++ worker pool)
@@ -268,8 +314,10 @@ def main():
         "side_stream_reductions": bool(args.overlap),
         "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count(),
                          "cpu_share": round(share, 1)},
-        "allreduce": ("per-bucket, overlapped with the backward pass" if world > 1 else None),
+        "allreduce": None,
     }
+    if world > 1:
+        out["allreduce"] = measure_allreduce(trainer, eng, dev)
 
     flops_node = train_flops_per_node(d, I, L, S)
     out["train_gflop_per_node"] = round(flops_node / 1e9, 3)
@@ -378,6 +426,43 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()                      # nobody tears the group down while a peer is still inside a collective
         dist.destroy_process_group()
+
+
+def measure_allreduce(trainer, eng, dev):
+    """The exchange step in numbers (every rank runs this; same collectives in the same order): the slices the trainer
+    all-reduced in its last step, all-reduced again back to back on an otherwise idle GPU and timed with events on the stream
+    they are ordered against -- the un-overlapped cost of one step's exchange (in the timed steps they run next to the
+    backward pass of the earlier layers)."""
+    import torch.distributed as dist
+    ex = trainer._exchange
+    sent = list(getattr(ex, "last_sent", [])) if ex is not None else [(0, eng.n_params)]
+    if not sent:
+        sent = [(0, eng.n_params)]
+    scratch = torch.zeros_like(eng.grads)
+    avg = dist.get_backend() == "nccl"
+    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    reps = 10
+    for _ in range(2):
+        for off, n in sent:
+            dist.all_reduce(scratch[off: off + n], op=op)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        works = [dist.all_reduce(scratch[off: off + n], op=op, async_op=True) for off, n in sent]
+        for w in works:
+            w.wait()
+    e1.record()
+    torch.cuda.synchronize()
+    alone_ms = e0.elapsed_time(e1) / reps
+    tt = torch.tensor([alone_ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return {"buckets": len(sent), "mb": round(sum(n for _, n in sent) * 4 / 1e6, 3), "ms_per_step": round(tt.item(), 4),
+            "bucket_mb": [round(n * 4 / 1e6, 3) for _, n in sent], "policy": trainer.buckets,
+            "overlapped_with_backward": ex is not None and trainer.buckets != "one",
+            "note": "ms_per_step = the step's collectives issued back to back on an idle GPU (max over ranks); in the timed steps "
+                    "they run next to the backward pass"}
 
 
 def cpu_baseline(cfg, graph, S, dropout):

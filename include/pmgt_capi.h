@@ -163,7 +163,7 @@ int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* 
  * writes and overlaps the rest of the backward pass.  Buckets arrive in backward order and tile the flat buffer exactly
  * once per backward call: NFR head (pmgt_pretrain_step only; pmgt_encode_backward produces no gradient for it and its
  * buckets tile the `bert.*` range), encoder layers L-1 .. 0, embeddings.  cb = NULL switches it off.  With the
- * side-stream reductions on (pmgt_engine_set_overlap) one bucket covering the whole buffer is reported at the end. */
+ * options "side_stream_reduce" or "one_bucket" set, one bucket covering the whole buffer is reported at the end. */
 typedef void (*pmgt_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
 void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, void* user);
 
@@ -182,104 +182,15 @@ int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* st
 int pmgt_quantize_e4m3(const float* src, void* dst, int64_t n, float inv_scale, void* stream);
 int pmgt_dequantize_e4m3(const void* src, float* dst, int64_t n, float scale, void* stream);
 
-/* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
-/* per-row absmax e4m3 quantisation (weights per output channel, activations per token): scale[r] = max|row| / 448 */
-int pmgt_op_quant_rows_e4m3(int src_dtype, const void* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd,
-                            float* scale, void* stream);
-/* C (bf16) = (A8 B8^T) * a_scale(row) * b_row_scale[n] + bias on the fp8 MFMA; a_rows = optional row gather on A */
-int pmgt_op_gemm_nt_f8(const void* A, int64_t lda, const int64_t* a_rows, const float* a_row_scale, float a_scale,
-                       const void* B, int64_t ldb, const float* b_row_scale, void* C, int64_t ldc, int M, int N, int K,
-                       const float* bias, const int* m_dev, void* stream);
-/* weight gradient with an e4m3 Q operand (feature-table rows): out = P^T (Q8 * q_scale), P bf16 */
-int pmgt_op_gemm_tn_f8(const void* P, int64_t ldp, const void* Q8, int64_t ldq, float q_scale, const int64_t* q_rows, int M,
-                       int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream);
-/* fused projection + attention forward with the projection on the fp8 MFMA (d = 256): w8 [4d, d] e4m3, wscale [4d]; the layer
- * input either as bf16 x (quantised per row inside the kernel) or, x8 != NULL, as e4m3 rows + one scale per row */
-int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* x8, const float* xscale, const void* w8, const float* wscale, const float* bias, const float* mask,
-                                  void* qkvc, void* ctx, int n_seq, int S, int H, int dh, float beta, float drop_p,
-                                  uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream);
-int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
-                    int64_t ldc, int M, int N, int K, const float* bias, int epilogue, void* aux, int64_t ldaux,
-                    const void* residual, int64_t ldr, float drop_p, uint32_t drop_site, const uint64_t* rng,
-                    const int* m_dev, void* stream);
-int64_t pmgt_op_gemm_tn_slab_elems(int dtype, int M, int N1, int N2);
-int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, const int64_t* q_rows, int M,
-                    int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream);
-/* the same with the bias gradient (column sums of P; bias_slab: [512][N1] scratch) and the head-major row permutation of
- * the Q|K|V|C projection (perm_d = hidden size, perm_dh = head size; 0 = none) */
-int pmgt_op_gemm_tn_bias(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, int M, int N1, int N2, float* slab,
-                         float* out, float* bias_slab, float* bias_out, int perm_d, int perm_dh, void* stream);
-/* column sums of Y [M, N]; slab: ceil(M / 96) * N floats of scratch */
-int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream);
-int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const float* gamma, const float* beta,
-                          int M, int d, float eps, float drop_p, uint32_t drop_site, const uint64_t* rng, void* stream);
-/* part: [ceil(M/64)][3][d] scratch; dgamma_dbeta: [3*d] out = dgamma | dbeta | column sum of dx_drop (or dx) */
-int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
-                          void* dx_drop, float* part, float* dgamma_dbeta, int M, int d, float in_drop_p,
-                          uint32_t in_site, float out_drop_p, uint32_t out_site, const uint64_t* rng, void* stream);
-/* One linear layer through the engine's dispatcher: bf16 with K <= 256 runs the weight-stationary streaming
- * kernel (gemm_ws.hip), everything else the tiled one; ln_out != NULL adds LayerNorm(C) (fused when N == 256). */
-int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
-                   const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
-                   uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
-                   const float* ln_beta, float ln_eps, void* stream);
-/* A/B switch: 1 runs the last layer on every token even when last_hidden is not requested */
-void pmgt_debug_disable_last_layer_shortcut(int on);
-/* The engine owns a second HIP stream for work that is off the dependent chain: the partial-sum reductions of the
- * backward pass (weight-gradient slabs, bias and LayerNorm partials; double-buffered, fork/join by events) and the token
- * sort of the table mode.  Everything is joined before the call returns control of `stream`.  The sort always
- * overlaps the forward pass; the reductions move only with on = 1 (or PMGT_OVERLAP=1 at engine creation): measured
- * neutral on MI355X (the launch queue already hides them). */
-void pmgt_engine_set_overlap(pmgt_engine* e, int on);
-/* A/B switch: 1 selects the LDS-DMA variant of the tiled NT kernel (default: register-staged; same speed) */
-void pmgt_debug_enable_nt_dma(int on);
-/* A/B switch: 1 forces the register-staged tiled GEMM kernels everywhere (no streaming, no LDS-DMA) */
-void pmgt_debug_force_tile_gemm(int on);
-/* A/B switch: 1 routes bf16 attention through the generic fp32-VALU kernel instead of the MFMA one */
-void pmgt_debug_force_valu_attention(int on);
-/* A/B switch: 1 = one wave per (sequence, head) in the MFMA attention backward instead of NT cooperating waves */
-void pmgt_debug_disable_coop_attention_bwd(int on);
-/* Fused Q|K|V|C projection + attention forward (bf16; S = 32, dh = 32, hidden 128 or 256; returns -3 otherwise):
- * x [n_seq*S, d], w [4d, d] (rows q | k | v | c), bias [4d] fp32 -> qkvc [n_seq*S, 4d], ctx [n_seq*S, d]. */
-int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,
-                               int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
-                               const uint64_t* rng, void* stream);
-/* A/B switch: 1 projects features per token even when the whole table is smaller than half the batch's tokens */
-void pmgt_debug_disable_table_projection(int on);
-/* A/B switch: 1 keeps the per-token weight-gradient GEMM of the feature projection in table mode (no segment sums) */
-void pmgt_debug_disable_segment_sum(int on);
-/* A/B switch: 1 keeps Q|K|V|C in q | k | v | c column order between the fused forward and the attention backward
- * (default in training: head-major, 4 * dh contiguous elements per (row, head)) */
-void pmgt_debug_disable_head_major(int on);
-/* A/B switch (fp8 mode): 1 = layer inputs are quantised by their consumer (inside the fused projection + attention kernel)
- * instead of by the kernel that produces them (fused-LayerNorm epilogue of the FFN2 GEMM, embed_mix); bit-identical results */
-void pmgt_debug_disable_producer_quant(int on);
-/* A/B switch: 1 sums every set of partial sums of the backward pass (weight-gradient slabs, bias and LayerNorm partials) with a
- * launch of its own right after its producer, instead of one batched launch per gradient bucket */
-void pmgt_debug_disable_deferred_reductions(int on);
-/* A/B switch: 1 makes every LayerNorm site store its input for the backward pass; by default the sites whose LayerNorm runs in the
- * epilogue of the streaming GEMM (bf16, hidden size 256) do not, and their backward takes the normalised row from the LayerNorm
- * OUTPUT: x^ = (y - beta) / gamma */
-void pmgt_debug_disable_layernorm_from_output(int on);
-/* A/B switch: 1 keeps the attention backward and the Q|K|V|C weight gradient as two kernels */
-void pmgt_debug_disable_fused_attention_backward(int on);
-/* A/B switch: 1 keeps the projection GEMM and the attention as two kernels */
-void pmgt_debug_disable_fused_qkvc_attention(int on);
-int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,
-                          int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
-                          const uint64_t* rng, void* stream);
-int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq,
-                          int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
-                          const uint64_t* rng, void* stream);
-/* Attention backward fused with the weight / bias gradient of the Q|K|V|C projection (bf16, S = 32, head size 32, hidden 128 or
- * 256; replaces pmgt_op_attention_bwd + the [M, 4d]^T [M, d] weight-gradient GEMM, i.e. autograd through
- * pmgt/pmgt/modeling_pmgt.py:429-433 and :435-526).  x = the layer input [n_seq * 32, d]; dqkvc as pmgt_op_attention_bwd;
- * slab [parts][4d * d] / bias_slab [parts][4d] (parts = pmgt_op_attention_bwd_wgrad_parts(H)) receive per-workgroup partial
- * sums in q | k | v | c row order, to be added up by the caller.  head_major = the column layout of qkvc / dqkvc. */
-int pmgt_op_attention_bwd_wgrad_parts(int H);
-int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void* dctx, const void* x, void* dqkvc, float* slab,
-                                float* bias_slab, int n_seq, int H, float beta, float drop_p, uint32_t site1, uint32_t site2,
-                                const uint64_t* rng, int head_major, void* stream);
+/* Path options: PER-ENGINE switches between the fused / streaming kernels of the product path and their plain
+ * counterparts (parity A/B, bisecting).  key = one of the names listed in include/pmgt_ops.h ("store_ln_input",
+ * "no_fused_attention_bwd", ...), value 0 = product path (default), 1 = alternative.  Returns 0, or -2 for an unknown key.
+ * Options are state of THIS engine only: two engines in one process do not see each other's choices, and nothing in the
+ * library reads the environment.  Set them before the first pmgt_workspace_bytes / step call of a shape (workspace
+ * carving depends on some of them). */
+int pmgt_engine_set_option(pmgt_engine* e, const char* key, int value);
+/* current value (0 / 1), or -2 for an unknown key */
+int pmgt_engine_get_option(const pmgt_engine* e, const char* key);
 
 /* ---- host MCNSampling (libpmgt_sampler.so; pure host code, no HIP) --------------------------------
  * Replaces _sample_context_neigh / get_input_tensor / PMGTDataset.__getitem__ / pmgt_collate_fn
@@ -301,11 +212,13 @@ int pmgt_sampler_context(pmgt_sampler* s, int64_t target, int64_t* ids, float* m
  * Returns total pairs or <0. */
 int pmgt_sampler_batch(pmgt_sampler* s, const int64_t* targets, int n, int mode, int64_t* tgt_ids, float* tgt_mask,
                        int64_t* pair_ids, float* pair_mask, int64_t* num_pairs, float* labels);
-/* Same batch layout, sampled by n_threads host threads; every target gets its own stream seeded from
- * (base_seed, counter), so results do not depend on the thread count (statistical, not bit, parity
- * with the reference — the reference's own worker streams depend on the torch version). */
+/* Same batch layout, sampled by n_threads host threads; target i gets its own stream seeded from
+ * (base_seed, counter + counter_stride * i), so results do not depend on the thread count (statistical, not bit, parity
+ * with the reference — the reference's own worker streams depend on the torch version).  counter_stride = 1
+ * for consecutive items; a rank that evaluates items r, r + W, r + 2W, ... of a list passes counter = r (+ W * offset)
+ * and counter_stride = W and so draws exactly what a single process draws for the same items. */
 int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mode, uint64_t base_seed,
-                          uint64_t counter, int n_threads, int64_t* tgt_ids, float* tgt_mask, int64_t* pair_ids,
+                          uint64_t counter, uint64_t counter_stride, int n_threads, int64_t* tgt_ids, float* tgt_mask, int64_t* pair_ids,
                           float* pair_mask, int64_t* num_pairs, float* labels);
 int pmgt_sampler_max_pairs(const pmgt_sampler* s, int mode);
 /* legacy-stream primitives exposed for tests */

@@ -1,0 +1,100 @@
+/*
+ * pmgt_ops.h -- TEST AND A/B SURFACE of libpmgt_hip.so: single-kernel entry points (unit / parity tests of each kernel
+ * against the oracle) and the catalogue of path options.  Not needed to use the engine (include/pmgt_capi.h is the
+ * product ABI); same conventions as there.
+ */
+#ifndef PMGT_OPS_H
+#define PMGT_OPS_H
+
+#include "pmgt_capi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- path options ---------------------------------------------------------------------------------
+ * Keys of the per-engine option setter declared in pmgt_capi.h, and the bit each one has in the `path_opts` argument of the pmgt_op_* entry
+ * points below (which have no engine).  0 everywhere = the product path. */
+#define PMGT_OPT_TILE_GEMM (1u << 0)                 /* "tile_gemm": register-staged 128 x 128 GEMM tiles only (no streaming kernel, LDS-DMA or 256 x 256 tiles) */
+#define PMGT_OPT_VALU_ATTENTION (1u << 1)            /* "valu_attention": bf16 attention on the generic fp32-VALU kernel instead of the MFMA one */
+#define PMGT_OPT_WAVE_ATTENTION_BWD (1u << 2)        /* "wave_attention_bwd": MFMA attention backward with one wave per (sequence, head) instead of cooperating waves */
+#define PMGT_OPT_NO_SHORTCUT (1u << 3)               /* "no_shortcut": last layer on every token even when last_hidden is not requested */
+#define PMGT_OPT_NO_FUSED_QKVC_ATTENTION (1u << 4)   /* "no_fused_qkvc_attention": projection GEMM and attention as two kernels */
+#define PMGT_OPT_NO_HEAD_MAJOR (1u << 5)             /* "no_head_major": Q|K|V|C stays q | k | v | c between the fused forward and the backward */
+#define PMGT_OPT_NO_TABLE_PROJECTION (1u << 6)       /* "no_table_projection": features projected per token even when the table is smaller than half the batch's tokens */
+#define PMGT_OPT_NO_SEGMENT_SUM (1u << 7)            /* "no_segment_sum": table mode keeps the per-token weight-gradient GEMM of the feature projection */
+#define PMGT_OPT_CONSUMER_QUANT (1u << 8)            /* "consumer_quant": fp8 mode, layer inputs quantised inside the fused forward instead of by their producer (bit-identical) */
+#define PMGT_OPT_NO_FUSED_ATTENTION_BWD (1u << 9)    /* "no_fused_attention_bwd": attention backward and Q|K|V|C weight gradient as two kernels */
+#define PMGT_OPT_STORE_LN_INPUT (1u << 10)           /* "store_ln_input": every LayerNorm site stores its input; default (bf16, hidden 256): x^ = (y - beta) / gamma from the OUTPUT */
+#define PMGT_OPT_EAGER_REDUCE (1u << 11)             /* "eager_reduce": partial sums reduced by a launch per producer instead of one per gradient bucket */
+#define PMGT_OPT_SIDE_STREAM_REDUCE (1u << 12)       /* "side_stream_reduce": ... on the engine's second stream (fork / join by events); measured neutral */
+#define PMGT_OPT_UNFUSED_LN (1u << 13)               /* "unfused_ln": LayerNorm as its own launch after the streaming GEMM */
+#define PMGT_OPT_ONE_BUCKET (1u << 14)               /* "one_bucket": the gradient-ready callback fires once per backward pass (whole buffer) */
+#define PMGT_OPT_SMALL_ARENA (1u << 15)              /* "small_arena": (test) partial-sum arena sized for one producer: a batched reduction per producer */
+
+/* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
+/* per-row absmax e4m3 quantisation (weights per output channel, activations per token): scale[r] = max|row| / 448 */
+int pmgt_op_quant_rows_e4m3(int src_dtype, const void* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd,
+                            float* scale, void* stream);
+/* C (bf16) = (A8 B8^T) * a_scale(row) * b_row_scale[n] + bias on the fp8 MFMA; a_rows = optional row gather on A */
+int pmgt_op_gemm_nt_f8(const void* A, int64_t lda, const int64_t* a_rows, const float* a_row_scale, float a_scale,
+                       const void* B, int64_t ldb, const float* b_row_scale, void* C, int64_t ldc, int M, int N, int K,
+                       const float* bias, const int* m_dev, void* stream);
+/* weight gradient with an e4m3 Q operand (feature-table rows): out = P^T (Q8 * q_scale), P bf16 */
+int pmgt_op_gemm_tn_f8(const void* P, int64_t ldp, const void* Q8, int64_t ldq, float q_scale, const int64_t* q_rows, int M,
+                       int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream);
+/* fused projection + attention forward with the projection on the fp8 MFMA (d = 256): w8 [4d, d] e4m3, wscale [4d]; the layer
+ * input either as bf16 x (quantised per row inside the kernel) or, x8 != NULL, as e4m3 rows + one scale per row */
+int pmgt_op_qkvc_attention_fwd_f8(const void* x, const void* x8, const float* xscale, const void* w8, const float* wscale, const float* bias, const float* mask,
+                                  void* qkvc, void* ctx, int n_seq, int S, int H, int dh, float beta, float drop_p,
+                                  uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream);
+int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
+                    int64_t ldc, int M, int N, int K, const float* bias, int epilogue, void* aux, int64_t ldaux,
+                    const void* residual, int64_t ldr, float drop_p, uint32_t drop_site, const uint64_t* rng,
+                    const int* m_dev, uint32_t path_opts, void* stream);
+int64_t pmgt_op_gemm_tn_slab_elems(int dtype, int M, int N1, int N2, uint32_t path_opts);
+int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, const int64_t* q_rows, int M,
+                    int N1, int N2, float* slab, float* out, int accumulate, const int* m_dev, uint32_t path_opts, void* stream);
+/* the same with the bias gradient (column sums of P; bias_slab: [512][N1] scratch) and the head-major row permutation of
+ * the Q|K|V|C projection (perm_d = hidden size, perm_dh = head size; 0 = none) */
+int pmgt_op_gemm_tn_bias(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, int M, int N1, int N2, float* slab,
+                         float* out, float* bias_slab, float* bias_out, int perm_d, int perm_dh, uint32_t path_opts, void* stream);
+/* column sums of Y [M, N]; slab: ceil(M / 96) * N floats of scratch */
+int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream);
+int pmgt_op_layernorm_fwd(int dtype, const void* x, void* y, float* stats, const float* gamma, const float* beta,
+                          int M, int d, float eps, float drop_p, uint32_t drop_site, const uint64_t* rng, void* stream);
+/* part: [ceil(M/64)][3][d] scratch; dgamma_dbeta: [3*d] out = dgamma | dbeta | column sum of dx_drop (or dx) */
+int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                          void* dx_drop, float* part, float* dgamma_dbeta, int M, int d, float in_drop_p,
+                          uint32_t in_site, float out_drop_p, uint32_t out_site, const uint64_t* rng, void* stream);
+/* One linear layer through the engine's dispatcher: bf16 with K <= 256 runs the weight-stationary streaming
+ * kernel (gemm_ws.hip), everything else the tiled one; ln_out != NULL adds LayerNorm(C) (fused when N == 256). */
+int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                   const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
+                   uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
+                   const float* ln_beta, float ln_eps, uint32_t path_opts, void* stream);
+/* Fused Q|K|V|C projection + attention forward (bf16; S = 32, dh = 32, hidden 128 or 256; returns -3 otherwise):
+ * x [n_seq*S, d], w [4d, d] (rows q | k | v | c), bias [4d] fp32 -> qkvc [n_seq*S, 4d], ctx [n_seq*S, d]. */
+int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,
+                               int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                               const uint64_t* rng, void* stream);
+int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,
+                          int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                          const uint64_t* rng, uint32_t path_opts, void* stream);
+int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq,
+                          int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                          const uint64_t* rng, uint32_t path_opts, void* stream);
+/* Attention backward fused with the weight / bias gradient of the Q|K|V|C projection (bf16, S = 32, head size 32, hidden 128 or
+ * 256; replaces pmgt_op_attention_bwd + the [M, 4d]^T [M, d] weight-gradient GEMM, i.e. autograd through
+ * pmgt/pmgt/modeling_pmgt.py:429-433 and :435-526).  x = the layer input [n_seq * 32, d]; dqkvc as pmgt_op_attention_bwd;
+ * slab [parts][4d * d] / bias_slab [parts][4d] (parts = pmgt_op_attention_bwd_wgrad_parts(H)) receive per-workgroup partial
+ * sums in q | k | v | c row order, to be added up by the caller.  head_major = the column layout of qkvc / dqkvc. */
+int pmgt_op_attention_bwd_wgrad_parts(int H);
+int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void* dctx, const void* x, void* dqkvc, float* slab,
+                                float* bias_slab, int n_seq, int H, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                                const uint64_t* rng, int head_major, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMGT_OPS_H */

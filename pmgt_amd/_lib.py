@@ -48,17 +48,25 @@ GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 FLAG_TRAINING, FLAG_BACKWARD, FLAG_ACCUMULATE = 1, 2, 4
 EPI_NONE, EPI_GELU, EPI_GELU_GRAD = 0, 1, 2
 
-# every symbol include/pmgt_capi.h declares for libpmgt_hip.so
+# every symbol include/pmgt_capi.h (product ABI) and include/pmgt_ops.h (single-kernel test entries) declare for libpmgt_hip.so
 HIP_SYMBOLS = [
     "pmgt_last_error", "pmgt_abi_version", "pmgt_engine_create", "pmgt_engine_destroy", "pmgt_param_count",
     "pmgt_param_num_entries", "pmgt_param_entry", "pmgt_workspace_bytes", "pmgt_pretrain_step", "pmgt_encode_ids",
-    "pmgt_encode_feats", "pmgt_encode_train", "pmgt_encode_backward", "pmgt_optimizer_step", "pmgt_profile_begin", "pmgt_profile_end", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_op_gemm_nt",
-    "pmgt_op_gemm_tn_slab_elems", "pmgt_op_gemm_tn", "pmgt_op_colsum", "pmgt_op_layernorm_fwd",
-    "pmgt_op_layernorm_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd", "pmgt_debug_force_valu_attention", "pmgt_debug_force_tile_gemm", "pmgt_debug_enable_nt_dma", "pmgt_engine_set_overlap", "pmgt_op_qkvc_attention_fwd", "pmgt_debug_disable_fused_qkvc_attention", "pmgt_debug_disable_table_projection", "pmgt_debug_disable_segment_sum", "pmgt_debug_disable_head_major", "pmgt_debug_disable_coop_attention_bwd", "pmgt_debug_disable_last_layer_shortcut", "pmgt_op_linear",
-    "pmgt_quantize_e4m3", "pmgt_dequantize_e4m3", "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8",
-    "pmgt_op_qkvc_attention_fwd_f8", "pmgt_op_gemm_tn_bias", "pmgt_debug_disable_producer_quant",
-    "pmgt_engine_set_grad_ready_callback", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts", "pmgt_debug_disable_fused_attention_backward", "pmgt_debug_disable_deferred_reductions", "pmgt_debug_disable_layernorm_from_output",
+    "pmgt_encode_feats", "pmgt_encode_train", "pmgt_encode_backward", "pmgt_optimizer_step", "pmgt_profile_begin",
+    "pmgt_profile_end", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_quantize_e4m3", "pmgt_dequantize_e4m3",
+    "pmgt_engine_set_grad_ready_callback", "pmgt_engine_set_option", "pmgt_engine_get_option",
 ]
+OPS_SYMBOLS = [
+    "pmgt_op_gemm_nt", "pmgt_op_gemm_tn_slab_elems", "pmgt_op_gemm_tn", "pmgt_op_gemm_tn_bias", "pmgt_op_colsum",
+    "pmgt_op_layernorm_fwd", "pmgt_op_layernorm_bwd", "pmgt_op_linear", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd",
+    "pmgt_op_qkvc_attention_fwd", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts",
+    "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8", "pmgt_op_qkvc_attention_fwd_f8",
+]
+# path options: pmgt_engine_set_option keys -> bit in the `path_opts` argument of the pmgt_op_* entries (include/pmgt_ops.h)
+OPT = {k: 1 << i for i, k in enumerate((
+    "tile_gemm", "valu_attention", "wave_attention_bwd", "no_shortcut", "no_fused_qkvc_attention", "no_head_major",
+    "no_table_projection", "no_segment_sum", "consumer_quant", "no_fused_attention_bwd", "store_ln_input", "eager_reduce",
+    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena"))}
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
     "pmgt_sampler_context", "pmgt_sampler_batch", "pmgt_sampler_batch_mt", "pmgt_sampler_max_pairs",
@@ -112,50 +120,24 @@ def hip():
     L.pmgt_profile_end.argtypes = [vp, C.c_char_p, i]
     L.pmgt_cast_from_f32.argtypes = [i, vp, vp, i64, vp]
     L.pmgt_cast_to_f32.argtypes = [i, vp, vp, i64, vp]
-    L.pmgt_op_gemm_nt.argtypes = [i, vp, i64, vp, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, vp]
+    L.pmgt_op_gemm_nt.argtypes = [i, vp, i64, vp, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, u32, vp]
     L.pmgt_op_gemm_tn_slab_elems.restype = i64
-    L.pmgt_op_gemm_tn_slab_elems.argtypes = [i, i, i, i]
-    L.pmgt_op_gemm_tn.argtypes = [i, vp, i64, vp, i64, vp, i, i, i, vp, vp, i, vp, vp]
+    L.pmgt_op_gemm_tn_slab_elems.argtypes = [i, i, i, i, u32]
+    L.pmgt_op_gemm_tn.argtypes = [i, vp, i64, vp, i64, vp, i, i, i, vp, vp, i, vp, u32, vp]
     L.pmgt_op_colsum.argtypes = [i, vp, i64, i, i, vp, vp, vp]
     L.pmgt_op_layernorm_fwd.argtypes = [i, vp, vp, vp, vp, vp, i, i, f, f, u32, vp, vp]
     L.pmgt_op_layernorm_bwd.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, i, i, f, u32, f, u32, vp, vp]
-    L.pmgt_debug_disable_last_layer_shortcut.argtypes = [i]
-    L.pmgt_debug_disable_last_layer_shortcut.restype = None
     L.pmgt_op_qkvc_attention_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
-    L.pmgt_debug_disable_coop_attention_bwd.argtypes = [i]
-    L.pmgt_debug_disable_coop_attention_bwd.restype = None
-    L.pmgt_debug_disable_head_major.argtypes = [i]
-    L.pmgt_debug_disable_head_major.restype = None
-    L.pmgt_debug_disable_segment_sum.argtypes = [i]
-    L.pmgt_debug_disable_segment_sum.restype = None
-    L.pmgt_debug_disable_table_projection.argtypes = [i]
-    L.pmgt_debug_disable_table_projection.restype = None
-    L.pmgt_debug_disable_fused_qkvc_attention.argtypes = [i]
-    L.pmgt_debug_disable_fused_qkvc_attention.restype = None
     L.pmgt_engine_set_grad_ready_callback.argtypes = [vp, GRAD_READY_FN, vp]
     L.pmgt_engine_set_grad_ready_callback.restype = None
-    L.pmgt_engine_set_overlap.argtypes = [vp, i]
-    L.pmgt_engine_set_overlap.restype = None
-    L.pmgt_debug_enable_nt_dma.argtypes = [i]
-    L.pmgt_debug_enable_nt_dma.restype = None
-    L.pmgt_debug_force_tile_gemm.argtypes = [i]
-    L.pmgt_debug_force_tile_gemm.restype = None
-    L.pmgt_op_linear.argtypes = [i, vp, i64, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, vp, vp, vp, f, vp]
-    L.pmgt_debug_force_valu_attention.argtypes = [i]
-    L.pmgt_debug_force_valu_attention.restype = None
-    L.pmgt_op_attention_fwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
-    L.pmgt_op_attention_bwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
+    L.pmgt_engine_set_option.argtypes = [vp, C.c_char_p, i]
+    L.pmgt_engine_get_option.argtypes = [vp, C.c_char_p]
+    L.pmgt_op_linear.argtypes = [i, vp, i64, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, vp, vp, vp, f, u32, vp]
+    L.pmgt_op_attention_fwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]
+    L.pmgt_op_attention_bwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]
     L.pmgt_op_attention_bwd_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, f, f, u32, u32, vp, i, vp]
     L.pmgt_op_attention_bwd_wgrad_parts.argtypes = [i]
-    L.pmgt_debug_disable_fused_attention_backward.argtypes = [i]
-    L.pmgt_debug_disable_layernorm_from_output.argtypes = [i]
-    L.pmgt_debug_disable_layernorm_from_output.restype = None
-    L.pmgt_debug_disable_deferred_reductions.argtypes = [i]
-    L.pmgt_debug_disable_deferred_reductions.restype = None
-    L.pmgt_debug_disable_fused_attention_backward.restype = None
-    L.pmgt_op_gemm_tn_bias.argtypes = [i, vp, i64, vp, i64, i, i, i, vp, vp, vp, vp, i, i, vp]
-    L.pmgt_debug_disable_producer_quant.argtypes = [i]
-    L.pmgt_debug_disable_producer_quant.restype = None
+    L.pmgt_op_gemm_tn_bias.argtypes = [i, vp, i64, vp, i64, i, i, i, vp, vp, vp, vp, i, i, u32, vp]
     L.pmgt_quantize_e4m3.argtypes = [vp, vp, i64, f, vp]
     L.pmgt_dequantize_e4m3.argtypes = [vp, vp, i64, f, vp]
     L.pmgt_op_quant_rows_e4m3.argtypes = [i, vp, i64, i, i, vp, i64, vp, vp]
@@ -164,6 +146,39 @@ def hip():
     L.pmgt_op_qkvc_attention_fwd_f8.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, vp]
     _hip = L
     return L
+
+
+class Ops:
+    """The library as the per-kernel tests and profiling tools call it: every pmgt_op_* entry that takes a `path_opts` bit
+    mask (include/pmgt_ops.h) gets it from `self.path` (an int, or option names through `use`), so call sites read as the
+    kernel's own argument list.  Everything else passes straight through to the CDLL."""
+    _BEFORE_STREAM = {"pmgt_op_gemm_nt", "pmgt_op_gemm_tn", "pmgt_op_gemm_tn_bias", "pmgt_op_linear", "pmgt_op_attention_fwd",
+                      "pmgt_op_attention_bwd"}
+    _LAST = {"pmgt_op_gemm_tn_slab_elems"}
+
+    def __init__(self, lib=None):
+        self._L = lib if lib is not None else hip()
+        self.path = 0
+
+    def use(self, *names):
+        """Select path options by name for the following calls (no names = the product path); returns self."""
+        self.path = 0
+        for n in names:
+            self.path |= OPT[n]
+        return self
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+        if name in Ops._BEFORE_STREAM:
+            return lambda *a: fn(*a[:-1], self.path, a[-1])
+        if name in Ops._LAST:
+            return lambda *a: fn(*a, self.path)
+        return fn
+
+
+def ops():
+    """A fresh Ops view of libpmgt_hip.so (path options start at 0)."""
+    return Ops()
 
 
 def check(rc):
@@ -187,7 +202,7 @@ def sampler():
     L.pmgt_sampler_seed.restype = None
     L.pmgt_sampler_context.argtypes = [vp, i64, vp, vp]
     L.pmgt_sampler_batch.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, vp]
-    L.pmgt_sampler_batch_mt.argtypes = [vp, vp, i, i, C.c_uint64, C.c_uint64, i, vp, vp, vp, vp, vp, vp]
+    L.pmgt_sampler_batch_mt.argtypes = [vp, vp, i, i, C.c_uint64, C.c_uint64, C.c_uint64, i, vp, vp, vp, vp, vp, vp]
     L.pmgt_sampler_max_pairs.argtypes = [vp, i]
     L.pmgt_sampler_random_sample.restype = C.c_double
     L.pmgt_sampler_random_sample.argtypes = [vp]

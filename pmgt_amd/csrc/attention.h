@@ -21,13 +21,11 @@ struct AttnArgs {
     bool hm = false;
     const void* dctx = nullptr;   // backward: [Tseq*S, d]
     void* dqkvc = nullptr;        // backward: [Tseq*S, 4d]
+    uint32_t opts = 0;            // PathOpt bits: OPT_VALU_ATTENTION, OPT_WAVE_ATTENTION_BWD
 };
 // bf16 MFMA path (attention_mfma.hip): S <= 64, head size 32 or 64
 bool attn_mfma_supported(const AttnArgs& a);
 int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st);
-void attn_force_valu(int on);   // debugging / A-B: route bf16 through the generic VALU kernel
-bool attn_valu_forced();
-void attn_bwd_disable_coop(int on);   // A/B: one wave per (sequence, head) in the MFMA backward instead of NT cooperating waves
 template <typename T> int attn_fwd(const AttnArgs& a, hipStream_t st);
 template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
 
@@ -67,6 +65,7 @@ struct QkvcAttn {
     // with row stride ldx BYTES and one scale per row; X is then not read
     const void* X8 = nullptr;
     const float* xscale = nullptr;
+    uint32_t opts = 0;                            // PathOpt bits of the calling engine (none is read here today)
 };
 bool qkvc_attn_supported(const QkvcAttn& a);
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st);

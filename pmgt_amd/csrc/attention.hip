@@ -366,14 +366,10 @@ template <typename T, int DH> static int launch_gs(const AttnArgs& a, bool bwd, 
     return launch<T, DH, 128>(a, bwd, st);       // 64 < S <= 100: two waves per (sequence, head), one query row per lane
 }
 
-static int g_force_valu = 0;
-void attn_force_valu(int on) { g_force_valu = on; }
-bool attn_valu_forced() { return g_force_valu != 0; }
-
 template <typename T> static int dispatch(const AttnArgs& a, bool bwd, hipStream_t st) {
     if (a.Tseq <= 0) return 0;
     if constexpr (sizeof(T) == 2) {
-        if (!g_force_valu && attn_mfma_supported(a)) return attn_mfma(a, bwd, st);   // bf16 perf path
+        if (!(a.opts & OPT_VALU_ATTENTION) && attn_mfma_supported(a)) return attn_mfma(a, bwd, st);   // bf16 perf path
     }
     PMGT_CHECK(a.S >= 1 && a.S <= 100, -3,
                "attention: sequence length %d exceeds the reference's max_position_embeddings default of 100 "

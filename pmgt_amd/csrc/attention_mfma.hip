@@ -397,9 +397,6 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     }
 }
 
-static int g_bwd_no_coop = 0;
-void attn_bwd_disable_coop(int on) { g_bwd_no_coop = on; }
-
 template <int DH, int NT> struct BwdSmem {
     static constexpr int SP = NT * 16, SP2 = (SP + 31) / 32 * 32;
     static constexpr int TILE = SP2 * DH * 2;         // Q, K, dO, C-hat
@@ -1193,11 +1190,9 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
 
 template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
     const int groups = a.Tseq * a.H;
-    static int coop = -1;
-    if (coop < 0) { const char* ev = getenv("PMGT_ATTN_COOP"); coop = ev ? atoi(ev) : 1; }
     // NT cooperating waves per (sequence, head) everywhere except S in 17..32 with head size 32, where the
     // one-wave form measures faster (464 vs 555 us backward at 98k pairs: the shared loads outweigh the occupancy)
-    const bool use_coop = coop && !g_bwd_no_coop && !(NT == 2 && DH == 32);
+    const bool use_coop = !(a.opts & OPT_WAVE_ATTENTION_BWD) && !(NT == 2 && DH == 32);
     if (!bwd && use_coop) {
         constexpr int G = CoopCfg<NT>::G;
         const size_t shmem = (size_t)FwdSmem<DH, NT>::BYTES * G;
@@ -1221,14 +1216,11 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
             return 0;
         }
         const size_t per = BwdSmemW<DH, NT>::BYTES;
-        static int env_nw = -1;
-        if (env_nw < 0) { const char* ev = getenv("PMGT_ATTN_BWD_NW"); env_nw = ev ? atoi(ev) : 0; }
         // waves per workgroup: 2 when that raises the LDS-limited wave count per CU (S=32/dh=32: 14.5 KiB per wave ->
         // 5 x 2 waves instead of 2 x 4; measured 476 vs 500 us at 98k (sequence, head) pairs), never 1 (slower)
         constexpr size_t LDS = 160 * 1024;
         int nw = per * 2 <= LDS ? 2 : 1;
         if (per * 4 <= LDS && (LDS / (per * 4)) * 4 > (LDS / (per * 2)) * 2) nw = 4;
-        if ((env_nw == 1 || env_nw == 2 || env_nw == 4) && per * env_nw <= LDS) nw = env_nw;
         const size_t shmem = per * nw;
         const bool full = a.S == NT * 16 && NT % 2 == 0;
         auto kern = full ? attn_bwd_mfma_kernel<DH, NT, true> : attn_bwd_mfma_kernel<DH, NT, false>;

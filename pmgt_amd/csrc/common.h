@@ -270,6 +270,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(a, b);
 }
 
+// ---- path options ---------------------------------------------------------------------------------
+// Per-engine state (pmgt_engine_set_option; keys in include/pmgt_ops.h), carried into the kernel dispatchers by the `opts` field
+// of their argument structs: nothing here is a process global, two engines in one process do not see each other's choices.
+// 0 = the product path; a set bit takes an alternative (parity A/B of a fused form against the plain one).
+enum PathOpt : uint32_t {
+    OPT_TILE_GEMM = 1u << 0,            // register-staged tiled GEMMs everywhere (no streaming kernel, no LDS-DMA, no 256 x 256 tiles)
+    OPT_VALU_ATTENTION = 1u << 1,       // bf16 attention on the generic fp32-VALU kernel
+    OPT_WAVE_ATTENTION_BWD = 1u << 2,   // MFMA attention backward: one wave per (sequence, head) instead of cooperating waves
+    OPT_NO_SHORTCUT = 1u << 3,          // last layer on every token even when last_hidden is not requested
+    OPT_NO_FUSED_QKVC_ATTENTION = 1u << 4,
+    OPT_NO_HEAD_MAJOR = 1u << 5,        // Q|K|V|C stays q | k | v | c between the fused forward and the backward
+    OPT_NO_TABLE_PROJECTION = 1u << 6,  // feature projection per token even on small graphs
+    OPT_NO_SEGMENT_SUM = 1u << 7,       // table mode keeps the per-token weight-gradient GEMM of the feature projection
+    OPT_CONSUMER_QUANT = 1u << 8,       // fp8 mode: layer inputs quantised by their consumer instead of their producer
+    OPT_NO_FUSED_ATTENTION_BWD = 1u << 9,
+    OPT_STORE_LN_INPUT = 1u << 10,      // every LayerNorm site stores its input (no x^ from the LayerNorm output)
+    OPT_EAGER_REDUCE = 1u << 11,        // partial sums reduced by a launch per producer instead of one per gradient bucket
+    OPT_SIDE_STREAM_REDUCE = 1u << 12,  // ... on the engine's side stream (implies the per-producer launches)
+    OPT_UNFUSED_LN = 1u << 13,          // LayerNorm as its own launch after the streaming GEMM
+    OPT_ONE_BUCKET = 1u << 14,          // gradient-ready callback once per backward pass instead of per layer
+    OPT_SMALL_ARENA = 1u << 15,         // test: the partial-sum arena holds ONE producer's regions, so every take flushes the previous ones
+};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

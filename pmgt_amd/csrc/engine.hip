@@ -12,7 +12,7 @@
 #include <map>
 #include <vector>
 
-#include "../../include/pmgt_capi.h"
+#include "../../include/pmgt_ops.h"
 #include "attention.h"
 #include "fp8.h"
 #include "gemm.h"
@@ -96,11 +96,12 @@ struct pmgt_engine {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> sync_ev;
     size_t sync_next = 0;
-    bool overlap = false;     // partial-sum reductions on the side stream (see SideReduce): measured neutral, opt-in
+    uint32_t opts = 0;        // PathOpt bits (pmgt_engine_set_option): per engine, read by every dispatch decision below
+    bool overlap() const { return (opts & OPT_SIDE_STREAM_REDUCE) != 0; }     // partial-sum reductions on the side stream (see SideReduce): measured neutral, opt-in
     // data-parallel exchange: called when a contiguous range of the flat gradient buffer is final in stream order
     pmgt_grad_ready_fn grad_cb = nullptr;
     void* grad_cb_user = nullptr;
-    bool grad_cb_fine() const { return grad_cb != nullptr && !(overlap && side != nullptr); }
+    bool grad_cb_fine() const { return grad_cb != nullptr && !(overlap() && side != nullptr) && !(opts & OPT_ONE_BUCKET); }
     void grad_ready(int64_t off, int64_t numel) const { if (grad_cb && numel > 0) grad_cb(grad_cb_user, off, numel); }
     hipEvent_t next_sync() {
         if (sync_ev.empty()) {
@@ -244,9 +245,6 @@ struct Carver {
 template <typename T> struct LayerBufs {
     T *qkvc, *ctx, *ao_pre, *u, *ff_pre, *g, *fo_pre, *hout;
     float *stats1, *stats2;
-    // set by the forward pass: the fused-LayerNorm GEMM of that site did not store its pre-LayerNorm sum (ao_pre / fo_pre hold nothing) and
-    // the backward takes x^ from the LayerNorm output (u / hout) instead
-    bool ln1_from_y = false, ln2_from_y = false;
 };
 
 template <typename T> struct Bufs {
@@ -302,9 +300,6 @@ template <typename T> struct Bufs {
     T *c_dh = nullptr, *c_bB = nullptr, *c_bC = nullptr, *c_bD = nullptr, *c_big = nullptr;
 };
 
-static int g_no_defer_reduce = 0;
-static inline bool g_no_defer_reduce_flag() { return g_no_defer_reduce != 0; }
-
 static int64_t sort_temp_bytes(int M) {      // rocPRIM's size query, cached per token count
     static std::map<int, int64_t> cache;
     auto itr = cache.find(M);
@@ -314,9 +309,9 @@ static int64_t sort_temp_bytes(int M) {      // rocPRIM's size query, cached per
     return v;
 }
 
-static int64_t tn_slab_elems(int dtype, int M, int N1, int N2) {
+static int64_t tn_slab_elems(int dtype, int M, int N1, int N2, uint32_t opts) {
     const int bkm = dtype != PMGT_DTYPE_F32 ? 64 : 32;
-    return (int64_t)gemm_tn_pick_splits(M, N1, N2, bkm) * N1 * N2;
+    return (int64_t)gemm_tn_pick_splits(M, N1, N2, bkm, opts) * N1 * N2;
 }
 
 template <typename T>
@@ -367,14 +362,14 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     b.big = c.get<T>(M * std::max(I, 4 * d));
     int64_t slab = 0;
     const int dt = e->cfg.dtype;
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, 4 * d, d));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, 4 * d, d, e->opts));
     slab = std::max(slab, (int64_t)attn_bwd_wgrad_parts(e->H) * 4 * d * d);          // fused attention backward + weight gradient
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, d));
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, I, d));
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, I));
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Fv));
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Ft));
-    slab = std::max(slab, tn_slab_elems(dt, std::max(256, cap / 5), F, d));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, d, e->opts));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, I, d, e->opts));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, I, e->opts));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Fv, e->opts));
+    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Ft, e->opts));
+    slab = std::max(slab, tn_slab_elems(dt, std::max(256, cap / 5), F, d, e->opts));
     b.slab_elems = align_up(slab, 64);
     b.slab = c.get<float>(2 * b.slab_elems);
     int64_t part = 0;
@@ -390,8 +385,10 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     b.ln_part_elems = align_up((int64_t)ln_bwd_parts((int)M) * 3 * d, 64);
     b.ln_part = c.get<float>(2 * b.ln_part_elems);
     b.arena_elems = 2 * b.slab_elems + 4 * b.part_side_elems + 2 * b.ln_part_elems + align_up(part, 64);
+    if (e->opts & OPT_SMALL_ARENA)      // room for the largest single producer (slab + bias slab, or one set of row partials) and nothing more
+        b.arena_elems = std::max(b.slab_elems + b.part_side_elems, std::max(b.ln_part_elems, align_up(part, 64))) + 128;
     b.arena = c.get<float>(b.arena_elems);
-    b.defer = !g_no_defer_reduce_flag() && !(e->overlap && e->side != nullptr);      // side-stream reductions keep the per-producer launches
+    b.defer = !(e->opts & OPT_EAGER_REDUCE) && !(e->overlap() && e->side != nullptr);      // side-stream reductions keep the per-producer launches
     b.sg_keys = c.get<uint32_t>(M); b.sg_vals = c.get<uint32_t>(M); b.sg_skeys = c.get<uint32_t>(M); b.sg_perm = c.get<uint32_t>(M);
     b.sg_off = c.get<int>(M / 2 + 4);                     // table mode implies N + 2 <= M / 2
     b.sg_tmp_bytes = sort_temp_bytes((int)M);
@@ -463,27 +460,20 @@ static const void* zero_page() {
     }
     return g_zero_page;
 }
-static int g_force_tile = 0;
-static int g_no_shortcut = 0;
-static int g_no_fused_qa = 0;
-static int g_no_hm = 0;
-static int g_no_table_proj = 0;
-static int g_no_segsum = 0;
-static int g_no_producer_quant = 0;
-static int g_no_fused_abw = 0;
-static int g_no_ln_from_y = 0;       // 1: every LayerNorm site stores its input (pre-LayerNorm sum) for the backward pass
-
-// whether linear() will run `g` as a streaming GEMM with the LayerNorm in its epilogue (then the pre-LayerNorm sum need not be stored)
+// Whether the LayerNorm site behind a [Mt, K] x [d, K]^T dense block keeps NO copy of its input: the fused-LayerNorm streaming GEMM then
+// skips the store of the pre-LayerNorm sum (ao_pre / fo_pre hold nothing) and the backward takes x^ from the LayerNorm OUTPUT (u / hout).
+// A pure function of configuration, shape and options -- the forward and a SEPARATE backward call (pmgt_encode_backward carves its own
+// Bufs) must take the same decision; linear() refuses (loudly) a skip_c it cannot honour.
 template <typename T>
-static inline bool linear_fuses_ln(const GemmWS& g) {
-    if constexpr (sizeof(T) == 2) return !g_force_tile && g.ln_out != nullptr && gemm_ws_supported(g) && gemm_ws_fuses_ln(g);
-    return false;
+static inline bool ln_from_y_applies(const pmgt_engine* e, int Mt, int K, bool compacted) {
+    if (sizeof(T) != 2 || compacted || (e->opts & (OPT_STORE_LN_INPUT | OPT_TILE_GEMM | OPT_UNFUSED_LN))) return false;
+    return e->d == 256 && Mt >= 64 && K >= 64 && K <= 512 && (K & (K - 1)) == 0;
 }
 
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        if (!g_force_tile && gemm_ws_supported(g)) {
+        if (!(g.opts & OPT_TILE_GEMM) && gemm_ws_supported(g)) {
             PMGT_CHECK(!g.skip_c || gemm_ws_fuses_ln(g), -2, "linear: skip_c needs the fused-LayerNorm form");
             RUNP(name, gemm_ws(g, st));
             if (g.ln_out && !gemm_ws_fuses_ln(g))
@@ -512,12 +502,12 @@ static int build_mirrors(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b
 // a pure function of the configuration, the shape and the debug switches, so a separate backward call can re-derive it
 template <typename T>
 static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool want_probs) {
-    if (sizeof(T) != 2 || g_no_fused_qa || g_force_tile || want_probs || attn_valu_forced()) return false;
+    if (sizeof(T) != 2 || (e->opts & (OPT_NO_FUSED_QKVC_ATTENTION | OPT_TILE_GEMM | OPT_VALU_ATTENTION)) || want_probs) return false;
     return S == 32 && e->dh == 32 && (e->d == 256 || e->d == 128) && e->H % 2 == 0 && Tseq >= 2;
 }
 
-static inline bool use_table_projection(const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {
-    return by_ids && !g_no_table_proj && t->n_nodes > 0 && (t->n_nodes + 2) * 2 <= n_tokens;
+static inline bool use_table_projection(const pmgt_engine* e, const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {
+    return by_ids && !(e->opts & OPT_NO_TABLE_PROJECTION) && t->n_nodes > 0 && (t->n_nodes + 2) * 2 <= n_tokens;
 }
 
 // ---- encoder forward ---------------------------------------------------------------------------
@@ -536,11 +526,11 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     // [N+2, F] -> [N+2, 2d], and let the mix kernel pick rows by node id -- M / (N+2) times fewer flops and
     // table bytes, same value per token (a row's projection does not depend on which rows share its tile).
     const int64_t n_rows = t->n_nodes + 2;
-    const bool table_mode = use_table_projection(t, M, ids != nullptr);
+    const bool table_mode = use_table_projection(e, t, M, ids != nullptr);
     b.e_by_id = table_mode;
     PMGT_CHECK(!e->fp8 || ids != nullptr, -3, "fp8 mode gathers e4m3 feature rows by node id: pre-gathered feature tensors are not supported");
     for (int mod = 0; mod < 2 && e->fp8; ++mod) {      // e4m3 table rows x e4m3 weights on the fp8 MFMA
-        GemmF8 g;
+        GemmF8 g; g.opts = e->opts;
         const int F = mod == 0 ? e->Fv : e->Ft;
         g.A = mod == 0 ? t->table_v : t->table_t; g.lda = F; g.a_rows = table_mode ? nullptr : ids;
         g.a_scale = mod == 0 ? t->table_scale_v : t->table_scale_t;
@@ -551,7 +541,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         RUNP("fwd.gemm_featproj", gemm_nt_f8(g, st));
     }
     for (int mod = 0; mod < 2 && !e->fp8; ++mod) {
-        GemmNT g;
+        GemmNT g; g.opts = e->opts;
         const int F = mod == 0 ? e->Fv : e->Ft;
         if (ids) { g.A = mod == 0 ? t->table_v : t->table_t; g.a_rows = table_mode ? nullptr : ids; }
         else g.A = mod == 0 ? (const void*)feat_v : (const void*)feat_t;
@@ -571,8 +561,8 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
         // fp8 mode: whoever PRODUCES a layer input also writes it as per-row e4m3 (x8 / xscale), so the projection that
         // consumes it neither re-reads the bf16 row nor quantises it (x8_ok tracks whether the current `hin` has that copy)
-        const bool pq = e->fp8 && !g_no_producer_quant;
-        if (table_mode && !g_no_segsum) {
+        const bool pq = e->fp8 && !(e->opts & OPT_CONSUMER_QUANT);
+        if (table_mode && !(e->opts & OPT_NO_SEGMENT_SUM)) {
             // the modality mix a0 e_v + a1 e_t depends on the node only: once per node, then one [d] row per token
             T* F_all = b.E + n_rows * 2 * d;                 // fits: (N + 2) * 3d <= M * 2d
             m.phase = 1; m.M = (int)n_rows; m.E = b.E; m.pre = F_all;
@@ -586,7 +576,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
         }
     }
-    bool x8_ok = e->fp8 && !g_no_producer_quant;
+    bool x8_ok = e->fp8 && !(e->opts & OPT_CONSUMER_QUANT);
     if (hidden_states) PMGT_HIP(hipMemcpyAsync(hidden_states, b.h0, (size_t)M * d * sizeof(T), hipMemcpyDeviceToDevice, st));
     const T* hin = b.h0;
     for (int l = 0; l < L; ++l) {
@@ -594,14 +584,14 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         LayerBufs<T>& lb = b.layer[l];
         bool fused = false;
         if constexpr (sizeof(T) == 2) {   // headline shape: projection + attention in one kernel (Q|K|V|C never re-read from HBM)
-            QkvcAttn f;
+            QkvcAttn f; f.opts = e->opts;
             f.X = hin; f.ldx = d; f.W = b.mirror + o.mWqkvc; f.ldw = d; f.bias = P + o.bqkvc;
             f.qkvc = lb.qkvc; f.ldq = 4 * d; f.ctx = lb.ctx; f.ldc = d; f.mask = mask;
             f.Tseq = Tseq; f.S = S; f.H = H; f.dh = e->dh; f.beta = e->cfg.beta;
             f.drop1 = dropcfg(t, train, pa, l, SITE_A1);
             f.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             f.cls_only_seqs = (shortcut && l == L - 1) ? n_cls_only : 0;
-            f.hm = train && !g_no_hm;        // the backward that reads it understands the layout; inference keeps q | k | v | c
+            f.hm = train && !(e->opts & OPT_NO_HEAD_MAJOR);        // the backward that reads it understands the layout; inference keeps q | k | v | c
             if (e->fp8) { f.W8 = b.mirror8 + o.m8Wqkvc; f.wscale = b.mscale + o.s8Wqkvc; }
             if (e->fp8 && x8_ok) { f.X8 = b.x8; f.xscale = b.xscale; f.ldx = d; }
             if (fused_qa_applies<T>(e, Tseq, S, attn_probs != nullptr) && qkvc_attn_supported(f)) {
@@ -612,18 +602,18 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         }
         if (!fused && e->fp8) {   // per-row e4m3 of the layer input, then the fp8 GEMM
             if (!x8_ok) RUNP("fwd.quant_x", quant_rows_e4m3<T>(hin, d, M, d, b.x8, d, b.xscale, st));
-            GemmF8 g;
+            GemmF8 g; g.opts = e->opts;
             g.A = b.x8; g.lda = d; g.a_row_scale = b.xscale; g.B = b.mirror8 + o.m8Wqkvc; g.ldb = d; g.b_row_scale = b.mscale + o.s8Wqkvc;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
             RUNP("fwd.gemm_qkvc", gemm_nt_f8(g, st));
         } else if (!fused) {   // Q,K,V,C projections as one [M,d] x [4d,d]^T GEMM
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = hin; g.lda = d; g.B = wsel<T>(e, t, b, o.Wqkvc, o.mWqkvc); g.ldb = d;
             g.C = lb.qkvc; g.ldc = 4 * d; g.M = M; g.N = 4 * d; g.K = d; g.bias = P + o.bqkvc;
             RUN(linear<T>(e, "fwd.gemm_qkvc", g, st));
         }
         if (!fused) {
-            AttnArgs a;
+            AttnArgs a; a.opts = e->opts;
             a.qkvc = lb.qkvc; a.mask = mask; a.ctx = lb.ctx;
             a.probs = attn_probs ? attn_probs + (int64_t)l * Tseq * H * S * S : nullptr;
             a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
@@ -639,24 +629,24 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         const int64_t* rows = sc ? b.need_rows : nullptr;
         const int* mdev = sc ? b.need_cnt : nullptr;
         {   // BertSelfOutput: LN(dropout(dense(ctx)) + hin)
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = lb.ctx; g.lda = d; g.a_rows = rows; g.B = wsel<T>(e, t, b, o.Wo, o.mWo); g.ldb = d;
             g.C = tb.ao_pre; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.bias = P + o.bo; g.m_dev = mdev;
             g.drop = dropcfg(t, train, pd, l, SITE_AO);
             g.res = hin; g.ldr = d; g.res_gather = sc;
             g.ln_out = tb.u; g.ln_stats = tb.stats1; g.ln_gamma = P + o.ln1g; g.ln_beta = P + o.ln1b; g.ln_eps = e->cfg.layer_norm_eps;
-            g.skip_c = tb.ln1_from_y = !g_no_ln_from_y && linear_fuses_ln<T>(g);
+            g.skip_c = ln_from_y_applies<T>(e, Mt, d, sc);
             RUN(linear<T>(e, "fwd.gemm_attn_out", g, st));
         }
         {   // BertIntermediate: gelu(dense(u))
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = tb.u; g.lda = d; g.B = wsel<T>(e, t, b, o.W1, o.mW1); g.ldb = d;
             g.C = tb.g; g.ldc = I; g.M = Mt; g.N = I; g.K = d; g.bias = P + o.b1; g.m_dev = mdev;
             g.epi = EPI_GELU; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "fwd.gemm_ffn1", g, st));
         }
         {   // BertOutput: LN(dropout(dense(g)) + u)
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = tb.g; g.lda = I; g.B = wsel<T>(e, t, b, o.W2, o.mW2); g.ldb = I;
             g.C = tb.fo_pre; g.ldc = d; g.M = Mt; g.N = d; g.K = I; g.bias = P + o.b2; g.m_dev = mdev;
             g.drop = dropcfg(t, train, pd, l, SITE_FO);
@@ -664,14 +654,14 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             g.ln_out = tb.hout; g.ln_stats = tb.stats2; g.ln_gamma = P + o.ln2g; g.ln_beta = P + o.ln2b; g.ln_eps = e->cfg.layer_norm_eps;
             x8_ok = false;
             if constexpr (sizeof(T) == 2) {
-                if (e->fp8 && !g_no_producer_quant && !sc && l + 1 < L) {
+                if (e->fp8 && !(e->opts & OPT_CONSUMER_QUANT) && !sc && l + 1 < L) {
                     // the next layer's input, quantised where it is produced: the fused-LayerNorm epilogue of the streaming GEMM,
                     // or the LayerNorm launch that follows the tiled GEMM (d = 512 shapes)
                     g.q8 = b.x8; g.q8_scale = b.xscale;
                     x8_ok = true;
                 }
             }
-            g.skip_c = tb.ln2_from_y = !g_no_ln_from_y && linear_fuses_ln<T>(g);
+            g.skip_c = ln_from_y_applies<T>(e, Mt, I, sc);
             RUN(linear<T>(e, "fwd.gemm_ffn2", g, st));
         }
         if (hidden_states)
@@ -691,7 +681,7 @@ struct SideReduce {
     pmgt_engine* e;
     hipStream_t main;
     bool on;
-    SideReduce(const pmgt_engine* eng, hipStream_t m) : e(const_cast<pmgt_engine*>(eng)), main(m), on(eng->overlap && eng->side != nullptr) {}
+    SideReduce(const pmgt_engine* eng, hipStream_t m) : e(const_cast<pmgt_engine*>(eng)), main(m), on(eng->overlap() && eng->side != nullptr) {}
     // before a producer overwrites a partial buffer: the reduction that last read it is done
     int acquire(hipEvent_t& done) {
         if (done) PMGT_HIP(hipStreamWaitEvent(main, done, 0));
@@ -733,6 +723,18 @@ static int take_partials(const pmgt_engine* e, Bufs<T>& b, int64_t n, float** ou
     b.arena_cur += n;
     return 0;
 }
+// Two regions that one producer launch fills (weight-gradient slab + its bias slab): flush BEFORE the first take if the pair does not
+// fit, so that the flush (which rewinds the arena) can never come between them -- the first region is handed out but not queued
+// yet at that point, and producers behind the rewind would overwrite it before multi_reduce reads it.
+template <typename T>
+static int take_partials2(const pmgt_engine* e, Bufs<T>& b, int64_t n1, float** out1, int64_t n2, float** out2, hipStream_t st) {
+    const int64_t need = align_up(n1, 64) + (out2 ? align_up(n2, 64) : 0);
+    PMGT_CHECK(need <= b.arena_elems, -4, "partial-sum arena too small: %lld > %lld floats", (long long)need, (long long)b.arena_elems);
+    if (b.arena_cur + need > b.arena_elems) RUN(flush_reduces<T>(e, b, st));
+    RUN(take_partials<T>(e, b, n1, out1, st));
+    if (out2) RUN(take_partials<T>(e, b, n2, out2, st));
+    return 0;
+}
 template <typename T>
 static int queue_reduce(const pmgt_engine* e, Bufs<T>& b, const float* src, int rows, int64_t n, float* dst, bool acc, hipStream_t st) {
     for (const ReduceJob& j : b.pend)
@@ -753,14 +755,13 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
                  float* bias_dst = nullptr, int perm_d = 0, int perm_dh = 0, float q_f8_scale = 0.f) {
     if (b.defer) {
         hipStream_t st = main;
-        GemmTN g;
+        GemmTN g; g.opts = e->opts;
         g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
         g.m_dev = m_dev; g.zeros = e->zeros; g.perm_d = perm_d; g.perm_dh = perm_dh;
         g.q_f8 = q_f8_scale > 0.f; g.q_scale = q_f8_scale;
-        g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
-        RUN(take_partials<T>(e, b, (int64_t)g.splits * N1 * N2, &g.slab, main));
+        g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>(), e->opts);
         g.bias_slab = nullptr;
-        if (bias_dst) RUN(take_partials<T>(e, b, (int64_t)g.splits * N1, &g.bias_slab, main));
+        RUN(take_partials2<T>(e, b, (int64_t)g.splits * N1 * N2, &g.slab, (int64_t)g.splits * N1, bias_dst ? &g.bias_slab : nullptr, main));
         RUNP(name, gemm_tn<T>(g, main));
         RUN(queue_reduce<T>(e, b, g.slab, g.splits, (int64_t)N1 * N2, dst, acc, main));
         if (bias_dst) RUN(queue_reduce<T>(e, b, g.bias_slab, g.splits, N1, bias_dst, acc, main));
@@ -772,11 +773,11 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
     float* bpart = b.part_side + (int64_t)slot * b.part_side_elems;
     RUN(sr.acquire(b.wg_done[slot]));
     hipStream_t st = main;
-    GemmTN g;
+    GemmTN g; g.opts = e->opts;
     g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
     g.slab = slab; g.m_dev = m_dev; g.zeros = e->zeros; g.perm_d = perm_d; g.perm_dh = perm_dh;
     g.q_f8 = q_f8_scale > 0.f; g.q_scale = q_f8_scale;      // fp8 mode: Q = e4m3 feature table
-    g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>());
+    g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>(), e->opts);
     g.bias_slab = bias_dst ? bpart : nullptr;          // [splits <= 512][N1]
     RUNP(name, gemm_tn<T>(g, st));
     RUN(sr.begin(&st));
@@ -847,31 +848,32 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         T* gC = sc ? b.c_bC : b.bC;
         T* gD = sc ? b.c_bD : b.bD;
         T* gbig = sc ? b.c_big : b.big;
+        const bool ln1_from_y = ln_from_y_applies<T>(e, Mt, d, sc), ln2_from_y = ln_from_y_applies<T>(e, Mt, I, sc);      // as the forward decided
         // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
-        RUN(ln_bwd_reduce<T>(e, b, gA, tb.ln2_from_y ? tb.hout : tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d,
-                             dropcfg(t, train, pd, l, SITE_FO), mdev, G + o.ln2g, acc, st, tb.ln2_from_y ? P + o.ln2b : nullptr));                                              // dgamma | dbeta | db2
+        RUN(ln_bwd_reduce<T>(e, b, gA, ln2_from_y ? tb.hout : tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d,
+                             dropcfg(t, train, pd, l, SITE_FO), mdev, G + o.ln2g, acc, st, ln2_from_y ? P + o.ln2b : nullptr));                                              // dgamma | dbeta | db2
         const T* dY2 = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = gbig; g.ldc = I; g.m_dev = mdev;
             g.M = Mt; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
         RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1));
         {   // du = dff W1 + residual branch
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gD; g.ldc = d; g.m_dev = mdev;
             g.M = Mt; g.N = d; g.K = I; g.res = gB; g.ldr = d;
             RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
         }
         // LN1 backward
-        RUN(ln_bwd_reduce<T>(e, b, gD, tb.ln1_from_y ? tb.u : tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d,
-                             dropcfg(t, train, pd, l, SITE_AO), mdev, G + o.ln1g, acc, st, tb.ln1_from_y ? P + o.ln1b : nullptr));                                              // dgamma | dbeta | dbo
+        RUN(ln_bwd_reduce<T>(e, b, gD, ln1_from_y ? tb.u : tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d,
+                             dropcfg(t, train, pd, l, SITE_AO), mdev, G + o.ln1g, acc, st, ln1_from_y ? P + o.ln1b : nullptr));                                              // dgamma | dbeta | dbo
         const T* dYo = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
         {   // dctx = dYo Wo
-            GemmWS g;
+            GemmWS g; g.opts = e->opts;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = gD; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.m_dev = mdev;
             RUN(linear<T>(e, "bwd.dgrad_attn_out", g, st));
         }
@@ -883,7 +885,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
         bool fused_bw = false;
         {
-            AttnArgs a;
+            AttnArgs a; a.opts = e->opts;
             a.qkvc = lb.qkvc; a.mask = b.mask; a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
             a.drop1 = dropcfg(t, train, pa, l, SITE_A1);
             a.drop2 = dropcfg(t, train, pa, l, SITE_A2);
@@ -901,16 +903,15 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                 const int slot = b.wg_idx & 1;
                 w.slab = b.slab + (int64_t)slot * b.slab_elems;
                 w.bias_slab = b.part_side + (int64_t)slot * b.part_side_elems;
-                if (!g_no_fused_abw && !g_force_tile && !attn_valu_forced() && (int64_t)parts * 4 * d * d <= b.slab_elems &&
-                    (int64_t)parts * 4 * d <= b.part_side_elems && attn_bwd_wgrad_supported(w) && b.defer) {
-                    RUN(take_partials<T>(e, b, (int64_t)parts * 4 * d * d, &w.slab, st));
-                    RUN(take_partials<T>(e, b, (int64_t)parts * 4 * d, &w.bias_slab, st));
+                const bool abw_ok = !(e->opts & (OPT_NO_FUSED_ATTENTION_BWD | OPT_TILE_GEMM | OPT_VALU_ATTENTION)) && (int64_t)parts * 4 * d * d <= b.slab_elems &&
+                                    (int64_t)parts * 4 * d <= b.part_side_elems && attn_bwd_wgrad_supported(w);
+                if (abw_ok && b.defer) {
+                    RUN(take_partials2<T>(e, b, (int64_t)parts * 4 * d * d, &w.slab, (int64_t)parts * 4 * d, &w.bias_slab, st));
                     RUNP("bwd.attention_wgrad", attn_bwd_wgrad(w, st));
                     RUN(queue_reduce<T>(e, b, w.slab, parts, (int64_t)4 * d * d, G + o.Wqkvc, acc, st));
                     RUN(queue_reduce<T>(e, b, w.bias_slab, parts, 4 * d, G + o.bqkvc, acc, st));
                     fused_bw = true;
-                } else if (!g_no_fused_abw && !g_force_tile && !attn_valu_forced() && (int64_t)parts * 4 * d * d <= b.slab_elems &&
-                    (int64_t)parts * 4 * d <= b.part_side_elems && attn_bwd_wgrad_supported(w)) {
+                } else if (abw_ok) {
                     ++b.wg_idx;
                     RUN(sr.acquire(b.wg_done[slot]));
                     RUNP("bwd.attention_wgrad", attn_bwd_wgrad(w, st));
@@ -931,7 +932,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         // every gradient of layer l is final in stream order: let the data-parallel exchange of this bucket start now
         if (e->grad_cb_fine()) e->grad_ready(o.Wqkvc, (l + 1 < L ? e->layers[l + 1].Wqkvc : e->Wn) - o.Wqkvc);
         {   // d hin = dqkvc Wqkvc + residual branch
-            GemmNT g;
+            GemmNT g; g.opts = e->opts;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + (b.qkvc_hm ? o.mWqkvcT_hm : o.mWqkvcT); g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
             g.M = M; g.N = d; g.K = 4 * d; g.res = sc ? nullptr : b.bB; g.ldr = d;
             RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
@@ -944,7 +945,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         m.S = S; m.d = d; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a;
         m.stats = b.emb_stats; m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
         m.part = b.part;
-        const bool by_node = b.e_by_id && !g_no_segsum;
+        const bool by_node = b.e_by_id && !(e->opts & OPT_NO_SEGMENT_SUM);
         PMGT_CHECK(!e->fp8 || (feat_v == nullptr && feat_t == nullptr), -3, "fp8 mode: pre-gathered feature tensors are not supported");
         const float sv8 = e->fp8 ? t->table_scale_v : 0.f, st8 = e->fp8 ? t->table_scale_t : 0.f;     // > 0: the tables are e4m3
         if (by_node) {
@@ -1030,7 +1031,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     // Table mode backward needs the tokens ordered by node id; the ids are final here, so the (latency-bound, many small
     // launches) stable sort runs on the engine's side stream next to the whole forward pass.
     b.sort_done = nullptr;
-    if (bwd && use_table_projection(t, (int64_t)Tseq * S, true) && !g_no_segsum && e->side) {
+    if (bwd && use_table_projection(e, t, (int64_t)Tseq * S, true) && !(e->opts & OPT_NO_SEGMENT_SUM) && e->side) {
         hipEvent_t ev = e->next_sync();
         PMGT_HIP(hipEventRecord(ev, st));
         PMGT_HIP(hipStreamWaitEvent(e->side, ev, 0));
@@ -1041,7 +1042,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     RUN(build_mirrors<T>(e, t, b, st));
     // Training fast path: the caller does not ask for last_hidden_state, so the last layer's attn-out/FFN blocks
     // only run on the rows the loss reads (compact order: B target CLS, P pair CLS, masked rows).
-    const bool sc = train && !g_no_shortcut && o->last_hidden == nullptr;
+    const bool sc = train && !(e->opts & OPT_NO_SHORTCUT) && o->last_hidden == nullptr;
     if (sc) RUN(build_need_rows(B, Pn, S, b.nfr_rows, b.nfr_count, b.need_rows, b.need_cnt, st));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, (const T*)nullptr, (const T*)nullptr, b.mask, train, (T*)nullptr,
                            (float*)nullptr, st, sc, B + Pn));
@@ -1062,7 +1063,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     const T* hN = sc ? hL + (int64_t)(B + Pn) * d : hL;
     const int64_t* nrows = sc ? nullptr : b.nfr_rows;
     if (train) {
-        GemmNT g;   // projections of the masked rows
+        GemmNT g; g.opts = e->opts;   // projections of the masked rows
         g.A = hN; g.lda = d; g.a_rows = nrows; g.B = wsel<T>(e, t, b, e->Wn, e->mWn); g.ldb = d;
         g.C = b.pred; g.ldc = F; g.M = cap; g.N = F; g.K = d; g.bias = t->params + e->bn; g.m_dev = b.nfr_count;
         RUNP("loss.gemm_nfr", gemm_nt<T>(g, st));
@@ -1080,7 +1081,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         RUN(wgrad<T>("bwd.wgrad_nfr", e, b, b.pred, F, hN, d, nrows, cap, msp, F, d, t->grads + e->Wn, acc, b.nfr_count, st, t->grads + e->bn));
         RUN(flush_reduces<T>(e, b, st));
         if (e->grad_cb_fine()) e->grad_ready(e->Wn, e->total - e->Wn);          // NFR head bucket
-        GemmNT g;
+        GemmNT g; g.opts = e->opts;
         g.A = b.pred; g.lda = F; g.B = b.mirror + e->mWnT; g.ldb = F; g.M = cap; g.N = d; g.K = F; g.m_dev = b.nfr_count;
         g.C = sc ? dhL + (int64_t)(B + Pn) * d : b.dq; g.ldc = d;      // compacted: the masked rows ARE rows B+P.. of dhL
         RUNP("bwd.dgrad_nfr", gemm_nt<T>(g, st));
@@ -1152,8 +1153,8 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv
     PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
     pmgt_tensors tt = *t;
     tt.rng_state = (uint64_t*)b.rng_snap;          // the forward's (seed, step)
-    b.e_by_id = use_table_projection(t, (int64_t)Tseq * S, fv == nullptr);      // same decisions as the forward took
-    b.qkvc_hm = train && !g_no_hm && fused_qa_applies<T>(e, Tseq, S, false);
+    b.e_by_id = use_table_projection(e, t, (int64_t)Tseq * S, fv == nullptr);      // same decisions as the forward took
+    b.qkvc_hm = train && !(e->opts & OPT_NO_HEAD_MAJOR) && fused_qa_applies<T>(e, Tseq, S, false);
     PMGT_HIP(hipMemcpyAsync(b.bA, d_last, (size_t)Tseq * S * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
     RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, (const T*)fv, (const T*)ft));
     return 0;
@@ -1167,7 +1168,7 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv
 extern "C" {
 
 const char* pmgt_last_error(void) { return g_err; }
-int pmgt_abi_version(void) { return 2; }
+int pmgt_abi_version(void) { return 3; }
 
 pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     if (!cfg) { set_error("config is NULL"); return nullptr; }
@@ -1190,15 +1191,7 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
     build_layout(e);
     e->zeros = zero_page();
-    {
-        const char* fa = getenv("PMGT_FUSED_ABW");        // A/B: 1 = attention backward fused with the Q|K|V|C weight gradient
-        if (fa) g_no_fused_abw = atoi(fa) == 1 ? 0 : 1;
-    }
-    {
-        const char* ev = getenv("PMGT_OVERLAP");
-        e->overlap = ev && atoi(ev) == 1;
-        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
-    }
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
     if (!e->desc.empty()) {
         if (hipMalloc((void**)&e->desc_dev, e->desc.size() * sizeof(MirrorDesc)) != hipSuccess ||
             hipMemcpy(e->desc_dev, e->desc.data(), e->desc.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1353,8 +1346,8 @@ int pmgt_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* st
 int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows, const void* B, int64_t ldb, void* C,
                     int64_t ldc, int M, int N, int K, const float* bias, int epilogue, void* aux, int64_t ldaux,
                     const void* residual, int64_t ldr, float drop_p, uint32_t drop_site, const uint64_t* rng, const int* m_dev,
-                    void* stream) {
-    GemmNT g;
+                    uint32_t path_opts, void* stream) {
+    GemmNT g; g.opts = path_opts;
     g.A = A; g.lda = lda; g.a_rows = a_rows; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux; g.res = residual; g.ldr = ldr;
     g.drop = DropCfg{rng, rng ? drop_p : 0.f, drop_site}; g.m_dev = m_dev;
@@ -1362,14 +1355,14 @@ int pmgt_op_gemm_nt(int dtype, const void* A, int64_t lda, const int64_t* a_rows
     return gemm_nt<float>(g, (hipStream_t)stream);
 }
 
-int64_t pmgt_op_gemm_tn_slab_elems(int dtype, int M, int N1, int N2) { return tn_slab_elems(dtype, M, N1, N2); }
+int64_t pmgt_op_gemm_tn_slab_elems(int dtype, int M, int N1, int N2, uint32_t path_opts) { return tn_slab_elems(dtype, M, N1, N2, path_opts); }
 
 int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, const int64_t* q_rows, int M, int N1,
-                    int N2, float* slab, float* out, int accumulate, const int* m_dev, void* stream) {
-    GemmTN g;
+                    int N2, float* slab, float* out, int accumulate, const int* m_dev, uint32_t path_opts, void* stream) {
+    GemmTN g; g.opts = path_opts;
     g.P = P; g.ldp = ldp; g.Q = Q; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2; g.slab = slab; g.m_dev = m_dev;
     g.zeros = zero_page();
-    g.splits = gemm_tn_pick_splits(M, N1, N2, dtype == PMGT_DTYPE_BF16 ? 64 : 32);
+    g.splits = gemm_tn_pick_splits(M, N1, N2, dtype == PMGT_DTYPE_BF16 ? 64 : 32, path_opts);
     int rc = dtype == PMGT_DTYPE_BF16 ? gemm_tn<bf16>(g, (hipStream_t)stream) : gemm_tn<float>(g, (hipStream_t)stream);
     if (rc) return rc;
     return slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, accumulate != 0, (hipStream_t)stream);
@@ -1378,11 +1371,11 @@ int pmgt_op_gemm_tn(int dtype, const void* P, int64_t ldp, const void* Q, int64_
 // weight gradient + bias gradient (column sums of P riding along as ones-MFMAs) + optional head-major row permutation:
 // exactly what the engine's wgrad helper launches for the Q|K|V|C projection
 int pmgt_op_gemm_tn_bias(int dtype, const void* P, int64_t ldp, const void* Q, int64_t ldq, int M, int N1, int N2, float* slab,
-                         float* out, float* bias_slab, float* bias_out, int perm_d, int perm_dh, void* stream) {
-    GemmTN g;
+                         float* out, float* bias_slab, float* bias_out, int perm_d, int perm_dh, uint32_t path_opts, void* stream) {
+    GemmTN g; g.opts = path_opts;
     g.P = P; g.ldp = ldp; g.Q = Q; g.ldq = ldq; g.M = M; g.N1 = N1; g.N2 = N2; g.slab = slab; g.bias_slab = bias_slab;
     g.zeros = zero_page(); g.perm_d = perm_d; g.perm_dh = perm_dh;
-    g.splits = gemm_tn_pick_splits(M, N1, N2, dtype != PMGT_DTYPE_F32 ? 64 : 32);
+    g.splits = gemm_tn_pick_splits(M, N1, N2, dtype != PMGT_DTYPE_F32 ? 64 : 32, path_opts);
     PMGT_CHECK(g.splits <= 512, -2, "pmgt_op_gemm_tn_bias: bias_slab holds at most 512 splits");
     int rc = dtype != PMGT_DTYPE_F32 ? gemm_tn<bf16>(g, (hipStream_t)stream) : gemm_tn<float>(g, (hipStream_t)stream);
     if (rc) return rc;
@@ -1417,28 +1410,45 @@ int pmgt_op_layernorm_bwd(int dtype, const void* dy, const void* x, const float*
 }
 
 static AttnArgs mk_attn(const void* qkvc, const float* mask, int n_seq, int S, int H, int dh, float beta, float drop_p,
-                        uint32_t s1, uint32_t s2, const uint64_t* rng) {
-    AttnArgs a;
+                        uint32_t s1, uint32_t s2, const uint64_t* rng, uint32_t path_opts = 0) {
+    AttnArgs a; a.opts = path_opts;
     a.qkvc = qkvc; a.mask = mask; a.Tseq = n_seq; a.S = S; a.H = H; a.dh = dh; a.beta = beta;
     a.drop1 = DropCfg{rng, rng ? drop_p : 0.f, s1};
     a.drop2 = DropCfg{rng, rng ? drop_p : 0.f, s2};
     return a;
 }
 
-void pmgt_debug_force_valu_attention(int on) { attn_force_valu(on); }
-void pmgt_debug_disable_coop_attention_bwd(int on) { attn_bwd_disable_coop(on); }
-void pmgt_debug_force_tile_gemm(int on) { g_force_tile = on; gemm_tn_disable_dma(on); gemm_nt_disable_big(on); gemm_tn_disable_big(on); }
-void pmgt_debug_enable_nt_dma(int on) { gemm_nt_disable_dma(on ? 0 : 1); }
-void pmgt_debug_disable_last_layer_shortcut(int on) { g_no_shortcut = on; }
-void pmgt_debug_disable_fused_qkvc_attention(int on) { g_no_fused_qa = on; }
-void pmgt_debug_disable_table_projection(int on) { g_no_table_proj = on; }
-void pmgt_debug_disable_segment_sum(int on) { g_no_segsum = on; }
-void pmgt_debug_disable_head_major(int on) { g_no_hm = on; }
-void pmgt_debug_disable_producer_quant(int on) { g_no_producer_quant = on; }
-void pmgt_debug_disable_fused_attention_backward(int on) { g_no_fused_abw = on; }
-void pmgt_debug_disable_layernorm_from_output(int on) { g_no_ln_from_y = on; }
-void pmgt_debug_disable_deferred_reductions(int on) { g_no_defer_reduce = on; }
-void pmgt_engine_set_overlap(pmgt_engine* e, int on) { if (e) e->overlap = on != 0; }
+// ---- path options: per-engine state, no process globals, no environment reads ------------------------
+static_assert(PMGT_OPT_TILE_GEMM == OPT_TILE_GEMM && PMGT_OPT_VALU_ATTENTION == OPT_VALU_ATTENTION && PMGT_OPT_WAVE_ATTENTION_BWD == OPT_WAVE_ATTENTION_BWD &&
+              PMGT_OPT_NO_SHORTCUT == OPT_NO_SHORTCUT && PMGT_OPT_NO_FUSED_QKVC_ATTENTION == OPT_NO_FUSED_QKVC_ATTENTION && PMGT_OPT_NO_HEAD_MAJOR == OPT_NO_HEAD_MAJOR &&
+              PMGT_OPT_NO_TABLE_PROJECTION == OPT_NO_TABLE_PROJECTION && PMGT_OPT_NO_SEGMENT_SUM == OPT_NO_SEGMENT_SUM && PMGT_OPT_CONSUMER_QUANT == OPT_CONSUMER_QUANT &&
+              PMGT_OPT_NO_FUSED_ATTENTION_BWD == OPT_NO_FUSED_ATTENTION_BWD && PMGT_OPT_STORE_LN_INPUT == OPT_STORE_LN_INPUT && PMGT_OPT_EAGER_REDUCE == OPT_EAGER_REDUCE &&
+              PMGT_OPT_SIDE_STREAM_REDUCE == OPT_SIDE_STREAM_REDUCE && PMGT_OPT_UNFUSED_LN == OPT_UNFUSED_LN && PMGT_OPT_ONE_BUCKET == OPT_ONE_BUCKET && PMGT_OPT_SMALL_ARENA == OPT_SMALL_ARENA,
+              "include/pmgt_ops.h and csrc/common.h disagree on the option bits");
+static uint32_t option_bit(const char* key) {
+    static const struct { const char* name; uint32_t bit; } tab[] = {
+        {"tile_gemm", OPT_TILE_GEMM}, {"valu_attention", OPT_VALU_ATTENTION}, {"wave_attention_bwd", OPT_WAVE_ATTENTION_BWD},
+        {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
+        {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
+        {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}};
+    for (const auto& t : tab)
+        if (key && strcmp(key, t.name) == 0) return t.bit;
+    return 0;
+}
+int pmgt_engine_set_option(pmgt_engine* e, const char* key, int value) {
+    PMGT_CHECK(e != nullptr, -2, "pmgt_engine_set_option: NULL engine");
+    const uint32_t bit = option_bit(key);
+    PMGT_CHECK(bit != 0, -2, "pmgt_engine_set_option: unknown option '%s'", key ? key : "(null)");
+    e->opts = value ? (e->opts | bit) : (e->opts & ~bit);
+    return 0;
+}
+int pmgt_engine_get_option(const pmgt_engine* e, const char* key) {
+    PMGT_CHECK(e != nullptr, -2, "pmgt_engine_get_option: NULL engine");
+    const uint32_t bit = option_bit(key);
+    PMGT_CHECK(bit != 0, -2, "pmgt_engine_get_option: unknown option '%s'", key ? key : "(null)");
+    return (e->opts & bit) ? 1 : 0;
+}
 void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, void* user) {
     if (e) { e->grad_cb = cb; e->grad_cb_user = user; }
 }
@@ -1446,8 +1456,8 @@ void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, 
 int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
                    uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
-                   const float* ln_beta, float ln_eps, void* stream) {
-    GemmWS g;
+                   const float* ln_beta, float ln_eps, uint32_t path_opts, void* stream) {
+    GemmWS g; g.opts = path_opts;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux; g.res = residual; g.ldr = ldr;
     g.drop = DropCfg{rng, rng ? drop_p : 0.f, drop_site};
@@ -1460,8 +1470,8 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
 }
 
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S, int H,
-                          int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, void* stream) {
-    AttnArgs a = mk_attn(qkvc, mask, n_seq, S, H, dh, beta, drop_p, site1, site2, rng);
+                          int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, uint32_t path_opts, void* stream) {
+    AttnArgs a = mk_attn(qkvc, mask, n_seq, S, H, dh, beta, drop_p, site1, site2, rng, path_opts);
     a.ctx = ctx; a.probs = probs;
     if (dtype == PMGT_DTYPE_BF16) return attn_fwd<bf16>(a, (hipStream_t)stream);
     return attn_fwd<float>(a, (hipStream_t)stream);
@@ -1482,8 +1492,8 @@ int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, 
 
 int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq, int S,
                           int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng,
-                          void* stream) {
-    AttnArgs a = mk_attn(qkvc, mask, n_seq, S, H, dh, beta, drop_p, site1, site2, rng);
+                          uint32_t path_opts, void* stream) {
+    AttnArgs a = mk_attn(qkvc, mask, n_seq, S, H, dh, beta, drop_p, site1, site2, rng, path_opts);
     a.dctx = dctx; a.dqkvc = dqkvc;
     if (dtype == PMGT_DTYPE_BF16) return attn_bwd<bf16>(a, (hipStream_t)stream);
     return attn_bwd<float>(a, (hipStream_t)stream);

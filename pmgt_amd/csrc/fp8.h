@@ -40,6 +40,7 @@ struct GemmF8 {
     int M = 0, N = 0, K = 0;
     const float* bias = nullptr;
     const int* m_dev = nullptr;
+    uint32_t opts = 0;                             // PathOpt bits (OPT_TILE_GEMM: 128 x 128 tile only)
 };
 int gemm_nt_f8(const GemmF8& g, hipStream_t st);
 

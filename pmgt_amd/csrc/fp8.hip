@@ -308,8 +308,7 @@ int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
     PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 8) == 0, -2, "gemm_nt_f8: unaligned operands");
     PMGT_CHECK((g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0) && (g.b_row_scale == nullptr || ((uintptr_t)g.b_row_scale % 16) == 0), -2,
                "gemm_nt_f8: bias / scale vectors must be 16-byte aligned");
-    static const bool no_big = [] { const char* e = getenv("PMGT_F8_NO_BIG"); return e && atoi(e) == 1; }();      // A/B
-    if (f8_big_ok(g) && !no_big) {
+    if (f8_big_ok(g) && !(g.opts & OPT_TILE_GEMM)) {
         constexpr int smem = 4 * (256 + 256) * 64;
         static bool attr_set = false;
         if (!attr_set) {

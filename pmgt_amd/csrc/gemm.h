@@ -21,10 +21,9 @@ struct GemmNT {
     const void* res = nullptr; int64_t ldr = 0;   // residual added last (same dtype as C)
     bool res_gather = false;           // residual row = a_rows[m] (compacted-row GEMMs)
     const int* m_dev = nullptr;        // optional device-side row count (<= M)
+    uint32_t opts = 0;                 // PathOpt bits of the calling engine (OPT_TILE_GEMM: register-staged 128 x 128 tile only)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
-void gemm_nt_disable_dma(int on);     // A/B: force the register-staged tile kernel
-void gemm_nt_disable_big(int on);     // A/B: never use the 256 x 256 tile
 
 // Weight-stationary streaming variant for K <= 256 in bf16 (gemm_ws.hip); optional fused LayerNorm of the
 // output row when N == 256: ln_out = LN(C) with C the (bf16-rounded) epilogue result, stats = {mean, rstd}.
@@ -62,11 +61,10 @@ struct GemmTN {
     int perm_d = 0, perm_dh = 0;
     bool q_f8 = false;                          // fp8 mode: Q is an e4m3 feature table (ldq in bytes), value = byte * q_scale
     float q_scale = 1.f;
+    uint32_t opts = 0;                          // PathOpt bits (OPT_TILE_GEMM: register-staged kernel only)
 };
-void gemm_tn_disable_dma(int on);
-void gemm_tn_disable_big(int on);     // A/B: never use the 256 x 256 weight-gradient tile
 template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st);
-int gemm_tn_pick_splits(int M, int N1, int N2, int bkm);
+int gemm_tn_pick_splits(int M, int N1, int N2, int bkm, uint32_t opts = 0);
 template <typename T> int gemm_tn_bkm();
 
 // dst[i] (+)= sum_s slab[s*n + i]   (n % 4 == 0; the slab is used as scratch and clobbered)

@@ -219,107 +219,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// NT, bf16, LDS-DMA pipeline (same idea as gemm_tn_dma_kernel): 128x128 tile, K-step 32 (64-byte LDS rows),
-// 4-stage ring with three stages in flight, fragments by inline-asm ds_read_b128.  A DMA instruction moves
-// 16 rows x 64 B; the 16-byte chunk index is XOR-swizzled by nt_swz(row) on the SOURCE side so the
-// fragment reads of 16 rows x same k-chunk are bank-conflict free.  Row gather on A comes for free (the
-// source address is per lane; the tile's rows are fixed, so the indices are read once before the loop).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT g) {
-    typedef bf16 T;
-    constexpr int BM = 128, BN = 128, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = 4;     // 16 KiB per stage
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-    const int num_n = (g.N + BN - 1) / BN;
-    const int num_m = (g.M + BM - 1) / BM;
-    const int b = blockIdx.x;
-    const int grp = b / (8 * num_n), within = b % (8 * num_n);
-    const int m_tile = grp * 8 + (within & 7), n_tile = within >> 3;
-    if (m_tile >= num_m) return;
-    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-    if (m0 >= Mlim) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 15, q = lane >> 4;
-
-    // DMA ownership: wave w moves rows 32 w + 16 j + (lane >> 2), j = 0, 1, of both operand tiles;
-    // LDS slot (lane & 3) of a row receives global chunk (lane & 3) ^ nt_swz(row)
-    const char* asrc[2];
-    const char* bsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 32 * wave + 16 * j + (lane >> 2);
-        const int ch = (lane & 3) ^ nt_swz(row);
-        const int m = min(m0 + row, Mlim - 1);
-        const int64_t arow = g.a_rows ? g.a_rows[m] : (int64_t)m;
-        const int n = min(n0 + row, g.N - 1);
-        asrc[j] = (const char*)g.A + arow * g.lda * 2 + ch * 16;
-        bsrc[j] = (const char*)g.B + (int64_t)n * g.ldb * 2 + ch * 16;
-    }
-    if (g.a_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // index loads retired before DMA counting starts
-    auto issue = [&](int kt) {
-        char* st = smem + (kt & (NST - 1)) * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + (int64_t)kt * ROWB),
-                                             (lds_void_t*)(st + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + (int64_t)kt * ROWB),
-                                             (lds_void_t*)(st + BM * ROWB + (32 * wave + 16 * j) * ROWB), 16, 0, 0);
-        }
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    uint32_t offa[4], offb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = wm * 64 + i * 16 + r, rb = wn * 64 + i * 16 + r;
-        offa[i] = (uint32_t)(ra * ROWB + ((q ^ nt_swz(ra)) << 4));
-        offb[i] = (uint32_t)(BM * ROWB + rb * ROWB + ((q ^ nt_swz(rb)) << 4));
-    }
-    const int nk = g.K / 32;
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int younger = min(2, nk - 1 - kt);
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3);
-        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
-        u32x4 t[8];
-        asm volatile(
-            "ds_read_b128 %0, %8\n\t"
-            "ds_read_b128 %1, %9\n\t"
-            "ds_read_b128 %2, %10\n\t"
-            "ds_read_b128 %3, %11\n\t"
-            "ds_read_b128 %4, %12\n\t"
-            "ds_read_b128 %5, %13\n\t"
-            "ds_read_b128 %6, %14\n\t"
-            "ds_read_b128 %7, %15\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
-            : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
-              "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
-            : "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t[i]), __builtin_bit_cast(bf16x8, t[4 + j]),
-                                                                    acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_barrier();       // every wave is done reading the ring before it becomes the staging buffer
-    nt_epilogue<T, BM, BN>(g, acc, smem, m0, n0, Mlim, tid, wm, wn, r, q);
-}
-
-// ------------------------------------------------------------------------------------------------
 // NT, bf16, 256 x 256 tile, 512 threads (8 waves as 2 x 4, 128 x 64 outputs each), same 4-stage LDS-DMA ring
 // (K-step 32).  The 128 x 128 kernels re-read the W tile once per 128 rows and A once per 128 columns, all
 // through L2 (for dX = dQKVC W at M = 393k, K = 1024, N = 256 that is 3.2 GB of L2 -> CU traffic for 1.2 GB of
@@ -740,20 +639,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
 #endif
 }
 
-static int g_nt_no_big = 0;
-void gemm_nt_disable_big(int on) { g_nt_no_big = on; }
 static bool nt_big_ok(const GemmNT& g) {
-    return !g_nt_no_big && g.a_rows == nullptr && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 128 == 0 && g.K % 32 == 0 &&
+    return !(g.opts & OPT_TILE_GEMM) && g.a_rows == nullptr && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 128 == 0 && g.K % 32 == 0 &&
            g.K >= 128 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
            (g.aux == nullptr || g.ldaux % 8 == 0) && ((uintptr_t)g.C % 16) == 0 && (g.res == nullptr || ((uintptr_t)g.res % 16) == 0) &&
            (g.aux == nullptr || ((uintptr_t)g.aux % 16) == 0) && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0);
 }
-
-// The LDS-DMA NT kernel measures the same as the register-staged tile kernel on this model's shapes (both are
-// bound by re-reading A for the second N tile), so the simpler kernel stays the default; PMGT_NT_DMA=1 or
-// gemm_nt_disable_dma(0) selects it (tests run both).
-static int g_nt_no_dma = -1;
-void gemm_nt_disable_dma(int on) { g_nt_no_dma = on; }
 
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
@@ -771,10 +662,8 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     const int grid = cdiv(num_m, 8) * 8 * num_n;
     if constexpr (sizeof(T) == 2) {
         if (nt_big_ok(g)) {
-            static int narrow = -1;
-            if (narrow < 0) { const char* ev = getenv("PMGT_NT_BIG_BN"); narrow = ev ? atoi(ev) : 0; }
             const int nm = cdiv(g.M, 256);
-            if (g.N % 256 == 0 && g.K % 64 == 0 && narrow != 128) {      // (K % 64: the 256-wide tile walks k-steps in pairs)
+            if (g.N % 256 == 0 && g.K % 64 == 0) {      // (K % 64: the 256-wide tile walks k-steps in pairs)
                 constexpr int smem = 4 * (256 + 256) * 64;
                 static bool attr_set = false;
                 if (!attr_set) {
@@ -791,12 +680,6 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
                 }
                 hipLaunchKernelGGL((gemm_nt_big_kernel<128, 4>), dim3(cdiv(nm, 8) * 8 * (g.N / 128)), dim3(256), smem, st, g);
             }
-            PMGT_LAUNCH_OK();
-            return 0;
-        }
-        if (g_nt_no_dma < 0) { const char* ev = getenv("PMGT_NT_DMA"); g_nt_no_dma = (ev && atoi(ev) == 1) ? 0 : 1; }
-        if (!g_nt_no_dma && g.K % 32 == 0 && g.K >= 64) {
-            hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(grid), dim3(256), 0, st, g);
             PMGT_LAUNCH_OK();
             return 0;
         }
@@ -1454,18 +1337,13 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
         }
 }
 
-static int g_tn_no_dma = 0;
-void gemm_tn_disable_dma(int on) { g_tn_no_dma = on; }
-
-static int g_tn_no_big = 0;
-void gemm_tn_disable_big(int on) { g_tn_no_big = on; }
 // the 256 x 256 tile pays off when the 128 x 128 kernel would re-read its operands through L2 four times or more
-static bool tn_big_shape(int M, int N1, int N2, int bkm) {
-    return bkm == 64 && !g_tn_no_big && !g_tn_no_dma && M >= 65536 && N1 % 256 == 0 && N2 % 256 == 0 && N1 * N2 >= 4 * 256 * 256;
+static bool tn_big_shape(int M, int N1, int N2, int bkm, uint32_t opts) {
+    return bkm == 64 && !(opts & OPT_TILE_GEMM) && M >= 65536 && N1 % 256 == 0 && N2 % 256 == 0 && N1 * N2 >= 4 * 256 * 256;
 }
 
-int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
-    if (tn_big_shape(M, N1, N2, bkm)) {
+int gemm_tn_pick_splits(int M, int N1, int N2, int bkm, uint32_t opts) {
+    if (tn_big_shape(M, N1, N2, bkm, opts)) {
         const int tiles = (N1 / 256) * (N2 / 256);
         int splits = cdiv(256, tiles);                   // one 8-wave workgroup per CU
         splits = std::max(8, splits / 8 * 8);
@@ -1474,9 +1352,7 @@ int gemm_tn_pick_splits(int M, int N1, int N2, int bkm) {
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
     // one workgroup per CU: the LDS-DMA ring hides the latency by itself, and the slab traffic (splits * N1 * N2 * 4 B
     // written here, read again by slab_reduce) halves against two per CU -- measured 11.49 vs 11.57 ms/step (c2, B = 1024)
-    static int target = 0;
-    if (!target) { const char* ev = getenv("PMGT_TN_WGS"); target = ev ? std::max(64, atoi(ev)) : 256; }
-    int splits = cdiv(target, tiles);
+    int splits = cdiv(256, tiles);
     const int max_by_rows = std::max(1, M / (4 * bkm));  // at least 4 K-steps per split
     splits = std::max(1, std::min(splits, max_by_rows));
     if (splits > 8) splits = splits / 8 * 8;             // whole XCD groups (see the block mapping in the kernel)
@@ -1490,7 +1366,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
     PMGT_CHECK(g.ldp % EPC == 0 && g.ldq % EPC == 0, -2, "gemm_tn: leading dims must be multiples of %d", EPC);
     PMGT_CHECK(((uintptr_t)g.P % 16) == 0 && ((uintptr_t)g.Q % (g.q_f8 ? 8 : 16)) == 0, -2, "gemm_tn: operands must be 16-byte aligned");
     PMGT_CHECK(g.splits >= 1 && g.slab, -2, "gemm_tn: bad splits/slab");
-    PMGT_CHECK(g.perm_dh == 0 || (sizeof(T) == 2 && !g_tn_no_dma && g.zeros != nullptr), -2, "gemm_tn: the row permutation needs the LDS-DMA kernel");
+    PMGT_CHECK(g.perm_dh == 0 || (sizeof(T) == 2 && !(g.opts & OPT_TILE_GEMM) && g.zeros != nullptr), -2, "gemm_tn: the row permutation needs the LDS-DMA kernel");
     const int bkm = gemm_tn_bkm<T>();
     int chunk = cdiv(cdiv(std::max(g.M, 1), g.splits), bkm) * bkm;
     const int tiles = cdiv(g.N1, 128) * cdiv(g.N2, 128);
@@ -1506,8 +1382,8 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (g.q_rows == nullptr && g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm) &&
-            g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm)) {
+        if (g.q_rows == nullptr && g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm, g.opts) &&
+            g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm, g.opts)) {
             constexpr int smem = 4 * 2 * 32 * 512;
             static bool attr_set = false;
             if (!attr_set) {
@@ -1520,7 +1396,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
             PMGT_LAUNCH_OK();
             return 0;
         }
-        if (!g_tn_no_dma && g.zeros != nullptr) {
+        if (!(g.opts & OPT_TILE_GEMM) && g.zeros != nullptr) {
             constexpr size_t ring = 4 * 2 * 32 * 256;
             if (g.q_rows == nullptr) {
                 hipLaunchKernelGGL(gemm_tn_dma_kernel<false>, grid, dim3(256), ring, st, g, chunk);

@@ -363,8 +363,7 @@ static int ws_mode(const GemmWS& g) {
     if (g.epi == EPI_NONE && !g.res && !drop) return WS_PLAIN;
     if (g.epi == EPI_GELU && !g.res && !drop) return WS_GELU;
     if (g.epi == EPI_GELU_GRAD && !g.res && !drop) return WS_GELU_GRAD;
-    static const bool no_ln = [] { const char* e = getenv("PMGT_WS_NO_LN"); return e && atoi(e) == 1; }();      // A/B: LayerNorm as its own launch
-    if (g.epi == EPI_NONE && g.res) return (g.ln_out && g.N == 256 && !no_ln) ? WS_RES_LN : WS_RES;
+    if (g.epi == EPI_NONE && g.res) return (g.ln_out && g.N == 256 && !(g.opts & OPT_UNFUSED_LN)) ? WS_RES_LN : WS_RES;
     return -1;
 }
 
@@ -382,10 +381,8 @@ bool gemm_ws_fuses_ln(const GemmWS& g) { return gemm_ws_supported(g) && ws_mode(
 //   residual loaded in its pass instead of prefetched, so that nothing spills next to the 128 VGPRs of W: 254 VGPRs; with
 //   the prefetch 30 were spilled and the launches took 0.68 / 0.66): these launches are served from the Infinity Cache to
 //   a large part, and one tile in flight per workgroup instead of two costs them memory-level parallelism.
-// PMGT_WS_FORM=1 / 2 forces one form everywhere (the two-workgroup form needs K >= 128: chunks per thread).
+// (the two-workgroup form needs K >= 128: chunks per thread)
 static int ws_form(int mode) {
-    static const int v = [] { const char* e = getenv("PMGT_WS_FORM"); return e ? atoi(e) : 0; }();
-    if (v == 1 || v == 2) return v;
     return (mode == WS_GELU || mode == WS_GELU_GRAD || mode == WS_PLAIN) ? 2 : 1;
 }
 

@@ -85,18 +85,6 @@ __device__ unsigned int g_qa3_prof[16][8];
 #define QA3_PROF_FLUSH do { } while (0)
 #endif
 
-template <int KS> struct QaCfg {
-    static constexpr int K = 32 * KS;
-    static constexpr int ROWB = K * 2;
-    static constexpr int CPR = K / 8;
-    static constexpr int TILEB = 64 * ROWB;
-    static constexpr int LPT = 64 * CPR / 512;
-    static_assert(LPT * 512 == 64 * CPR, "tile must be a whole number of chunks per thread");
-    static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
-    static constexpr int QT_ROWB = 512;                       // projection tile: 64 rows x 256 bf16
-    static constexpr int QTB = 64 * QT_ROWB;
-    static constexpr int SMEM = 2 * TILEB + QTB + 8 * 64 * 4; // A ring + projection tile + per-wave {rho[32], madd[32]}
-};
 
 // reduction over the 4 lanes l, l^16, l^32, l^48 on the LDS crossbar (ds_swizzle xor 16 inside the 32-lane halves, ds_bpermute for
 // l ^ 32): two LDS-port instructions and two VALU instructions.  The v_permlane16/32_swap form cost 8 VALU instructions (each swap needs
@@ -259,151 +247,9 @@ __device__ __forceinline__ QaAttnConst qa_attn_const(const QkvcAttn& a, int r, i
     return kc;
 }
 
-template <int KS>
-__global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
-    using C = QaCfg<KS>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* qt = smem + 2 * C::TILEB;
-    float* wl = (float*)(qt + C::QTB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int d = a.H * 32, M = a.Tseq * 32;
-
-    const int ny = a.H / 2;
-    const int b = blockIdx.x;
-    const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
-    const int gx = gridDim.x / ny;
-    const int num_mt = (M + 63) / 64;
-    // local column c of the slab -> column of q | k | v | c
-    auto gcol = [&](int c) { return (c >> 6) * d + (2 * y + ((c >> 5) & 1)) * 32 + (c & 31); };
-    // ... and the column it is STORED at: the same, or head-major (head, matrix, w): 256 contiguous bytes per (row, head)
-    auto ocol = [&](int c) { return a.hm ? ((2 * y + ((c >> 5) & 1)) * 4 + (c >> 6)) * 32 + (c & 31) : gcol(c); };
-
-    // ---- resident W fragments (A operand now): rows n = gcol(32 wave + 16 j + r), k = 32 ks + 8 q
-    bf16x8 wf[2][KS];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = gcol(32 * wave + 16 * j + r);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[j][ks] = *(const bf16x8*)((const bf16*)a.W + (int64_t)n * a.ldw + 32 * ks + 8 * q);
-    }
-    // bias of the 4 consecutive output columns this lane owns in each of its two 16-column blocks
-    f32x4 bj[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = gcol(32 * wave + 16 * j + 4 * q);
-        bj[j] = a.bias ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    u32x4 ra[2][C::LPT];
-    auto gload = [&](int mt, int set) {
-#pragma unroll
-        for (int i = 0; i < C::LPT; ++i) {
-            const int idx = tid + 512 * i;
-            const int row = idx / C::CPR, ch = idx % C::CPR;
-            const int m = min(mt * 64 + row, M - 1);
-            ra[set][i] = *(const u32x4*)((const char*)a.X + ((int64_t)m * a.ldx) * 2 + ch * 16);
-        }
-    };
-    auto sstore = [&](int buf, int set) {
-#pragma unroll
-        for (int i = 0; i < C::LPT; ++i) {
-            const int idx = tid + 512 * i;
-            const int row = idx / C::CPR, ch = idx % C::CPR;
-            *(u32x4*)(sA + buf * C::TILEB + row * C::ROWB + ((ch ^ (row & C::SWZ)) << 4)) = ra[set][i];
-        }
-    };
-
-    const QaAttnConst kc = qa_attn_const(a, r, q);
-    // attention role of this wave
-    const int us = wave >> 2, uh = (wave >> 1) & 1, it = wave & 1;
-    const int h = 2 * y + uh;
-    float* rho = wl + wave * 64;
-    float* madd = rho + 32;
-    bf16* QKVC = (bf16*)a.qkvc;
-    bf16* CTX = (bf16*)a.ctx;
-    const int erow = tid >> 5, ech = tid & 31;
-
-    QA_PROF_DECL
-    auto tile_step = [&](auto Pc, int mt) {
-        constexpr int P = decltype(Pc)::value;
-#ifdef PMGT_QA_PROF
-        ++pacc[7];
-#endif
-        QA_STAMP(0);
-        sstore(P, P);
-        if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
-        __syncthreads();                 // A tile visible; every wave is past the previous tile's attention phase
-        QA_STAMP(1);
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-        const char* a_base = sA + P * C::TILEB;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 fa[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 16 * i + r;
-                fa[i] = *(const bf16x8*)(a_base + row * C::ROWB + (((4 * ks + q) ^ (row & C::SWZ)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {      // D[n = 4 q + e][m = r]: acc[i][j][e] = out[16 i + r][16 j + 4 q + e]
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], fa[i], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], fa[i], acc[i][1], 0, 0, 0);
-            }
-        }
-        QA_STAMP(2);
-        // ---- + bias, bf16, into the projection tile (8 bytes per lane per block)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = 16 * i + r;
-                const f32x4 v = acc[i][j] + bj[j];
-                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *(bf16x4*)(qt + qt_addr(row, 4 * wave + 2 * j + (q >> 1)) + 8 * (q & 1)) = o;
-            }
-        QA_STAMP(3);
-        __syncthreads();
-        QA_STAMP(4);
-        // ---- (a) projection tile -> HBM, 16 bytes per lane, rows contiguous inside each 64-byte head block
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int row = erow + 16 * ps;
-            const int m = mt * 64 + row;
-            if (m < M) *(u32x4*)(QKVC + (int64_t)m * a.ldq + ocol(8 * ech)) = *(const u32x4*)(qt + qt_addr(row, ech));
-        }
-        QA_STAMP(5);
-        // ---- (b) attention of (sequence 2 mt + us, head h, queries 16 it .. 16 it + 15)
-        const int t = 2 * mt + us;
-        const bool act = t < a.Tseq;
-        if (it == 1 && t < a.cls_only_seqs) return;      // (wave-uniform) only query row 0 of this sequence is ever read
-        const float mv = (a.mask && act) ? (1.f - a.mask[(int64_t)t * 32 + (lane & 31)]) * -10000.f : 0.f;
-        qa_attention(kc, qt, 32 * us, uh, it, min(t, a.Tseq - 1), h, a.H, a.mask != nullptr, mv, rho, madd,
-                     CTX + ((int64_t)min(t, a.Tseq - 1) * 32 + 16 * it + r) * a.ldc + h * 32, act, r, q, lane, [] {});
-        QA_STAMP(6);
-        // The next tile_step's first barrier orders this phase's LDS reads before the next projection-tile
-        // writes (which come after that step's second barrier anyway).
-    };
-
-    int mt = x;
-    if (mt < num_mt) gload(mt, 0);
-    if (mt + gx < num_mt) gload(mt + gx, 1);
-    while (mt < num_mt) {
-        tile_step(std::integral_constant<int, 0>{}, mt);
-        mt += gx;
-        if (mt >= num_mt) break;
-        tile_step(std::integral_constant<int, 1>{}, mt);
-        mt += gx;
-    }
-    QA_PROF_FLUSH;
-}
-
 // ------------------------------------------------------------------------------------------------
-// Two-workgroups-per-CU form.  In-kernel timestamps of the kernel above (PMGT_QA_PROF) show its tile step as a
-// SEQUENCE of phases bound by different units -- projection (MFMA pipe + LDS fragment reads, ~2850 cycles for the two
+// Two-workgroups-per-CU form (fp8 projection modes).  In-kernel timestamps of a one-8-wave-workgroup form (round 1, removed) showed
+// its tile step as a SEQUENCE of phases bound by different units -- projection (MFMA pipe + LDS fragment reads, ~2850 cycles for the two
 // waves of a SIMD), attention (VALU issue: ~390 instructions x 4 cycles x 2 waves, ~3700 cycles) -- that one 8-wave
 // workgroup marches through in lockstep, so the MFMA pipe idles during attention and the VALU during projection.
 // Here a workgroup has FOUR waves, each holding a 64-column block of the slab's W (128 VGPRs), and works on one
@@ -411,8 +257,9 @@ __global__ __launch_bounds__(512) void qkvc_attn_fwd_kernel(QkvcAttn a) {
 // phase, so one's projection overlaps the other's attention.  Every A-tile fragment read now feeds 8 MFMAs instead of
 // 4: half the LDS traffic per row.
 //   wave w = (head uh = w >> 1, matrix pair mh = w & 1: {Q, K} or {V, C});  attention role (head uh, query half w & 1).
-// F8: 0 = bf16, 1 = fp8 projection with x quantised inside the kernel, 2 = fp8 projection on x that arrives as e4m3 rows + scales
-template <int KS, int F8 = 0> struct QaCfg2 {
+// F8: 1 = fp8 projection with x quantised inside the kernel, 2 = fp8 projection on x that arrives as e4m3 rows + scales
+// (0 was the bf16 instance of this form: superseded by the role-split kernel below and no longer instantiated)
+template <int KS, int F8> struct QaCfg2 {
     static constexpr int K = 32 * KS;
     static constexpr int ROWB = F8 ? K : K * 2;               // LDS bytes per row of the x tile (e4m3 in the fp8 mode)
     static constexpr int CPR = K / 8;                         // 8-element chunks per row (16 B of bf16 in HBM)
@@ -420,7 +267,7 @@ template <int KS, int F8 = 0> struct QaCfg2 {
     static constexpr int LPT = 32 * CPR / 256;
     static_assert(LPT * 256 == 32 * CPR, "tile must be a whole number of chunks per thread");
     static_assert(!F8 || CPR == 32, "fp8 form: one row per 32 lanes (hidden size 256)");
-    static_assert(F8 >= 0 && F8 <= 2, "F8 mode");
+    static_assert(F8 >= 1 && F8 <= 2, "F8 mode");
     static constexpr int SWZ = CPR >= 16 ? 15 : CPR - 1;
     static constexpr int QTB = 32 * 512;                      // projection tile: 32 rows x 256 bf16
     // A ring + projection tile + per-wave {rho, madd} + bias (+ fp8: channel scales of W, row scales of the two x tiles)
@@ -869,8 +716,15 @@ __global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
     QA3_PROF_FLUSH;
 }
 
+// the role-split form addresses x and Q|K|V|C with 32-bit byte offsets
+static bool qa3_ok(const QkvcAttn& a) {
+    const int d = a.H * 32;
+    return (int64_t)a.Tseq * 32 * a.ldx * 2 < ((int64_t)1 << 32) && (int64_t)a.Tseq * 32 * a.ldq * 2 < ((int64_t)1 << 32) && (d == 256 || d == 128);
+}
+
 bool qkvc_attn_supported(const QkvcAttn& a) {
     const int d = a.H * 32;
+    if (!a.W8 && !qa3_ok(a)) return false;      // bf16: the role-split form only
     if (a.W8 && !(d == 256 && a.wscale && ((uintptr_t)a.W8 % 8) == 0)) return false;
     if (a.X8 && !(a.W8 && a.xscale && ((uintptr_t)a.X8 % 8) == 0)) return false;
     return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.H % 2 == 0 && a.Tseq >= 2 && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
@@ -879,22 +733,8 @@ bool qkvc_attn_supported(const QkvcAttn& a) {
            (a.W != nullptr || a.W8 != nullptr);
 }
 
-template <int KS> static int launch_qa(const QkvcAttn& a, hipStream_t st) {
-    using C = QaCfg<KS>;
-    auto kern = qkvc_attn_fwd_kernel<KS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-        attr_done = true;
-    }
-    const int ny = a.H / 2, num_mt = cdiv(a.Tseq * 32, 64);
-    const int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(512), C::SMEM, st, a);
-    PMGT_LAUNCH_OK();
-    return 0;
-}
 
-template <int KS, int F8 = 0> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
+template <int KS, int F8> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
     using C = QaCfg2<KS, F8>;
     auto kern = qkvc_attn_fwd2_kernel<KS, F8>;
     static bool attr_done = false;
@@ -924,16 +764,6 @@ template <int KS> static int launch_qa3(const QkvcAttn& a, hipStream_t st) {
     return 0;
 }
 
-// 1 = the 8-wave two-sequence form, 2 = two 4-wave workgroups per CU, 3 (default) = the role-split 16-wave form
-static int qa_form() {
-    static const int v = [] { const char* e = getenv("PMGT_QA_FORM"); const int f = e ? atoi(e) : 3; return f >= 1 && f <= 3 ? f : 3; }();
-    return v;
-}
-// the role-split form addresses x and Q|K|V|C with 32-bit byte offsets
-static bool qa3_ok(const QkvcAttn& a) {
-    const int d = a.H * 32;
-    return (int64_t)a.Tseq * 32 * a.ldx * 2 < ((int64_t)1 << 32) && (int64_t)a.Tseq * 32 * a.ldq * 2 < ((int64_t)1 << 32) && (d == 256 || d == 128);
-}
 
 
 int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
@@ -941,9 +771,7 @@ int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
     PMGT_CHECK(qkvc_attn_supported(a), -2, "qkvc_attn_fwd: unsupported shape S=%d dh=%d H=%d", a.S, a.dh, a.H);
     if (a.W8 && a.X8) return launch_qa2<8, 2>(a, st);
     if (a.W8) return launch_qa2<8, 1>(a, st);
-    if (qa_form() == 1) return a.H * 32 == 256 ? launch_qa<8>(a, st) : launch_qa<4>(a, st);
-    if (qa_form() == 3 && qa3_ok(a)) return a.H * 32 == 256 ? launch_qa3<8>(a, st) : launch_qa3<4>(a, st);
-    return a.H * 32 == 256 ? launch_qa2<8>(a, st) : launch_qa2<4>(a, st);
+    return a.H * 32 == 256 ? launch_qa3<8>(a, st) : launch_qa3<4>(a, st);
 }
 
 }  // namespace pmgt

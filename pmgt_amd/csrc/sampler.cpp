@@ -483,7 +483,7 @@ int pmgt_sampler_batch(pmgt_sampler* s, const int64_t* targets, int n, int mode,
 }
 
 int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mode, uint64_t base_seed, uint64_t counter,
-                          int n_threads, int64_t* tgt_ids, float* tgt_mask, int64_t* pair_ids, float* pair_mask,
+                          uint64_t counter_stride, int n_threads, int64_t* tgt_ids, float* tgt_mask, int64_t* pair_ids, float* pair_mask,
                           int64_t* num_pairs, float* labels) {
     const int S = s->max_ctx + 1, mp = max_pairs(s, mode);
     if (n <= 0) return 0;
@@ -513,7 +513,7 @@ int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mo
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n || fail.load()) break;
-            sc.rng.seed(mix_seed(base_seed, counter + (uint64_t)i));
+            sc.rng.seed(mix_seed(base_seed, counter + counter_stride * (uint64_t)i));
             const int rc = sample_item(s, sc, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
                                        pid.data() + (size_t)i * mp * S, pmk.data() + (size_t)i * mp * S, lab.data() + (size_t)i * mp);
             if (rc < 0) { errs[tid] = g_err; fail.store(rc); break; }

@@ -74,9 +74,9 @@ class MCNSampler:
                     num_pairs=mk((n,), torch.int64), labels=mk((n * mp,), torch.float32))
 
     def batch(self, targets: np.ndarray, mode: int = MODE_TRAIN, out=None, threads: int = 0, base_seed: int = 0,
-              counter: int = 0):
+              counter: int = 0, counter_stride: int = 1):
         """Sample one collated batch.  threads == 0: the sequential reference-order stream;
-        threads >= 1: per-target seeded streams on that many host threads."""
+        threads >= 1: per-target seeded streams on that many host threads (target i: stream counter + counter_stride * i)."""
         targets = np.ascontiguousarray(targets, dtype=np.int64)
         n = len(targets)
         buf = out if out is not None else self.alloc(n, mode)
@@ -85,7 +85,7 @@ class MCNSampler:
         if threads <= 0:
             tot = self._check(self.lib.pmgt_sampler_batch(self.h, _p(targets), n, mode, *args))
         else:
-            tot = self._check(self.lib.pmgt_sampler_batch_mt(self.h, _p(targets), n, mode, base_seed, counter, threads, *args))
+            tot = self._check(self.lib.pmgt_sampler_batch_mt(self.h, _p(targets), n, mode, base_seed, counter, counter_stride, threads, *args))
         tgt = {"node_ids": buf["tgt_ids"][:n], "attention_mask": buf["tgt_mask"][:n]}
         if mode == MODE_INFERENCE:
             return tgt

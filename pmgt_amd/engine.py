@@ -1,4 +1,4 @@
-"""Device-side state of one PMGT replica and thin wrappers over the C ABI (include/pmgt_capi.h).
+"""Device-side state of one PMGT replica and thin wrappers over the C ABI (include/pmgt_capi.h, include/pmgt_ops.h).
 
 PyTorch is used here only as plumbing: device memory (torch tensors own every buffer handed to the
 library), the current HIP stream, and torch.distributed for the data-parallel gradient all-reduce.
@@ -102,6 +102,42 @@ class Engine:
     def load_params(self, params: Dict[str, torch.Tensor]):
         for e in self.entries:
             self.view(e["name"]).copy_(params[e["name"]].to(torch.float32))
+        self.check_layernorm_carrier()
+
+    # The default bf16 path at hidden size 256 keeps no copy of a LayerNorm's input: the backward takes the normalised row from the
+    # LayerNorm OUTPUT, x^ = (y - beta) / gamma.  y is bf16, so x^ comes back with an absolute error of 2^-9 (|x^| + |beta / gamma|):
+    # harmless for the reference's initialisation (gamma = 1, beta = 0) and anything near it, not for a checkpoint whose LayerNorm has
+    # |beta| >> |gamma| in some channel.  Loading parameters checks that ratio and falls back to stored inputs ("store_ln_input").
+    LN_CARRIER_MAX_RATIO = 8.0
+
+    def check_layernorm_carrier(self) -> float:
+        """max over the encoder's LayerNorm channels of |beta| / |gamma| (channels with gamma == 0 are handled exactly by the
+        kernel and skipped); above LN_CARRIER_MAX_RATIO the engine switches to stored LayerNorm inputs."""
+        worst = 0.0
+        for e in self.entries:
+            if e["name"].endswith("LayerNorm.weight") and "encoder.layer" in e["name"]:
+                g = self.view(e["name"]).abs()
+                b = self.view(e["name"][:-len("weight")] + "bias").abs()
+                nz = g > 0
+                if bool(nz.any()):
+                    worst = max(worst, float((b[nz] / g[nz]).max()))
+        if worst > self.LN_CARRIER_MAX_RATIO and not self.get_option("store_ln_input"):
+            import warnings
+            warnings.warn(f"pmgt_amd: LayerNorm |beta / gamma| reaches {worst:.1f}: x^ from the LayerNorm output would lose "
+                          "precision, storing LayerNorm inputs instead (option store_ln_input)")
+            self.set_option("store_ln_input", 1)
+        return worst
+
+    # ---- path options (include/pmgt_ops.h): state of THIS engine, not of the process ----------------
+    def set_option(self, key: str, value) -> None:
+        _lib.check(self.lib.pmgt_engine_set_option(self.h, key.encode(), 1 if value else 0))
+        self.__dict__.pop("_ws_bytes", None)          # workspace carving depends on some options
+
+    def get_option(self, key: str) -> bool:
+        v = int(self.lib.pmgt_engine_get_option(self.h, key.encode()))
+        if v < 0:
+            raise KeyError(self.lib.pmgt_last_error().decode())
+        return bool(v)
 
     def set_tables(self, visual, textual):
         """Frozen feature tables [N+2, F_m] (pmgt/pmgt/models.py:40-54), cast once to the engine dtype."""
@@ -163,31 +199,42 @@ class Engine:
         return cache[key]
 
     OUTPUT_RING = 4
+    OUTPUT_RINGS_MAX = 8
 
-    def _outputs(self, B: int, P: int, S: int, want_hidden: bool):
-        """Output tensors of pretrain_step from a ring of OUTPUT_RING persistent sets per shape (no allocator call and no
-        memset launch on the step's critical path): what a call returns stays valid until OUTPUT_RING - 1 further calls
-        with the same shape have been made -- clone a result that must live longer."""
-        key = (B, P, S, bool(want_hidden))
+    def _outputs(self, B: int, P: int, S: int, want_hidden: bool, private: bool = False):
+        """Output tensors of pretrain_step from a ring of OUTPUT_RING persistent sets (no allocator call and no memset launch
+        on the step's critical path): what a call returns stays valid until OUTPUT_RING - 1 further calls of the same kind
+        have been made -- clone a result that must live longer.  A ring is keyed by (B, S, want_hidden) and sized for the
+        LARGEST pair count seen so far (the pair count changes with almost every live batch: logits are a [:P] view of a
+        capacity-sized buffer, grown geometrically); rings are evicted least-recently-used, never all at once.
+        private = True hands out a set of its own that no later call reuses (hipGraph capture: replays keep writing it)."""
+        d = self.config.hidden_size
+
+        def make(cap):
+            return (torch.empty(3, dtype=torch.float32, device=self.device),
+                    torch.empty(cap, dtype=torch.float32, device=self.device),
+                    torch.empty(B, S, d, dtype=self.torch_dtype, device=self.device) if want_hidden else None,
+                    torch.zeros(1, dtype=torch.int32, device=self.device))
+        if private:
+            loss, logits, hidden, count = make(P)
+            return loss, logits, hidden, count
+        key = (B, S, bool(want_hidden))
         rings = self.__dict__.setdefault("_out_rings", {})
-        ring = rings.get(key)
-        if ring is None:
-            if len(rings) > 16:          # ragged last batches etc.: do not grow without bound
-                rings.clear()
-            d = self.config.hidden_size
-            ring = rings[key] = dict(next=0, sets=[(
-                torch.empty(3, dtype=torch.float32, device=self.device),
-                torch.empty(P, dtype=torch.float32, device=self.device),
-                torch.empty(B, S, d, dtype=self.torch_dtype, device=self.device) if want_hidden else None,
-                torch.zeros(1, dtype=torch.int32, device=self.device)) for _ in range(self.OUTPUT_RING)])
-        out = ring["sets"][ring["next"]]
+        ring = rings.pop(key, None)
+        if ring is None or ring["cap"] < P:
+            cap = max(P, 0 if ring is None else int(ring["cap"] * 1.25) + 1, B * 10)
+            ring = dict(next=0, cap=cap, sets=[make(cap) for _ in range(self.OUTPUT_RING)])
+        rings[key] = ring                     # dicts keep insertion order: re-inserting marks the ring most recently used
+        while len(rings) > self.OUTPUT_RINGS_MAX:
+            rings.pop(next(iter(rings)))
+        loss, logits, hidden, count = ring["sets"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % self.OUTPUT_RING
-        return out
+        return loss, logits[:P], hidden, count
 
     # ---- PMGT.forward (+ backward) ---------------------------------------------------------------
     def pretrain_step(self, batch, training: bool, backward: bool = False, accumulate: bool = False,
                       nfr_inject=None, random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16,
-                      want_hidden: bool = True, grad_buffer: Optional[torch.Tensor] = None):
+                      want_hidden: bool = True, grad_buffer: Optional[torch.Tensor] = None, private_outputs: bool = False):
         """batch = (target_dict, pair_dict, num_pairs, labels) of device tensors (pmgt_collate_fn layout).
         nfr_inject = (masked_ids [B,S] int64, nfr_targets [B,S] int64 with -1 = not masked)."""
         tgt, pair, num_pairs, labels = batch
@@ -196,7 +243,7 @@ class Engine:
         P = int(pair["node_ids"].shape[0])
         n_seq = B + P + (B if training else 0)
         ws = self._workspace(self._workspace_bytes(n_seq, S, B, training))
-        loss, logits, hidden, count = self._outputs(B, P, S, want_hidden)
+        loss, logits, hidden, count = self._outputs(B, P, S, want_hidden, private_outputs)
         if not training:
             count.zero_()                # only the training path writes the number of masked rows
         keep = [ids, tgt["attention_mask"].contiguous(), pair["node_ids"].contiguous(),
@@ -311,8 +358,8 @@ class Engine:
             raise err
 
     def set_overlap(self, on: bool):
-        """Partial-sum reductions of the backward pass on the engine's side stream (default) or on the caller's stream."""
-        self.lib.pmgt_engine_set_overlap(self.h, 1 if on else 0)
+        """Partial-sum reductions of the backward pass on the engine's side stream, or (default) on the caller's stream."""
+        self.set_option("side_stream_reduce", on)
 
     # ---- phase timers -------------------------------------------------------------------------------------
     def profile_begin(self):

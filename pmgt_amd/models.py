@@ -175,7 +175,7 @@ class PMGT(PMGTPretrainedModel):
             names = [n for n, p in self.named_parameters() if p.requires_grad]
             params = [p for _, p in self.named_parameters() if p.requires_grad]
             loss = _PretrainLoss.apply(loss, scratch, [self._engine_name(n) for n in names], eng, *params)
-        last = out["last_hidden_state"].float()
+        last = out["last_hidden_state"].to(torch.float32, copy=True)      # a copy in fp32 mode too (.float() would alias the ring buffer)
         if not return_dict:
             return (loss, logits, last, None) + tuple(v for v in (hidden, attn) if v is not None)
         return PMGTForPreTrainingOutput(loss=loss, prediction_logits=logits, last_hidden_state=last,

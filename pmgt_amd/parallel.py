@@ -41,24 +41,51 @@ class BucketedAllReduce:
     the launches enqueued so far, next to the rest of the backward pass; `wait()` orders the caller's stream after all of
     them (no host block on RCCL) and returns the number of elements exchanged so the caller can check coverage."""
 
-    def __init__(self, flat: torch.Tensor):
+    def __init__(self, flat: torch.Tensor, boundaries=()):
+        """boundaries: offsets into the flat buffer at which a collective is issued.  () = one collective per engine bucket
+        (NFR head, each layer, embeddings: 0.8 - 3 MB each at L4 / d256).  The engine reports ranges in DESCENDING offset
+        order; adjacent ranges are coalesced and the coalesced range is sent as soon as its low end reaches a boundary (or
+        offset 0), so `boundaries = (offset of layer 0,)` gives TWO collectives -- NFR head + encoder layers, started while
+        the embedding backward still runs, then the embeddings -- latency-sized messages merged into bandwidth-sized ones."""
         self.flat = flat
         self.enabled = True
+        self.boundaries = frozenset(int(b) for b in boundaries)
         self._pending = []
         self._elems = 0
+        self._held = None            # (offset, numel) coalesced, not yet sent
+        self.sent = []               # (offset, numel) of the collectives of the current step, in issue order
 
-    def bucket_ready(self, offset: int, numel: int):
-        if not self.enabled:
-            return
+    def _send(self, offset: int, numel: int):
         import torch.distributed as dist
         sl = self.flat[offset: offset + numel]
         avg = dist.get_backend() == "nccl"
         work = dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self._pending.append((work, sl, avg))
         self._elems += numel
+        self.sent.append((offset, numel))
+
+    def bucket_ready(self, offset: int, numel: int):
+        if not self.enabled:
+            return
+        if not self.boundaries:
+            self._send(offset, numel)
+            return
+        if self._held is not None and offset + numel == self._held[0]:
+            self._held = (offset, numel + self._held[1])              # grows downwards
+        else:
+            if self._held is not None:                                # not adjacent: what is held goes out as it is
+                self._send(*self._held)
+            self._held = (offset, numel)
+        if self._held[0] == 0 or self._held[0] in self.boundaries:
+            self._send(*self._held)
+            self._held = None
 
     def wait(self) -> int:
         ws = world()[1]
+        if self._held is not None:
+            self._send(*self._held)
+            self._held = None
+        self.last_sent, self.sent = self.sent, []
         for work, sl, avg in self._pending:
             work.wait()
             if not avg:

@@ -26,7 +26,8 @@ from .parallel import BucketedAllReduce, allreduce_mean_, broadcast_, gather_pre
 class Trainer:
     def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
-                 random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True):
+                 random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True,
+                 buckets: str = "layer"):
         self.engine = engine
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
@@ -38,8 +39,18 @@ class Trainer:
         # world_size > 1: per-bucket all-reduce started from the engine's gradient-ready hook while the backward pass of
         # the earlier layers is still running (overlap_allreduce=False: ONE blocking all-reduce after the backward pass)
         self._exchange = None
+        # buckets: "layer" = one collective per engine bucket (NFR head, every layer, embeddings); "two" = NFR head + encoder
+        # layers as one collective (issued when layer 0's gradients are final), embeddings as the second; "one" = the whole buffer
+        # after the backward pass (engine option one_bucket)
+        if buckets not in ("layer", "two", "one"):
+            raise ValueError(f"buckets={buckets!r}: expected 'layer', 'two' or 'one'")
+        self.buckets = buckets
         if world_size > 1 and overlap_allreduce:
-            self._exchange = BucketedAllReduce(engine.grads)
+            bounds = ()
+            if buckets == "two" and engine.config.num_hidden_layers > 0:
+                bounds = (engine.entry("bert.encoder.layer.0.attention.self.query.weight")["offset"],)
+            engine.set_option("one_bucket", buckets == "one")
+            self._exchange = BucketedAllReduce(engine.grads, boundaries=bounds)
             engine.set_grad_ready_hook(self._exchange.bucket_ready)
 
     def broadcast_parameters(self, src: int = 0):
@@ -54,8 +65,9 @@ class Trainer:
             self._exchange.enabled = self.world_size > 1 and self._micro == self.accum - 1
         out = self.engine.pretrain_step(batch, training=True, backward=True, accumulate=self._micro > 0,
                                         random_node_ratio=self.random_node_ratio, mask_node_ratio=self.mask_node_ratio,
-                                        want_hidden=False)
+                                        want_hidden=False, private_outputs=getattr(self, "_capturing", False))
         self.last_loss = out["loss"]
+        self.last_outputs = out
         return out["loss"]
 
     def optimizer_step(self):
@@ -97,8 +109,13 @@ class Trainer:
                 self.train_step(batch)
             st.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=st):
-                loss = self.train_step(batch)
+            self._capturing = True        # the graph gets an output set of its own: replays keep writing it, eager steps never do
+            try:
+                with torch.cuda.graph(graph, stream=st):
+                    loss = self.train_step(batch)
+                    outputs = self.last_outputs
+            finally:
+                self._capturing = False
         torch.cuda.current_stream(dev).wait_stream(st)
 
         def replay():
@@ -106,6 +123,7 @@ class Trainer:
             self.last_loss = loss
             return loss
         replay.graph = graph
+        replay.outputs = outputs          # loss / logits / nfr_count the replays write (kept alive with the graph)
         return replay
 
     # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
@@ -258,7 +276,8 @@ def evaluate(engine, sampler, node_ids: np.ndarray, batch_size: int = 256, threa
     per target, sigmoid(logits) vs labels -> {'loss/val', 'val/auc'}.  `loss/val` is the mean of the per-batch losses
     (what `self.log("loss/val", ...)` aggregates over an epoch, weighted by batch size).  distributed=True under an
     initialised process group: rank r evaluates node_ids[r::W] and the predictions of all ranks are gathered, so every
-    rank reports the same AUC over the whole validation set (the reference's AUC is per rank: no sync_dist)."""
+    rank reports the same AUC over the whole validation set (the reference's AUC is per rank: no sync_dist); every node
+    draws from the stream of its GLOBAL index, so the result equals the single-process evaluation of the same list."""
     node_ids = np.asarray(node_ids)
     rank, ws = world() if distributed else (0, 1)
     mine = node_ids[rank::ws]
@@ -266,7 +285,8 @@ def evaluate(engine, sampler, node_ids: np.ndarray, batch_size: int = 256, threa
     loss_sum = 0.0
     for lo in range(0, len(mine), batch_size):
         tg = mine[lo: lo + batch_size]
-        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_EVAL, threads=threads, base_seed=seed, counter=rank + ws * lo)
+        tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_EVAL, threads=threads, base_seed=seed, counter=rank + ws * lo,
+                                                      counter_stride=ws)      # item j of this rank = item rank + ws * j of the list
         cu = lambda d: {k: v.to(engine.device) for k, v in d.items()}
         out = engine.pretrain_step((cu(tgt), cu(pair), num_pairs.to(engine.device), labels.to(engine.device)),
                                    training=False, want_hidden=False)

@@ -44,7 +44,7 @@ pmgt_sampler* make() {
 }
 
 int run_mt(pmgt_sampler* s, const std::vector<int64_t>& tg, int threads, uint64_t seed, uint64_t ctr, Batch& b) {
-    return pmgt_sampler_batch_mt(s, tg.data(), (int)tg.size(), 0, seed, ctr, threads, b.tid.data(), b.tmk.data(), b.pid.data(),
+    return pmgt_sampler_batch_mt(s, tg.data(), (int)tg.size(), 0, seed, ctr, 1, threads, b.tid.data(), b.tmk.data(), b.pid.data(),
                                  b.pmk.data(), b.np.data(), b.lab.data());
 }
 }  // namespace

@@ -104,7 +104,7 @@ def test_grad_ready_buckets_tile_the_buffer_and_are_final():
     eng.pretrain_step(b, training=True, backward=True, nfr_inject=i, want_hidden=False)       # and the engine is still usable
 
 
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, buckets="layer"):
     import torch.distributed as dist
     from pmgt_amd.trainer import Trainer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -114,12 +114,14 @@ def _dp_worker(rank, world, port, out_dir):
         eng, batch, inj = make_world()
         if rank == 1:
             eng.params.mul_(1.5)                 # replicas start different: the broadcast must fix that
-        tr = Trainer(eng, lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0, world_size=world)
+        tr = Trainer(eng, lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0, world_size=world, buckets=buckets)
         tr.broadcast_parameters()
         half = B // world
         b, i = shard(batch, inj, rank * half, (rank + 1) * half)
         eng.pretrain_step(b, training=True, backward=True, nfr_inject=i, want_hidden=False)    # the hook exchanges the buckets
         assert tr._exchange.wait() == eng.n_params
+        n_coll = {"layer": CFG["num_hidden_layers"] + 2, "two": 2, "one": 1}[buckets]
+        assert len(tr._exchange.last_sent) == n_coll, tr._exchange.last_sent
         torch.cuda.synchronize()
         torch.save(eng.grads.cpu(), os.path.join(out_dir, f"g{rank}.pt"))
         # 5 optimizer steps through the Trainer (overlapped exchange + clip + AdamW); dropout stays 0, NFR masks from the device RNG
@@ -132,9 +134,10 @@ def _dp_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_rank_and_replicas_stay_identical(tmp_path):
+@pytest.mark.parametrize("buckets", ["layer", "two", "one"])
+def test_two_rank_gradients_equal_single_rank_and_replicas_stay_identical(tmp_path, buckets):
     import torch.multiprocessing as mp
-    mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path), buckets), nprocs=2, join=True)
     g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
     assert torch.equal(g0, g1)                                              # every rank holds the same reduced gradient
     eng, batch, inj = make_world()
@@ -158,14 +161,21 @@ def test_two_rank_gradients_equal_single_rank_and_replicas_stay_identical(tmp_pa
     assert torch.equal(p0, p1) and torch.isfinite(p0).all()
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
-    """The exact launch line of the driver at N = 2 (torch.distributed.run, one process per rank), with both ranks on
-    this GPU and gloo instead of RCCL: rendezvous, parameter broadcast, sharded staging, bucketed exchange, barriers, MAX
-    over ranks, the symmetric phase / end-to-end passes and the barrier -> destroy teardown."""
+@pytest.mark.parametrize("launch", ["driver", "self"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path, launch):
+    """launch = "driver": the exact launch line of the driver at N = 2 (torch.distributed.run, one process per rank);
+    launch = "self": `python bench.py --gpus 2` alone, which starts the two ranks itself.  Both ranks on this GPU and gloo
+    instead of RCCL: rendezvous, parameter broadcast, sharded staging, bucketed exchange, barriers, MAX over ranks, the
+    symmetric phase pass, the all-reduce measurement and the barrier -> destroy teardown."""
     env = dict(os.environ, PMGT_BENCH_BACKEND="gloo", PMGT_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "64", "--sampler-threads", "2"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--sampler-threads", "2"]
+    if launch == "driver":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail + ["--buckets", "two"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -174,3 +184,6 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["loss_last"])
     assert "phases" in out and "cpu_baseline" not in out and "end_to_end" not in out       # the live pipeline is an N = 1 (or opt-in) pass
+    ar = out["allreduce"]
+    assert ar["buckets"] == (6 if launch == "driver" else 2) and ar["ms_per_step"] > 0
+    assert abs(ar["mb"] - 4 * 3.06) < 0.5                                                   # the whole flat gradient buffer, once

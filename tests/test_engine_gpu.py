@@ -173,7 +173,7 @@ def test_side_stream_reductions_give_identical_gradients():
     batch = dev_batch(case["batch"])
     inj, _ = inject_for(case)
     ref = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
-    ref.set_overlap(False)
+    assert not ref.get_option("side_stream_reduce")          # off by default
     out0 = ref.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
     torch.cuda.synchronize()
     eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
@@ -190,22 +190,17 @@ def test_side_stream_reductions_give_identical_gradients():
 def test_fused_qkvc_attention_in_the_engine_matches_unfused(name):
     """bf16 engine at the headline shape (d=256, H=8, S=32): the fused projection+attention forward is on by
     default; switching it off must give the same loss and gradients up to bf16 round-off of the context."""
-    from pmgt_amd import _lib
-    L = _lib.hip()
     case = gu.model_case(name)
     batch = dev_batch(case["batch"])
     inj, _ = inject_for(case)
     res = {}
     for off in (0, 1):
-        L.pmgt_debug_disable_fused_qkvc_attention(off)
-        try:
-            eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
-            eng.profile_begin()
-            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
-            prof = eng.profile_end()
-            res[off] = (out["loss"].item(), eng.grads.clone(), prof)
-        finally:
-            L.pmgt_debug_disable_fused_qkvc_attention(0)
+        eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        eng.set_option("no_fused_qkvc_attention", off)
+        eng.profile_begin()
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+        prof = eng.profile_end()
+        res[off] = (out["loss"].item(), eng.grads.clone(), prof)
     assert "fwd.qkvc_attention" in res[0][2] and "fwd.qkvc_attention" not in res[1][2]
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-3)
     rel = ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item()
@@ -216,22 +211,16 @@ def test_fused_qkvc_attention_in_the_engine_matches_unfused(name):
 def test_table_projection_mode_matches_per_token_projection(name, dtype):
     """Small graphs: the engine projects the whole feature table once and gathers projected rows by node id
     (default whenever 2 (N+2) <= tokens).  The per-token path (large graphs) must give the same loss/gradients."""
-    from pmgt_amd import _lib
-    L = _lib.hip()
     case = gu.model_case(name)
     batch = dev_batch(case["batch"])
     inj, _ = inject_for(case)
     res = {}
     for off in (0, 1):
-        L.pmgt_debug_disable_table_projection(off)
-        L.pmgt_debug_disable_segment_sum(1)           # isolate the forward: same per-token weight-gradient GEMM in both runs
-        try:
-            eng = make_engine(case, dtype=dtype)
-            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
-            res[off] = (out["loss"].item(), out["last_hidden_state"].float().clone(), eng.grads.clone())
-        finally:
-            L.pmgt_debug_disable_table_projection(0)
-            L.pmgt_debug_disable_segment_sum(0)
+        eng = make_engine(case, dtype=dtype)
+        eng.set_option("no_table_projection", off)
+        eng.set_option("no_segment_sum", 1)           # isolate the forward: same per-token weight-gradient GEMM in both runs
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
+        res[off] = (out["loss"].item(), out["last_hidden_state"].float().clone(), eng.grads.clone())
     if dtype == "fp32":
         np.testing.assert_allclose(res[0][0], case["gold"]["train_loss"], rtol=1e-4)
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])       # identical forward values
@@ -243,20 +232,15 @@ def test_table_projection_mode_matches_per_token_projection(name, dtype):
 def test_segment_sum_wgrad_matches_per_token_wgrad(name, dtype):
     """Table mode backward: the feature-projection weight gradient goes through a stable sort by node id + ordered
     segment sums + a GEMM over N+2 rows.  Must equal the per-token GEMM (and the reference), run to run identical."""
-    from pmgt_amd import _lib
-    L = _lib.hip()
     case = gu.model_case(name)
     batch = dev_batch(case["batch"])
     inj, _ = inject_for(case)
     res = {}
     for off in (0, 1, 0):
-        L.pmgt_debug_disable_segment_sum(off)
-        try:
-            eng = make_engine(case, dtype=dtype)
-            eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
-            res.setdefault(off, []).append(eng.grads.clone())
-        finally:
-            L.pmgt_debug_disable_segment_sum(0)
+        eng = make_engine(case, dtype=dtype)
+        eng.set_option("no_segment_sum", off)
+        eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
+        res.setdefault(off, []).append(eng.grads.clone())
     assert torch.equal(res[0][0], res[0][1])                      # deterministic
     for k in ("bert.embeddings.feat_linear.0.weight", "bert.embeddings.feat_linear.1.weight", "bert.embeddings.feat_linear.0.bias"):
         e = eng.entry(k)
@@ -343,20 +327,15 @@ def test_head_major_qkvc_layout_is_transparent():
     """Training at the headline shape stores Q|K|V|C (and its gradient) head-major between the fused forward and the
     attention backward; the data-gradient GEMM reads a column-permuted W^T copy and the weight-gradient GEMM writes
     its rows back in q | k | v | c order.  Switching the layout off changes nothing but summation order."""
-    from pmgt_amd import _lib
-    L = _lib.hip()
     case = gu.model_case("m3")
     batch = dev_batch(case["batch"])
     inj, _ = inject_for(case)
     res = {}
     for off in (0, 1):
-        L.pmgt_debug_disable_head_major(off)
-        try:
-            eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
-            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
-            res[off] = (out["loss"].item(), eng.grads.clone())
-        finally:
-            L.pmgt_debug_disable_head_major(0)
+        eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        eng.set_option("no_head_major", off)
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+        res[off] = (out["loss"].item(), eng.grads.clone())
     assert res[0][0] == res[1][0]                      # the forward is bit-identical
     # the data-gradient GEMM sums its K = 4d products in permuted order: bf16 round-off of dX, then propagated
     rel = ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item()

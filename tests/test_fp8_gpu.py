@@ -253,20 +253,16 @@ def test_fp8_engine_paths_agree_and_train():
     base = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
     g0 = eng.grads.clone()
     # layer inputs quantised by their producer (default) or by their consumer: the same bytes, hence the same step
-    L.pmgt_debug_disable_producer_quant(1)
-    try:
+    eng.set_option("consumer_quant", 1)
+    eng.rng_state[1] = 0
+    o = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
+    eng.set_option("consumer_quant", 0)
+    assert o["loss"].item() == base["loss"].item() and torch.equal(eng.grads, g0)
+    for key in ("no_fused_qkvc_attention", "no_table_projection", "no_shortcut"):
+        eng.set_option(key, 1)
         eng.rng_state[1] = 0
         o = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
-    finally:
-        L.pmgt_debug_disable_producer_quant(0)
-    assert o["loss"].item() == base["loss"].item() and torch.equal(eng.grads, g0)
-    for switch in (L.pmgt_debug_disable_fused_qkvc_attention, L.pmgt_debug_disable_table_projection, L.pmgt_debug_disable_last_layer_shortcut):
-        switch(1)
-        try:
-            eng.rng_state[1] = 0
-            o = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj)
-        finally:
-            switch(0)
+        eng.set_option(key, 0)
         np.testing.assert_allclose(o["loss"].item(), base["loss"].item(), rtol=3e-3)
         assert torch.nn.functional.cosine_similarity(eng.grads, g0, dim=0).item() > 0.999
     losses = []

@@ -46,22 +46,13 @@ def step(eng, world, **kw):
 
 
 def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
-    from pmgt_amd import _lib
-    L = _lib.hip()
     fast = engine(world)
+    plain = engine(world)           # two engines alive in one process, each with its own options
+    for k in ("no_table_projection", "no_fused_qkvc_attention", "no_head_major", "no_shortcut", "tile_gemm", "no_segment_sum",
+              "no_fused_attention_bwd", "eager_reduce", "store_ln_input"):
+        plain.set_option(k, 1)
+    o_plain = step(plain, world, want_hidden=True)
     o_fast = step(fast, world, want_hidden=False)
-    switches = [L.pmgt_debug_disable_table_projection, L.pmgt_debug_disable_fused_qkvc_attention, L.pmgt_debug_disable_head_major,
-                L.pmgt_debug_disable_last_layer_shortcut, L.pmgt_debug_force_tile_gemm, L.pmgt_debug_disable_segment_sum,
-                L.pmgt_debug_disable_fused_attention_backward, L.pmgt_debug_disable_deferred_reductions,
-                L.pmgt_debug_disable_layernorm_from_output]
-    for f in switches:
-        f(1)
-    try:
-        plain = engine(world)
-        o_plain = step(plain, world, want_hidden=True)
-    finally:
-        for f in switches:
-            f(0)
     assert np.isfinite(o_fast["loss"].item())
     np.testing.assert_allclose(o_fast["loss"].item(), o_plain["loss"].item(), rtol=2e-3)
     np.testing.assert_allclose(o_fast["gsr"].item(), o_plain["gsr"].item(), rtol=2e-3)
@@ -87,23 +78,17 @@ def test_layernorm_backward_from_the_layernorm_output_matches_the_stored_input_f
     """Where the LayerNorm runs in the streaming GEMM's epilogue, the forward does not store the pre-LayerNorm sum and the backward takes
     x^ = (y - beta) / gamma from the LayerNorm output (rowops.h).  Same forward values exactly (the switch only drops a store); gradients
     equal up to the bf16 round-off of the two carriers of x^ -- with gamma away from 1 and beta away from 0, so that neither drops out."""
-    from pmgt_amd import _lib
-    L = _lib.hip()
-
     def run(stored):
-        L.pmgt_debug_disable_layernorm_from_output(1 if stored else 0)
-        try:
-            eng = engine(world)
-            g = torch.Generator().manual_seed(11)
-            for l in range(4):
-                for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
-                    w = eng.view(f"bert.encoder.layer.{l}.{ln}.weight")
-                    w.copy_((0.6 + 0.8 * torch.rand(w.shape, generator=g)).to(w.device))
-                    bb = eng.view(f"bert.encoder.layer.{l}.{ln}.bias")
-                    bb.copy_((0.3 * torch.randn(bb.shape, generator=g)).to(bb.device))
-            return eng, step(eng, world, want_hidden=False)
-        finally:
-            L.pmgt_debug_disable_layernorm_from_output(0)
+        eng = engine(world)
+        eng.set_option("store_ln_input", stored)
+        g = torch.Generator().manual_seed(11)
+        for l in range(4):
+            for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
+                w = eng.view(f"bert.encoder.layer.{l}.{ln}.weight")
+                w.copy_((0.6 + 0.8 * torch.rand(w.shape, generator=g)).to(w.device))
+                bb = eng.view(f"bert.encoder.layer.{l}.{ln}.bias")
+                bb.copy_((0.3 * torch.randn(bb.shape, generator=g)).to(bb.device))
+        return eng, step(eng, world, want_hidden=False)
 
     ey, oy = run(False)
     es, os_ = run(True)

@@ -15,7 +15,7 @@ DT = {"fp32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
 
 def _setup():
     from pmgt_amd import _lib
-    return _lib, _lib.hip()
+    return _lib, _lib.ops()       # pmgt_op_* with the path_opts argument taken from L.path (L.use("tile_gemm"), ...)
 
 
 def P(t):
@@ -61,12 +61,10 @@ def test_gemm_nt_plain(dt, M, N, K):
     assert rel_err(Cd, ref) < tol(dt), rel_err(Cd, ref)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16", "bf16-dma"])
-@pytest.mark.parametrize("K", [72, 96, 256])      # bf16-dma: the LDS-DMA variant of the tile kernel (K % 32 == 0)
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("K", [72, 96, 256])
 def test_gemm_nt_epilogues_and_gather(dt, K):
     _lib, L = _setup()
-    L.pmgt_debug_enable_nt_dma(1 if dt == "bf16-dma" else 0)
-    dt = dt.split("-")[0]
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(5)
     M, N, R = 333, 136, 50
@@ -103,7 +101,6 @@ def test_gemm_nt_epilogues_and_gather(dt, K):
     ref3 = rounded(A, tdt) @ rounded(B, tdt).T
     assert rel_err(Cd[:100], ref3[:100]) < tol(dt)
     assert bool((Cd[100:].float() == 7.0).all())
-    L.pmgt_debug_enable_nt_dma(0)
 
 
 # ------------------------------------------------------------------------------------------- gemm_tn
@@ -316,9 +313,9 @@ def test_attention_backward_fused_with_qkvc_weight_gradient(T, H, hm, p):
         assert rel_err(got, xr.grad) < 2e-2
     # the unfused one-wave MFMA backward on the same inputs (same dropout masks: same (seed, step, site, row, column) hash)
     dx2 = torch.empty_like(dx)
-    L.pmgt_debug_disable_coop_attention_bwd(1)
+    L.use("wave_attention_bwd")
     _lib.check(L.pmgt_op_attention_bwd(1, P(qd), P(md), P(dod), P(dx2), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
-    L.pmgt_debug_disable_coop_attention_bwd(0)
+    L.use()
     assert rel_err(got, dx2) < 2e-2
     assert ((got.float() == 0) == (dx2.float() == 0)).float().mean() > 0.995
     # weight / bias gradient: exactly the sums of what the kernel stored (fp32 accumulation of bf16 products), q | k | v | c rows
@@ -335,7 +332,7 @@ def test_attention_backward_fused_with_qkvc_weight_gradient(T, H, hm, p):
                                            (11, 64, 8, 32, 0.4), (3, 17, 2, 64, 0.6)])
 def test_attention_fwd_bwd(dt, T, S, H, dh, beta):
     _lib, L = _setup()
-    L.pmgt_debug_disable_coop_attention_bwd(1 if dt == "bf16-wave" else 0)
+    L.use(*(["wave_attention_bwd"] if dt == "bf16-wave" else []))
     dt = dt.split("-")[0]
     code, tdt = DT[dt]
     d = H * dh
@@ -364,7 +361,6 @@ def test_attention_fwd_bwd(dt, T, S, H, dh, beta):
     _lib.check(L.pmgt_op_attention_fwd(code, P(xd), None, P(ctx), None, T, S, H, dh, beta, 0.0, 0, 0, None, stream()))
     ref1, _ = _attn_ref(rounded(x, tdt), torch.ones(T, S, dtype=torch.float64), H, beta)
     assert rel_err(ctx, ref1) < tol(dt)
-    L.pmgt_debug_disable_coop_attention_bwd(0)
 
 
 def test_attention_dropout_forward_backward_consistent():
@@ -407,14 +403,13 @@ def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
     rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
     outs = {}
     for force in (0, 1):
-        L.pmgt_debug_force_valu_attention(force)
+        L.use(*(['valu_attention'] if force else []))
         ctx = torch.empty(T, S, d, device="cuda", dtype=torch.bfloat16)
         probs = torch.empty(T, H, S, S, device="cuda")
         dx = torch.empty(T, S, 4 * d, device="cuda", dtype=torch.bfloat16)
         _lib.check(L.pmgt_op_attention_fwd(1, P(x), P(mask), P(ctx), P(probs), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
         _lib.check(L.pmgt_op_attention_bwd(1, P(x), P(mask), P(dctx), P(dx), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
         outs[force] = (ctx.float(), probs, dx.float())
-    L.pmgt_debug_force_valu_attention(0)
     ctx, probs, dx = outs[0]
     v = x.float()[..., 2 * d:3 * d].view(T, S, H, dh).permute(0, 2, 1, 3)
     do = dctx.float().view(T, S, H, dh).permute(0, 2, 1, 3)
@@ -455,7 +450,7 @@ def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, 
     rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
     outs = []
     for force in (0, 1):
-        L.pmgt_debug_force_tile_gemm(force)
+        L.use(*(['tile_gemm'] if force else []))
         Cd = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         aux = aux_in.clone() if epi == 2 else torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         lno = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if ln else None
@@ -464,7 +459,6 @@ def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, 
                                     P(R), N, drop, 33, P(rng), P(lno), P(stats), P(gam) if ln else None, P(bet) if ln else None,
                                     1e-12, stream()))
         outs.append((Cd.float(), aux.float(), None if lno is None else lno.float(), stats))
-    L.pmgt_debug_force_tile_gemm(0)
     ws, tile = outs
     assert rel_err(ws[0], tile[0]) < 1e-2
     if epi == 1:
@@ -601,11 +595,11 @@ def test_gemm_nt_big_tile_epilogues(M, N, K):
     rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
     _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(Cd), N, M, N, K, P(bd), 0, None, 0, P(rd), N, 0.25, 21, P(rng), None, stream()))
     C2 = torch.empty_like(Cd)
-    L.pmgt_debug_force_tile_gemm(1)
+    L.use("tile_gemm")
     try:
         _lib.check(L.pmgt_op_gemm_nt(1, P(Ad), K, None, P(Bd), K, P(C2), N, M, N, K, P(bd), 0, None, 0, P(rd), N, 0.25, 21, P(rng), None, stream()))
     finally:
-        L.pmgt_debug_force_tile_gemm(0)
+        L.use()
     assert rel_err(Cd, C2.double()) < 1e-3
     kept = ((Cd.double() - rounded(res, tdt).cuda()).abs() > 1e-6).double().mean().item()
     assert abs(kept - 0.75) < 0.02

@@ -1,0 +1,155 @@
+"""Per-engine path options (include/pmgt_ops.h) and the engine-state regressions of round 2's review:
+two engines with different options in one process, the separate backward call at the headline hidden size (the
+LayerNorm-from-output decision must be re-derived, not remembered), a partial-sum arena that flushes between the two
+regions of one producer, the output ring under changing pair counts, graph capture with outputs of its own."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+from tests.test_engine_gpu import dev_batch, inject_for, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_engines_with_different_options_keep_their_own_paths():
+    case = gu.model_case("m3")          # d = 256, H = 8, S = 32: every fused kernel applies
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    a = make_engine(case, dtype="bf16")
+    b = make_engine(case, dtype="bf16")
+    for k in ("no_fused_qkvc_attention", "no_fused_attention_bwd", "store_ln_input"):
+        b.set_option(k, 1)
+        assert b.get_option(k) and not a.get_option(k)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        a.set_option("no_such_option", 1)
+    with pytest.raises(KeyError):
+        a.get_option("no_such_option")
+    prof = {}
+    for rnd in range(2):                # interleaved: neither engine's choice leaks into the other's next step
+        for name, eng in (("a", a), ("b", b)):
+            eng.rng_state[1] = 0
+            eng.profile_begin()
+            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+            prof[name] = eng.profile_end()
+            assert np.isfinite(out["loss"].item())
+    assert "fwd.qkvc_attention" in prof["a"] and "bwd.attention_wgrad" in prof["a"]
+    assert "fwd.qkvc_attention" not in prof["b"] and "bwd.attention_wgrad" not in prof["b"] and "bwd.wgrad_qkvc" in prof["b"]
+    assert "fwd.layernorm" not in prof["b"]            # the fused LayerNorm epilogue stays on in b: only its input store differs
+    cos = torch.nn.functional.cosine_similarity(a.grads, b.grads, dim=0).item()
+    assert cos > 0.999, cos
+    b.set_option("no_fused_qkvc_attention", 0)
+    b.profile_begin()
+    b.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+    assert "fwd.qkvc_attention" in b.profile_end()
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_separate_backward_call_at_hidden_256_rederives_the_layernorm_carrier(dropout):
+    """pmgt_encode_train + pmgt_encode_backward (PMGT_NCF, PMGTModel autograd) in bf16 at d = 256: the forward does not store the
+    pre-LayerNorm sums, and the backward -- a separate call that carves its own buffers -- must know that (round 2 read the
+    never-written buffers there).  Checked against the same engine with stored inputs and against the fp32 engine."""
+    case = gu.model_case("m3")
+    tgt = case["batch"][1]              # the pair sequences: 10 x B sequences of 32
+    ids, mask = tgt["node_ids"].cuda(), tgt["attention_mask"].cuda()
+    w = torch.from_numpy(np.random.RandomState(5).standard_normal(tuple(ids.shape) + (256,)).astype(np.float32)).cuda()
+    grads = {}
+    for key, dtype, stored in (("y", "bf16", 0), ("x", "bf16", 1), ("f32", "fp32", 0)):
+        eng = make_engine(case, dtype=dtype, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+        eng.set_option("store_ln_input", stored)
+        g = torch.Generator().manual_seed(3)
+        for l in range(case["cfg"]["num_hidden_layers"]):
+            for ln in ("attention.output.LayerNorm", "output.LayerNorm"):       # gamma away from 1, beta away from 0
+                eng.view(f"bert.encoder.layer.{l}.{ln}.weight").copy_((0.7 + 0.6 * torch.rand(256, generator=g)).cuda())
+                eng.view(f"bert.encoder.layer.{l}.{ln}.bias").copy_((0.2 * torch.randn(256, generator=g)).cuda())
+        # the workspace of the call comes from torch's caching allocator: hand it a block full of NaN bit patterns, so that a
+        # backward pass that reads a buffer the forward never wrote shows up as NaN gradients, not as plausible noise
+        nbytes = int(eng.lib.pmgt_workspace_bytes(eng.h, ids.shape[0], ids.shape[1], 1, 1))
+        poison = torch.full((nbytes // 4 + 1,), float("nan"), device="cuda")[: nbytes // 4].view(torch.uint8)[:nbytes]
+        torch.cuda.synchronize()
+        del poison
+        last, state = eng.encode_train(ids=ids, attention_mask=mask, training=dropout > 0)
+        eng.grads.fill_(float("nan"))
+        eng.encode_backward(state, w.to(last.dtype))
+        torch.cuda.synchronize()
+        grads[key] = eng.grads.clone()
+        n_bert = eng.entry("nfr_loss.projections.0.weight")["offset"]
+        assert torch.isfinite(grads[key][:n_bert]).all(), key
+        grads[key] = grads[key][:n_bert]
+    cos_xy = torch.nn.functional.cosine_similarity(grads["y"], grads["x"], dim=0).item()
+    assert cos_xy > 0.999, cos_xy
+    if dropout == 0.0:
+        for key in ("y", "x"):
+            cos = torch.nn.functional.cosine_similarity(grads[key], grads["f32"], dim=0).item()
+            assert cos > 0.995, (key, cos)
+
+
+def test_partial_sum_arena_that_holds_one_producer_gives_the_same_gradients():
+    """With the arena sized for ONE producer every take flushes what is queued; a flush between the slab and the bias slab of one
+    weight-gradient launch would rewind the arena under a region that is handed out but not queued yet."""
+    case = gu.model_case("m3")
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = []
+    for small in (0, 1):
+        eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        eng.set_option("small_arena", small)
+        eng.profile_begin()
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+        prof = eng.profile_end()
+        res.append((out["loss"].item(), eng.grads.clone(), prof["bwd.slab_reduce"][0]))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])          # the reductions sum in a fixed order whatever launch carries them
+    assert res[1][2] > res[0][2]                      # ... and the small arena really did flush more often
+
+
+def test_output_ring_follows_the_pair_count_and_graph_capture_owns_its_outputs():
+    from pmgt_amd.trainer import Trainer
+    case = gu.model_case("m3")
+    tgt, pair, num_pairs, labels = dev_batch(case["batch"])
+    eng = make_engine(case, dtype="bf16")
+    B = tgt["node_ids"].shape[0]
+    full = eng.pretrain_step((tgt, pair, num_pairs, labels), training=False, want_hidden=False)
+    ref_logits = full["logits"].clone()
+    ptrs = set()
+    for drop in range(0, 6):            # a different pair count per step, as live eval / training batches have
+        np_ = num_pairs.clone()
+        np_[-1] -= min(drop, int(np_[-1]) - 1)
+        P = int(np_.sum())
+        sub = ({k: v for k, v in tgt.items()}, {k: v[:P] for k, v in pair.items()}, np_, labels[:P])
+        out = eng.pretrain_step(sub, training=False, want_hidden=False)
+        assert out["logits"].shape[0] == P
+        torch.testing.assert_close(out["logits"][: P - 1], ref_logits[: P - 1], rtol=1e-3, atol=1e-3)
+        ptrs.add(out["logits"].data_ptr())
+    assert len(ptrs) <= eng.OUTPUT_RING            # one ring serves every pair count: no allocation per new P
+    assert len(eng._out_rings) == 1
+    for b in range(1, eng.OUTPUT_RINGS_MAX + 3):   # many shapes: least-recently-used rings go, never all at once
+        eng._outputs(b, 10 * b, 32, False)
+        assert 1 <= len(eng._out_rings) <= eng.OUTPUT_RINGS_MAX
+    # a captured step writes outputs of its own: eager steps of the same shape do not clobber them
+    tr = Trainer(eng, lr=1e-3, max_grad_norm=5.0)
+    batch = (tgt, pair, num_pairs, labels)
+    replay = tr.capture_step(batch, warmup=1)
+    l1 = replay().clone()
+    torch.cuda.synchronize()
+    held = replay.outputs["logits"]
+    snap = held.clone()
+    for _ in range(eng.OUTPUT_RING + 1):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(held, snap)                 # untouched by the eager steps
+    assert np.isfinite(l1.item()) and replay.outputs["loss"].data_ptr() == replay().data_ptr()
+
+
+def test_layernorm_carrier_guard_switches_to_stored_inputs():
+    case = gu.model_case("m3")
+    eng = make_engine(case, dtype="bf16")
+    assert not eng.get_option("store_ln_input") and eng.check_layernorm_carrier() < 1.0
+    bad = {k: v.clone() for k, v in case["params"].items()}
+    bad["bert.encoder.layer.1.output.LayerNorm.weight"][7] = 1e-3
+    bad["bert.encoder.layer.1.output.LayerNorm.bias"][7] = 0.5
+    with pytest.warns(UserWarning, match="store_ln_input"):
+        eng.load_params(bad)
+    assert eng.get_option("store_ln_input")
+    out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, want_hidden=False)
+    assert np.isfinite(out["loss"].item()) and torch.isfinite(eng.grads).all()

@@ -116,3 +116,50 @@ def test_bench_control_flow_is_symmetric_across_ranks():
     # the rank-0-only blocks are the print and the CPU baseline
     r0 = [ast.unparse(n) for n in ast.walk(main) if isinstance(n, ast.If) and ast.unparse(n.test).startswith("rank == 0")]
     assert all(("print(" in b or "cpu_baseline" in b) for b in r0), r0
+
+
+def test_bench_gpus_flag_starts_its_own_ranks_and_refuses_a_mismatch():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run as a child, before
+    any GPU call) and reports n_gpus = 2; under a launcher whose WORLD_SIZE differs from --gpus it refuses to print a line.
+    --rehearse-launch keeps the engine out of it (no GPU here): rendezvous, one collective, symmetric teardown."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 1.0
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--rehearse-launch"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 8" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bucket_policy_coalesces_descending_ranges_at_the_boundaries():
+    """The engine reports gradient ranges in descending offset order (NFR head, layers L-1 .. 0, embeddings); with a boundary at
+    layer 0's offset the exchange issues TWO collectives (head + layers | embeddings), with none one per range."""
+    from pmgt_amd.parallel import BucketedAllReduce
+    flat = torch.zeros(100)
+    ranges = [(90, 10), (70, 20), (50, 20), (30, 20), (0, 30)]       # head, layers 2..0, embeddings
+
+    def run(bounds):
+        ex = BucketedAllReduce(flat, boundaries=bounds)
+        sent = []
+        ex._send = lambda off, n: sent.append((off, n))               # no process group here: record instead of all-reducing
+        for off, n in ranges:
+            ex.bucket_ready(off, n)
+        assert ex._held is None
+        return sent
+    assert run(()) == ranges
+    assert run((30,)) == [(30, 70), (0, 30)]
+    assert run((70, 30)) == [(70, 30), (30, 40), (0, 30)]
+    # a range that is not adjacent to what is held flushes it first (pmgt_encode_backward: no NFR head bucket)
+    ex = BucketedAllReduce(flat, boundaries=(30,))
+    sent = []
+    ex._send = lambda off, n: sent.append((off, n))
+    for off, n in [(70, 20), (30, 20), (0, 30)]:
+        ex.bucket_ready(off, n)
+    assert sent == [(70, 20), (30, 20), (0, 30)]

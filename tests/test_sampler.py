@@ -193,18 +193,38 @@ def test_train_valid_split_matches_sklearn_golden():
 
 
 def test_capi_symbols_exported():
-    """Both shared objects load and export every symbol include/pmgt_capi.h declares (no compute here)."""
+    """Both shared objects load and export every symbol include/pmgt_capi.h and include/pmgt_ops.h declare (no compute here)."""
     import ctypes
     import os
     import re
     from pmgt_amd import _build
-    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pmgt_capi.h")).read()
-    declared = set(re.findall(r"\b(pmgt_[a-z0-9_]+)\s*\(", hdr))
-    assert declared == set(_lib.HIP_SYMBOLS) | set(_lib.SAMPLER_SYMBOLS), declared ^ (set(_lib.HIP_SYMBOLS) | set(_lib.SAMPLER_SYMBOLS))
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    decl = lambda f: set(re.findall(r"\b(pmgt_[a-z0-9_]+)\s*\(", open(os.path.join(inc, f)).read()))
+    pub, ops = decl("pmgt_capi.h"), decl("pmgt_ops.h")
+    assert pub == set(_lib.HIP_SYMBOLS) | set(_lib.SAMPLER_SYMBOLS), pub ^ (set(_lib.HIP_SYMBOLS) | set(_lib.SAMPLER_SYMBOLS))
+    assert ops == set(_lib.OPS_SYMBOLS), ops ^ set(_lib.OPS_SYMBOLS)
+    assert not [s for s in pub | ops if "debug" in s]            # no process-global switches: options are per engine
     hip = ctypes.CDLL(_build.hip_lib_path())
     smp = ctypes.CDLL(_build.sampler_lib_path())
-    for s in _lib.HIP_SYMBOLS:
+    for s in _lib.HIP_SYMBOLS + _lib.OPS_SYMBOLS:
         assert hasattr(hip, s), s
     for s in _lib.SAMPLER_SYMBOLS:
         assert hasattr(smp, s), s
-    assert _lib.hip().pmgt_abi_version() == 2      # 2: pmgt_tensors gained the fp8 table scales
+    assert _lib.hip().pmgt_abi_version() == 3      # 3: per-engine options, path_opts on the pmgt_op_* entries, sampler counter stride
+
+
+def test_strided_counters_reproduce_the_single_process_streams():
+    """evaluate(distributed=True): rank r samples items r, r + W, ... of the node list with counter = r + W * offset and
+    counter_stride = W, i.e. every item draws from the stream of its GLOBAL index -- the rows a single process draws."""
+    from pmgt_amd.datasets import MODE_EVAL
+    smp = MCNSampler(csr("A"), 15)
+    nodes = np.arange(2, 2 + 37)
+    one = smp.batch(nodes, MODE_EVAL, threads=3, base_seed=11, counter=5)
+    W = 3
+    for r in range(W):
+        part = smp.batch(nodes[r::W], MODE_EVAL, threads=2, base_seed=11, counter=5 + r, counter_stride=W)
+        assert torch.equal(part[0]["node_ids"], one[0]["node_ids"][r::W])
+        assert torch.equal(part[0]["attention_mask"], one[0]["attention_mask"][r::W])
+        ends = np.cumsum(one[2].numpy())
+        rows = np.concatenate([np.arange(e - n, e) for e, n in zip(ends[r::W], one[2].numpy()[r::W])])
+        assert torch.equal(part[1]["node_ids"], one[1]["node_ids"][rows]) and torch.equal(part[3], one[3][rows])

@@ -9,7 +9,6 @@ from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
 from pmgt_amd.graph import synthetic_graph
 from pmgt_amd.models import synthetic_features, reference_init
 from pmgt_amd.engine import Engine
-L = _lib.hip()
 graph = synthetic_graph(7252, 88606, seed=0)
 vis, txt = synthetic_features(7252, seed=0)
 cfg = PMGTConfig(hidden_size=256, num_hidden_layers=4, num_attention_heads=8, intermediate_size=256, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, beta=0.5)
@@ -21,21 +20,17 @@ for c in range(8):
     cu = lambda d: {k: v.cuda() for k, v in d.items()}
     batches.append((cu(tgt), cu(pair), num_pairs.cuda(), labels.cuda()))
 def run(plain):
-    sw = [L.pmgt_debug_disable_fused_qkvc_attention, L.pmgt_debug_disable_fused_attention_backward, L.pmgt_debug_disable_layernorm_from_output,
-          L.pmgt_debug_disable_last_layer_shortcut, L.pmgt_debug_disable_deferred_reductions]
-    for f in sw: f(1 if plain else 0)
-    try:
-        eng = Engine(cfg, dtype="bf16", seed=5)
-        reference_init(eng, seed=0)
-        eng.set_tables(vis, txt)
-        losses = []
-        for s in range(160):
-            out = eng.pretrain_step(batches[s % 8], training=True, backward=True)
-            eng.optimizer_step(lr=3e-4, weight_decay=1e-2, max_grad_norm=5.0)
-            losses.append(out["loss"].item())
-        return np.array(losses)
-    finally:
-        for f in sw: f(0)
+    eng = Engine(cfg, dtype=os.environ.get("PMGT_AB_DTYPE", "bf16"), seed=5)
+    for k in ("no_fused_qkvc_attention", "no_fused_attention_bwd", "store_ln_input", "no_shortcut", "eager_reduce"):
+        eng.set_option(k, 1 if plain else 0)
+    reference_init(eng, seed=0)
+    eng.set_tables(vis, txt)
+    losses = []
+    for s in range(160):
+        out = eng.pretrain_step(batches[s % 8], training=True, backward=True)
+        eng.optimizer_step(lr=3e-4, weight_decay=1e-2, max_grad_norm=5.0)
+        losses.append(out["loss"].item())
+    return np.array(losses)
 a = run(False); b = run(True)
 for k in (0, 1, 10, 40, 80, 120, 159): print(k, "fast %.5f plain %.5f" % (a[k], b[k]))
 print("mean last 20: fast %.5f plain %.5f; max |diff| over the run %.4f" % (a[-20:].mean(), b[-20:].mean(), np.abs(a - b).max()))

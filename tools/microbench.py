@@ -10,7 +10,7 @@ DROP = float(os.environ.get('MB_DROP', '0.1'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmgt_amd import _lib  # noqa: E402
 
-L = _lib.hip()
+L = _lib.ops()
 P = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -38,12 +38,12 @@ def nt(M, N, K, res=False, name=""):
     byts = (M * K + M * N * (2 if res else 1)) * 2
     out = {}
     for mode in (0, 1):
-        L.pmgt_debug_enable_nt_dma(1 - mode)
+        L.use(*(["tile_gemm"] if mode else []))
         f = lambda: _lib.check(L.pmgt_op_gemm_nt(1, P(A), K, None, P(W), K, P(Cc), N, M, N, K, None, 0, None, 0, P(R), N, 0.0, 0, None, None, st()))
         out[mode] = timeit(f)
-    L.pmgt_debug_enable_nt_dma(0)
-    print(f"NT {name} M={M} N={N} K={K} res={res}: dma {out[0][0]:.1f}us ({byts / out[0][0] / 1e6:.2f} TB/s, {2 * M * N * K / out[0][0] / 1e6:.0f} TF/s) | "
-          f"regstage {out[1][0]:.1f}us ({byts / out[1][0] / 1e6:.2f} TB/s)")
+    L.use()
+    print(f"NT {name} M={M} N={N} K={K} res={res}: product path {out[0][0]:.1f}us ({byts / out[0][0] / 1e6:.2f} TB/s, {2 * M * N * K / out[0][0] / 1e6:.0f} TF/s) | "
+          f"128x128 tile {out[1][0]:.1f}us ({byts / out[1][0] / 1e6:.2f} TB/s)")
 
 
 def linear(M, N, K, res=False, ln=False, name=""):
@@ -57,11 +57,11 @@ def linear(M, N, K, res=False, ln=False, name=""):
     byts = (M * K + M * N * (1 + (1 if res else 0) + (1 if ln else 0))) * 2
     out = {}
     for mode in (0, 1):
-        L.pmgt_debug_force_tile_gemm(mode)
+        L.use(*(["tile_gemm"] if mode else []))
         f = lambda: _lib.check(L.pmgt_op_linear(1, P(A), K, P(W), K, P(Cc), N, M, N, K, None, 0, None, 0, P(R), N, 0.0, 0, None,
                                                 P(lno), P(stats), P(g) if ln else None, P(g) if ln else None, 1e-12, st()))
         out[mode] = timeit(f)
-    L.pmgt_debug_force_tile_gemm(0)
+    L.use()
     print(f"LINEAR {name} M={M} N={N} K={K} res={res} ln={ln}: stream {out[0][0]:.1f}us ({byts / out[0][0] / 1e6:.2f} TB/s) | "
           f"tile {out[1][0]:.1f}us ({byts / out[1][0] / 1e6:.2f} TB/s)")
 
@@ -74,10 +74,10 @@ def tn(M, N1, N2, name=""):
     byts = M * (N1 + N2) * 2
     out = {}
     for mode in (0, 1):
-        L.pmgt_debug_force_tile_gemm(mode)
+        L.use(*(["tile_gemm"] if mode else []))
         f = lambda: _lib.check(L.pmgt_op_gemm_tn(1, P(Pm), N1, P(Q), N2, None, M, N1, N2, P(slab), P(o), 0, None, st()))
         out[mode] = timeit(f)
-    L.pmgt_debug_force_tile_gemm(0)
+    L.use()
     print(f"TN {name} M={M} N1={N1} N2={N2}: dma {out[0][0]:.1f}us ({byts / out[0][0] / 1e6:.2f} TB/s, {2 * M * N1 * N2 / out[0][0] / 1e6:.0f} TF/s) | "
           f"regstage {out[1][0]:.1f}us ({byts / out[1][0] / 1e6:.2f} TB/s)")
 
@@ -90,10 +90,10 @@ def tn_gather(M, N1, N2, R, name=""):
     o = torch.empty(N1, N2, device="cuda")
     out = {}
     for mode in (0, 1):
-        L.pmgt_debug_force_tile_gemm(mode)
+        L.use(*(["tile_gemm"] if mode else []))
         f = lambda: _lib.check(L.pmgt_op_gemm_tn(1, P(Pm), 2 * N1, P(table), N2, P(rows), M, N1, N2, P(slab), P(o), 0, None, st()))
         out[mode] = timeit(f)
-    L.pmgt_debug_force_tile_gemm(0)
+    L.use()
     print(f"TN-gather {name} M={M} N1={N1} N2={N2}: dma {out[0][0]:.1f}us ({2 * M * N1 * N2 / out[0][0] / 1e6:.0f} TF/s) | "
           f"regstage {out[1][0]:.1f}us ({2 * M * N1 * N2 / out[1][0] / 1e6:.0f} TF/s)")
 

@@ -3,7 +3,7 @@ import ctypes as C, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pmgt_amd import _lib
-L = _lib.hip()
+L = _lib.ops()
 P = lambda t: C.c_void_p(t.data_ptr())
 T, S, H, dh = 12288, 32, 8, 32
 d = H * dh

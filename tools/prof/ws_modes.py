@@ -6,7 +6,7 @@ import ctypes as C, sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pmgt_amd import _lib
-L = _lib.hip()
+L = _lib.ops()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 M, N, K = 12 * 1024 * 32, 256, 256
 NS = 3
