@@ -714,26 +714,24 @@ static int flush_reduces(const pmgt_engine* e, Bufs<T>& b, hipStream_t st) {
     b.arena_cur = 0;          // later producers are stream-ordered behind the launch that read the arena
     return 0;
 }
-template <typename T>
-static int take_partials(const pmgt_engine* e, Bufs<T>& b, int64_t n, float** out, hipStream_t st) {
-    n = align_up(n, 64);
-    PMGT_CHECK(n <= b.arena_elems, -4, "partial-sum arena too small: %lld > %lld floats", (long long)n, (long long)b.arena_elems);
-    if (b.arena_cur + n > b.arena_elems) RUN(flush_reduces<T>(e, b, st));
-    *out = b.arena + b.arena_cur;
-    b.arena_cur += n;
-    return 0;
-}
-// Two regions that one producer launch fills (weight-gradient slab + its bias slab): flush BEFORE the first take if the pair does not
-// fit, so that the flush (which rewinds the arena) can never come between them -- the first region is handed out but not queued
-// yet at that point, and producers behind the rewind would overwrite it before multi_reduce reads it.
+// One or two regions of the arena for ONE producer launch (weight-gradient slab + its bias slab).  The flush that makes room comes
+// BEFORE the first region is handed out, never between the two: a flush rewinds the arena, and the first region -- handed out but
+// not queued yet -- would be overwritten by later producers before multi_reduce reads it.
 template <typename T>
 static int take_partials2(const pmgt_engine* e, Bufs<T>& b, int64_t n1, float** out1, int64_t n2, float** out2, hipStream_t st) {
-    const int64_t need = align_up(n1, 64) + (out2 ? align_up(n2, 64) : 0);
-    PMGT_CHECK(need <= b.arena_elems, -4, "partial-sum arena too small: %lld > %lld floats", (long long)need, (long long)b.arena_elems);
-    if (b.arena_cur + need > b.arena_elems) RUN(flush_reduces<T>(e, b, st));
-    RUN(take_partials<T>(e, b, n1, out1, st));
-    if (out2) RUN(take_partials<T>(e, b, n2, out2, st));
+    n1 = align_up(n1, 64);
+    n2 = out2 ? align_up(n2, 64) : 0;
+    PMGT_CHECK(n1 + n2 <= b.arena_elems, -4, "partial-sum arena too small: %lld > %lld floats", (long long)(n1 + n2), (long long)b.arena_elems);
+    // (small_arena, a test option: every producer starts from an empty arena, i.e. the jobs queued so far are reduced first)
+    if (b.arena_cur + n1 + n2 > b.arena_elems || ((e->opts & OPT_SMALL_ARENA) && b.arena_cur > 0)) RUN(flush_reduces<T>(e, b, st));
+    *out1 = b.arena + b.arena_cur;
+    b.arena_cur += n1;
+    if (out2) { *out2 = b.arena + b.arena_cur; b.arena_cur += n2; }
     return 0;
+}
+template <typename T>
+static int take_partials(const pmgt_engine* e, Bufs<T>& b, int64_t n, float** out, hipStream_t st) {
+    return take_partials2<T>(e, b, n, out, 0, nullptr, st);
 }
 template <typename T>
 static int queue_reduce(const pmgt_engine* e, Bufs<T>& b, const float* src, int rows, int64_t n, float* dst, bool acc, hipStream_t st) {

@@ -57,6 +57,27 @@ def train_flops_per_node(d, I, L, S, Fv=1536, Ft=768, pairs=10):
     return tok * (3 * enc + 2 * proj) + nfr
 
 
+def executed_flops_per_node(d, I, L, S, n_nodes, batch, Fv=1536, Ft=768, pairs=10, shortcut=True):
+    """FLOPs the engine actually EXECUTES per target node for the same step (same conventions as train_flops_per_node), with its
+    two structural savings taken out: table mode (2 (N + 2) <= tokens: the feature projection and its weight gradient run over
+    N + 2 table rows per step instead of one row per token) and the last-layer shortcut (the last layer's attention-output and
+    FFN blocks, forward and backward, run on the B target-CLS + pairs * B pair-CLS + masked rows only)."""
+    F = Fv + Ft
+    seqs = pairs + 2
+    tok = seqs * S
+    masked = 0.16 * (S - 1)
+    per_tok_attn = 8 * d * d + 6 * S * d                     # Q|K|V|C projection + the two score / context products
+    per_tok_dense = 2 * d * d + 4 * d * I                    # attention output + FFN
+    full_layers = L - 1 if shortcut else L
+    enc = tok * (full_layers * (per_tok_attn + per_tok_dense) + 8 * d)
+    if shortcut:
+        enc += tok * per_tok_attn + (1 + pairs + masked) * per_tok_dense
+    table_mode = 2 * (n_nodes + 2) <= batch * tok
+    proj_rows = (n_nodes + 2) / batch if table_mode else tok
+    nfr = 3 * masked * 2 * d * F
+    return 3 * enc + 2 * proj_rows * 2 * F * d + nfr
+
+
 # ================================================================================================
 # PMGT: the reference's pre-training module surface (pmgt/pmgt/models.py:22-176)
 # ================================================================================================

@@ -47,6 +47,7 @@ GRAPHS = {
     "A": dict(n=60, e=200, seed=1),
     "B": dict(n=40, e=44, seed=2),      # sparse: contexts get padded
     "C": dict(n=300, e=1500, seed=3),
+    "VG": dict(n=7252, e=88606, seed=4),   # BASELINE.json configs[1]: VG item graph size (synthetic edges: the data does not ship)
 }
 
 
@@ -135,6 +136,10 @@ MODEL_CASES = {
     "m2": ("A", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, beta=0.5), 16, 3, 2, 13),
     "m3": ("C", dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256, beta=0.5), 32, 2, 3, 14),
     "m4": ("C", dict(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, intermediate_size=512, beta=0.3), 6, 5, 4, 15),
+    # the reference's own two entry configurations: CLI defaults (train.py:225-272: hidden 128, ONE head of size 128, 5 layers,
+    # max_ctx_neigh 5) and the author's script (scripts/run_pmgt.sh:18-25: hidden 32, 3 layers, beta 1.0, the other defaults)
+    "e_cli": ("C", dict(hidden_size=128, num_attention_heads=1, num_hidden_layers=5, intermediate_size=128, beta=0.5), 6, 6, 5, 16),
+    "e_script": ("C", dict(hidden_size=32, num_attention_heads=1, num_hidden_layers=3, intermediate_size=128, beta=1.0), 6, 6, 6, 17),
 }
 
 
@@ -173,8 +178,10 @@ def draw_nfr(seed, ids, n):
     return r1, repl, r2
 
 
-def make_model():
+def make_model(only=None):
     for name, (gname, cfgkw, S, B, sseed, pseed) in MODEL_CASES.items():
+        if only and name not in only:
+            continue
         n, edges, w, g = graph(gname)
         cfg, model, tables = ref_model(n, cfgkw, pseed)
         out = {"S": np.int64(S), "B": np.int64(B), "graph": np.array(gname), "pseed": np.int64(pseed),
@@ -254,6 +261,8 @@ def make_model():
         np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
         print("model", name, "eval", float(out["eval_loss"]), "train", float(out["train_loss"]), losses)
 
+    if only:
+        return
     # ---- G6: init statistics of a fresh reference model (pmgt/pmgt/modeling_pmgt.py:44-58)
     torch.manual_seed(0)
     cfg = po.default_cfg(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128)
@@ -317,9 +326,17 @@ def make_ncf():
 # ------------------------------------------------------------------------------------------
 # G9: a 30-step pre-training loss curve over FRESH batches (reference sampler + model + clip + DenseSparseAdamW)
 # ------------------------------------------------------------------------------------------
-def make_curve():
-    name, gname, S, B, steps, sseed, pseed = "curve_c", "C", 16, 6, 30, 9, 41
-    cfgkw = dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)
+CURVES = {
+    # name: (graph, S, B, steps, sampler seed, param seed, lr, cfg kwargs)
+    "curve_c": ("C", 16, 6, 30, 9, 41, 1e-3, dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)),
+    # the benchmark configuration (BASELINE.json configs[1] shapes: 7 252-node graph, L4 H8 d256 S32) at the author's batch size
+    # and learning rate (scripts/run_pmgt.sh:11-13): 20 optimizer steps of the reference on fresh batches
+    "curve_c2": ("VG", 32, 32, 20, 10, 42, 1e-4, dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256, beta=0.5)),
+}
+
+
+def make_curve(name="curve_c"):
+    gname, S, B, steps, sseed, pseed, lr, cfgkw = CURVES[name]
     n, edges, w, g = graph(gname)
     cfg, model, tables = ref_model(n, cfgkw, pseed)
     np.random.seed(sseed)                                   # the sampler's process-global stream (pmgt/utils/base.py:37)
@@ -328,14 +345,14 @@ def make_curve():
     no_decay = ["bias", "LayerNorm.weight"]
     groups = [
         {"params": [p for nme, p in model.named_parameters() if p.requires_grad and not any(nd in nme for nd in no_decay)],
-         "weight_decay": 1e-2, "lr": 1e-3},
+         "weight_decay": 1e-2, "lr": lr},
         {"params": [p for nme, p in model.named_parameters() if p.requires_grad and any(nd in nme for nd in no_decay)],
-         "weight_decay": 0.0, "lr": 1e-3},
+         "weight_decay": 0.0, "lr": lr},
     ]
     opt = DenseSparseAdamW(groups)
     model.train()
     out = {"S": np.int64(S), "B": np.int64(B), "steps": np.int64(steps), "sseed": np.int64(sseed), "pseed": np.int64(pseed),
-           "order": order}
+           "order": order, "lr": np.float64(lr)}
     losses, norms = [], []
     for step in range(steps):
         idx = order[(step * B) % (n - B): (step * B) % (n - B) + B]
@@ -352,6 +369,7 @@ def make_curve():
         norms.append(float(tn))
         if step in (0, steps - 1):
             out[f"tgt_ids_{step}"] = t2n(batch[0]["node_ids"])
+        print("curve", name, step, losses[-1], norms[-1], flush=True)
     out["losses"] = np.array(losses, dtype=np.float64)
     out["gradnorms"] = np.array(norms, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -359,8 +377,12 @@ def make_curve():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "curve":
-        make_curve()
+    if len(sys.argv) > 1 and sys.argv[1] == "curve":          # curve [name ...]
+        for nm in (sys.argv[2:] or ["curve_c"]):
+            make_curve(nm)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "model":          # model name [name ...]: only these cases
+        make_model(set(sys.argv[2:]))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ncf":
         make_ncf()
@@ -368,6 +390,7 @@ if __name__ == "__main__":
     make_sampler()
     make_model()
     make_ncf()
-    make_curve()
+    for nm in CURVES:
+        make_curve(nm)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("total fixture bytes", tot)

@@ -11,7 +11,8 @@ from oracle import sampler_oracle as so
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STRIDE = 37
 
-GRAPHS = {"A": dict(n=60, e=200, seed=1), "B": dict(n=40, e=44, seed=2), "C": dict(n=300, e=1500, seed=3)}
+GRAPHS = {"A": dict(n=60, e=200, seed=1), "B": dict(n=40, e=44, seed=2), "C": dict(n=300, e=1500, seed=3),
+          "VG": dict(n=7252, e=88606, seed=4)}      # BASELINE.json configs[1]: the VG item graph's size (synthetic edges)
 
 MODEL_CASES = {
     "m1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)),
@@ -21,6 +22,9 @@ MODEL_CASES = {
     "m2": ("A", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=2, intermediate_size=128, beta=0.5)),
     "m3": ("C", dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256, beta=0.5)),
     "m4": ("C", dict(hidden_size=128, num_attention_heads=2, num_hidden_layers=1, intermediate_size=512, beta=0.3)),
+    # the reference's two entry configurations: CLI defaults (train.py:225-272) and the author's script (scripts/run_pmgt.sh:18-25)
+    "e_cli": ("C", dict(hidden_size=128, num_attention_heads=1, num_hidden_layers=5, intermediate_size=128, beta=0.5)),
+    "e_script": ("C", dict(hidden_size=32, num_attention_heads=1, num_hidden_layers=3, intermediate_size=128, beta=1.0)),
 }
 
 
@@ -115,15 +119,22 @@ def ncf_case(name, dtype=torch.float32):
 
 
 # ---- G9: 30-step loss curve over fresh batches ---------------------------------------------------------------
-def curve_case(dtype=torch.float32):
-    gold = load("curve_c")
-    gname = "C"
+CURVES = {
+    "curve_c": ("C", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5)),
+    # the benchmark configuration: VG-sized graph, L4 H8 d256 S32, B = 32, lr 1e-4 (BASELINE.json configs[1], scripts/run_pmgt.sh:11-13)
+    "curve_c2": ("VG", dict(hidden_size=256, num_attention_heads=8, num_hidden_layers=4, intermediate_size=256, beta=0.5)),
+}
+
+
+def curve_case(name="curve_c", dtype=torch.float32):
+    gold = load(name)
+    gname, cfgkw = CURVES[name]
     n = GRAPHS[gname]["n"]
-    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, hidden_size=64, num_attention_heads=4,
-                         num_hidden_layers=2, intermediate_size=64, beta=0.5)
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfgkw)
     params = po.synth_params(cfg, int(gold["pseed"]), dtype)
     tables = po.synth_tables(n, cfg["feat_hidden_sizes"], 77, dtype)
-    return dict(cfg=cfg, params=params, tables=tables, n_nodes=n, gold=gold, gname=gname)
+    lr = float(gold["lr"]) if "lr" in gold.files else 1e-3
+    return dict(cfg=cfg, params=params, tables=tables, n_nodes=n, gold=gold, gname=gname, lr=lr)
 
 
 def curve_batches(case):

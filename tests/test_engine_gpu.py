@@ -294,33 +294,36 @@ def test_whole_step_replays_as_one_hip_graph():
     assert np.all(np.diff(lb) != 0)                                         # not one frozen step replayed
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_thirty_step_loss_curve_matches_reference(dtype):
-    """north_star: "pre-training loss curve matching the reference within 1e-3".  G9 = 30 optimizer steps of the
-    reference (its sampler, model, clip, DenseSparseAdamW) on fresh batches; here: C++ sampler (regenerates the same
-    batches from the seed) -> HIP engine through the C ABI.  fp32 mode must stay within 1e-3 relative at every step
-    (measured 1.4e-7); the bf16 throughput mode holds the same 1e-3 bound (measured 1.5e-4)."""
-    c = gu.curve_case()
+@pytest.mark.parametrize("name,dtype,bound", [("curve_c", "fp32", 1e-4), ("curve_c", "bf16", 1e-3),
+                                              ("curve_c2", "fp32", 1e-4), ("curve_c2", "bf16", 1e-3)])
+def test_loss_curve_matches_reference(name, dtype, bound):
+    """north_star: "pre-training loss curve matching the reference within 1e-3".  G9 = optimizer steps of the reference (its
+    sampler, model, clip, DenseSparseAdamW) on fresh batches: curve_c = 30 steps of a toy configuration, curve_c2 = 20 steps
+    at the BENCHMARK shapes (7 252-node graph, L4 H8 d256 S32, B = 32, lr 1e-4: every fused kernel, table mode and the
+    last-layer shortcut are on the path).  Here: C++ sampler (regenerates the same batches from the seed) -> HIP engine
+    through the C ABI.  Per step: fp32 within 1e-4 relative (and gradient norms within 5e-3), bf16 within 1e-3."""
+    c = gu.curve_case(name)
     gold = c["gold"]
     eng = make_engine(dict(cfg=c["cfg"], params=c["params"], tables=c["tables"]), dtype=dtype)
     losses, norms = [], []
     for step, batch in gu.curve_batches(c):
         ids = batch[0]["node_ids"]
+        if step == 0:
+            assert np.array_equal(ids.numpy(), gold["tgt_ids_0"])
         masked, m2, tidx = po.nfr_masking(ids, c["n_nodes"], torch.from_numpy(gold[f"r1_{step}"]),
                                           torch.from_numpy(gold[f"repl_{step}"]), torch.from_numpy(gold[f"r2_{step}"]))
         full = torch.full_like(ids, -1)
         full[:, 1:][m2] = tidx
-        out = eng.pretrain_step(dev_batch(batch), training=True, backward=True, nfr_inject=(masked.cuda(), full.cuda()))
-        eng.optimizer_step(lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
+        out = eng.pretrain_step(dev_batch(batch), training=True, backward=True, nfr_inject=(masked.cuda(), full.cuda()),
+                                want_hidden=False)
+        eng.optimizer_step(lr=c["lr"], weight_decay=1e-2, max_grad_norm=5.0)
         losses.append(out["loss"].item())
         norms.append(eng.grad_norm().item())
     rel = np.abs(np.array(losses) / gold["losses"] - 1.0)
+    print(f"loss-curve max relative deviation ({name}, {dtype}): {rel.max():.2e}")
+    assert rel.max() < bound, (rel.max(), losses, gold["losses"])
     if dtype == "fp32":
-        assert rel.max() < 1e-3, rel.max()
         np.testing.assert_allclose(norms, gold["gradnorms"], rtol=5e-3)
-    else:
-        assert rel.max() < 1e-3, rel.max()
-    print(f"loss-curve max relative deviation ({dtype}): {rel.max():.2e}")
 
 
 def test_head_major_qkvc_layout_is_transparent():

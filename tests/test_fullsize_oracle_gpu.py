@@ -8,11 +8,17 @@ data-gradient tiles (M >= 65 536 tokens), last-layer shortcut, sorted segment su
     22-node islands, where EVERY context is padded and masked (10 of 32 positions);
   * C4 / C5: 10^6 nodes (feature rows beyond the 2 GiB offset), L = 6 H8 d512 S64, bf16 and fp8, B = 4;
 
+  * the BENCH's batch: C2 at B = 1 024 targets (393 216 tokens: every split / row-chunk count, the two-level reductions and the
+    32-bit index headroom of the benchmark line), the oracle evaluated in chunks of 128 targets and recombined;
+
 with dropout 0 and injected NFR draws (torch's RNG stream cannot be matched on the device).  Tolerances: fp32 -- loss
 rtol 1e-4 (north_star), gradients 2e-3 of the tensor's scale; bf16 / fp8 -- loss rtol 2e-2 and per-tensor gradient
-cosine >= 0.99, where a BIAS gradient (a sum of ~1e5 signed terms that cancels to ~1e-6) may instead agree to 2 % of the
-scale of its own layer's weight gradient: that is the noise floor bf16 activations put under such a sum, and it still
-rejects a wrong sum by orders of magnitude (the round-1 bias bug produced 1e27)."""
+cosine >= 0.99.  A BIAS gradient is a sum of ~1e5 signed terms that cancels to ~1e-6, so bf16 rounding noise can dominate
+it; such a tensor is then compared with the FP32 ENGINE on the same inputs (same kernels' summation structure, so what
+differs is the rounding of the activations alone): its deviation must stay within 8x the largest deviation the SAME
+run shows on the sibling weight gradient (dW[n, :] = sum_m dY[m, n] x[m, :] and db[n] = sum_m dY[m, n] carry the same
+noise in dY, and |x| = O(1)).  A bias gradient that is wrong by its own magnitude passes only if that magnitude is
+itself at the measured noise level of its layer -- not, as before, whenever biases are small against weights."""
 import numpy as np
 import pytest
 import torch
@@ -89,13 +95,15 @@ def run_oracle(case, tables, fp8=False):
     return p, ref
 
 
-def compare(eng, out, p, ref, dtype):
+def compare(eng, out, p, ref, dtype, fp32_engine=None):
+    """fp32_engine: callable -> engine that ran the same step in fp32 (built only if a bias gradient needs the tie-breaker)."""
     tol = 1e-4 if dtype == "fp32" else 2e-2
     for k in ("loss", "gsr", "nfr"):
-        np.testing.assert_allclose(out[k].item(), ref[k].item(), rtol=tol, err_msg=k)
+        np.testing.assert_allclose(out[k].item(), ref[k].item() if torch.is_tensor(ref[k]) else ref[k], rtol=tol, err_msg=k)
     np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].detach().numpy(), rtol=0, atol=2e-4 if dtype == "fp32" else 3e-2)
     grads = {e["name"]: eng.view(e["name"], grad=True).detach().cpu().double().flatten() for e in eng.entries}
     want = {k: v.grad.double().flatten() for k, v in p.items()}
+    f32 = {}
     gscale = max(float(v.abs().max()) for v in want.values())
     assert all(torch.isfinite(v).all() for v in grads.values()) and max(float(v.abs().max()) for v in grads.values()) < 10 * gscale
     bad = []
@@ -113,8 +121,16 @@ def compare(eng, out, p, ref, dtype):
         if cos >= 0.99:
             continue
         sibling = name[:-4] + "weight"
-        if name.endswith(".bias") and sibling in want and err <= 2e-2 * float(want[sibling].abs().max()):
-            continue                     # cancellation-dominated sum: within the bf16 noise floor of its own layer
+        if name.endswith(".bias") and sibling in want and fp32_engine is not None:
+            if not f32:                  # the same step on the fp32 engine: isolates the rounding of the activations
+                e32 = fp32_engine()
+                f32.update({e["name"]: e32.view(e["name"], grad=True).detach().cpu().double().flatten() for e in e32.entries})
+            noise = float((grads[sibling] - f32[sibling]).abs().max())
+            dev = float((a - f32[name]).abs().max())
+            if dev <= 8.0 * noise:
+                continue                 # cancellation-dominated sum at the measured noise level of its own layer
+            bad.append((name, cos, err, float(b.abs().max()), "vs fp32 engine", dev, noise))
+            continue
         bad.append((name, cos, err, float(b.abs().max())))
     assert not bad, bad
     flat_a, flat_b = torch.cat([grads[e["name"]] for e in eng.entries]), torch.cat([want[e["name"]] for e in eng.entries])
@@ -134,7 +150,50 @@ def test_full_size_step_matches_the_oracle(graph, dtype):
     tables = po.synth_tables(n, case["cfg"]["feat_hidden_sizes"], 9)
     eng, out = run_engine(case, dtype, [t.numpy() for t in tables])
     p, ref = run_oracle(case, tables)
-    compare(eng, out, p, ref, dtype)
+    compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tables])[0])
+
+
+def run_oracle_chunked(case, tables, chunk):
+    """The oracle on `chunk` targets at a time, recombined exactly: GSR is a mean over targets (weight B_c / B), NFR a mean over
+    masked rows (weight M_c / M) -- pmgt/pmgt/models.py:111-126,158-162 -- so loss = sum_c (B_c / B) gsr_c + (M_c / M) nfr_c and
+    the gradient is the same weighted sum of chunk gradients."""
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    tgt, pair, num_pairs, labels = case["batch"]
+    masked, m2, tidx = case["inj_cpu"]
+    B = tgt["node_ids"].shape[0]
+    Mtot = int(m2.sum())
+    poff = torch.cat([torch.zeros(1, dtype=torch.int64), num_pairs.cumsum(0)])
+    moff = torch.cat([torch.zeros(1, dtype=torch.int64), m2.sum(1).cumsum(0)])
+    p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items()}
+    tot = dict(loss=0.0, gsr=0.0, nfr=0.0)
+    logits = []
+    for lo in range(0, B, chunk):
+        hi = min(lo + chunk, B)
+        p0, p1, m0, m1 = int(poff[lo]), int(poff[hi]), int(moff[lo]), int(moff[hi])
+        sl = lambda d, a, b: {k: v[a:b] for k, v in d.items()}
+        sub = (sl(tgt, lo, hi), sl(pair, p0, p1), num_pairs[lo:hi], labels[p0:p1])
+        ref = po.pretrain_forward(p, case["cfg"], tables, sub, training=True, nfr_inject=(masked[lo:hi], m2[lo:hi], tidx[m0:m1]))
+        wg, wn = (hi - lo) / B, (m1 - m0) / max(Mtot, 1)
+        (wg * ref["gsr"] + wn * ref["nfr"]).backward()
+        tot["gsr"] += wg * ref["gsr"].item()
+        tot["nfr"] += wn * ref["nfr"].item()
+        logits.append(ref["logits"].detach())
+    tot["loss"] = tot["gsr"] + tot["nfr"]
+    return p, dict(tot, logits=torch.cat(logits))
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_c2_step_at_the_bench_batch_matches_the_oracle(dtype):
+    """The batch the benchmark line is quoted on (B = 1 024 targets per GPU: M = 393 216 tokens) against the oracle: 5x more row
+    chunks per weight-gradient split than the B = 192 case, multi_reduce's second level, 32-bit byte offsets of the fused
+    kernels near their limit -- the sizes behind round 1's bias-gradient bug, which no test reached."""
+    B = 1024
+    case = make_case(7252, 88606, C2, S=32, B=B, seed=27)
+    tables = po.synth_tables(7252, case["cfg"]["feat_hidden_sizes"], 9)
+    eng, out = run_engine(case, dtype, [t.numpy() for t in tables])
+    p, ref = run_oracle_chunked(case, tables, chunk=128)
+    compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tables])[0])
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
@@ -166,7 +225,7 @@ def test_million_node_tables_l6_d512_s64_match_the_oracle(dtype):
     rm = lambda d: {"node_ids": remap[d["node_ids"]], "attention_mask": d["attention_mask"]}
     case_o = dict(case, batch=(rm(tgt), rm(pair), num_pairs, labels), inj_cpu=(remap[masked], m2, remap[tidx]))
     p, ref = run_oracle(case_o, small, fp8=dtype == "fp8")
-    compare(eng, out, p, ref, dtype)
+    compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", tabs_seen)[0])
 
 
 def test_hidden_128_context_32_takes_the_fused_kernels_and_matches_the_oracle():
@@ -178,4 +237,4 @@ def test_hidden_128_context_32_takes_the_fused_kernels_and_matches_the_oracle():
     for dtype in ("bf16", "fp32"):
         eng, out = run_engine(case, dtype, [t.numpy() for t in tables])
         p, ref = run_oracle(case, tables)
-        compare(eng, out, p, ref, dtype)
+        compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tables])[0])

@@ -35,7 +35,6 @@ def test_two_engines_with_different_options_keep_their_own_paths():
             assert np.isfinite(out["loss"].item())
     assert "fwd.qkvc_attention" in prof["a"] and "bwd.attention_wgrad" in prof["a"]
     assert "fwd.qkvc_attention" not in prof["b"] and "bwd.attention_wgrad" not in prof["b"] and "bwd.wgrad_qkvc" in prof["b"]
-    assert "fwd.layernorm" not in prof["b"]            # the fused LayerNorm epilogue stays on in b: only its input store differs
     cos = torch.nn.functional.cosine_similarity(a.grads, b.grads, dim=0).item()
     assert cos > 0.999, cos
     b.set_option("no_fused_qkvc_attention", 0)

@@ -130,27 +130,28 @@ def test_ncf_second_caller_matches_reference(name):
         gu.check_stored(gold, "grad/" + k, g, 2e-4, 2e-4 * scale + 1e-9)       # key.bias grads are exactly 0 in theory
 
 
-def test_loss_curve_over_fresh_batches_matches_reference():
-    """G9: 30 steps of sampler -> PMGT.forward -> backward -> clip 5.0 -> DenseSparseAdamW on fresh batches.  The C++
-    sampler regenerates the reference's batches from the seed alone (bit-exact stream), the oracle reproduces the
-    loss curve and gradient norms (CPU, first 8 steps to keep the suite short)."""
-    c = gu.curve_case()
+@pytest.mark.parametrize("name,nsteps", [("curve_c", 8), ("curve_c2", 2)])
+def test_loss_curve_over_fresh_batches_matches_reference(name, nsteps):
+    """G9: the reference's sampler + model + clip + DenseSparseAdamW over fresh batches -- the toy configuration (30 steps) and
+    the BENCHMARK configuration (curve_c2: 7 252-node graph, L4 H8 d256 S32, B = 32, lr 1e-4, 20 steps; north_star: "loss curve
+    matching the reference within 1e-3").  The C++ sampler regenerates the batches from the seed; the oracle must reproduce
+    the loss curve and gradient norms (CPU: the first steps only, to keep the suite short)."""
+    c = gu.curve_case(name)
     gold = c["gold"]
-    p = {k: v.clone() for k, v in c["params"].items()}
+    params = {k: v.clone() for k, v in c["params"].items()}
     state = {}
     for step, batch in gu.curve_batches(c):
-        if step in (0, int(gold["steps"]) - 1):
-            np.testing.assert_array_equal(batch[0]["node_ids"].numpy(), gold[f"tgt_ids_{step}"])
-        if step >= 8:
-            continue
-        pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        if step >= nsteps:
+            break
+        if step == 0:
+            assert np.array_equal(batch[0]["node_ids"].numpy(), gold["tgt_ids_0"])
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         inj = po.nfr_masking(batch[0]["node_ids"], c["n_nodes"], torch.from_numpy(gold[f"r1_{step}"]),
                              torch.from_numpy(gold[f"repl_{step}"]), torch.from_numpy(gold[f"r2_{step}"]))
-        out = po.pretrain_forward(pp, c["cfg"], c["tables"], batch, training=True, nfr_inject=inj)
+        out = po.pretrain_forward(p, c["cfg"], c["tables"], batch, training=True, nfr_inject=inj)
         out["loss"].backward()
-        grads = {k: v.grad for k, v in pp.items()}
+        grads = {k: v.grad for k, v in p.items()}
         norm = po.clip_grad_norm(grads, 5.0)
-        p = {k: v.detach() for k, v in pp.items()}
-        po.adamw_step(p, grads, state, lr=1e-3, wd=1e-2)           # in place
-        np.testing.assert_allclose(out["loss"].item(), gold["losses"][step], rtol=2e-5)
-        np.testing.assert_allclose(norm, gold["gradnorms"][step], rtol=2e-4)
+        po.adamw_step(params, grads, state, lr=c["lr"], wd=1e-2)
+        np.testing.assert_allclose(out["loss"].item(), gold["losses"][step], rtol=3e-5)
+        np.testing.assert_allclose(float(norm), gold["gradnorms"][step], rtol=3e-4)
