@@ -563,7 +563,8 @@ def test_fused_qkvc_attention_fully_masked_sequence():
 
 
 # ------------------------------------------------------------------------------------------- 256 x 256 NT tile
-@pytest.mark.parametrize("M,N,K", [(4096, 256, 1024), (5001, 512, 160), (4100, 256, 128), (4100, 384, 96), (6000, 128, 256)])   # N % 256 != 0: the 256 x 128 variant
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 1024), (5001, 512, 160), (4100, 256, 128), (4100, 384, 96), (6000, 128, 256),   # N % 256 != 0: the 256 x 128 variant
+                                   (16640, 512, 512), (16385, 256, 1024), (20000, 768, 256)])
 def test_gemm_nt_big_tile_epilogues(M, N, K):
     """The 256 x 256 LDS-DMA tile (bf16, M >= 4096, N % 256 == 0, K % 32 == 0) against fp64 torch for every
     epilogue it implements, and against the 128 x 128 kernel for the dropout mask (same counter-based keys)."""
