@@ -563,10 +563,11 @@ def test_fused_qkvc_attention_fully_masked_sequence():
 
 
 # ------------------------------------------------------------------------------------------- 256 x 256 NT tile
-@pytest.mark.parametrize("M,N,K", [(4096, 256, 1024), (5001, 512, 160), (4100, 256, 128), (4100, 384, 96), (6000, 128, 256),   # N % 256 != 0: the 256 x 128 variant
-                                   (16640, 512, 512), (16385, 256, 1024), (20000, 768, 256)])
+@pytest.mark.parametrize("M,N,K", [(24577, 256, 1024), (12300, 512, 160), (24600, 256, 128), (12300, 384, 96), (24600, 128, 256),   # N % 256 != 0: the 256 x 128 variant
+                                   (16640, 512, 512), (20000, 768, 256),
+                                   (4096, 256, 1024), (6000, 128, 256)])       # < 96 tiles: stays on the 128 x 128 kernel (same checks)
 def test_gemm_nt_big_tile_epilogues(M, N, K):
-    """The 256 x 256 LDS-DMA tile (bf16, M >= 4096, N % 256 == 0, K % 32 == 0) against fp64 torch for every
+    """The 256 x 256 LDS-DMA tile (bf16, >= 96 tiles of 256 rows, N % 128 == 0, K % 32 == 0) against fp64 torch for every
     epilogue it implements, and against the 128 x 128 kernel for the dropout mask (same counter-based keys)."""
     _lib, L = _setup()
     tdt = torch.bfloat16
