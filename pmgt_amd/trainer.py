@@ -27,7 +27,7 @@ class Trainer:
     def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
                  random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True,
-                 buckets: str = "layer"):
+                 buckets: str = "layer", check_carrier_every: int = 0):
         self.engine = engine
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
@@ -36,6 +36,10 @@ class Trainer:
         self.random_node_ratio, self.mask_node_ratio = random_node_ratio, mask_node_ratio
         self.last_loss = None
         self._micro = 0
+        # every N optimizer steps re-check that the LayerNorm parameters still allow x^ = (y - beta) / gamma from the bf16 output
+        # (Engine.check_layernorm_carrier: one small device -> host read per LayerNorm; 0 = only when parameters are loaded)
+        self.check_carrier_every = int(check_carrier_every)
+        self._opt_steps = 0
         # world_size > 1: per-bucket all-reduce started from the engine's gradient-ready hook while the backward pass of
         # the earlier layers is still running (overlap_allreduce=False: ONE blocking all-reduce after the backward pass)
         self._exchange = None
@@ -82,6 +86,9 @@ class Trainer:
             eng.grads.div_(self.accum)
         eng.optimizer_step(lr=self.lr, weight_decay=self.weight_decay, betas=self.betas, eps=self.eps,
                            max_grad_norm=self.max_grad_norm)
+        self._opt_steps += 1
+        if self.check_carrier_every and self._opt_steps % self.check_carrier_every == 0 and not getattr(self, "_capturing", False):
+            eng.check_layernorm_carrier()
 
     def train_step(self, batch) -> torch.Tensor:
         """One micro-batch; steps the optimizer every `accumulate_grad_batches` calls."""

@@ -21,18 +21,27 @@ PHASE_KERNELS = {           # bench.py phase name -> substring of the kernel tha
 }
 
 
-def parse(path):
+def parse(path, counts=None):
     rows = {}
     for line in open(path).read().splitlines()[1:]:
         m = re.match(r"^(.*?)\s+(\d+)\s+([0-9.]+)\s*$", line)
         if m:
             rows[m.group(1).strip()] = float(m.group(3))
+            if counts is not None:
+                counts[m.group(1).strip()] = int(m.group(2))
     return rows
+
+
+PMC_STEPS = 3        # tools/gpu_profile.sh runs the counter passes with --steps 2 --warmup 1
 
 
 def main():
     prefix = sys.argv[1]
-    fetch, write = parse(prefix + "_pmc_fetch_size.txt"), parse(prefix + "_pmc_write_size.txt")
+    nf, nw = {}, {}
+    fetch, write = parse(prefix + "_pmc_fetch_size.txt", nf), parse(prefix + "_pmc_write_size.txt", nw)
+    # the whole step: every pmgt kernel's dispatches x its average, per training step (one-off setup kernels of the process -- table
+    # casts, parameter init -- are launched once and do not belong to a step: only kernels launched a multiple of PMC_STEPS times count)
+    step_kib = sum((2.0 * fetch[k] * nf[k] + write.get(k, 0.0) * nw.get(k, 0)) / PMC_STEPS for k in fetch if nf[k] % PMC_STEPS == 0)
     phases = {}
     for ph, sub in PHASE_KERNELS.items():
         kf = next((k for k in fetch if sub in k), None)
@@ -64,11 +73,13 @@ def main():
         "source": f"{prefix}_pmc_fetch_size.txt + {os.path.basename(prefix)}_pmc_write_size.txt "
                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
         "correction": "HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE; counters in KiB",
+        "step_hbm_gb": round(step_kib * 1024.0 / 1e9, 2),
         "phases": phases,
     }
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(phases, indent=1))
+    print("HBM traffic per training step: %.2f GB" % out["step_hbm_gb"])
 
 
 if __name__ == "__main__":

@@ -129,7 +129,7 @@ def attn(T, S, H, dh, name=""):
     b = lambda: _lib.check(L.pmgt_op_attention_bwd(1, P(x), None, P(do), P(dx), T, S, H, dh, 0.5, DROP, 1, 2, P(rng), st()))
     tf, tb = timeit(f), timeit(b)
     M = T * S
-    print(f"ATTN {name} T={T} S={S} H={H} dh={dh} nw={os.environ.get('PMGT_ATTN_BWD_NW', 'default')}: fwd {tf[0]:.1f}us ({M * 5 * d * 2 / tf[0] / 1e6:.2f} TB/s) "
+    print(f"ATTN {name} T={T} S={S} H={H} dh={dh} : fwd {tf[0]:.1f}us ({M * 5 * d * 2 / tf[0] / 1e6:.2f} TB/s) "
           f"bwd {tb[0]:.1f}us ({M * 9 * d * 2 / tb[0] / 1e6:.2f} TB/s)")
 
 

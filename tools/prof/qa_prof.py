@@ -23,7 +23,7 @@ for k in range(9):
 ev[1].record()
 torch.cuda.synchronize()
 print("last launch: %.1f us" % (ev[0].elapsed_time(ev[1]) * 1e3))
-if hasattr(C.CDLL(_lib._build.hip_lib_path()), "pmgt_debug_qa3_prof_read") and os.environ.get("PMGT_QA_FORM", "3") == "3":
+if hasattr(C.CDLL(_lib._build.hip_lib_path()), "pmgt_debug_qa3_prof_read"):      # bf16: the role-split form is the only one
     # role-split form: workgroup 0, [wave][interval]: 0 = work that ends at a barrier (incl. the vmcnt / lgkmcnt waits), 1 = barrier wait,
     # GEMM waves: 2 = loop top, 3 = copy-out, 4 = DMA issue + fragment reads + MFMAs, 5 = bias / projection-tile writes;
     # attention waves: 2 = second half of a problem (the first half ends at the mid barrier: interval 0)
