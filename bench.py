@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--buckets", default="layer", choices=["layer", "two", "one"],
                     help="N > 1: gradient all-reduce per engine bucket (NFR head, each layer, embeddings), as two collectives "
                          "(head + encoder layers | embeddings), or as one after the backward pass")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="KEY",
+                    help="A/B: set a path option of the engine (include/pmgt_ops.h, e.g. no_role_split_ln); repeatable; reported in the line")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher check that needs no GPU: the ranks rendezvous over gloo, all-reduce their ranks and rank 0 prints "
                          "a line with n_gpus = world and value = null")
@@ -221,6 +223,8 @@ def main():
     eng = Engine(cfg, dtype=args.dtype, device=dev, seed=1234)
     if args.overlap:
         eng.set_overlap(True)
+    for key in args.engine_option:
+        eng.set_option(key, 1)
     reference_init(eng, seed=0)
     eng.set_tables(vis, txt)
     del vis, txt
@@ -312,6 +316,7 @@ def main():
         "loss_last": round(loss_last, 5),
         "grad_norm_last": round(grad_norm_last, 5),
         "side_stream_reductions": bool(args.overlap),
+        "engine_options": list(args.engine_option),
         "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count(),
                          "cpu_share": round(share, 1)},
         "allreduce": None,

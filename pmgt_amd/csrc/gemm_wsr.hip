@@ -1,0 +1,219 @@
+// Role-split weight-stationary GEMM with the residual + LayerNorm epilogue (bf16, K = N = 256): the attention-output and FFN2
+// launches of the forward pass,  y = LayerNorm(dropout(A W^T + b) + res).
+//
+// gemm_ws_kernel<8, WS_RES_LN> runs its 64 MFMAs per wave and 64-row tile and then ~760 VALU instructions of epilogue per wave, in
+// sequence inside one 8-wave workgroup per CU: 3.7 TB/s on 3U of traffic, vector-issue-bound.  Two workgroups per CU that drift out
+// of phase would overlap the two phases, but a wave that holds 64 VGPRs of W next to the LayerNorm epilogue's temporaries does not fit
+// the 128 registers sixteen waves leave (52 spilled: profiles/r03).  Here ONE 16-wave workgroup per CU splits the ROLES, as the fused
+// attention kernels do -- a role needs only its own registers:
+//   waves 0-7  (GEMM role):     W columns 32 g .. 32 g + 31 in 64 VGPRs; the 32-row A tile of step t arrives by LDS-DMA in a 3-slot ring
+//                               (two steps ahead, counted vmcnt), 32 MFMAs, the fp32 result into staging buffer t & 1;
+//   waves 8-15 (epilogue role): bias, dropout, residual (prefetched one step ahead), bf16 rounding, LayerNorm of the row (32 lanes per
+//                               row), 16-byte stores -- of step t - 1, from staging buffer (t - 1) & 1, while the GEMM role computes step t.
+// One s_barrier per step.  Results are bit-identical to gemm_ws_kernel<8, WS_RES_LN> (same arithmetic per element, same order).
+#include "gemm.h"
+
+namespace pmgt {
+
+typedef __attribute__((address_space(3))) void lds_void_wsr_t;
+typedef __attribute__((address_space(1))) const void gbl_void_wsr_t;
+
+struct WsrCfg {
+    static constexpr int TR = 32, ROWB = 512, TILEB = TR * ROWB, NR = 3, ES = 256 + 4, STG = TR * ES * 4;
+    static constexpr int SMEM = NR * TILEB + 2 * STG;
+};
+
+__global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
+    using C = WsrCfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = blockIdx.x, gx = gridDim.x;
+    const int num_mt = (g.M + C::TR - 1) / C::TR;
+    const int n = x < num_mt ? (num_mt - x + gx - 1) / gx : 0;      // steps of this workgroup: tiles x, x + gx, ...
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_wsr_t*)smem;
+    const uint32_t stg0 = lds0 + C::NR * C::TILEB;
+
+    if (wave < 8) {
+        // ================================================================ GEMM role
+        const int gw = wave, r = lane & 15, q = lane >> 4;
+        bf16x8 wf[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wf[j][ks] = *(const bf16x8*)((const bf16*)g.B + (int64_t)(32 * gw + 16 * j + r) * g.ldb + 32 * ks + 8 * q);
+        // LDS-DMA of one A tile: wave gw moves rows 4 gw .. 4 gw + 3 as two 1-KB pieces (2 rows each); LDS slot `lane & 31` of a row
+        // takes source chunk slot ^ (row & 15)
+        auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+            const int mt = x + t * gx;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = 4 * gw + 2 * p + (lane >> 5);
+                const int m = min(mt * C::TR + row, g.M - 1);
+                const char* src = (const char*)g.A + (int64_t)m * g.lda * 2 + (((lane & 31) ^ (row & 15)) << 4);
+                __builtin_amdgcn_global_load_lds((gbl_void_wsr_t*)src, (lds_void_wsr_t*)(smem + slot * C::TILEB + (4 * gw + 2 * p) * C::ROWB), 16, 0, 0);
+            }
+        };
+        // fragment address of k-step 0 in row-tile 0: row r, chunk q ^ (r & 15); k-step ks = XOR (ks << 6); row-tile 1 = + 16 * ROWB
+        const uint32_t fr0 = (uint32_t)(r * C::ROWB + ((((r >> 2) & 3) << 2 | (q ^ (r & 3))) << 4));
+        // staging address of acc[0][0][0]: row 4 q, column 32 gw + r
+        const uint32_t sw0 = (uint32_t)((4 * q * C::ES + 32 * gw + r) * 4);
+        if (0 < n) dma(0, 0);
+        if (1 < n) dma(1, 1);
+        if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it <= n; ++it) {
+            if (it < n) {
+                const int slot = it % C::NR;
+                if (it + 2 < n) dma(it + 2, (it + 2) % C::NR);      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
+                const uint32_t ab = lds0 + (uint32_t)(slot * C::TILEB);
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                u32x4 fa[2][2];      // [k-step parity][row tile]
+                auto rd = [&](int ks) __attribute__((always_inline)) {
+                    const uint32_t ad = (fr0 ^ (uint32_t)(ks << 6)) + ab;      // XOR inside the row, then the tile base
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192" : "=&v"(fa[ks & 1][0]), "=&v"(fa[ks & 1][1]) : "v"(ad) : "memory");
+                };
+                rd(0);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks + 1 < 8) {
+                        rd(ks + 1);
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[ks & 1][0]), "+v"(fa[ks & 1][1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks & 1][0]), "+v"(fa[ks & 1][1]));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][i]), wf[j][ks], acc[i][j], 0, 0, 0);
+                }
+                // (the staging writes below are inline asm: the compiler's hazard recogniser does not put the wait states between an MFMA
+                // and an LDS instruction that reads its result there -- without them every row 4 q + 0 carried a stale value)
+                // (tied to the four accumulator tiles: every MFMA is issued before it, every staging write after it)
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+                // fp32 tile -> staging buffer it & 1: element (row 16 i + 4 q + e, column 32 gw + 16 j + r)
+                const uint32_t sb = stg0 + (uint32_t)((it & 1) * C::STG) + sw0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t ad = sb + (uint32_t)(((16 * i + e) * C::ES + 16 * j) * 4);
+                            asm volatile("ds_write_b32 %0, %1" :: "v"(ad), "v"(acc[i][j][e]) : "memory");
+                        }
+                // the staging tile is in LDS before the barrier hands it to the epilogue role; the A tile of step it + 1 has landed
+                // for this wave (issued a whole step ago; the pieces of step it + 2 stay in flight)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (it + 1 < n) {
+                    if (it + 2 < n) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // ==================================================================== epilogue role: 512 threads, 32 lanes per row, 16 rows per pass
+    const int te = tid - 512;
+    const int erow = te >> 5, ecol = (te & 31) * 8;
+    const DropKey dk = make_drop_key(g.drop);
+    bf16* Cp = (bf16*)g.C;
+    const bf16* R = (const bf16*)g.res;
+    bf16* LNO = (bf16*)g.ln_out;
+    float bias[8], gam[8], bet[8];      // this lane's eight columns, for the life of the workgroup
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias[e] = g.bias ? g.bias[ecol + e] : 0.f;
+        gam[e] = g.ln_gamma[ecol + e];
+        bet[e] = g.ln_beta[ecol + e];
+    }
+    bf16x8 pf[2];
+    auto load_pf = [&](int t) __attribute__((always_inline)) {
+        const int mt = x + t * gx;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int m = min(mt * C::TR + erow + 16 * ps, g.M - 1);
+            pf[ps] = *(const bf16x8*)(R + (int64_t)m * g.ldr + ecol);
+        }
+    };
+    if (0 < n) load_pf(0);
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it <= n; ++it) {
+        if (it >= 1) {
+            const int tt = it - 1, mt = x + tt * gx;
+            const float* stage = (const float*)(smem + C::NR * C::TILEB + (tt & 1) * C::STG);
+            bf16x8 rv[2] = {pf[0], pf[1]};
+            if (tt + 1 < n) load_pf(tt + 1);      // the next step's residual rows travel under this step's arithmetic
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int row = erow + 16 * ps;
+                const int m = mt * C::TR + row;
+                const bool ok = m < g.M;
+                float v[8];
+                const f32x4 s0 = *(const f32x4*)(stage + row * C::ES + ecol), s1 = *(const f32x4*)(stage + row * C::ES + ecol + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = s0[e] + bias[e]; v[4 + e] = s1[e] + bias[4 + e]; }
+                if (dk.on) {
+                    float d0[4], d1[4];
+                    drop_mul4(dk, (uint32_t)m, (uint32_t)ecol >> 2, d0);
+                    drop_mul4(dk, (uint32_t)m, ((uint32_t)ecol >> 2) + 1, d1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[ps][e];
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = ok ? (float)o[e] : 0.f; }   // LN sees what a stored C would hold
+                if (ok && !g.skip_c) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ecol) = o;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[e];
+                s = sum_lanes32(s);
+                const float mean = s * (1.f / 256.f);
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
+                ss = sum_lanes32(ss);
+                const float rstd = __builtin_amdgcn_rsqf(ss * (1.f / 256.f) + g.ln_eps);
+                if (ok) {
+                    if ((te & 31) == 0) *(float2*)(g.ln_stats + 2 * (int64_t)m) = make_float2(mean, rstd);
+                    bf16x8 y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16)((v[e] - mean) * rstd * gam[e] + bet[e]);
+                    *(bf16x8*)(LNO + (int64_t)m * g.ldc + ecol) = y;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+bool gemm_wsr_ok(const GemmWS& g) {
+    return !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN | OPT_UNFUSED_LN)) && g.K == 256 && g.N == 256 && g.M >= 8192 && g.epi == EPI_NONE && g.res != nullptr && g.ln_out != nullptr && g.ln_stats != nullptr &&
+           g.a_rows == nullptr && g.m_dev == nullptr && g.q8 == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.ldr % 8 == 0 &&
+           ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 &&
+           ((uintptr_t)g.ln_out % 16) == 0 && ((uintptr_t)g.ln_stats % 8) == 0;
+}
+
+int gemm_wsr(const GemmWS& g, hipStream_t st) {
+    PMGT_CHECK(gemm_wsr_ok(g), -2, "gemm_wsr: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
+    static bool attr_done = false;
+    if (!attr_done) {
+        PMGT_HIP(hipFuncSetAttribute((const void*)gemm_wsr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WsrCfg::SMEM));
+        attr_done = true;
+    }
+    const int num_mt = cdiv(g.M, WsrCfg::TR);
+    const int gx = std::max(8, std::min(256, num_mt) / 8 * 8);      // one 16-wave workgroup per CU
+    hipLaunchKernelGGL(gemm_wsr_kernel, dim3(gx), dim3(1024), WsrCfg::SMEM, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace pmgt

@@ -49,7 +49,7 @@ def test_fast_paths_agree_with_the_plain_path_at_full_size(world):
     fast = engine(world)
     plain = engine(world)           # two engines alive in one process, each with its own options
     for k in ("no_table_projection", "no_fused_qkvc_attention", "no_head_major", "no_shortcut", "tile_gemm", "no_segment_sum",
-              "no_fused_attention_bwd", "eager_reduce", "store_ln_input"):
+              "no_fused_attention_bwd", "eager_reduce", "store_ln_input", "no_role_split_ln"):
         plain.set_option(k, 1)
     o_plain = step(plain, world, want_hidden=True)
     o_fast = step(fast, world, want_hidden=False)

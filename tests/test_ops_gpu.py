@@ -421,6 +421,42 @@ def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
     assert rel_err(dx, outs[1][2]) < 4e-2
 
 
+@pytest.mark.parametrize("M,drop", [(8192, 0.1), (8193, 0.0), (9000, 0.1), (65537, 0.1), (12288, 0.0)])
+def test_role_split_layernorm_gemm_is_bit_identical_to_the_streaming_kernel(M, drop):
+    """gemm_wsr.hip (sixteen waves per CU: eight keep W and run the MFMAs, eight run the bias / dropout / residual / LayerNorm
+    epilogue of the previous 32-row tile) against gemm_ws_kernel<8, WS_RES_LN>: the same arithmetic per element in the same
+    order, so the sum, the LayerNorm output and the statistics must agree BIT FOR BIT; ragged M, one step and many steps per
+    workgroup, dropout on and off; and against fp64 torch."""
+    _lib, L = _setup()
+    N = K = 256
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.2).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda().bfloat16()
+    gam = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    bet = (0.1 * torch.randn(N, generator=g)).cuda()
+    rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
+    outs = []
+    for opts in ((), ("no_role_split_ln",)):
+        L.use(*opts)
+        Cd = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        lno = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        stats = torch.full((M, 2), float("nan"), device="cuda")
+        _lib.check(L.pmgt_op_linear(1, P(A), K, P(W), K, P(Cd), N, M, N, K, P(bias), 0, None, N, P(R), N, drop, 33, P(rng),
+                                    P(lno), P(stats), P(gam), P(bet), 1e-12, stream()))
+        torch.cuda.synchronize()
+        outs.append((Cd, lno, stats))
+    L.use()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b)
+    if drop == 0.0:
+        x = (A.double().cpu() @ W.double().cpu().T + bias.double().cpu() + R.double().cpu()).to(torch.bfloat16).double()
+        ref = torch.nn.functional.layer_norm(x, (N,), gam.double().cpu(), bet.double().cpu(), 1e-12)
+        assert rel_err(outs[0][1], ref) < 2e-2
+
+
 @pytest.mark.parametrize("M,N,K,epi,res,drop,ln", [
     (4096, 256, 256, 0, True, 0.1, True),      # attn-out / FFN2 shape: dropout + residual + fused LayerNorm
     (1000, 256, 256, 1, False, 0.0, False),    # FFN1: GELU + pre-activation store, ragged M
