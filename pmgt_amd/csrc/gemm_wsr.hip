@@ -6,8 +6,8 @@
 // of phase would overlap the two phases, but a wave that holds 64 VGPRs of W next to the LayerNorm epilogue's temporaries does not fit
 // the 128 registers sixteen waves leave (52 spilled: profiles/r03).  Here ONE 16-wave workgroup per CU splits the ROLES, as the fused
 // attention kernels do -- a role needs only its own registers:
-//   waves 0-7  (GEMM role):     W columns 32 g .. 32 g + 31 in 64 VGPRs; the 32-row A tile of step t arrives by LDS-DMA in a 3-slot ring
-//                               (two steps ahead, counted vmcnt), 32 MFMAs, the fp32 result into staging buffer t & 1;
+//   waves 0-7  (GEMM role):     W columns 32 g .. 32 g + 31 in 64 VGPRs; the 32-row A tile of step t arrives by LDS-DMA in a 4-slot ring
+//                               (three steps ahead, counted vmcnt), 32 MFMAs, the fp32 result into staging buffer t & 1;
 //   waves 8-15 (epilogue role): bias, dropout, residual (prefetched one step ahead), bf16 rounding, LayerNorm of the row (32 lanes per
 //                               row), 16-byte stores -- of step t - 1, from staging buffer (t - 1) & 1, while the GEMM role computes step t.
 // One s_barrier per step.  Results are bit-identical to gemm_ws_kernel<8, WS_RES_LN> (same arithmetic per element, same order).
@@ -19,7 +19,7 @@ typedef __attribute__((address_space(3))) void lds_void_wsr_t;
 typedef __attribute__((address_space(1))) const void gbl_void_wsr_t;
 
 struct WsrCfg {
-    static constexpr int TR = 32, ROWB = 512, TILEB = TR * ROWB, NR = 3, ES = 256 + 4, STG = TR * ES * 4;
+    static constexpr int TR = 32, ROWB = 512, TILEB = TR * ROWB, NR = 4, ES = 256 + 4, STG = TR * ES * 4;      // NR - 1 A tiles in flight
     static constexpr int SMEM = NR * TILEB + 2 * STG;
 };
 
@@ -59,14 +59,22 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
         const uint32_t fr0 = (uint32_t)(r * C::ROWB + ((((r >> 2) & 3) << 2 | (q ^ (r & 3))) << 4));
         // staging address of acc[0][0][0]: row 4 q, column 32 gw + r
         const uint32_t sw0 = (uint32_t)((4 * q * C::ES + 32 * gw + r) * 4);
-        if (0 < n) dma(0, 0);
-        if (1 < n) dma(1, 1);
-        if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // counted wait: all but the `younger` most recently issued tiles (2 DMA pieces each) have landed
+        auto wait_tiles = [&](int younger) __attribute__((always_inline)) {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        static_assert(C::NR == 4, "wait_tiles: at most two younger tiles");
+#pragma unroll
+        for (int t = 0; t < C::NR - 1; ++t)
+            if (t < n) dma(t, t);
+        wait_tiles(min(C::NR - 2, n - 1));      // tile 0 has landed for this wave (the W loads are older and drain first)
         __builtin_amdgcn_s_barrier();
         for (int it = 0; it <= n; ++it) {
             if (it < n) {
                 const int slot = it % C::NR;
-                if (it + 2 < n) dma(it + 2, (it + 2) % C::NR);      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
+                if (it + C::NR - 1 < n) dma(it + C::NR - 1, (it + C::NR - 1) % C::NR);      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
                 const uint32_t ab = lds0 + (uint32_t)(slot * C::TILEB);
                 f32x4 acc[2][2];
 #pragma unroll
@@ -111,9 +119,7 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 // the staging tile is in LDS before the barrier hands it to the epilogue role; the A tile of step it + 1 has landed
                 // for this wave (issued a whole step ago; the pieces of step it + 2 stay in flight)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (it + 1 < n) {
-                    if (it + 2 < n) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (it + 1 < n) wait_tiles(min(it + C::NR - 1, n - 1) - (it + 1));
             }
             __builtin_amdgcn_s_barrier();
         }
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[ps][e];
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = ok ? (float)o[e] : 0.f; }   // LN sees what a stored C would hold
+                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what a stored C would hold (rows past M: clamped inputs, never stored)
                 if (ok && !g.skip_c) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ecol) = o;
                 float s = 0.f;
 #pragma unroll
