@@ -925,8 +925,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
 // indices of a stage are themselves fetched by LDS-DMA (one 4-byte-per-lane instruction, issued six stages ahead
 // by every wave into the same 256-byte slot of an 8-slot ring) and read back next to the fragments, three stages
 // before the data DMA that needs them: no register-destination load ever enters the counted vmcnt sequence.
-template <bool GATHER>
-__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_rows) {
+// NW = 8 (non-gather form; round 3): the same 128 x 128 tile on EIGHT waves (2 x 4, 64 x 32 outputs each).  With four waves -- one per
+// SIMD -- a wave walks through "wait for its DMA, barrier, issue 4 DMA pieces (~70 cycles each), 16 transposed reads + lgkmcnt(0), 16
+// MFMAs" strictly in sequence and nobody else uses the SIMD meanwhile: ~670 cycles per 32-row stage against 256 of MFMA, 3.5 TB/s on
+// HBM bytes the Infinity Cache has already cut to 0.7 of the algorithmic ones.  Two waves per SIMD (2 DMA pieces, 12 reads, 8 MFMAs per
+// stage each) fill each other's waits.
+template <bool GATHER, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_dma_kernel(GemmTN g, int chunk_rows) {
+    static_assert(NW == 4 || (NW == 8 && !GATHER), "8 waves: non-gather form only");
+    constexpr int WN = NW / 2, JN = 8 / WN, NJ = 8 / NW, RPW = 32 / NW, PER = 2 * NJ;     // wave grid 2 x WN, 64 x 16 JN outputs per wave
     constexpr int BKM = 32, ROWB = 256, STAGE = 2 * BKM * ROWB, NST = 4;     // 16 KiB per stage (P + Q)
     constexpr int IDX_SLOTS = 8, IDX_BYTES = BKM * 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];              // NST * STAGE (+ IDX_SLOTS * IDX_BYTES)
@@ -938,20 +945,20 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, q = lane >> 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][JN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = g.bias_slab != nullptr && n2_0 == 0 && wn == 0;
     f32x4 accb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // this lane's part of a stage: rows 8 wave + 4 j + (lane >> 4), j = 0, 1; LDS chunk slot lane & 15 holds
+    // this lane's part of a stage: rows RPW wave + 4 j + (lane >> 4), j < NJ; LDS chunk slot lane & 15 holds
     // global chunk (lane & 15) ^ swz(row)
     const char* zero = (const char*)g.zeros;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
@@ -960,16 +967,16 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
         const int mb = mbeg + kt * BKM;
         char* st = smem + (kt & (NST - 1)) * STAGE;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 8 * wave + 4 * j + (lane >> 4);
+        for (int j = 0; j < NJ; ++j) {
+            const int row = RPW * wave + 4 * j + (lane >> 4);
             const int ch = (lane & 15) ^ (tn_f(row) << 1);
             const int m = mb + row;
             const int cp = n1_0 + ch * 8, cq = n2_0 + ch * 8;
             const int64_t qrow = GATHER ? (int64_t)(j == 0 ? q0 : q1) : (int64_t)m;
             const char* sp = (m < mend && cp < g.N1) ? (const char*)g.P + ((int64_t)m * g.ldp + cp) * 2 : zero;
             const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + (qrow * g.ldq + cq) * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (8 * wave + 4 * j) * ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (8 * wave + 4 * j) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (RPW * wave + 4 * j) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (RPW * wave + 4 * j) * ROWB), 16, 0, 0);
         }
     };
     // index DMA of stage kt: lane l fetches dword l of q_rows[mb .. mb + 32) (clamped inside the array)
@@ -1008,7 +1015,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
         const int sw = tn_f(row) << 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ca = wm * 64 + i * 16 + 4 * (r & 3), cb = wn * 64 + i * 16 + 4 * (r & 3);
+            const int ca = wm * 64 + i * 16 + 4 * (r & 3), cb = wn * (16 * JN) + (i % JN) * 16 + 4 * (r & 3);
             offa[i] = (uint32_t)(row * ROWB + (((ca >> 3) ^ sw) << 4) + ((ca & 7) << 1));
             offb[i] = (uint32_t)(row * ROWB + (((cb >> 3) ^ sw) << 4) + ((cb & 7) << 1));
         }
@@ -1031,9 +1038,15 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
                 default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
         } else {
-            if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PER == 4) {
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __builtin_amdgcn_s_barrier();
         if constexpr (GATHER) issue_idx(kt + 6);
@@ -1044,6 +1057,27 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
         // sit in ONE statement with early-clobber outputs (cdna_hip_programming.md section 5.7, form (i)).
         const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
         u32x2 t[16];
+        if constexpr (NW == 8) {      // four P fragments, two Q fragments
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %12\n\t"
+                "ds_read_b64_tr_b16 %1, %12 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %2, %13\n\t"
+                "ds_read_b64_tr_b16 %3, %13 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %4, %14\n\t"
+                "ds_read_b64_tr_b16 %5, %14 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %6, %15\n\t"
+                "ds_read_b64_tr_b16 %7, %15 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %8, %16 offset:8192\n\t"
+                "ds_read_b64_tr_b16 %9, %16 offset:9216\n\t"
+                "ds_read_b64_tr_b16 %10, %17 offset:8192\n\t"
+                "ds_read_b64_tr_b16 %11, %17 offset:9216\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                  "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11])
+                : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
+                  "v"(sbase + offb[0]), "v"(sbase + offb[1])
+                : "memory");
+        } else
         asm volatile(
             "ds_read_b64_tr_b16 %0, %16\n\t"
             "ds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
@@ -1074,16 +1108,17 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
                          : "=&v"(q0), "=&v"(q1) : "v"(ia) : "memory");
             if (kt + 3 < nk) issue(kt + 3, q0, q1);
         }
-        bf16x8 fa[4], fb[4];
+        bf16x8 fa[4], fb[JN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
             fa[i] = __builtin_bit_cast(bf16x8, (u32x4){t[2 * i][0], t[2 * i][1], t[2 * i + 1][0], t[2 * i + 1][1]});
+#pragma unroll
+        for (int i = 0; i < JN; ++i)
             fb[i] = __builtin_bit_cast(bf16x8, (u32x4){t[8 + 2 * i][0], t[8 + 2 * i][1], t[9 + 2 * i][0], t[9 + 2 * i][1]});
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < JN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         if (do_bias) {
             const bf16 one = (bf16)1.f;
@@ -1112,8 +1147,8 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(GemmTN g, int chunk_ro
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n2 = n2_0 + wn * 64 + j * 16 + r;
+        for (int j = 0; j < JN; ++j) {
+            const int n2 = n2_0 + wn * (16 * JN) + j * 16 + r;
             if (n2 >= g.N2) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1402,7 +1437,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
         if (!(g.opts & OPT_TILE_GEMM) && g.zeros != nullptr) {
             constexpr size_t ring = 4 * 2 * 32 * 256;
             if (g.q_rows == nullptr) {
-                hipLaunchKernelGGL(gemm_tn_dma_kernel<false>, grid, dim3(256), ring, st, g, chunk);
+                hipLaunchKernelGGL((gemm_tn_dma_kernel<false, 8>), grid, dim3(512), ring, st, g, chunk);
             } else {
                 PMGT_CHECK(g.M >= 1, -2, "gemm_tn: gather needs at least one row");
                 constexpr size_t smem = ring + 8 * 32 * 8;
