@@ -11,6 +11,7 @@
 //   waves 8-15 (epilogue role): bias, dropout, residual (prefetched one step ahead), bf16 rounding, LayerNorm of the row (32 lanes per
 //                               row), 16-byte stores -- of step t - 1, from staging buffer (t - 1) & 1, while the GEMM role computes step t.
 // One s_barrier per step.  Results are bit-identical to gemm_ws_kernel<8, WS_RES_LN> (same arithmetic per element, same order).
+#include "fp8.h"
 #include "gemm.h"
 
 namespace pmgt {
@@ -194,6 +195,24 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = (bf16)((v[e] - mean) * rstd * gam[e] + bet[e]);
                     *(bf16x8*)(LNO + (int64_t)m * g.ldc + ecol) = y;
+                    if (g.q8) {      // (uniform) fp8 mode: the row additionally as e4m3 + one scale, for the next layer's fp8 projection (fp8.h contract)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (float)y[e];      // the quantisation of the STORED bf16 row
+                    }
+                }
+                if (g.q8) {      // every lane of the row joins the maximum (rows past M: values unused)
+                    float mx = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx = raw_max(mx, fabsf(v[e]));
+                    mx = max_lanes32(mx);
+                    const float inv = mx > 0.f ? E4M3_MAX / mx : 1.f;
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(v[e] * inv, -E4M3_MAX, E4M3_MAX);
+                    if (ok) {
+                        *(u32x2*)((char*)g.q8 + (int64_t)m * g.N + ecol) = pack8_e4m3(f);
+                        if ((te & 31) == 0) g.q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
+                    }
                 }
             }
         }
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
 
 bool gemm_wsr_ok(const GemmWS& g) {
     return !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN | OPT_UNFUSED_LN)) && g.K == 256 && g.N == 256 && g.M >= 8192 && g.epi == EPI_NONE && g.res != nullptr && g.ln_out != nullptr && g.ln_stats != nullptr &&
-           g.a_rows == nullptr && g.m_dev == nullptr && g.q8 == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.ldr % 8 == 0 &&
+           g.a_rows == nullptr && g.m_dev == nullptr && (g.q8 == nullptr || (g.q8_scale != nullptr && ((uintptr_t)g.q8 % 8) == 0)) && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.ldr % 8 == 0 &&
            ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 &&
            ((uintptr_t)g.ln_out % 16) == 0 && ((uintptr_t)g.ln_stats % 8) == 0;
 }
