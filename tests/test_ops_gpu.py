@@ -107,7 +107,8 @@ def test_gemm_nt_epilogues_and_gather(dt, K):
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("M,N1,N2", [(500, 64, 96), (4096, 256, 256), (130, 24, 1536), (3000, 1024, 256),
                                      (40000, 128, 256), (70001, 128, 128),      # long splits: steady state of the DMA rings
-                                     (70016, 1024, 256), (66000, 512, 512)])      # 256 x 256 tile (bf16, M >= 65536)
+                                     (70016, 1024, 256), (66000, 512, 512),      # 256 x 256 tile (bf16, M >= 65536)
+                                     (70001, 256, 256), (65600, 128, 256), (66011, 256, 512)])      # large M on the 128 x 128 tile, ragged tails
 def test_gemm_tn(dt, M, N1, N2):
     _lib, L = _setup()
     code, tdt = DT[dt]
@@ -129,11 +130,17 @@ def test_gemm_tn(dt, M, N1, N2):
     _lib.check(L.pmgt_op_gemm_tn(code, P(Pd), N1, P(td), N2, P(rowd), M, N1, N2, P(slab), P(out), 1, P(cnt), stream()))
     ref2 = ref + rounded(Pm, tdt)[: M - 37].T @ rounded(table, tdt)[rows[: M - 37]]
     assert rel_err(out, ref2) < (1e-5 if dt == "fp32" else 2e-3)
+    # device row count without a gather (the compacted last layer's weight gradients), overwrite
+    _lib.check(L.pmgt_op_gemm_tn(code, P(Pd), N1, P(Qd), N2, None, M, N1, N2, P(slab), P(out), 0, P(cnt), stream()))
+    ref3 = rounded(Pm, tdt)[: M - 37].T @ rounded(Q, tdt)[: M - 37]
+    assert rel_err(out, ref3) < (1e-5 if dt == "fp32" else 2e-3)
 
 
 @pytest.mark.parametrize("dt,M,N1,N2,hm", [("fp32", 700, 256, 64, False), ("bf16", 3000, 1024, 256, False), ("bf16", 3000, 1024, 256, True),
                                            ("bf16", 70016, 1024, 256, False), ("bf16", 70016, 1024, 256, True),      # 256 x 256 tile
-                                           ("bf16", 66000, 512, 512, False), ("bf16", 40000, 256, 1536, False)])
+                                           ("bf16", 66000, 512, 512, False), ("bf16", 40000, 256, 1536, False),
+                                           ("bf16", 70001, 256, 256, False), ("bf16", 70001, 256, 256, True),      # 8-wave 128 x 128 tile, ragged tail
+                                           ("bf16", 65600, 128, 512, False)])
 def test_gemm_tn_bias_sums_and_head_major_rows(dt, M, N1, N2, hm):
     """The bias gradient rides along in the weight-gradient kernels as MFMAs against a ones fragment, and the Q|K|V|C
     projection's P operand arrives head-major (rows of the result are permuted back to q | k | v | c): every TN kernel
