@@ -30,14 +30,19 @@ extern "C" {
  * the optimizer as in PMGT_DTYPE_BF16. */
 #define PMGT_DTYPE_FP8 2
 
+/* Modalities: PMGTEmbeddings / PMGTNodeConstructLoss / PMGT.feat_embeddings are generic over len(feat_hidden_sizes)
+ * (pmgt/pmgt/modeling_pmgt.py:163-173,195-201,549-569; pmgt/pmgt/models.py:38-54); the reference's trainer builds two
+ * (visual 1536, textual 768; pmgt/pmgt/trainer.py:114-125).  The engine takes 1 .. PMGT_MAX_FEATS of them. */
+#define PMGT_MAX_FEATS 4
+
 /* Mirrors PMGTConfig (pmgt/pmgt/configuration_pmgt.py:11-41). */
 typedef struct pmgt_config {
     int hidden_size;
     int num_hidden_layers;
     int num_attention_heads;
     int intermediate_size;
-    int feat_size_v; /* feat_hidden_sizes[0] (visual, 1536) */
-    int feat_size_t; /* feat_hidden_sizes[1] (textual, 768) */
+    int n_feats;                     /* len(feat_hidden_sizes) */
+    int feat_sizes[PMGT_MAX_FEATS];  /* feat_hidden_sizes (each a multiple of 8); entries past n_feats are ignored */
     int max_position_embeddings;
     float layer_norm_eps;
     float beta;
@@ -71,13 +76,12 @@ int64_t pmgt_workspace_bytes(const pmgt_engine* e, int n_seq, int seq_len, int n
 typedef struct pmgt_tensors {
     float* params;       /* [pmgt_param_count] fp32 master weights */
     float* grads;        /* same shape; written (or accumulated) by pmgt_pretrain_step */
-    const void* table_v; /* [n_nodes + 2, feat_size_v] frozen features in the engine dtype (models.py:40-54); e4m3 in fp8 mode */
-    const void* table_t; /* [n_nodes + 2, feat_size_t] */
+    const void* tables[PMGT_MAX_FEATS]; /* tables[m]: [n_nodes + 2, feat_sizes[m]] frozen features in the engine dtype
+                                          * (PMGT.feat_embeddings, models.py:40-54); e4m3 bytes in fp8 mode */
     int64_t n_nodes;
     uint64_t* rng_state; /* device [2]: {seed, step}; drives dropout + NFR masking */
-    /* PMGT_DTYPE_FP8 only: the tables are e4m3 bytes, feature value = byte value * table_scale_{v,t} (pmgt_quantize_e4m3) */
-    float table_scale_v;
-    float table_scale_t;
+    /* PMGT_DTYPE_FP8 only: the tables are e4m3 bytes, feature value = byte value * table_scales[m] (pmgt_quantize_e4m3) */
+    float table_scales[PMGT_MAX_FEATS];
 } pmgt_tensors;
 
 /* One collated batch, exactly what pmgt_collate_fn returns (pmgt/pmgt/datasets.py:186-208). */
@@ -121,24 +125,25 @@ int pmgt_pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* 
 int pmgt_encode_ids(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const float* mask, int n_seq,
                     int seq_len, void* last_hidden, void* hidden_states, float* attn_probs, void* workspace,
                     int64_t workspace_bytes, void* stream);
-/* PMGTModel.forward(*input_feat_embeds) on already-gathered features [n_seq, S, F_m] in the engine dtype. */
-int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t,
+/* PMGTModel.forward(*input_feat_embeds) on already-gathered features: feats[m] = [n_seq, S, feat_sizes[m]] in the engine
+ * dtype, m < n_feats (a host array of device pointers). */
+int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* const* feats,
                       const float* mask, int n_seq, int seq_len, void* last_hidden, void* hidden_states,
                       float* attn_probs, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* PMGTModel.forward + backward for a caller that owns the head (second caller of the boundary: PMGT_NCF,
  * pmgt/pmgt_ncf/models.py:77-105 -- `self.bert(*input_feat_embeds, attention_mask=...)[0][:, 0]` followed by
  * autograd).  pmgt_encode_train runs the encoder on node ids (ids != NULL, gather fused) or on gathered features
- * (feat_v/feat_t [n_seq, S, F_m], engine dtype), keeps every activation in `workspace`
+ * (ids == NULL: feats[m] = [n_seq, S, feat_sizes[m]], engine dtype), keeps every activation in `workspace`
  * (pmgt_workspace_bytes(e, n_seq, S, 1, 1) bytes, untouched until the backward call) and snapshots the dropout
  * counter; PMGT_FLAG_TRAINING turns dropout on and advances the counter.  pmgt_encode_backward takes
  * d loss / d last_hidden_state [n_seq, S, d] (engine dtype) and leaves the gradients of every `bert.*` entry in
  * t->grads (= or += with PMGT_FLAG_ACCUMULATE; pass the same TRAINING flag); the frozen tables get none
- * (pmgt/pmgt_ncf/models.py:45-47).  feat_v/feat_t are needed again only when the forward used them. */
-int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* feat_v, const void* feat_t,
+ * (pmgt/pmgt_ncf/models.py:45-47).  `feats` is needed again only when the forward used it (NULL otherwise). */
+int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* const* feats,
                       const float* mask, int n_seq, int seq_len, void* last_hidden, void* workspace,
                       int64_t workspace_bytes, int flags, void* stream);
-int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t,
+int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* const* feats,
                          const void* d_last_hidden, int n_seq, int seq_len, void* workspace, int64_t workspace_bytes,
                          int flags, void* stream);
 

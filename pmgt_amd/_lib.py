@@ -12,16 +12,19 @@ c_i64p = C.POINTER(C.c_int64)
 c_f32p = C.POINTER(C.c_float)
 
 
+MAX_FEATS = 4      # PMGT_MAX_FEATS (include/pmgt_capi.h)
+
+
 class PMGTConfigC(C.Structure):
     _fields_ = [("hidden_size", C.c_int), ("num_hidden_layers", C.c_int), ("num_attention_heads", C.c_int),
-                ("intermediate_size", C.c_int), ("feat_size_v", C.c_int), ("feat_size_t", C.c_int),
+                ("intermediate_size", C.c_int), ("n_feats", C.c_int), ("feat_sizes", C.c_int * MAX_FEATS),
                 ("max_position_embeddings", C.c_int), ("layer_norm_eps", C.c_float), ("beta", C.c_float),
                 ("hidden_dropout_prob", C.c_float), ("attention_probs_dropout_prob", C.c_float), ("dtype", C.c_int)]
 
 
 class TensorsC(C.Structure):
-    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("table_v", C.c_void_p), ("table_t", C.c_void_p),
-                ("n_nodes", C.c_int64), ("rng_state", C.c_void_p), ("table_scale_v", C.c_float), ("table_scale_t", C.c_float)]
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("tables", C.c_void_p * MAX_FEATS),
+                ("n_nodes", C.c_int64), ("rng_state", C.c_void_p), ("table_scales", C.c_float * MAX_FEATS)]
 
 
 class BatchC(C.Structure):
@@ -112,9 +115,10 @@ def hip():
     L.pmgt_workspace_bytes.argtypes = [vp, i, i, i, i]
     L.pmgt_pretrain_step.argtypes = [vp, C.POINTER(TensorsC), C.POINTER(BatchC), C.POINTER(OutputsC), vp, i64, i, vp]
     L.pmgt_encode_ids.argtypes = [vp, C.POINTER(TensorsC), vp, vp, i, i, vp, vp, vp, vp, i64, vp]
-    L.pmgt_encode_feats.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, i, i, vp, vp, vp, vp, i64, vp]
-    L.pmgt_encode_train.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, vp, i, i, vp, vp, i64, i, vp]
-    L.pmgt_encode_backward.argtypes = [vp, C.POINTER(TensorsC), vp, vp, vp, i, i, vp, i64, i, vp]
+    featp = C.POINTER(C.c_void_p)      # const void* const* feats: host array of n_feats device pointers, or NULL
+    L.pmgt_encode_feats.argtypes = [vp, C.POINTER(TensorsC), featp, vp, i, i, vp, vp, vp, vp, i64, vp]
+    L.pmgt_encode_train.argtypes = [vp, C.POINTER(TensorsC), vp, featp, vp, i, i, vp, vp, i64, i, vp]
+    L.pmgt_encode_backward.argtypes = [vp, C.POINTER(TensorsC), featp, vp, i, i, vp, i64, i, vp]
     L.pmgt_optimizer_step.argtypes = [vp, C.POINTER(TensorsC), C.POINTER(AdamC), vp]
     L.pmgt_profile_begin.argtypes = [vp]
     L.pmgt_profile_end.argtypes = [vp, C.c_char_p, i]

@@ -72,17 +72,19 @@ using namespace pmgt;
 
 struct pmgt_engine {
     pmgt_config cfg;
-    int d, L, H, I, Fv, Ft, dh;
-    // flat parameter layout (floats)
-    int64_t pos, role, Wv, Wt, bvt, ln_g, ln_b, Wa, ba, Wn, bn, total;
+    int d, L, H, I, dh;
+    // modalities (PMGTConfig.feat_hidden_sizes): sizes, their sum, and each one's first column in the concatenated NFR projection
+    int NF = 0, F[PMGT_MAX_FEATS] = {0, 0, 0, 0}, Fsum = 0, Foff[PMGT_MAX_FEATS] = {0, 0, 0, 0};
+    // flat parameter layout (floats); Wf[m] = feat_linear.m.weight, bf = the NF feat_linear biases side by side
+    int64_t pos, role, Wf[PMGT_MAX_FEATS], bf, ln_g, ln_b, Wa, ba, Wn, bn, total;
     std::vector<LayerOff> layers;
     std::vector<ParamEntry> entries;
     // mirror
-    int64_t mWv, mWt, mWn, mWnT, mirror_elems;
+    int64_t mWf[PMGT_MAX_FEATS], mWn, mWnT, mirror_elems;
     // fp8 mode (PMGT_DTYPE_FP8): bf16 engine + e4m3 copies (per-output-channel scales) of the feature-projection and
     // Q|K|V|C weights, rebuilt every forward by one launch; the frozen tables arrive as e4m3 from the caller
     bool fp8 = false;
-    int64_t m8Wv = -1, m8Wt = -1, s8Wv = -1, s8Wt = -1, mirror8_bytes = 0, mscale_elems = 0;
+    int64_t m8Wf[PMGT_MAX_FEATS] = {-1, -1, -1, -1}, s8Wf[PMGT_MAX_FEATS] = {-1, -1, -1, -1}, mirror8_bytes = 0, mscale_elems = 0;
     std::vector<QuantDesc> desc8;
     QuantDesc* desc8_dev = nullptr;
     int desc8_rows = 0;
@@ -129,21 +131,22 @@ static void add_entry(pmgt_engine* e, const std::string& name, int64_t off, int 
 }
 
 static void build_layout(pmgt_engine* e) {
-    const int d = e->d, I = e->I, Fv = e->Fv, Ft = e->Ft, P = e->cfg.max_position_embeddings;
+    const int d = e->d, I = e->I, NF = e->NF, P = e->cfg.max_position_embeddings;
     int64_t cur = 0;
     const std::string em = "bert.embeddings.";
     e->pos = take(cur, (int64_t)P * d);   add_entry(e, em + "position_embeddings.weight", e->pos, P, d);
     e->role = take(cur, 2 * d);           add_entry(e, em + "role_embeddings.weight", e->role, 2, d);
-    e->Wv = take(cur, (int64_t)d * Fv);   add_entry(e, em + "feat_linear.0.weight", e->Wv, d, Fv);
-    e->Wt = take(cur, (int64_t)d * Ft);   add_entry(e, em + "feat_linear.1.weight", e->Wt, d, Ft);
-    e->bvt = take(cur, 2 * d);
-    add_entry(e, em + "feat_linear.0.bias", e->bvt, d, 0);
-    add_entry(e, em + "feat_linear.1.bias", e->bvt + d, d, 0);
-    // ln_g | ln_b | Wa | ba are contiguous in exactly the order of embed_mix_bwd's partials (6d + 4)
+    for (int m = 0; m < NF; ++m) {
+        e->Wf[m] = take(cur, (int64_t)d * e->F[m]);
+        add_entry(e, em + "feat_linear." + std::to_string(m) + ".weight", e->Wf[m], d, e->F[m]);
+    }
+    e->bf = take(cur, NF * d);
+    for (int m = 0; m < NF; ++m) add_entry(e, em + "feat_linear." + std::to_string(m) + ".bias", e->bf + (int64_t)m * d, d, 0);
+    // ln_g | ln_b | Wa | ba are contiguous in exactly the order of embed_mix_bwd's partials (embed_part_elems(d, NF))
     e->ln_g = take(cur, d);               add_entry(e, em + "LayerNorm.weight", e->ln_g, d, 0);
     e->ln_b = take(cur, d);               add_entry(e, em + "LayerNorm.bias", e->ln_b, d, 0);
-    e->Wa = take(cur, 4 * d);             add_entry(e, em + "attention.1.weight", e->Wa, 2, 2 * d);
-    e->ba = take(cur, 4);                 add_entry(e, em + "attention.1.bias", e->ba, 2, 0);
+    e->Wa = take(cur, (int64_t)NF * NF * d);   add_entry(e, em + "attention.1.weight", e->Wa, NF, NF * d);
+    e->ba = take(cur, 4);                 add_entry(e, em + "attention.1.bias", e->ba, NF, 0);
     e->layers.resize(e->L);
     for (int l = 0; l < e->L; ++l) {
         LayerOff& o = e->layers[l];
@@ -165,12 +168,11 @@ static void build_layout(pmgt_engine* e) {
         o.ln2b = take(cur, d);             add_entry(e, p + "output.LayerNorm.bias", o.ln2b, d, 0);
         o.b2 = take(cur, d);               add_entry(e, p + "output.dense.bias", o.b2, d, 0);
     }
-    e->Wn = take(cur, (int64_t)(Fv + Ft) * d);
-    add_entry(e, "nfr_loss.projections.0.weight", e->Wn, Fv, d);
-    add_entry(e, "nfr_loss.projections.1.weight", e->Wn + (int64_t)Fv * d, Ft, d);
-    e->bn = take(cur, Fv + Ft);
-    add_entry(e, "nfr_loss.projections.0.bias", e->bn, Fv, 0);
-    add_entry(e, "nfr_loss.projections.1.bias", e->bn + Fv, Ft, 0);
+    // the NF projections of the NFR head stacked: one [sum F_m, d] weight = one GEMM over the masked rows
+    e->Wn = take(cur, (int64_t)e->Fsum * d);
+    for (int m = 0; m < NF; ++m) add_entry(e, "nfr_loss.projections." + std::to_string(m) + ".weight", e->Wn + (int64_t)e->Foff[m] * d, e->F[m], d);
+    e->bn = take(cur, e->Fsum);
+    for (int m = 0; m < NF; ++m) add_entry(e, "nfr_loss.projections." + std::to_string(m) + ".bias", e->bn + e->Foff[m], e->F[m], 0);
     e->total = cur;
 
     // ---- mirror layout
@@ -198,8 +200,7 @@ static void build_layout(pmgt_engine* e) {
         if (copy || transpose) e->desc.push_back(m);
         else tiles = m.tile_start;
     };
-    add_m(e->Wv, d, Fv, half, false, &e->mWv, nullptr);
-    add_m(e->Wt, d, Ft, half, false, &e->mWt, nullptr);
+    for (int m = 0; m < NF; ++m) add_m(e->Wf[m], d, e->F[m], half, false, &e->mWf[m], nullptr);
     for (int l = 0; l < e->L; ++l) {
         LayerOff& o = e->layers[l];
         add_m(o.Wqkvc, 4 * d, d, half, true, &o.mWqkvc, &o.mWqkvcT, half ? &o.mWqkvcT_hm : nullptr);
@@ -207,7 +208,7 @@ static void build_layout(pmgt_engine* e) {
         add_m(o.W1, I, d, half, true, &o.mW1, &o.mW1T);
         add_m(o.W2, d, I, half, true, &o.mW2, &o.mW2T);
     }
-    add_m(e->Wn, Fv + Ft, d, half, true, &e->mWn, &e->mWnT);
+    add_m(e->Wn, e->Fsum, d, half, true, &e->mWn, &e->mWnT);
     e->mirror_elems = mc;
     e->mirror_tiles = tiles;
     if (e->fp8) {
@@ -222,8 +223,7 @@ static void build_layout(pmgt_engine* e) {
             rows += r;
             e->desc8.push_back(q);
         };
-        add_q(e->Wv, d, Fv, &e->m8Wv, &e->s8Wv);
-        add_q(e->Wt, d, Ft, &e->m8Wt, &e->s8Wt);
+        for (int m = 0; m < NF; ++m) add_q(e->Wf[m], d, e->F[m], &e->m8Wf[m], &e->s8Wf[m]);
         for (int l = 0; l < e->L; ++l) add_q(e->layers[l].Wqkvc, 4 * d, d, &e->layers[l].m8Wqkvc, &e->layers[l].s8Wqkvc);
         e->mirror8_bytes = bc; e->mscale_elems = sc; e->desc8_rows = rows;
     }
@@ -316,7 +316,7 @@ static int64_t tn_slab_elems(int dtype, int M, int N1, int N2, uint32_t opts) {
 
 template <typename T>
 static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, int B, bool training) {
-    const int d = e->d, I = e->I, L = e->L, F = e->Fv + e->Ft;
+    const int d = e->d, I = e->I, L = e->L, F = e->Fsum, NF = e->NF;
     const int64_t M = (int64_t)Tseq * S;
     b.rng_snap = c.get<int64_t>(2);
     b.ids = c.get<int64_t>(M);
@@ -328,8 +328,8 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
         b.x8 = c.get<char>(M * d);
         b.xscale = c.get<float>(M);
     }
-    b.E = c.get<T>(M * 2 * d);
-    b.a = c.get<float>(M * 2);
+    b.E = c.get<T>(M * std::max(NF, 2) * d);
+    b.a = c.get<float>(M * NF);
     b.emb_pre = c.get<T>(M * d);
     b.emb_stats = c.get<float>(M * 2);
     b.h0 = c.get<T>(M * d);
@@ -367,15 +367,14 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     slab = std::max(slab, tn_slab_elems(dt, (int)M, d, d, e->opts));
     slab = std::max(slab, tn_slab_elems(dt, (int)M, I, d, e->opts));
     slab = std::max(slab, tn_slab_elems(dt, (int)M, d, I, e->opts));
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Fv, e->opts));
-    slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->Ft, e->opts));
+    for (int m = 0; m < NF; ++m) slab = std::max(slab, tn_slab_elems(dt, (int)M, d, e->F[m], e->opts));
     slab = std::max(slab, tn_slab_elems(dt, std::max(256, cap / 5), F, d, e->opts));
     b.slab_elems = align_up(slab, 64);
     b.slab = c.get<float>(2 * b.slab_elems);
     int64_t part = 0;
     part = std::max(part, (int64_t)ln_bwd_parts((int)M) * 3 * d);
-    part = std::max(part, (int64_t)embed_bwd_parts((int)M) * (6 * d + 4));
-    part = std::max(part, colsum_slab_elems((int)M, std::max(std::max(I, 4 * d), 2 * d)));
+    part = std::max(part, (int64_t)embed_bwd_parts((int)M) * embed_part_elems(d, NF));
+    part = std::max(part, colsum_slab_elems((int)M, std::max(I, 4 * d)));
     part = std::max(part, colsum_slab_elems(Tseq, S * d));
     part = std::max(part, colsum_slab_elems(cap, F));
     part = std::max(part, (int64_t)512 * std::max(std::max(I, 4 * d), F));     // wgrad bias slabs [splits <= 512][N1]
@@ -395,7 +394,7 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     b.sg_tmp = c.raw(b.sg_tmp_bytes);
     b.sg_part = c.get<float>(seg_part_elems((int)M, 2 * d));
     b.possum = c.get<float>((int64_t)S * d);
-    b.sse_part = c.get<float>((int64_t)nfr_diff_parts(cap) * 2);
+    b.sse_part = c.get<float>((int64_t)nfr_diff_parts(cap) * MAX_FEATS);
     b.nfr_masked = c.get<int64_t>((int64_t)B * S);
     b.nfr_tgt = c.get<int64_t>((int64_t)B * S);
     b.nfr_rows = c.get<int64_t>(cap);
@@ -507,15 +506,17 @@ static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool 
 }
 
 static inline bool use_table_projection(const pmgt_engine* e, const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {
-    return by_ids && !(e->opts & OPT_NO_TABLE_PROJECTION) && t->n_nodes > 0 && (t->n_nodes + 2) * 2 <= n_tokens;
+    // (the per-node buffers of the table mode live inside per-token buffers: [N+2, (NF+1) d] in E [M, max(NF, 2) d],
+    //  dE [N+2, NF d] in a [M, d] temporary)
+    return by_ids && !(e->opts & OPT_NO_TABLE_PROJECTION) && t->n_nodes > 0 && (t->n_nodes + 2) * std::max(2, e->NF) <= n_tokens;
 }
 
 // ---- encoder forward ---------------------------------------------------------------------------
 template <typename T>
 static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, const int64_t* ids,
-                           const T* feat_v, const T* feat_t, const float* mask, bool train, T* hidden_states,
+                           const void* const* feats, const float* mask, bool train, T* hidden_states,
                            float* attn_probs, hipStream_t st, bool shortcut = false, int n_cls_only = 0) {
-    const int d = e->d, I = e->I, L = e->L, H = e->H;
+    const int d = e->d, I = e->I, L = e->L, H = e->H, NF = e->NF;
     const int M = Tseq * S;
     const float* P = t->params;
     PMGT_CHECK(S <= e->cfg.max_position_embeddings, -2, "sequence length %d exceeds max_position_embeddings %d", S,
@@ -523,39 +524,39 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
     // Feature projections.  Token mode: gather fused into the A-operand load, one projected row per token.
     // Table mode (small graphs: every node appears many times in a batch): project the WHOLE table once,
-    // [N+2, F] -> [N+2, 2d], and let the mix kernel pick rows by node id -- M / (N+2) times fewer flops and
+    // [N+2, F_m] -> [N+2, NF d], and let the mix kernel pick rows by node id -- M / (N+2) times fewer flops and
     // table bytes, same value per token (a row's projection does not depend on which rows share its tile).
     const int64_t n_rows = t->n_nodes + 2;
     const bool table_mode = use_table_projection(e, t, M, ids != nullptr);
     b.e_by_id = table_mode;
     PMGT_CHECK(!e->fp8 || ids != nullptr, -3, "fp8 mode gathers e4m3 feature rows by node id: pre-gathered feature tensors are not supported");
-    for (int mod = 0; mod < 2 && e->fp8; ++mod) {      // e4m3 table rows x e4m3 weights on the fp8 MFMA
+    for (int mod = 0; mod < NF && e->fp8; ++mod) {      // e4m3 table rows x e4m3 weights on the fp8 MFMA
         GemmF8 g; g.opts = e->opts;
-        const int F = mod == 0 ? e->Fv : e->Ft;
-        g.A = mod == 0 ? t->table_v : t->table_t; g.lda = F; g.a_rows = table_mode ? nullptr : ids;
-        g.a_scale = mod == 0 ? t->table_scale_v : t->table_scale_t;
-        g.B = b.mirror8 + (mod == 0 ? e->m8Wv : e->m8Wt); g.ldb = F; g.b_row_scale = b.mscale + (mod == 0 ? e->s8Wv : e->s8Wt);
-        g.C = b.E + mod * d; g.ldc = 2 * d;
+        const int F = e->F[mod];
+        g.A = t->tables[mod]; g.lda = F; g.a_rows = table_mode ? nullptr : ids;
+        g.a_scale = t->table_scales[mod];
+        g.B = b.mirror8 + e->m8Wf[mod]; g.ldb = F; g.b_row_scale = b.mscale + e->s8Wf[mod];
+        g.C = b.E + mod * d; g.ldc = NF * d;
         g.M = table_mode ? (int)n_rows : M; g.N = d; g.K = F;
-        g.bias = P + e->bvt + mod * d;
+        g.bias = P + e->bf + mod * d;
         RUNP("fwd.gemm_featproj", gemm_nt_f8(g, st));
     }
-    for (int mod = 0; mod < 2 && !e->fp8; ++mod) {
+    for (int mod = 0; mod < NF && !e->fp8; ++mod) {
         GemmNT g; g.opts = e->opts;
-        const int F = mod == 0 ? e->Fv : e->Ft;
-        if (ids) { g.A = mod == 0 ? t->table_v : t->table_t; g.a_rows = table_mode ? nullptr : ids; }
-        else g.A = mod == 0 ? (const void*)feat_v : (const void*)feat_t;
+        const int F = e->F[mod];
+        if (ids) { g.A = t->tables[mod]; g.a_rows = table_mode ? nullptr : ids; }
+        else g.A = feats[mod];
         g.lda = F;
-        g.B = wsel<T>(e, t, b, mod == 0 ? e->Wv : e->Wt, mod == 0 ? e->mWv : e->mWt);
+        g.B = wsel<T>(e, t, b, e->Wf[mod], e->mWf[mod]);
         g.ldb = F;
-        g.C = b.E + mod * d; g.ldc = 2 * d;
+        g.C = b.E + mod * d; g.ldc = NF * d;
         g.M = table_mode ? (int)n_rows : M; g.N = d; g.K = F;
-        g.bias = P + e->bvt + mod * d;
+        g.bias = P + e->bf + mod * d;
         RUNP("fwd.gemm_featproj", gemm_nt<T>(g, st));
     }
     {
         EmbedMix m;
-        m.S = S; m.d = d; m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
+        m.S = S; m.d = d; m.nf = NF; m.Wa = P + e->Wa; m.ba = P + e->ba; m.pos = P + e->pos; m.role = P + e->role;
         m.gamma = P + e->ln_g; m.beta = P + e->ln_b; m.eps = e->cfg.layer_norm_eps;
         m.a = b.a; m.stats = b.emb_stats; m.h0 = b.h0;
         m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
@@ -563,8 +564,8 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
         // consumes it neither re-reads the bf16 row nor quantises it (x8_ok tracks whether the current `hin` has that copy)
         const bool pq = e->fp8 && !(e->opts & OPT_CONSUMER_QUANT);
         if (table_mode && !(e->opts & OPT_NO_SEGMENT_SUM)) {
-            // the modality mix a0 e_v + a1 e_t depends on the node only: once per node, then one [d] row per token
-            T* F_all = b.E + n_rows * 2 * d;                 // fits: (N + 2) * 3d <= M * 2d
+            // the modality mix sum_k a_k e_k depends on the node only: once per node, then one [d] row per token
+            T* F_all = b.E + n_rows * NF * d;                // fits: (N + 2) * (NF + 1) d <= M * max(NF, 2) d
             m.phase = 1; m.M = (int)n_rows; m.E = b.E; m.pre = F_all;
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
             m.phase = 2; m.M = M; m.E = F_all; m.e_rows = ids; m.pre = b.emb_pre;
@@ -822,9 +823,9 @@ static inline int join_side_all(const pmgt_engine* e, Bufs<T>& b, hipStream_t ma
 // ---- encoder backward: dcur (in b.bA) = d loss / d h_L; leaves parameter grads in t->grads ----------
 template <typename T>
 static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b, int Tseq, int S, bool acc, hipStream_t st,
-                            bool shortcut = false, bool train = true, const T* feat_v = nullptr, const T* feat_t = nullptr,
+                            bool shortcut = false, bool train = true, const void* const* feats = nullptr,
                             int n_cls_only = 0, bool whole_buffer = false) {
-    const int d = e->d, I = e->I, L = e->L, H = e->H;
+    const int d = e->d, I = e->I, L = e->L, H = e->H, NF = e->NF;
     const int M = Tseq * S;
     const float* P = t->params;
     float* G = t->grads;
@@ -944,45 +945,48 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     // embeddings
     {
         EmbedMix m;
-        m.S = S; m.d = d; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a;
+        m.S = S; m.d = d; m.nf = NF; m.Wa = P + e->Wa; m.gamma = P + e->ln_g; m.a = b.a;
         m.stats = b.emb_stats; m.drop = dropcfg(t, train, pd, -1, SITE_EMB);
         m.part = b.part;
+        const int pe = embed_part_elems(d, NF);
         const bool by_node = b.e_by_id && !(e->opts & OPT_NO_SEGMENT_SUM);
-        PMGT_CHECK(!e->fp8 || (feat_v == nullptr && feat_t == nullptr), -3, "fp8 mode: pre-gathered feature tensors are not supported");
-        const float sv8 = e->fp8 ? t->table_scale_v : 0.f, st8 = e->fp8 ? t->table_scale_t : 0.f;     // > 0: the tables are e4m3
+        PMGT_CHECK(!e->fp8 || feats == nullptr, -3, "fp8 mode: pre-gathered feature tensors are not supported");
         if (by_node) {
             // Table mode: per token only the LayerNorm backward (dF); the segment sums of dF per node id feed the
-            // per-node backward of the modality mix, whose dE [N+2, 2d] is the P operand of the weight-gradient GEMM.
+            // per-node backward of the modality mix, whose dE [N+2, NF d] is the P operand of the weight-gradient GEMMs.
             const int n_rows = (int)t->n_nodes + 2;
             m.phase = 2; m.M = M; m.dh0 = b.bA; m.pre = b.emb_pre; m.dF = b.bB;
-            if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(M) * (6 * d + 4), &m.part, st));
+            if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(M) * pe, &m.part, st));
             RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
-            if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
-            else RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
+            if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(M), pe, G + e->ln_g, acc, st));
+            else RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), pe, G + e->ln_g, acc, st));
             RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
             RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
             if (b.sort_done) PMGT_HIP(hipStreamWaitEvent(st, b.sort_done, 0));
             else RUNP("bwd.segsum_featproj", seg_sort(b.ids, M, n_rows, b.sg_keys, b.sg_vals, b.sg_skeys, b.sg_perm, b.sg_off, b.sg_tmp, b.sg_tmp_bytes, st));
             RUNP("bwd.segsum_featproj", (seg_sum<T, float>(b.bB, d, b.sg_skeys, b.sg_perm, b.sg_off, M, n_rows, d, (float*)b.bC, b.sg_part, st)));     // (N+2) d fp32 <= M d bf16
-            m.phase = 1; m.M = n_rows; m.E = b.E; m.e_rows = nullptr; m.dF = b.bC; m.dF_f32 = true; m.dE = b.bD;
+            m.phase = 1; m.M = n_rows; m.E = b.E; m.e_rows = nullptr; m.dF = b.bC; m.dF_f32 = true; m.dE = b.bD;      // (N+2) NF d <= M d
             m.part = b.part;
-            if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(n_rows) * (6 * d + 4), &m.part, st));
+            if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(n_rows) * pe, &m.part, st));
             RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
-            if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(n_rows), 6 * d + 4, G + e->ln_g, true, st));
-            else RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(n_rows), 6 * d + 4, G + e->ln_g, true, st));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD, 2 * d, (const T*)t->table_v, e->Fv, nullptr, n_rows, n_rows, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt, 0, 0, sv8));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD + d, 2 * d, (const T*)t->table_t, e->Ft, nullptr, n_rows, n_rows, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d, 0, 0, st8));
+            if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(n_rows), pe, G + e->ln_g, true, st));
+            else RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(n_rows), pe, G + e->ln_g, true, st));
+            for (int mod = 0; mod < NF; ++mod)
+                RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.bD + mod * d, NF * d, (const T*)t->tables[mod], e->F[mod], nullptr, n_rows, n_rows, d, e->F[mod],
+                             G + e->Wf[mod], acc, nullptr, st, G + e->bf + mod * d, 0, 0, e->fp8 ? t->table_scales[mod] : 0.f));      // scale > 0: the table is e4m3
         } else {
             m.M = M; m.E = b.E; m.e_rows = b.e_by_id ? b.ids : nullptr; m.pre = b.emb_pre;
             m.dh0 = b.bA; m.dE = b.big; m.dF = b.bB;
-            if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(M) * (6 * d + 4), &m.part, st));
+            if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(M) * pe, &m.part, st));
             RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
-            if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
-            else RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), 6 * d + 4, G + e->ln_g, acc, st));
+            if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(M), pe, G + e->ln_g, acc, st));
+            else RUNP("bwd.slab_reduce", slab_reduce(b.part, embed_bwd_parts(M), pe, G + e->ln_g, acc, st));
             RUNP("bwd.colsum", colsum<T>(b.bB, (int64_t)S * d, Tseq, S * d, b.part, b.possum, false, nullptr, st));
             RUN(pos_role_finish(b.possum, S, d, e->cfg.max_position_embeddings, G + e->pos, G + e->role, acc, st));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big, 2 * d, feat_v ? feat_v : (const T*)t->table_v, e->Fv, feat_v ? nullptr : b.ids, M, M, d, e->Fv, G + e->Wv, acc, nullptr, st, G + e->bvt, 0, 0, sv8));
-            RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + d, 2 * d, feat_t ? feat_t : (const T*)t->table_t, e->Ft, feat_t ? nullptr : b.ids, M, M, d, e->Ft, G + e->Wt, acc, nullptr, st, G + e->bvt + d, 0, 0, st8));
+            for (int mod = 0; mod < NF; ++mod)
+                RUN(wgrad<T>("bwd.wgrad_featproj", e, b, b.big + mod * d, NF * d, feats ? (const T*)feats[mod] : (const T*)t->tables[mod], e->F[mod],
+                             feats ? nullptr : b.ids, M, M, d, e->F[mod], G + e->Wf[mod], acc, nullptr, st, G + e->bf + mod * d, 0, 0,
+                             e->fp8 ? t->table_scales[mod] : 0.f));
         }
     }
     RUN(flush_reduces<T>(e, b, st));
@@ -996,7 +1000,7 @@ template <typename T>
 static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* bt, const pmgt_outputs* o, void* ws,
                          int64_t ws_bytes, int flags, hipStream_t st) {
     const bool train = flags & PMGT_FLAG_TRAINING, bwd = flags & PMGT_FLAG_BACKWARD, acc = flags & PMGT_FLAG_ACCUMULATE;
-    const int B = bt->n_targets, Pn = bt->n_pairs, S = bt->seq_len, d = e->d, F = e->Fv + e->Ft;
+    const int B = bt->n_targets, Pn = bt->n_pairs, S = bt->seq_len, d = e->d, F = e->Fsum;
     PMGT_CHECK(B > 0 && S > 0, -2, "pretrain_step: empty batch");
     PMGT_CHECK(!bwd || train, -2, "pretrain_step: BACKWARD requires TRAINING (the workspace keeps activations only then)");
     PMGT_CHECK(Pn > 0 && bt->pair_ids && bt->labels && bt->num_pairs, -2,
@@ -1046,8 +1050,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     // only run on the rows the loss reads (compact order: B target CLS, P pair CLS, masked rows).
     const bool sc = train && !(e->opts & OPT_NO_SHORTCUT) && o->last_hidden == nullptr;
     if (sc) RUN(build_need_rows(B, Pn, S, b.nfr_rows, b.nfr_count, b.need_rows, b.need_cnt, st));
-    RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, (const T*)nullptr, (const T*)nullptr, b.mask, train, (T*)nullptr,
-                           (float*)nullptr, st, sc, B + Pn));
+    RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, nullptr, b.mask, train, (T*)nullptr, (float*)nullptr, st, sc, B + Pn));
     T* hL = sc ? b.ctail.hout : b.layer[e->L - 1].hout;
     T* dhL = sc ? b.c_dh : b.bA;
     const int M = Tseq * S;
@@ -1070,12 +1073,15 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         g.C = b.pred; g.ldc = F; g.M = cap; g.N = F; g.K = d; g.bias = t->params + e->bn; g.m_dev = b.nfr_count;
         RUNP("loss.gemm_nfr", gemm_nt<T>(g, st));
         NfrDiffArgs a;
-        a.pred = b.pred; a.tids = b.nfr_tids; a.count = b.nfr_count; a.cap = cap; a.Fv = e->Fv; a.Ft = e->Ft;
-        a.table_v = t->table_v; a.table_t = t->table_t; a.sse_part = b.sse_part;
-        a.tables_f8 = e->fp8; a.scale_v = t->table_scale_v; a.scale_t = t->table_scale_t;
+        a.pred = b.pred; a.tids = b.nfr_tids; a.count = b.nfr_count; a.cap = cap; a.nf = e->NF; a.sse_part = b.sse_part;
+        a.tables_f8 = e->fp8;
+        for (int m = 0; m < e->NF; ++m) { a.F[m] = e->F[m]; a.table[m] = t->tables[m]; a.scale[m] = t->table_scales[m]; }
         RUNP("loss.nfr_diff", nfr_diff<T>(a, st));
     }
-    RUN(loss_finish(b.gsr_part, B, train ? b.sse_part : nullptr, nfr_diff_parts(cap), b.nfr_count, e->Fv, e->Ft, train,
+    FeatSizes fs;
+    fs.nf = e->NF;
+    for (int m = 0; m < MAX_FEATS; ++m) fs.F[m] = e->F[m];
+    RUN(loss_finish(b.gsr_part, B, train ? b.sse_part : nullptr, nfr_diff_parts(cap), b.nfr_count, fs, train,
                     o->loss, st, train ? o->nfr_count : nullptr));
     if (o->last_hidden) PMGT_HIP(hipMemcpyAsync(o->last_hidden, hL, (size_t)bs * d * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (bwd) {
@@ -1088,14 +1094,14 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
         g.C = sc ? dhL + (int64_t)(B + Pn) * d : b.dq; g.ldc = d;      // compacted: the masked rows ARE rows B+P.. of dhL
         RUNP("bwd.dgrad_nfr", gemm_nt<T>(g, st));
         if (!sc) RUN(scatter_rows<T>(b.dq, b.nfr_rows, b.nfr_count, cap, d, b.bA, st));
-        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc, true, (const T*)nullptr, (const T*)nullptr, B + Pn, true));
+        RUN(encoder_backward<T>(e, t, b, Tseq, S, acc, st, sc, true, nullptr, B + Pn, true));
     }
     if (train) RUN(advance_rng(t->rng_state, st));
     return 0;
 }
 
 template <typename T>
-static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* fv, const void* ft,
+static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* const* feats,
                   const float* mask, int Tseq, int S, void* last_hidden, void* hidden_states, float* attn_probs, void* ws,
                   int64_t ws_bytes, hipStream_t st) {
     PMGT_CHECK(Tseq > 0 && S > 0, -2, "encode: empty input");
@@ -1108,7 +1114,7 @@ static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, con
         m = nullptr;
     }
     RUN(build_mirrors<T>(e, t, b, st));
-    RUN(encoder_forward<T>(e, t, b, Tseq, S, ids, (const T*)fv, (const T*)ft, m, false, (T*)hidden_states, attn_probs, st));
+    RUN(encoder_forward<T>(e, t, b, Tseq, S, ids, feats, m, false, (T*)hidden_states, attn_probs, st));
     if (last_hidden)
         PMGT_HIP(hipMemcpyAsync(last_hidden, b.layer[e->L - 1].hout, (size_t)Tseq * S * e->d * sizeof(T),
                                 hipMemcpyDeviceToDevice, st));
@@ -1119,13 +1125,13 @@ static int encode(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, con
 // Training-mode encoder pass for a caller with its own head (PMGT_NCF, pmgt/pmgt_ncf/models.py:77-105): keeps the
 // activations in the workspace and snapshots the dropout counter so encode_backward can replay the masks.
 template <typename T>
-static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* fv, const void* ft,
+static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* const* feats,
                         const float* mask, int Tseq, int S, void* last_hidden, void* ws, int64_t ws_bytes, int flags,
                         hipStream_t st) {
     const bool train = flags & PMGT_FLAG_TRAINING;
     PMGT_CHECK(Tseq > 0 && S > 0, -2, "encode_train: empty input");
     PMGT_CHECK(mask != nullptr, -2, "encode_train: attention_mask is required (pass ones for None)");
-    PMGT_CHECK((ids != nullptr) != (fv != nullptr && ft != nullptr), -2, "encode_train: pass node ids or both feature tensors");
+    PMGT_CHECK((ids != nullptr) != (feats != nullptr), -2, "encode_train: pass node ids or the feature tensors");
     Carver c(ws);
     Bufs<T> b;
     carve<T>(e, c, b, Tseq, S, 1, true);
@@ -1135,8 +1141,7 @@ static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* id
     if (ids) PMGT_HIP(hipMemcpyAsync(b.ids, ids, M * 8, hipMemcpyDeviceToDevice, st));
     PMGT_HIP(hipMemcpyAsync(b.mask, mask, M * 4, hipMemcpyDeviceToDevice, st));
     RUN(build_mirrors<T>(e, t, b, st));
-    RUN(encoder_forward<T>(e, t, b, Tseq, S, ids ? b.ids : nullptr, (const T*)fv, (const T*)ft, b.mask, train, (T*)nullptr,
-                           (float*)nullptr, st));
+    RUN(encoder_forward<T>(e, t, b, Tseq, S, ids ? b.ids : nullptr, feats, b.mask, train, (T*)nullptr, (float*)nullptr, st));
     if (last_hidden)
         PMGT_HIP(hipMemcpyAsync(last_hidden, b.layer[e->L - 1].hout, (size_t)M * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (train) RUN(advance_rng(t->rng_state, st));
@@ -1144,25 +1149,34 @@ static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* id
 }
 
 template <typename T>
-static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv, const void* ft, const void* d_last,
+static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* const* feats, const void* d_last,
                            int Tseq, int S, void* ws, int64_t ws_bytes, int flags, hipStream_t st) {
     const bool train = flags & PMGT_FLAG_TRAINING, acc = flags & PMGT_FLAG_ACCUMULATE;
     PMGT_CHECK(Tseq > 0 && S > 0 && d_last != nullptr, -2, "encode_backward: empty input");
-    PMGT_CHECK((fv == nullptr) == (ft == nullptr), -2, "encode_backward: pass both feature tensors or neither");
     Carver c(ws);
     Bufs<T> b;
     carve<T>(e, c, b, Tseq, S, 1, true);
     PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
     pmgt_tensors tt = *t;
     tt.rng_state = (uint64_t*)b.rng_snap;          // the forward's (seed, step)
-    b.e_by_id = use_table_projection(e, t, (int64_t)Tseq * S, fv == nullptr);      // same decisions as the forward took
+    b.e_by_id = use_table_projection(e, t, (int64_t)Tseq * S, feats == nullptr);      // same decisions as the forward took
     b.qkvc_hm = train && !(e->opts & OPT_NO_HEAD_MAJOR) && fused_qa_applies<T>(e, Tseq, S, false);
     PMGT_HIP(hipMemcpyAsync(b.bA, d_last, (size_t)Tseq * S * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
-    RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, (const T*)fv, (const T*)ft));
+    RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, feats));
     return 0;
 }
 
 }  // namespace pmgt
+
+static bool tables_set(const pmgt_engine* e, const pmgt_tensors* t) {
+    for (int m = 0; m < e->NF; ++m) if (!t->tables[m]) return false;
+    return true;
+}
+static bool feats_set(const pmgt_engine* e, const void* const* feats) {
+    if (!feats) return false;
+    for (int m = 0; m < e->NF; ++m) if (!feats[m]) return false;
+    return true;
+}
 
 // ======================================================================================================
 // C ABI
@@ -1170,7 +1184,7 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* fv
 extern "C" {
 
 const char* pmgt_last_error(void) { return g_err; }
-int pmgt_abi_version(void) { return 3; }
+int pmgt_abi_version(void) { return 4; }
 
 pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     if (!cfg) { set_error("config is NULL"); return nullptr; }
@@ -1180,9 +1194,18 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
         return nullptr;
     }
     const int ali = cfg->dtype == PMGT_DTYPE_FP8 ? 16 : (cfg->dtype == PMGT_DTYPE_BF16 ? 8 : 4);
-    if (cfg->hidden_size % ali || cfg->intermediate_size % ali || cfg->feat_size_v % ali || cfg->feat_size_t % ali ||
-        cfg->hidden_size > 1024) {
+    if (cfg->n_feats < 1 || cfg->n_feats > PMGT_MAX_FEATS) {
+        set_error("feat_hidden_sizes has %d entries: the HIP path takes 1 .. %d modalities", cfg->n_feats, PMGT_MAX_FEATS);
+        return nullptr;
+    }
+    bool feats_ok = true;
+    for (int m = 0; m < cfg->n_feats; ++m) feats_ok = feats_ok && cfg->feat_sizes[m] > 0 && cfg->feat_sizes[m] % ali == 0;
+    if (cfg->hidden_size % ali || cfg->intermediate_size % ali || !feats_ok || cfg->hidden_size > 1024) {
         set_error("HIP path needs hidden/intermediate/feature sizes that are multiples of %d and hidden_size <= 1024", ali);
+        return nullptr;
+    }
+    if ((int64_t)embed_part_elems(cfg->hidden_size, cfg->n_feats) * 4 > 65536) {
+        set_error("hidden_size %d with %d modalities: the embedding backward's workgroup sums exceed 64 KB of LDS", cfg->hidden_size, cfg->n_feats);
         return nullptr;
     }
     if (cfg->dtype != PMGT_DTYPE_F32 && cfg->dtype != PMGT_DTYPE_BF16 && cfg->dtype != PMGT_DTYPE_FP8) { set_error("unknown dtype %d", cfg->dtype); return nullptr; }
@@ -1190,7 +1213,9 @@ pmgt_engine* pmgt_engine_create(const pmgt_config* cfg) {
     e->cfg = *cfg;
     e->fp8 = cfg->dtype == PMGT_DTYPE_FP8;
     e->d = cfg->hidden_size; e->L = cfg->num_hidden_layers; e->H = cfg->num_attention_heads; e->I = cfg->intermediate_size;
-    e->Fv = cfg->feat_size_v; e->Ft = cfg->feat_size_t; e->dh = e->d / e->H;
+    e->dh = e->d / e->H;
+    e->NF = cfg->n_feats;
+    for (int m = 0; m < e->NF; ++m) { e->F[m] = cfg->feat_sizes[m]; e->Foff[m] = e->Fsum; e->Fsum += e->F[m]; }
     build_layout(e);
     e->zeros = zero_page();
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
@@ -1247,8 +1272,8 @@ int64_t pmgt_workspace_bytes(const pmgt_engine* e, int n_seq, int seq_len, int n
 int pmgt_pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* b, const pmgt_outputs* o, void* workspace,
                        int64_t workspace_bytes, int flags, void* stream) {
     PMGT_CHECK(e && t && b && o && workspace, -2, "pmgt_pretrain_step: NULL argument");
-    PMGT_CHECK(t->params && t->table_v && t->table_t && t->rng_state && o->loss && o->logits, -2, "pmgt_pretrain_step: NULL tensor");
-    PMGT_CHECK(!e->fp8 || (t->table_scale_v > 0.f && t->table_scale_t > 0.f), -2, "pmgt_pretrain_step: fp8 mode needs the table scales");
+    PMGT_CHECK(t->params && tables_set(e, t) && t->rng_state && o->loss && o->logits, -2, "pmgt_pretrain_step: NULL tensor");
+    for (int m = 0; m < e->NF; ++m) PMGT_CHECK(!e->fp8 || t->table_scales[m] > 0.f, -2, "pmgt_pretrain_step: fp8 mode needs the table scales");
     PMGT_CHECK(!(flags & PMGT_FLAG_BACKWARD) || t->grads, -2, "pmgt_pretrain_step: grads buffer is NULL");
     if (e->cfg.dtype != PMGT_DTYPE_F32) return pretrain_step<bf16>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
     return pretrain_step<float>(e, t, b, o, workspace, workspace_bytes, flags, (hipStream_t)stream);
@@ -1257,38 +1282,40 @@ int pmgt_pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch* 
 int pmgt_encode_ids(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const float* mask, int n_seq, int seq_len,
                     void* last_hidden, void* hidden_states, float* attn_probs, void* workspace, int64_t workspace_bytes,
                     void* stream) {
-    PMGT_CHECK(e && t && ids && workspace && t->params && t->table_v && t->table_t, -2, "pmgt_encode_ids: NULL argument");
+    PMGT_CHECK(e && t && ids && workspace && t->params && tables_set(e, t), -2, "pmgt_encode_ids: NULL argument");
     if (e->cfg.dtype != PMGT_DTYPE_F32)
-        return encode<bf16>(e, t, ids, nullptr, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
-    return encode<float>(e, t, ids, nullptr, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+        return encode<bf16>(e, t, ids, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+    return encode<float>(e, t, ids, nullptr, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t, const float* mask,
+int pmgt_encode_feats(pmgt_engine* e, const pmgt_tensors* t, const void* const* feats, const float* mask,
                       int n_seq, int seq_len, void* last_hidden, void* hidden_states, float* attn_probs, void* workspace,
                       int64_t workspace_bytes, void* stream) {
-    PMGT_CHECK(e && t && feat_v && feat_t && workspace && t->params, -2, "pmgt_encode_feats: NULL argument");
+    PMGT_CHECK(e && t && feats_set(e, feats) && workspace && t->params, -2, "pmgt_encode_feats: NULL argument");
     if (e->cfg.dtype != PMGT_DTYPE_F32)
-        return encode<bf16>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
-    return encode<float>(e, t, nullptr, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+        return encode<bf16>(e, t, nullptr, feats, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
+    return encode<float>(e, t, nullptr, feats, mask, n_seq, seq_len, last_hidden, hidden_states, attn_probs, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* feat_v, const void* feat_t,
+int pmgt_encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* ids, const void* const* feats,
                       const float* mask, int n_seq, int seq_len, void* last_hidden, void* workspace, int64_t workspace_bytes,
                       int flags, void* stream) {
     PMGT_CHECK(e && t && workspace && t->params && t->rng_state, -2, "pmgt_encode_train: NULL argument");
-    PMGT_CHECK(!ids || (t->table_v && t->table_t), -2, "pmgt_encode_train: feature tables are not set");
+    PMGT_CHECK(!ids || tables_set(e, t), -2, "pmgt_encode_train: feature tables are not set");
+    PMGT_CHECK(ids || feats_set(e, feats), -2, "pmgt_encode_train: pass node ids or one feature tensor per modality");
+    if (ids) feats = nullptr;
     if (e->cfg.dtype != PMGT_DTYPE_F32)
-        return encode_train<bf16>(e, t, ids, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
-    return encode_train<float>(e, t, ids, feat_v, feat_t, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
+        return encode_train<bf16>(e, t, ids, feats, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    return encode_train<float>(e, t, ids, feats, mask, n_seq, seq_len, last_hidden, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 
-int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* feat_v, const void* feat_t, const void* d_last_hidden,
+int pmgt_encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* const* feats, const void* d_last_hidden,
                          int n_seq, int seq_len, void* workspace, int64_t workspace_bytes, int flags, void* stream) {
     PMGT_CHECK(e && t && workspace && t->params && t->grads, -2, "pmgt_encode_backward: NULL argument");
-    PMGT_CHECK(feat_v || (t->table_v && t->table_t), -2, "pmgt_encode_backward: feature tables are not set");
+    PMGT_CHECK(feats ? feats_set(e, feats) : tables_set(e, t), -2, "pmgt_encode_backward: feature tables are not set");
     if (e->cfg.dtype != PMGT_DTYPE_F32)
-        return encode_backward<bf16>(e, t, feat_v, feat_t, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
-    return encode_backward<float>(e, t, feat_v, feat_t, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
+        return encode_backward<bf16>(e, t, feats, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
+    return encode_backward<float>(e, t, feats, d_last_hidden, n_seq, seq_len, workspace, workspace_bytes, flags, (hipStream_t)stream);
 }
 
 int pmgt_optimizer_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_adam* a, void* stream) {

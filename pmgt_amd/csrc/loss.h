@@ -24,16 +24,17 @@ struct GsrArgs {
 };
 template <typename T> int gsr_fwd_bwd(const GsrArgs& g, hipStream_t st);
 
+constexpr int MAX_FEATS = 4;        // == PMGT_MAX_FEATS (include/pmgt_capi.h)
 struct NfrDiffArgs {
-    void* pred = nullptr;           // [cap, Fv+Ft] in: projections; out: d loss / d pred
+    void* pred = nullptr;           // [cap, sum F_m] in: projections of every modality side by side; out: d loss / d pred
     const int64_t* tids = nullptr;  // [cap] ids to reconstruct
     const int* count = nullptr;     // device row count
-    int cap = 0, Fv = 0, Ft = 0;
-    const void* table_v = nullptr;  // [N+2, Fv]
-    const void* table_t = nullptr;  // [N+2, Ft]
-    bool tables_f8 = false;         // fp8 mode: the tables are e4m3 bytes, value = byte * scale_{v,t}
-    float scale_v = 1.f, scale_t = 1.f;
-    float* sse_part = nullptr;      // [nfr_diff_parts(cap)][2]
+    int cap = 0, nf = 0;
+    int F[MAX_FEATS] = {0, 0, 0, 0};
+    const void* table[MAX_FEATS] = {nullptr, nullptr, nullptr, nullptr};     // table[m]: [N+2, F[m]]
+    bool tables_f8 = false;         // fp8 mode: the tables are e4m3 bytes, value = byte * scale[m]
+    float scale[MAX_FEATS] = {1.f, 1.f, 1.f, 1.f};
+    float* sse_part = nullptr;      // [nfr_diff_parts(cap)][MAX_FEATS]
 };
 inline int nfr_diff_parts(int cap) { return cdiv(cap, 8); }
 template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st);
@@ -42,7 +43,8 @@ int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, i
 // rows the loss reads from the last layer: CLS of the B targets, CLS of the P pairs, then the masked rows
 int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
                     hipStream_t st);
-int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
+struct FeatSizes { int nf; int F[MAX_FEATS]; };
+int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, FeatSizes fs,
                 bool with_nfr, float* out, hipStream_t st, int* count_out = nullptr);
 
 }  // namespace pmgt

@@ -254,42 +254,61 @@ __device__ __forceinline__ f32x4 table_load4(const void* table, int64_t elem, fl
 
 template <typename T, bool F8>
 __global__ __launch_bounds__(256) void nfr_diff_kernel(NfrDiffArgs a) {
-    __shared__ float red[8];
+    __shared__ float red[4 * MAX_FEATS];
     const int n = *a.count;
     const int r0 = blockIdx.x * 8;
-    float sv = 0.f, stx = 0.f;
+    float ss[MAX_FEATS] = {0.f, 0.f, 0.f, 0.f};
     if (r0 < n) {
-        const int F = a.Fv + a.Ft;
-        const float cv = 1.f / ((float)n * (float)a.Fv), ct = 1.f / ((float)n * (float)a.Ft);   // d(0.5*(mse_v+mse_t))/dpred
+        int F = 0, c0[MAX_FEATS + 1];
+        float cm[MAX_FEATS];
+#pragma unroll
+        for (int f = 0; f < MAX_FEATS; ++f) {
+            c0[f] = F;
+            if (f < a.nf) F += a.F[f];
+            // d (mean over modalities of mse_f) / d pred = (2 / nf) diff / (n F_f)   (nf = 2: diff / (n F_f))
+            cm[f] = f < a.nf ? (2.f / (float)a.nf) / ((float)n * (float)a.F[f]) : 0.f;
+        }
+        c0[MAX_FEATS] = F;
         const int r1 = min(n, r0 + 8);
         for (int r = r0; r < r1; ++r) {
             const int64_t tid = a.tids[r];
             T* p = (T*)a.pred + (int64_t)r * F;
             for (int c4 = threadIdx.x * 4; c4 < F; c4 += 1024) {
-                const bool isv = c4 < a.Fv;
-                const f32x4 tgt = isv ? table_load4<T, F8>(a.table_v, tid * a.Fv + c4, a.scale_v)
-                                      : table_load4<T, F8>(a.table_t, tid * a.Ft + (c4 - a.Fv), a.scale_t);
-                f32x4 diff = load4<T>(p + c4) - tgt;
-                const float ss = sum4(diff * diff);
-                if (isv) sv += ss; else stx += ss;
-                store4<T>(p + c4, diff * (isv ? cv : ct));
+                // (a group of 4 columns never straddles two modalities: every F_f is a multiple of 4)
+                const int f = (c4 >= c0[1]) + (c4 >= c0[2] && a.nf > 2) + (c4 >= c0[3] && a.nf > 3);
+                f32x4 tgt, diff;
+                float cf;
+                if (f == 0) { tgt = table_load4<T, F8>(a.table[0], tid * a.F[0] + c4, a.scale[0]); cf = cm[0]; }
+                else if (f == 1) { tgt = table_load4<T, F8>(a.table[1], tid * a.F[1] + (c4 - c0[1]), a.scale[1]); cf = cm[1]; }
+                else if (f == 2) { tgt = table_load4<T, F8>(a.table[2], tid * a.F[2] + (c4 - c0[2]), a.scale[2]); cf = cm[2]; }
+                else { tgt = table_load4<T, F8>(a.table[3], tid * a.F[3] + (c4 - c0[3]), a.scale[3]); cf = cm[3]; }
+                diff = load4<T>(p + c4) - tgt;
+                const float s4 = sum4(diff * diff);
+                ss[0] += f == 0 ? s4 : 0.f;
+                ss[1] += f == 1 ? s4 : 0.f;
+                ss[2] += f == 2 ? s4 : 0.f;
+                ss[3] += f == 3 ? s4 : 0.f;
+                store4<T>(p + c4, diff * cf);
             }
         }
     }
-    sv = wave_sum(sv);
-    stx = wave_sum(stx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[wave] = sv; red[4 + wave] = stx; }
+#pragma unroll
+    for (int f = 0; f < MAX_FEATS; ++f) {
+        ss[f] = wave_sum(ss[f]);
+        if (lane == 0) red[4 * f + wave] = ss[f];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        a.sse_part[2 * (int64_t)blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        a.sse_part[2 * (int64_t)blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    if (threadIdx.x < MAX_FEATS) {
+        const int f = threadIdx.x;
+        a.sse_part[MAX_FEATS * (int64_t)blockIdx.x + f] = (red[4 * f] + red[4 * f + 1]) + (red[4 * f + 2] + red[4 * f + 3]);
     }
 }
 
 template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st) {
     if (a.cap <= 0) return 0;
-    PMGT_CHECK(a.Fv % 4 == 0 && a.Ft % 4 == 0, -2, "nfr_diff: feature sizes must be multiples of 4");
+    PMGT_CHECK(a.nf >= 1 && a.nf <= MAX_FEATS, -2, "nfr_diff: %d modalities (1 .. %d are built)", a.nf, MAX_FEATS);
+    for (int f = 0; f < a.nf; ++f) PMGT_CHECK(a.F[f] > 0 && a.F[f] % 4 == 0, -2, "nfr_diff: feature sizes must be multiples of 4");
     if (a.tables_f8) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((nfr_diff_kernel<T, true>), dim3(nfr_diff_parts(a.cap)), dim3(256), 0, st, a);
         else PMGT_CHECK(false, -2, "nfr_diff: e4m3 tables belong to the fp8 mode (bf16 activations)");
@@ -342,23 +361,35 @@ int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr
     return 0;
 }
 
-// out = {loss, gsr, nfr};  nfr = 0.5 * (sse_v / (n Fv) + sse_t / (n Ft)); n == 0 gives NaN like the reference
+// out = {loss, gsr, nfr};  nfr = mean over modalities of sse_f / (n F_f)  (torch.stack(loss).mean(), modeling_pmgt.py:565-569);
+// n == 0 gives NaN like the reference
 __global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict__ gsr_part, int B,
                                                          const float* __restrict__ sse_part, int nparts,
-                                                         const int* __restrict__ count, int Fv, int Ft, int with_nfr,
+                                                         const int* __restrict__ count, FeatSizes fs, int with_nfr,
                                                          float* __restrict__ out, int* __restrict__ count_out) {
     const int lane = threadIdx.x;
-    float g = 0.f, sv = 0.f, stx = 0.f;
+    float g = 0.f;
     for (int i = lane; i < B; i += 64) g += gsr_part[i];
     g = wave_sum(g);
     float nfr = 0.f;
     if (with_nfr) {
         const int n = *count;
         const int used = (n + 7) / 8;
-        for (int i = lane; i < used && i < nparts; i += 64) { sv += sse_part[2 * i]; stx += sse_part[2 * i + 1]; }
-        sv = wave_sum(sv);
-        stx = wave_sum(stx);
-        nfr = 0.5f * (sv / ((float)n * (float)Fv) + stx / ((float)n * (float)Ft));
+        float ss[MAX_FEATS] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < used && i < nparts; i += 64) {
+#pragma unroll
+            for (int f = 0; f < MAX_FEATS; ++f) ss[f] += sse_part[MAX_FEATS * i + f];
+        }
+        float tot = 0.f;
+#pragma unroll
+        for (int f = 0; f < MAX_FEATS; ++f) {
+            ss[f] = wave_sum(ss[f]);
+            if (f < fs.nf) {
+                const float mse = ss[f] / ((float)n * (float)fs.F[f]);
+                tot = f == 0 ? mse : tot + mse;
+            }
+        }
+        nfr = (1.f / (float)fs.nf) * tot;
     }
     if (lane == 0) {
         out[0] = g + nfr; out[1] = g; out[2] = nfr;
@@ -366,9 +397,9 @@ __global__ __launch_bounds__(64) void loss_finish_kernel(const float* __restrict
     }
 }
 
-int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, int Fv, int Ft,
+int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, FeatSizes fs,
                 bool with_nfr, float* out, hipStream_t st, int* count_out) {
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, gsr_part, B, sse_part, nparts, count, Fv, Ft,
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, gsr_part, B, sse_part, nparts, count, fs,
                        with_nfr ? 1 : 0, out, count_out);
     PMGT_LAUNCH_OK();
     return 0;

@@ -27,23 +27,24 @@ inline int ln_bwd_parts(int M) { return cdiv(M, ln_bwd_rows(M)); }
 // ---- embedding mix (pmgt/pmgt/modeling_pmgt.py:199-208) ----------------------------------------
 struct EmbedMix {
     int M = 0, S = 0, d = 0;
-    const void* E = nullptr;       // [M, 2d]: e_v | e_t (bias already added by the GEMM epilogue)
+    int nf = 2;                    // modalities (1 .. 4): len(feat_hidden_sizes)
+    const void* E = nullptr;       // [M, nf d]: e_0 | e_1 | ... (bias already added by the GEMM epilogue)
     const int64_t* e_rows = nullptr;   // optional: token m reads row e_rows[m] of E (E = projection of the whole table)
     // Table mode splits the work (the modality mix depends on the NODE only):
-    //   phase 1 (rows = nodes):  fwd: a[n], F[n] = a0 e_v + a1 e_t -> `pre` used as F_all [rows, d];
-    //                            bwd: df read from `dF` (= segment sums per node), writes dE [rows, 2d] + dWa / dba partials
+    //   phase 1 (rows = nodes):  fwd: a[n], F[n] = sum_k a_k e_k -> `pre` used as F_all [rows, d];
+    //                            bwd: df read from `dF` (= segment sums per node), writes dE [rows, nf d] + dWa / dba partials
     //   phase 2 (rows = tokens): fwd: x = F_all[e_rows[m]] (read through `E`, row stride d) + pos + role -> LN -> dropout;
     //                            bwd: LayerNorm backward only: writes dF, dgamma / dbeta partials
     int phase = 0;
     bool dF_f32 = false;           // phase 1 backward: `dF` holds fp32 segment sums
-    const float* Wa = nullptr;     // [2, 2d]
-    const float* ba = nullptr;     // [2]
+    const float* Wa = nullptr;     // [nf, nf d]
+    const float* ba = nullptr;     // [nf]
     const float* pos = nullptr;    // [max_pos, d]
     const float* role = nullptr;   // [2, d]
     const float* gamma = nullptr;
     const float* beta = nullptr;
     float eps = 1e-12f;
-    float* a = nullptr;            // [M, 2] modality weights (saved for backward)
+    float* a = nullptr;            // [M, nf] modality weights (saved for backward)
     void* pre = nullptr;           // [M, d] LayerNorm input (saved)
     float* stats = nullptr;        // [M, 2]
     void* h0 = nullptr;            // [M, d] output
@@ -52,10 +53,12 @@ struct EmbedMix {
     DropCfg drop = {nullptr, 0.f, 0};
     // backward only
     const void* dh0 = nullptr;     // [M, d]
-    void* dE = nullptr;            // [M, 2d]
+    void* dE = nullptr;            // [M, nf d]
     void* dF = nullptr;            // [M, d] gradient wrt (mix + pos + role), feeds the pos/role sums
-    float* part = nullptr;         // [embed_bwd_parts(M)][6d + 4]: dgamma | dbeta | dWa (2 x 2d) | dba
+    float* part = nullptr;         // [embed_bwd_parts(M)][embed_part_elems(d, nf)]: dgamma | dbeta | dWa (nf x nf d) | dba (padded to 4)
 };
+// floats per workgroup partial of the embedding backward = the parameter range LayerNorm.weight .. attention.1.bias of the flat layout
+__host__ __device__ inline int embed_part_elems(int d, int nf) { return (2 + nf * nf) * d + 4; }
 template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st);
 template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st);
 inline int embed_bwd_parts(int M) { return cdiv(M, ln_bwd_rows(M)); }

@@ -239,47 +239,70 @@ template int ln_bwd<float>(const float*, const float*, const float*, const float
 template int ln_bwd<bf16>(const bf16*, const bf16*, const float*, const float*, bf16*, bf16*, float*, int, int, DropCfg, DropCfg, hipStream_t, const int*, const float*);
 
 // ------------------------------------------------------------------------------------------------
-// Embedding mix forward: a = softmax(Wa tanh([e_v;e_t]) + ba); x = a0 e_v + a1 e_t + pos[s] + role[s>0];
-// h0 = dropout(LN(x)).   (pmgt/pmgt/modeling_pmgt.py:199-208)
+// Embedding mix forward: a = softmax(Wa tanh([e_0; e_1; ...]) + ba); x = sum_k a_k e_k + pos[s] + role[s>0];
+// h0 = dropout(LN(x)).   (pmgt/pmgt/modeling_pmgt.py:199-208; NF = len(feat_hidden_sizes))
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NCH, int PHASE>
+template <typename T, int NCH, int PHASE, int NF>
 __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
     if (m >= p.M) return;
     const int d = p.d, nch = d >> 2;
     const int s = m % p.S;
-    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * (PHASE == 2 ? d : 2 * d);
-    f32x4 ev[NCH], et[NCH];
-    float a0 = 1.f, a1 = 0.f;
+    const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * (PHASE == 2 ? d : NF * d);
+    constexpr int NE = PHASE == 2 ? 1 : NF;      // token phase of the table mode: one row, already mixed
+    f32x4 ev[NE][NCH];
+    float a[NE];
+    a[0] = 1.f;
     if (PHASE != 2) {
-        float z0 = 0.f, z1 = 0.f;
+        float z[NF];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) z[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                ev[i] = load4<T>(E + 4 * ch);
-                et[i] = load4<T>(E + d + 4 * ch);
-                f32x4 tv, tt;
+                f32x4 tv[NF];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { tv[e] = tanhf(ev[i][e]); tt[e] = tanhf(et[i][e]); }
-                z0 += sum4(tv * *(const f32x4*)(p.Wa + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + d + 4 * ch));
-                z1 += sum4(tv * *(const f32x4*)(p.Wa + 2 * d + 4 * ch)) + sum4(tt * *(const f32x4*)(p.Wa + 3 * d + 4 * ch));
+                for (int f = 0; f < NF; ++f) {
+                    ev[f][i] = load4<T>(E + f * d + 4 * ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tv[f][e] = tanhf(ev[f][i][e]);
+                }
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    float acc = sum4(tv[0] * *(const f32x4*)(p.Wa + (int64_t)k * NF * d + 4 * ch));
+#pragma unroll
+                    for (int f = 1; f < NF; ++f) acc += sum4(tv[f] * *(const f32x4*)(p.Wa + ((int64_t)k * NF + f) * d + 4 * ch));
+                    z[k] += acc;
+                }
             } else {
-                ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < NF; ++f) ev[f][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        z0 = wave_sum(z0) + p.ba[0];
-        z1 = wave_sum(z1) + p.ba[1];
-        const float zm = fmaxf(z0, z1);
-        const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
-        a0 = e0 / (e0 + e1); a1 = e1 / (e0 + e1);
-        if (lane == 0) { p.a[2 * (int64_t)m] = a0; p.a[2 * (int64_t)m + 1] = a1; }
-        if (PHASE == 1) {         // per-node mix only: F[n] = a0 e_v + a1 e_t
+        float zm = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) { z[k] = wave_sum(z[k]) + p.ba[k]; zm = fmaxf(zm, z[k]); }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) { z[k] = expf(z[k] - zm); den += z[k]; }
+#pragma unroll
+        for (int k = 0; k < NF; ++k) a[k] = z[k] / den;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NF; ++k) p.a[NF * (int64_t)m + k] = a[k];
+        }
+        if (PHASE == 1) {         // per-node mix only: F[n] = sum_k a_k e_k
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + 64 * i;
-                if (ch < nch) store4<T>((T*)p.pre + (int64_t)m * d + 4 * ch, ev[i] * a0 + et[i] * a1);
+                if (ch < nch) {
+                    f32x4 v = ev[0][i] * a[0];
+#pragma unroll
+                    for (int f = 1; f < NF; ++f) v += ev[f][i] * a[f];
+                    store4<T>((T*)p.pre + (int64_t)m * d + 4 * ch, v);
+                }
             }
             return;
         }
@@ -287,8 +310,7 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + 64 * i;
-            ev[i] = ch < nch ? load4<T>(E + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ev[0][i] = ch < nch ? load4<T>(E + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -300,7 +322,10 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-            f32x4 v = ev[i] * a0 + et[i] * a1 + *(const f32x4*)(pos + 4 * ch) + *(const f32x4*)(role + 4 * ch);
+            f32x4 v = ev[0][i] * a[0];
+#pragma unroll
+            for (int f = 1; f < NE; ++f) v += ev[f][i] * a[f];
+            v = v + *(const f32x4*)(pos + 4 * ch) + *(const f32x4*)(role + 4 * ch);
             store4<T>((T*)p.pre + (int64_t)m * d + 4 * ch, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = to_f<T>(from_f<T>(v[e]));   // LN sees what backward will re-read
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
 // Token phase of the table mode at d = 256 (the bench shape), FOUR rows per wave: the generic kernel above gives a wave one row
 // -- node id -> mixed row F[id] -> LayerNorm -> stores is one dependent chain of two memory round trips, and 32 resident waves
 // per CU keep 32 rows x 1.5 KB in flight (3.3 TB/s measured).  Here the four ids, then the four rows, are loaded back to back
-// before anything is consumed.  Same arithmetic in the same order as embed_mix_fwd_kernel<T, 1, 2> (bit-identical outputs).
+// before anything is consumed.  Same arithmetic in the same order as the token phase of embed_mix_fwd_kernel (bit-identical outputs).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_tok4_fwd_kernel(EmbedMix p) {
     constexpr int R = 4;
@@ -380,8 +405,7 @@ __global__ __launch_bounds__(256) void embed_tok4_fwd_kernel(EmbedMix p) {
         const int m = m0 + k;
         if (m >= p.M) break;
         const int s = m % p.S;
-        f32x4 v = x[k] * 1.f + (f32x4){0.f, 0.f, 0.f, 0.f} * 0.f + *(const f32x4*)(p.pos + (int64_t)s * d + 4 * lane) +
-                  *(const f32x4*)(p.role + (s > 0 ? d : 0) + 4 * lane);
+        f32x4 v = x[k] * 1.f + *(const f32x4*)(p.pos + (int64_t)s * d + 4 * lane) + *(const f32x4*)(p.role + (s > 0 ? d : 0) + 4 * lane);
         store4<T>((T*)p.pre + (int64_t)m * d + 4 * lane, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
@@ -423,17 +447,26 @@ template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st) {
         PMGT_LAUNCH_OK();
         return 0;
     }
+    PMGT_CHECK(e.nf >= 1 && e.nf <= 4, -2, "embed_mix_fwd: %d modalities (1 .. 4 are built)", e.nf);
     dim3 grid(cdiv(e.M, 4)), block(256);
+#define PMGT_EMB_FWD_NF(PH, NF_)                                                                                  \
+    do {                                                                                                          \
+        if (e.d <= 256) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 1, PH, NF_>), grid, block, 0, st, e);         \
+        else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 2, PH, NF_>), grid, block, 0, st, e);    \
+        else hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 4, PH, NF_>), grid, block, 0, st, e);                    \
+    } while (0)
 #define PMGT_EMB_FWD(PH)                                                                                          \
     do {                                                                                                          \
-        if (e.d <= 256) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 1, PH>), grid, block, 0, st, e);              \
-        else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 2, PH>), grid, block, 0, st, e);         \
-        else hipLaunchKernelGGL((embed_mix_fwd_kernel<T, 4, PH>), grid, block, 0, st, e);                         \
+        if (e.nf == 2 || PH == 2) PMGT_EMB_FWD_NF(PH, 2);                                                         \
+        else if (e.nf == 1) PMGT_EMB_FWD_NF(PH, 1);                                                               \
+        else if (e.nf == 3) PMGT_EMB_FWD_NF(PH, 3);                                                               \
+        else PMGT_EMB_FWD_NF(PH, 4);                                                                              \
     } while (0)
     if (e.phase == 1) PMGT_EMB_FWD(1);
     else if (e.phase == 2) PMGT_EMB_FWD(2);
     else PMGT_EMB_FWD(0);
 #undef PMGT_EMB_FWD
+#undef PMGT_EMB_FWD_NF
     PMGT_LAUNCH_OK();
     return 0;
 }
@@ -441,36 +474,40 @@ template int embed_mix_fwd<float>(const EmbedMix&, hipStream_t);
 template int embed_mix_fwd<bf16>(const EmbedMix&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
-// Embedding mix backward.  Partials per block: dgamma[d] | dbeta[d] | dWa[2][2d] | dba[2] (+2 pad)
+// Embedding mix backward.  Partials per block: dgamma[d] | dbeta[d] | dWa[NF][NF d] | dba[NF] (padded to 4 floats)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NCH, int PHASE>
+template <typename T, int NCH, int PHASE, int NF>
 __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
-    __shared__ float red[6 * 1024 + 4];
+    extern __shared__ float red[];       // embed_part_elems(d, NF) floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = p.d, nch = d >> 2;
     const float inv_d = 1.f / (float)d;
     const DropKey ik = make_drop_key(p.drop);
-    f32x4 gam[NCH], dgam[NCH], dbet[NCH], dw0v[NCH], dw0t[NCH], dw1v[NCH], dw1t[NCH];
-    f32x4 w0v[NCH], w0t[NCH], w1v[NCH], w1t[NCH];
-    float dba0 = 0.f, dba1 = 0.f;
+    constexpr int NW = PHASE == 2 ? 1 : NF;      // token phase of the table mode: LayerNorm backward only
+    f32x4 gam[NCH], dgam[NCH], dbet[NCH], dw[NW][NW][NCH], wa[NW][NW][NCH];     // [k][f]: row k of Wa, columns of modality f
+    float dba[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dba[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         const bool ok = ch < nch;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         gam[i] = ok ? *(const f32x4*)(p.gamma + 4 * ch) : z;
-        w0v[i] = ok ? *(const f32x4*)(p.Wa + 4 * ch) : z;
-        w0t[i] = ok ? *(const f32x4*)(p.Wa + d + 4 * ch) : z;
-        w1v[i] = ok ? *(const f32x4*)(p.Wa + 2 * d + 4 * ch) : z;
-        w1t[i] = ok ? *(const f32x4*)(p.Wa + 3 * d + 4 * ch) : z;
-        dgam[i] = dbet[i] = dw0v[i] = dw0t[i] = dw1v[i] = dw1t[i] = z;
+        dgam[i] = dbet[i] = z;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int f = 0; f < NW; ++f) {
+                wa[k][f][i] = (ok && PHASE != 2) ? *(const f32x4*)(p.Wa + ((int64_t)k * NF + f) * d + 4 * ch) : z;
+                dw[k][f][i] = z;
+            }
     }
     const int rpb = ln_bwd_rows(p.M);
     for (int it = 0; it < rpb / 4; ++it) {
         const int m = blockIdx.x * rpb + it * 4 + wave;
         if (m >= p.M) break;
-        const float a0 = PHASE == 2 ? 0.f : p.a[2 * (int64_t)m], a1 = PHASE == 2 ? 0.f : p.a[2 * (int64_t)m + 1];
-        f32x4 df[NCH], ev[NCH], et[NCH];
+        f32x4 df[NCH];
         if (PHASE != 1) {     // LayerNorm backward of token m -> df (gradient wrt the pre-LN sum)
             const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
             f32x4 g[NCH], xh[NCH];
@@ -481,9 +518,10 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
                 if (ch < nch) {
                     f32x4 dyv = load4<T>((const T*)p.dh0 + (int64_t)m * d + 4 * ch);
                     if (ik.on) {
-{ float dm[4]; drop_mul4(ik, (uint32_t)m, (uint32_t)ch, dm);
+                        float dm[4];
+                        drop_mul4(ik, (uint32_t)m, (uint32_t)ch, dm);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dyv[e] *= dm[e]; }
+                        for (int e = 0; e < 4; ++e) dyv[e] *= dm[e];
                     }
                     xh[i] = (load4<T>((const T*)p.pre + (int64_t)m * d + 4 * ch) - mean) * rstd;
                     g[i] = dyv * gam[i];
@@ -507,7 +545,6 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
                     df[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
-            if (PHASE == 2) continue;      // token phase of the table mode: the mix is differentiated per node
         } else {                // node phase: df = sum of the token gradients of node m
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -517,85 +554,113 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
                                               : load4<T>((const T*)p.dF + (int64_t)m * d + 4 * ch));
             }
         }
-        // through f = a0 e_v + a1 e_t
-        float da0 = 0.f, da1 = 0.f;
-        const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * 2 * d;
+        if constexpr (PHASE != 2) {      // (token phase of the table mode: the mix is differentiated per node)
+            // through f = sum_k a_k e_k
+            float a[NF], da[NF];
+            f32x4 ev[NF][NCH];
+            const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * NF * d;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < nch) {
-                ev[i] = load4<T>(E + 4 * ch);
-                et[i] = load4<T>(E + d + 4 * ch);
-                da0 += sum4(df[i] * ev[i]);
-                da1 += sum4(df[i] * et[i]);
-            } else {
-                ev[i] = et[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < NF; ++f) { a[f] = p.a[NF * (int64_t)m + f]; da[f] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (ch < nch) {
+                        ev[f][i] = load4<T>(E + f * d + 4 * ch);
+                        da[f] += sum4(df[i] * ev[f][i]);
+                    } else {
+                        ev[f][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             }
-        }
-        da0 = wave_sum(da0);
-        da1 = wave_sum(da1);
-        const float dot = a0 * da0 + a1 * da1;
-        const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
-        dba0 += dz0;
-        dba1 += dz1;
+            float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < nch) {
-                f32x4 tv, tt, dev, det;
+            for (int f = 0; f < NF; ++f) { da[f] = wave_sum(da[f]); dot = f == 0 ? a[0] * da[0] : dot + a[f] * da[f]; }
+            float dz[NF];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { tv[e] = tanhf(ev[i][e]); tt[e] = tanhf(et[i][e]); }
-                dw0v[i] += tv * dz0; dw0t[i] += tt * dz0;
-                dw1v[i] += tv * dz1; dw1t[i] += tt * dz1;
-                dev = df[i] * a0 + (1.f - tv * tv) * (w0v[i] * dz0 + w1v[i] * dz1);
-                det = df[i] * a1 + (1.f - tt * tt) * (w0t[i] * dz0 + w1t[i] * dz1);
-                store4<T>((T*)p.dE + (int64_t)m * 2 * d + 4 * ch, dev);
-                store4<T>((T*)p.dE + (int64_t)m * 2 * d + d + 4 * ch, det);
+            for (int k = 0; k < NF; ++k) { dz[k] = a[k] * (da[k] - dot); dba[k] += dz[k]; }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        f32x4 tv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tv[e] = tanhf(ev[f][i][e]);
+                        f32x4 back = wa[0][f][i] * dz[0];
+#pragma unroll
+                        for (int k = 0; k < NF; ++k) {
+                            dw[k][f][i] += tv * dz[k];
+                            if (k > 0) back += wa[k][f][i] * dz[k];
+                        }
+                        store4<T>((T*)p.dE + (int64_t)m * NF * d + f * d + 4 * ch, df[i] * a[f] + (1.f - tv * tv) * back);
+                    }
+                }
             }
         }
     }
+    // workgroup sums through LDS, wave after wave: dgamma | dbeta | dWa[k][f] | dba
+    constexpr int NV = 2 + NW * NW;
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + 64 * i;
                 if (ch < nch) {
-                    f32x4 v[6] = {dgam[i], dbet[i], dw0v[i], dw0t[i], dw1v[i], dw1t[i]};
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
+                    for (int k = 0; k < NV; ++k) {
+                        f32x4 v = k == 0 ? dgam[i] : (k == 1 ? dbet[i] : dw[(k - 2) / NW][(k - 2) % NW][i]);
                         float* dst = red + k * d + 4 * ch;
-                        if (w > 0) v[k] += *(f32x4*)dst;
-                        *(f32x4*)dst = v[k];
+                        if (w > 0) v += *(f32x4*)dst;
+                        *(f32x4*)dst = v;
                     }
                 }
             }
             if (lane == 0) {   // dz is wave-uniform, so lane 0 carries the row sums
-                red[6 * d] = (w > 0 ? red[6 * d] : 0.f) + dba0;
-                red[6 * d + 1] = (w > 0 ? red[6 * d + 1] : 0.f) + dba1;
-                red[6 * d + 2] = 0.f;
-                red[6 * d + 3] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red[NV * d + k] = k < NW ? (w > 0 ? red[NV * d + k] : 0.f) + dba[k < NW ? k : 0] : 0.f;
             }
         }
         __syncthreads();
     }
-    float* out = p.part + (int64_t)blockIdx.x * (6 * d + 4);
-    for (int i = threadIdx.x; i < 6 * d + 4; i += 256) out[i] = red[i];
+    // token phase of the table mode: the dWa / dba part of the partial is zero (the node phase adds its own)
+    const int n_out = embed_part_elems(d, NF), n_red = NV * d + 4;
+    float* out = p.part + (int64_t)blockIdx.x * n_out;
+    for (int i = threadIdx.x; i < n_out; i += 256) {
+        float v;
+        if (PHASE == 2 && NF != 1) v = i < 2 * d ? red[i] : 0.f;
+        else v = red[i];
+        out[i] = v;
+    }
+    (void)n_red;
 }
 
 template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st) {
     if (e.M <= 0) return 0;
     PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_bwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
+    PMGT_CHECK(e.nf >= 1 && e.nf <= 4, -2, "embed_mix_bwd: %d modalities (1 .. 4 are built)", e.nf);
     dim3 grid(embed_bwd_parts(e.M)), block(256);
+    const size_t lds = (size_t)embed_part_elems(e.d, e.nf) * sizeof(float);
+#define PMGT_EMB_BWD_NF(PH, NF_)                                                                                  \
+    do {                                                                                                          \
+        if (e.d <= 256) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 1, PH, NF_>), grid, block, lds, st, e);       \
+        else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 2, PH, NF_>), grid, block, lds, st, e);  \
+        else hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 4, PH, NF_>), grid, block, lds, st, e);                  \
+    } while (0)
 #define PMGT_EMB_BWD(PH)                                                                                          \
     do {                                                                                                          \
-        if (e.d <= 256) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 1, PH>), grid, block, 0, st, e);              \
-        else if (e.d <= 512) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 2, PH>), grid, block, 0, st, e);         \
-        else hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 4, PH>), grid, block, 0, st, e);                         \
+        if (e.nf == 2) PMGT_EMB_BWD_NF(PH, 2);                                                                    \
+        else if (e.nf == 1) PMGT_EMB_BWD_NF(PH, 1);                                                               \
+        else if (e.nf == 3) PMGT_EMB_BWD_NF(PH, 3);                                                               \
+        else PMGT_EMB_BWD_NF(PH, 4);                                                                              \
     } while (0)
     if (e.phase == 1) PMGT_EMB_BWD(1);
     else if (e.phase == 2) PMGT_EMB_BWD(2);
     else PMGT_EMB_BWD(0);
 #undef PMGT_EMB_BWD
+#undef PMGT_EMB_BWD_NF
     PMGT_LAUNCH_OK();
     return 0;
 }

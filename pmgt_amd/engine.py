@@ -35,16 +35,18 @@ class Engine:
         # "fp8": the bf16 engine with e4m3 feature tables and fp8-MFMA feature / Q|K|V|C projections (include/pmgt_capi.h)
         self.dtype_code = {"fp32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8": _lib.DTYPE_FP8}[dtype]
         self.torch_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.bfloat16}[dtype]
-        self.table_scale = (0.0, 0.0)
+        self.tables: List[torch.Tensor] = []          # frozen feature tables, one per modality (set_tables)
+        self.table_scale: tuple = ()                  # fp8 mode: value = e4m3 byte * table_scale[m]
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        feats = list(config.feat_hidden_sizes)
-        if len(feats) != 2:
-            raise ValueError(f"feat_hidden_sizes={feats}: the HIP path implements exactly the two modalities the reference's "
-                             "trainer builds (visual, textual; pmgt/pmgt/trainer.py:114-125) -- see INTEGRATION.md, limits")
+        feats = [int(f) for f in config.feat_hidden_sizes]
+        if not 1 <= len(feats) <= _lib.MAX_FEATS:
+            raise ValueError(f"feat_hidden_sizes={feats}: the HIP path takes 1 .. {_lib.MAX_FEATS} modalities "
+                             "(the reference's trainer builds two: visual, textual; pmgt/pmgt/trainer.py:114-125)")
+        self.n_feats = len(feats)
         self.cfg_c = _lib.PMGTConfigC(
             config.hidden_size, config.num_hidden_layers, config.num_attention_heads, config.intermediate_size,
-            feats[0], feats[1], config.max_position_embeddings, config.layer_norm_eps, config.beta,
+            len(feats), (C.c_int * _lib.MAX_FEATS)(*feats), config.max_position_embeddings, config.layer_norm_eps, config.beta,
             config.hidden_dropout_prob, config.attention_probs_dropout_prob, self.dtype_code)
         self.h = self.lib.pmgt_engine_create(C.byref(self.cfg_c))
         if not self.h:
@@ -68,7 +70,6 @@ class Engine:
                 dm[e["offset"]: e["offset"] + e["numel"]] = 1
         self.decay_mask = dm.to(self.device)
         self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
-        self.table_v = self.table_t = None
         self.n_nodes = 0
         self._ws: Optional[torch.Tensor] = None
         # optimizer state (created lazily)
@@ -139,10 +140,17 @@ class Engine:
             raise KeyError(self.lib.pmgt_last_error().decode())
         return bool(v)
 
-    def set_tables(self, visual, textual):
-        """Frozen feature tables [N+2, F_m] (pmgt/pmgt/models.py:40-54), cast once to the engine dtype."""
+    def set_tables(self, *tables):
+        """Frozen feature tables [N+2, F_m], one per modality in the order of `feat_hidden_sizes` (visual, textual for the
+        reference's trainer; pmgt/pmgt/models.py:40-54), cast once to the engine dtype."""
+        if len(tables) == 1 and isinstance(tables[0], (list, tuple)):
+            tables = tuple(tables[0])
+        if len(tables) != self.n_feats:
+            raise ValueError(f"set_tables: {len(tables)} tables for {self.n_feats} modalities (models.py:49-50)")
         tabs, scales = [], []
-        for a in (visual, textual):
+        for a, F in zip(tables, self.config.feat_hidden_sizes):
+            if tuple(a.shape)[1:] != (F,) or (tabs and a.shape[0] != tabs[0].shape[0]):
+                raise ValueError(f"set_tables: table of shape {tuple(a.shape)}, expected [n_nodes + 2, {F}]")
             t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
             if self.dtype_name == "fp8":
                 # one scale per table: value = e4m3 byte * (max|table| / 448), quantised once by the library's kernel
@@ -157,15 +165,15 @@ class Engine:
             else:
                 tabs.append(t.to(self.device, dtype=self.torch_dtype).contiguous())
                 scales.append(0.0)
-        self.table_v, self.table_t = tabs
+        self.tables = tabs
         self.table_scale = tuple(scales)
-        self.n_nodes = int(self.table_v.shape[0] - 2)
+        self.n_nodes = int(tabs[0].shape[0] - 2)
 
     def dequantized_tables(self):
         """fp8 mode: the feature values the kernels see (fp32 [N+2, F_m]) -- what a checker must use as the tables."""
         assert self.dtype_name == "fp8"
         out = []
-        for q, sc in zip((self.table_v, self.table_t), self.table_scale):
+        for q, sc in zip(self.tables, self.table_scale):
             o = torch.empty(q.shape, dtype=torch.float32, device=self.device)
             _lib.check(self.lib.pmgt_dequantize_e4m3(_ptr(q), _ptr(o), q.numel(), sc, _stream()))
             out.append(o)
@@ -180,10 +188,17 @@ class Engine:
 
     def _tensors(self, grad_buffer: Optional[torch.Tensor] = None):
         g = self.grads if grad_buffer is None else grad_buffer
-        return _lib.TensorsC(self.params.data_ptr(), g.data_ptr(),
-                             0 if self.table_v is None else self.table_v.data_ptr(),
-                             0 if self.table_t is None else self.table_t.data_ptr(), self.n_nodes,
-                             self.rng_state.data_ptr(), self.table_scale[0], self.table_scale[1])
+        ptrs = [t.data_ptr() for t in self.tables] + [None] * (_lib.MAX_FEATS - len(self.tables))
+        scales = list(self.table_scale) + [0.0] * (_lib.MAX_FEATS - len(self.table_scale))
+        return _lib.TensorsC(self.params.data_ptr(), g.data_ptr(), (C.c_void_p * _lib.MAX_FEATS)(*ptrs), self.n_nodes,
+                             self.rng_state.data_ptr(), (C.c_float * _lib.MAX_FEATS)(*scales))
+
+    def _feat_args(self, feats):
+        """[n_seq, S, F_m] tensors, one per modality -> (device copies kept alive by the caller, host pointer array)."""
+        if len(feats) != self.n_feats:
+            raise ValueError(f"{len(feats)} feature tensors for {self.n_feats} modalities (modeling_pmgt.py:195-201)")
+        dev = [f.to(self.device, self.torch_dtype).contiguous() for f in feats]
+        return dev, (C.c_void_p * self.n_feats)(*[f.data_ptr() for f in dev])
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
@@ -284,9 +299,8 @@ class Engine:
             _lib.check(self.lib.pmgt_encode_ids(self.h, C.byref(tc), _ptr(ids), _ptr(m), n_seq, S, _ptr(last), _ptr(hs),
                                                 _ptr(pr), _ptr(ws), ws.numel(), _stream()))
         else:
-            fv = feats[0].to(self.device, self.torch_dtype).contiguous()
-            ft = feats[1].to(self.device, self.torch_dtype).contiguous()
-            _lib.check(self.lib.pmgt_encode_feats(self.h, C.byref(tc), _ptr(fv), _ptr(ft), _ptr(m), n_seq, S, _ptr(last),
+            dev, fp = self._feat_args(feats)
+            _lib.check(self.lib.pmgt_encode_feats(self.h, C.byref(tc), fp, _ptr(m), n_seq, S, _ptr(last),
                                                   _ptr(hs), _ptr(pr), _ptr(ws), ws.numel(), _stream()))
         return last, hs, pr
 
@@ -297,11 +311,10 @@ class Engine:
         if ids is not None:
             n_seq, S = ids.shape
             ids = ids.to(self.device).contiguous()
-            fv = ft = None
+            dev, fp = None, None
         else:
             n_seq, S = feats[0].shape[:2]
-            fv = feats[0].to(self.device, self.torch_dtype).contiguous()
-            ft = feats[1].to(self.device, self.torch_dtype).contiguous()
+            dev, fp = self._feat_args(feats)
         m = torch.ones(n_seq, S, dtype=torch.float32, device=self.device) if attention_mask is None else \
             attention_mask.to(self.device, torch.float32).contiguous()
         nbytes = int(self.lib.pmgt_workspace_bytes(self.h, n_seq, S, 1, 1))
@@ -309,9 +322,9 @@ class Engine:
         last = torch.empty(n_seq, S, self.config.hidden_size, dtype=self.torch_dtype, device=self.device)
         tc = self._tensors()
         flags = _lib.FLAG_TRAINING if training else 0
-        _lib.check(self.lib.pmgt_encode_train(self.h, C.byref(tc), _ptr(ids), _ptr(fv), _ptr(ft), _ptr(m), n_seq, S, _ptr(last),
+        _lib.check(self.lib.pmgt_encode_train(self.h, C.byref(tc), _ptr(ids), fp, _ptr(m), n_seq, S, _ptr(last),
                                               _ptr(ws), nbytes, flags, _stream()))
-        return last, dict(ws=ws, fv=fv, ft=ft, n_seq=n_seq, S=S, flags=flags)
+        return last, dict(ws=ws, feats=dev, feat_ptrs=fp, n_seq=n_seq, S=S, flags=flags)
 
     def encode_backward(self, state: dict, d_last: torch.Tensor, accumulate: bool = False,
                         grad_buffer: Optional[torch.Tensor] = None):
@@ -321,7 +334,7 @@ class Engine:
         tc = self._tensors(grad_buffer)
         flags = state["flags"] | (_lib.FLAG_ACCUMULATE if accumulate else 0)
         ws = state["ws"]
-        _lib.check(self.lib.pmgt_encode_backward(self.h, C.byref(tc), _ptr(state["fv"]), _ptr(state["ft"]), _ptr(d_last),
+        _lib.check(self.lib.pmgt_encode_backward(self.h, C.byref(tc), state["feat_ptrs"], _ptr(d_last),
                                                  state["n_seq"], state["S"], _ptr(ws), ws.numel(), flags, _stream()))
         self._raise_hook_error()
 

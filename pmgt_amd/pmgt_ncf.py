@@ -71,11 +71,11 @@ class PMGT_NCF(PMGTPretrainedModel):
         with torch.no_grad():
             for i, w in enumerate(feat_init_emb):
                 self.feat_embeddings._modules[str(i)].weight.copy_(torch.as_tensor(w))
-        self.engine.set_tables(self.feat_embeddings._modules["0"].weight, self.feat_embeddings._modules["1"].weight)
+        self.engine.set_tables(*[emb.weight for emb in self.feat_embeddings.children()])
 
     def load_state_dict(self, state_dict, strict: bool = True):
         out = super().load_state_dict(state_dict, strict=strict)
-        self.engine.set_tables(self.feat_embeddings._modules["0"].weight, self.feat_embeddings._modules["1"].weight)
+        self.engine.set_tables(*[emb.weight for emb in self.feat_embeddings.children()])
         return out
 
     def forward(self, user: torch.LongTensor, item: Dict[str, torch.Tensor]) -> torch.Tensor:

@@ -140,6 +140,13 @@ MODEL_CASES = {
     # max_ctx_neigh 5) and the author's script (scripts/run_pmgt.sh:18-25: hidden 32, 3 layers, beta 1.0, the other defaults)
     "e_cli": ("C", dict(hidden_size=128, num_attention_heads=1, num_hidden_layers=5, intermediate_size=128, beta=0.5), 6, 6, 5, 16),
     "e_script": ("C", dict(hidden_size=32, num_attention_heads=1, num_hidden_layers=3, intermediate_size=128, beta=1.0), 6, 6, 6, 17),
+    # modality counts other than the trainer's two (modeling_pmgt.py:163-173,195-201,549-569 are generic over len(feat_hidden_sizes))
+    "f3": ("C", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5,
+                     feat_hidden_sizes=[1536, 768, 256]), 16, 4, 7, 18),
+    "f1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5,
+                     feat_hidden_sizes=[768]), 16, 4, 8, 19),
+    "f4": ("A", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=128, beta=0.5,
+                     feat_hidden_sizes=[64, 128, 32, 256]), 6, 5, 9, 20),
 }
 
 

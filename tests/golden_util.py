@@ -25,6 +25,13 @@ MODEL_CASES = {
     # the reference's two entry configurations: CLI defaults (train.py:225-272) and the author's script (scripts/run_pmgt.sh:18-25)
     "e_cli": ("C", dict(hidden_size=128, num_attention_heads=1, num_hidden_layers=5, intermediate_size=128, beta=0.5)),
     "e_script": ("C", dict(hidden_size=32, num_attention_heads=1, num_hidden_layers=3, intermediate_size=128, beta=1.0)),
+    # three, one and four modalities (the reference's modules are generic over len(feat_hidden_sizes); its trainer builds two)
+    "f3": ("C", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5,
+                     feat_hidden_sizes=[1536, 768, 256])),
+    "f1": ("A", dict(hidden_size=64, num_attention_heads=4, num_hidden_layers=2, intermediate_size=64, beta=0.5,
+                     feat_hidden_sizes=[768])),
+    "f4": ("A", dict(hidden_size=128, num_attention_heads=4, num_hidden_layers=1, intermediate_size=128, beta=0.5,
+                     feat_hidden_sizes=[64, 128, 32, 256])),
 }
 
 

@@ -47,7 +47,7 @@ def make_world():
     eng = Engine(PMGTConfig(**CFG), dtype="fp32", device="cuda:0", seed=0)
     eng.load_params(po.synth_params(ocfg, 3))
     tables = po.synth_tables(N, ocfg["feat_hidden_sizes"], 4)
-    eng.set_tables(tables[0].numpy(), tables[1].numpy())
+    eng.set_tables(*[t.numpy() for t in tables])
     smp = MCNSampler(graph, S - 1)
     tgt, pair, num_pairs, labels = smp.batch(np.arange(2, 2 + B), MODE_TRAIN, threads=2, base_seed=5, counter=0)
     ids = tgt["node_ids"]

@@ -27,7 +27,7 @@ def world():
     tables = po.synth_tables(N, ocfg["feat_hidden_sizes"], 13)
     eng = Engine(PMGTConfig(**CFG), dtype="fp32", seed=0)
     eng.load_params(params)
-    eng.set_tables(tables[0].numpy(), tables[1].numpy())
+    eng.set_tables(*[t.numpy() for t in tables])
     return dict(eng=eng, smp=MCNSampler(graph, S - 1), ocfg=ocfg, params=params, tables=tables)
 
 

@@ -21,7 +21,7 @@ def make_engine(case, dtype="fp32", **cfg_over):
     cfg.update(cfg_over)
     eng = Engine(PMGTConfig(**cfg), dtype=dtype, seed=0)
     eng.load_params(case["params"])
-    eng.set_tables(case["tables"][0].numpy(), case["tables"][1].numpy())
+    eng.set_tables(*[t.numpy() for t in case["tables"]])
     return eng
 
 

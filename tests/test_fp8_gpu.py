@@ -204,7 +204,7 @@ def _fp8_case(name):
     return case, list(deq), scales
 
 
-@pytest.mark.parametrize("name", ["m1", "m1_pad", "m2", "m3"])
+@pytest.mark.parametrize("name", ["m1", "m1_pad", "m2", "m3", "f3", "f1"])      # f3 / f1: three modalities, one
 def test_fp8_engine_matches_the_fp8_emulating_oracle(name):
     case, deq_tables, scales = _fp8_case(name)
     gold = case["gold"]
@@ -236,8 +236,9 @@ def test_fp8_engine_matches_the_fp8_emulating_oracle(name):
     flat_eng = torch.cat([eng.view(e["name"], grad=True).reshape(-1) for e in eng.entries]).cpu()
     cos = torch.nn.functional.cosine_similarity(flat_eng, flat_ref, dim=0).item()
     assert cos > 0.99, cos
-    for nm in ("bert.embeddings.feat_linear.0.weight", "bert.embeddings.feat_linear.1.weight",
-               "bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.0.attention.self.ctx_attention.weight"):
+    nf = len(case["cfg"]["feat_hidden_sizes"])
+    for nm in [f"bert.embeddings.feat_linear.{i}.weight" for i in range(nf)] + [
+            "bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.0.attention.self.ctx_attention.weight"]:
         c = torch.nn.functional.cosine_similarity(eng.view(nm, grad=True).reshape(-1).cpu(), p[nm].grad.reshape(-1), dim=0).item()
         assert c > 0.98, (nm, c)
 

@@ -78,7 +78,7 @@ def run_engine(case, dtype, tables):
     kw = {k: v for k, v in case["cfg"].items() if k != "fp8"}
     eng = Engine(PMGTConfig(**kw), dtype=dtype, seed=0)
     eng.load_params(case["params"])
-    eng.set_tables(tables[0], tables[1])
+    eng.set_tables(*tables)
     out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=case["inj"], want_hidden=False)
     torch.cuda.synchronize()
     return eng, out

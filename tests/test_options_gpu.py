@@ -118,7 +118,8 @@ def test_output_ring_follows_the_pair_count_and_graph_capture_owns_its_outputs()
         sub = ({k: v for k, v in tgt.items()}, {k: v[:P] for k, v in pair.items()}, np_, labels[:P])
         out = eng.pretrain_step(sub, training=False, want_hidden=False)
         assert out["logits"].shape[0] == P
-        torch.testing.assert_close(out["logits"][: P - 1], ref_logits[: P - 1], rtol=1e-3, atol=1e-3)
+        # (bf16: a different token count selects other GEMM tiles for the same rows -- rounding noise of a few 1e-3 on logits of O(0.1))
+        torch.testing.assert_close(out["logits"][: P - 1], ref_logits[: P - 1], rtol=1e-2, atol=4e-3)
         ptrs.add(out["logits"].data_ptr())
     assert len(ptrs) <= eng.OUTPUT_RING            # one ring serves every pair count: no allocation per new P
     assert len(eng._out_rings) == 1

@@ -210,7 +210,7 @@ def test_capi_symbols_exported():
         assert hasattr(hip, s), s
     for s in _lib.SAMPLER_SYMBOLS:
         assert hasattr(smp, s), s
-    assert _lib.hip().pmgt_abi_version() == 3      # 3: per-engine options, path_opts on the pmgt_op_* entries, sampler counter stride
+    assert _lib.hip().pmgt_abi_version() == 4      # 4: n modalities (pmgt_config.feat_sizes[], pmgt_tensors.tables[], feats arrays)
 
 
 def test_strided_counters_reproduce_the_single_process_streams():

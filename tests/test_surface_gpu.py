@@ -41,6 +41,35 @@ def test_state_dict_keys_are_the_reference_keys():
     assert all(lo <= p.data_ptr() < lo + 4 * model.engine.n_params for n, p in model.named_parameters() if p.requires_grad)
 
 
+@pytest.mark.parametrize("name", ["f3", "f1", "f4"])
+def test_other_modality_counts_through_the_reference_surface(name):
+    """len(feat_hidden_sizes) != 2 (modeling_pmgt.py:163-173,195-201,549-569; models.py:38-54): reference key names, eval loss /
+    logits / inference CLS rows and the training loss against the fixtures generated from the reference's PMGT."""
+    case = gu.model_case(name)
+    gold = case["gold"]
+    nf = len(case["cfg"]["feat_hidden_sizes"])
+    model = build(case)
+    keys = set(model.state_dict().keys())
+    assert {f"feat_embeddings.{i}.weight" for i in range(nf)} <= keys and f"feat_embeddings.{nf}.weight" not in keys
+    assert {f"bert.embeddings.feat_linear.{i}.weight" for i in range(nf)} <= keys
+    assert {f"nfr_loss.projections.{i}.bias" for i in range(nf)} <= keys
+    assert tuple(model.state_dict()["bert.embeddings.attention.1.weight"].shape) == (nf, nf * case["cfg"]["hidden_size"])
+    model.eval()
+    batch = case["batch"]
+    out = model(*batch)
+    np.testing.assert_allclose(out[0].item(), gold["eval_loss"], rtol=1e-4)
+    np.testing.assert_allclose(out[1].cpu().numpy(), gold["eval_logits"], rtol=1e-4, atol=1e-5)
+    inf = model(batch[0])
+    np.testing.assert_allclose(inf[0][:, 0].detach().cpu().numpy(), gold["inf_cls"], rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError, match="feature tensors"):       # one tensor per modality, like the reference's zip (:195-198)
+        feats = [f.cuda() for f in po.gather_feats(batch[0]["node_ids"], case["tables"])]
+        model.bert(*feats, feats[0])
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.engine import Engine
+    with pytest.raises(ValueError, match="modalities"):
+        Engine(PMGTConfig(**dict(case["cfg"], feat_hidden_sizes=[8, 8, 8, 8, 8])), dtype="fp32")
+
+
 def test_forward_outputs_index_like_the_reference():
     case = gu.model_case("m1")
     gold = case["gold"]
@@ -168,12 +197,13 @@ def test_ncf_second_caller_on_hip_encoder(name):
         np.testing.assert_allclose(model(c["user"], c["item"]).cpu().numpy(), gold["logits"], rtol=1e-4, atol=1e-5)
 
 
-def test_encoder_backward_on_materialised_features_matches_oracle():
+@pytest.mark.parametrize("name", ["m2", "f3", "f1", "f4"])      # two modalities as the trainer builds; three, one and four
+def test_encoder_backward_on_materialised_features_matches_oracle(name):
     """PMGTModel.forward(*input_feat_embeds) with autograd (the reference's own call form, pmgt_ncf/models.py:83-89)
     against torch autograd through the CPU oracle: arbitrary upstream gradient on the whole last_hidden_state."""
     from pmgt_amd.configuration_pmgt import PMGTConfig
     from pmgt_amd.modeling_pmgt import PMGTModel
-    case = gu.model_case("m2")
+    case = gu.model_case(name)
     cfg = case["cfg"]
     model = PMGTModel(PMGTConfig(**cfg), dtype="fp32")
     with torch.no_grad():
