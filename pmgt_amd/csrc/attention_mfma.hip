@@ -55,6 +55,33 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int c0, int 
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// Bank-conflict-free forms for 128-byte rows (head size 64 tiles, S = 64 images).  A 256-byte LDS bank row holds TWO such rows, so
+// rows of equal parity meet on the same banks: the plain layout makes the transposing reads below 4-way conflicted (a 32-lane half
+// touches 8 rows x 32 bytes) and the row reads of an image 4-way (measured at S = 64 / head size 64: 77 % of the backward kernel's LDS
+// cycles were conflict cycles, the LDS 59 % busy).  Tiles: the 16-byte chunk index is XORed with 2 * tkey(row) -- tkey takes four
+// different values on every set of equal-parity rows one transposing read touches ({0,2,8,10}+k, {0,2,4,6}+k, {4,6,12,14}+k), and
+// bit 0 stays clear because a lane group reads the chunk PAIR (c, c + 1) of a row.  Images: chunk ^ ((row >> 1) & 7), the eight
+// equal-parity rows a 16-lane group of ds_read_b128 touches get eight different chunks.
+__device__ __forceinline__ int tkey(int row) { return ((row >> 1) & 1) | ((((row >> 2) ^ (row >> 3)) & 1) << 1); }
+template <int PITCH, bool SWZ> __device__ __forceinline__ int tile_off(int row, int colb) {
+    if constexpr (SWZ && PITCH == 128) return row * 128 + ((((colb >> 4) ^ (tkey(row) << 1)) & 7) << 4) + (colb & 15);
+    else return row * PITCH + colb;
+}
+template <int PITCH, bool SWZ> __device__ __forceinline__ int image_off(int row, int colb) {
+    if constexpr (SWZ && PITCH == 128) return row * 128 + ((((colb >> 4) ^ (row >> 1)) & 7) << 4) + (colb & 15);
+    else return row * PITCH + colb;
+}
+// tr_frag on a tile written through tile_off<DH * 2, true>
+template <int DH, bool PERM>
+__device__ __forceinline__ bf16x8 tr_frag_swz(const char* tile, int k0, int c0, int r, int q) {
+    const int row_lo = PERM ? (k0 + 4 * q + (r >> 2)) : (k0 + 8 * q + (r >> 2));
+    const int row_hi = PERM ? (row_lo + 16) : (row_lo + 4);
+    const int colb = (c0 + 4 * (r & 3)) * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + tile_off<DH * 2, true>(row_lo, colb)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + tile_off<DH * 2, true>(row_hi, colb)));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // Combine the 4 lanes (q = 0..3) that share a query column: lanes l, l^16, l^32, l^48.  gfx950's
 // v_permlane16_swap / v_permlane32_swap do the two exchanges in the VALU (vdst = src = v: afterwards the two results
 // hold the even-row / odd-row, resp. lower-half / upper-half, copies) instead of two ds_bpermute round trips
@@ -789,11 +816,21 @@ template <int NT> __device__ __forceinline__ bf16x8 pack_col(const f32x4 (&x)[NT
 }
 
 template <int NT> struct CoopCfg { static constexpr int G = NT == 1 ? 4 : (NT == 2 ? 2 : 1), THREADS = 64 * NT * G; };
+// LDS of the cooperative backward.  Four query tiles (S = 64) with an image no larger than a tile (head size 64): the dS2^T image is
+// written INTO the K tile once every wave is done with it (one more barrier), 48.5 instead of 56.5 KB per workgroup -> three
+// workgroups per CU instead of two (the kernel is latency-bound: its waves wait for global loads and LDS round trips).
+template <int DH, int NT> struct BwdSmemC : BwdSmem<DH, NT> {
+    using B = BwdSmem<DH, NT>;
+    static constexpr bool ALIAS = NT == 4 && B::IMG <= B::TILE;
+    static constexpr int BYTES = 4 * B::TILE + (ALIAS ? 2 : 3) * B::IMG + 2 * 64 * 4;
+};
 
 template <int DH, int NT>
-__global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(AttnArgs a) {
-    using SM = BwdSmem<DH, NT>;
+__global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_coop_kernel(AttnArgs a) {
+    using SM = BwdSmemC<DH, NT>;
     constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2, G = CoopCfg<NT>::G;
+    constexpr bool TSW = DH == 64, ISW = SP2 == 64;      // 128-byte rows: swizzled layouts (tile_off / image_off)
+    constexpr int TP = DH * 2, IP = SP2 * 2;             // row pitches in bytes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int ul = wave / NT, it = wave % NT;
@@ -808,8 +845,8 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
     char* tC = tO + SM::TILE;
     char* iP = tC + SM::TILE;
     char* iS1 = iP + SM::IMG;
-    char* iS2 = iS1 + SM::IMG;
-    float* rho = (float*)(iS2 + SM::IMG);
+    char* iS2 = SM::ALIAS ? tK : iS1 + SM::IMG;
+    float* rho = (float*)(iS1 + (SM::ALIAS ? 1 : 2) * SM::IMG);
     float* madd = rho + 64;
     const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
     const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
@@ -818,6 +855,10 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
     const int Sv = act ? S : 0;
     const float isq = rsqrtf((float)DH);
     const int x = 16 * it + r;                  // this lane's row (query i in the first half, key j in the second)
+    auto trf = [&]<bool PERM>(const char* tile, int k0, int c0) {
+        if constexpr (TSW) return tr_frag_swz<DH, PERM>(tile, k0, c0, r, q);
+        else return tr_frag<DH, PERM>(tile, k0, c0, r, q);
+    };
 
     // ---- all global loads of the wave, unconditional and clamped
     bf16x8 fq[KD], fo[KD], fko[KD], fco[KD], fk[NT][KD], fc[NT][KD], fv[NT][KD];
@@ -853,7 +894,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
         }
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks) {
-            const int off = x * (DH * 2) + (32 * ks + 8 * q) * 2;
+            const int off = tile_off<TP, TSW>(x, (32 * ks + 8 * q) * 2);
             *(bf16x8*)(tQ + off) = fq[ks];
             *(bf16x8*)(tK + off) = fko[ks];
             *(bf16x8*)(tO + off) = fo[ks];
@@ -865,7 +906,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
         if (SP2 > SP && it == NT - 1) {        // zero rows [SP, SP2) of the four tiles (k padding of the transposed reads)
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int idx = lane; idx < (SP2 - SP) * (DH / 8); idx += 64) {
-                const int off = (SP + idx / (DH / 8)) * (DH * 2) + (idx % (DH / 8)) * 16;
+                const int off = tile_off<TP, TSW>(SP + idx / (DH / 8), (idx % (DH / 8)) * 16);
                 *(bf16x8*)(tQ + off) = z;
                 *(bf16x8*)(tK + off) = z;
                 *(bf16x8*)(tO + off) = z;
@@ -959,16 +1000,18 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
                 const float ds2 = a2[jt][e] * (g2[jt][e] - rd2);
                 a1[jt][e] = ds1;
                 a2[jt][e] = ds2;
-                *(bf16*)(iP + (j * SP2 + x) * 2) = (bf16)pm[jt][e];
-                *(bf16*)(iS1 + (j * SP2 + x) * 2) = (bf16)ds1;
-                *(bf16*)(iS2 + (j * SP2 + x) * 2) = (bf16)ds2;
+                const int io = image_off<IP, ISW>(j, x * 2);
+                *(bf16*)(iP + io) = (bf16)pm[jt][e];
+                *(bf16*)(iS1 + io) = (bf16)ds1;
+                if (!SM::ALIAS) *(bf16*)(iS2 + io) = (bf16)ds2;      // (aliased: after the dQ products below)
             }
         if (SP2 > SP && it == NT - 1) {     // zero the padding columns i in [SP, SP2) of the images
             for (int idx = lane; idx < SP * (SP2 - SP); idx += 64) {
                 const int j = idx / (SP2 - SP), i = SP + idx % (SP2 - SP);
-                *(bf16*)(iP + (j * SP2 + i) * 2) = (bf16)0.f;
-                *(bf16*)(iS1 + (j * SP2 + i) * 2) = (bf16)0.f;
-                *(bf16*)(iS2 + (j * SP2 + i) * 2) = (bf16)0.f;
+                const int io = image_off<IP, ISW>(j, i * 2);
+                *(bf16*)(iP + io) = (bf16)0.f;
+                *(bf16*)(iS1 + io) = (bf16)0.f;
+                if (!SM::ALIAS) *(bf16*)(iS2 + io) = (bf16)0.f;
             }
         }
     }
@@ -988,14 +1031,21 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
                 f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tK, 32 * ks, 16 * ct, r, q), b2[ks], dq, 0, 0, 0);
-                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, true>(tC, 32 * ks, 16 * ct, r, q), b1[ks], dc, 0, 0, 0);
+                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<true>(tK, 32 * ks, 16 * ct), b2[ks], dq, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<true>(tC, 32 * ks, 16 * ct), b1[ks], dc, 0, 0, 0);
                 }
                 dqv[u] = dq * isq;
                 dch[ct] = dc;
             }
             store_row32(rowq + 32 * cp, dqv[0], dqv[1], q, x < Sv);
         }
+    }
+    if constexpr (SM::ALIAS) {      // every wave is done with the K tile: the dS2^T image takes its place (SP2 == SP here: no padding columns)
+        __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(bf16*)(iS2 + image_off<IP, ISW>(16 * jt + 4 * q + e, x * 2)) = (bf16)a2[jt][e];
     }
     __syncthreads();
 
@@ -1004,7 +1054,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
         bf16x8 bt[KS], bp[KS], bs[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int off = (x * SP2 + 32 * ks + 8 * q) * 2;
+            const int off = image_off<IP, ISW>(x, (32 * ks + 8 * q) * 2);
             bt[ks] = *(const bf16x8*)(iS1 + off);
             bp[ks] = *(const bf16x8*)(iP + off);
             bs[ks] = *(const bf16x8*)(iS2 + off);
@@ -1020,14 +1070,14 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
                 f32x4 dc = dch[ct], dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tC, 32 * ks, 16 * ct, r, q), bt[ks], dc, 0, 0, 0);
-                    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tO, 32 * ks, 16 * ct, r, q), bp[ks], dv, 0, 0, 0);
-                    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH, false>(tQ, 32 * ks, 16 * ct, r, q), bs[ks], dk, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<false>(tC, 32 * ks, 16 * ct), bt[ks], dc, 0, 0, 0);
+                    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<false>(tO, 32 * ks, 16 * ct), bp[ks], dv, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<false>(tQ, 32 * ks, 16 * ct), bs[ks], dk, 0, 0, 0);
                 }
                 dvv[u] = dv;
                 dkv[u] = dk * isq;
                 dch[ct] = -dc;       // dN = -dS1
-                const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+                const f32x4 ch = load4<bf16>((const bf16*)(tC + tile_off<TP, TSW>(x, (16 * ct + 4 * q) * 2)));
                 dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
             }
             store_row32(rowx + 2 * d + 32 * cp, dvv[0], dvv[1], q, x < Sv);
@@ -1036,7 +1086,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_bwd_coop_kernel(Att
         dt = red_q<NT>(dt, false);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const f32x4 ch = load4<bf16>((const bf16*)(tC + (x * DH + 16 * ct + 4 * q) * 2));
+            const f32x4 ch = load4<bf16>((const bf16*)(tC + tile_off<TP, TSW>(x, (16 * ct + 4 * q) * 2)));
             dch[ct] = (dch[ct] - ch * dt) * rho_x;
         }
 #pragma unroll
@@ -1208,7 +1258,7 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
     } else {
         if (use_coop) {
             constexpr int G = CoopCfg<NT>::G;
-            const size_t shmem = (size_t)BwdSmem<DH, NT>::BYTES * G;
+            const size_t shmem = (size_t)BwdSmemC<DH, NT>::BYTES * G;
             auto kern = attn_bwd_coop_kernel<DH, NT>;
             if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             hipLaunchKernelGGL(kern, dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);

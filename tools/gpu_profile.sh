@@ -22,6 +22,10 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --outp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_sq2.err
 for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_sq1 $c > $OUT/pmc_$c.txt 2>&1; done
 for c in SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU; do python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_sq2 $c > $OUT/pmc_$c.txt 2>&1; done
+# LDS array cycles and the extra cycles bank conflicts add (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = share of LDS cycles lost to conflicts)
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq3 -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_sq3.err
+for c in SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_sq3 $c > $OUT/pmc_$c.txt 2>&1; done
+rm -rf $OUT/pmc_sq3
 # keep only the summaries (raw traces are large)
 rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2
 tail -n 45 $OUT/kernel_stats.txt
