@@ -471,3 +471,33 @@ def test_sequence_length_past_max_position_embeddings_is_refused():
     ids = torch.randint(2, 100, (2, 101)).cuda()
     with pytest.raises(Exception, match="max_position_embeddings"):
         eng.encode(ids=ids)
+
+
+@pytest.mark.parametrize("mode", ["table", "token"])
+@pytest.mark.parametrize("hidden,heads,feats", [(512, 8, [256, 128, 64]), (256, 8, [64, 32, 128, 96]), (512, 8, [96])])
+def test_modality_counts_at_wider_hidden_sizes(hidden, heads, feats, mode):
+    """Three, four and one modalities at hidden sizes 256 / 512 (two 256-column passes per row in the embedding kernels), per-node
+    (table mode) and per-token projections, against autograd through the oracle on the batch and NFR draws of fixture m1."""
+    base = gu.model_case("m1")
+    cfg = po.default_cfg(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, hidden_size=hidden, num_attention_heads=heads,
+                         num_hidden_layers=1, intermediate_size=hidden, beta=0.5, feat_hidden_sizes=feats)
+    case = dict(base, cfg=cfg, params=po.synth_params(cfg, 41), tables=po.synth_tables(base["n_nodes"], feats, 42))
+    inj, inj_cpu = inject_for(case)
+    p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items()}
+    ref = po.pretrain_forward(p, cfg, case["tables"], case["batch"], training=True, nfr_inject=inj_cpu)
+    ref["loss"].backward()
+    for dtype in ("fp32", "bf16"):
+        eng = make_engine(case, dtype=dtype)
+        if mode == "token":
+            eng.set_option("no_table_projection", True)
+        out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=inj)
+        np.testing.assert_allclose(out["loss"].item(), ref["loss"].item(), rtol=1e-4 if dtype == "fp32" else 2e-2)
+        np.testing.assert_allclose(out["nfr"].item(), ref["nfr"].item(), rtol=1e-4 if dtype == "fp32" else 2e-2)
+        for k, g in eng.named_views(grad=True).items():
+            a, b = g.float().cpu(), p[k].grad
+            if dtype == "fp32":
+                scale = float(b.double().pow(2).mean().sqrt())
+                np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-3, atol=2e-3 * scale + 1e-9, err_msg=k)
+            elif k.startswith("bert.embeddings.") and (k.endswith("weight") or "feat_linear" in k):
+                cos = torch.nn.functional.cosine_similarity(a.reshape(-1), b.reshape(-1), dim=0).item()
+                assert cos > 0.99, (k, cos)
