@@ -486,6 +486,7 @@ def test_modality_counts_at_wider_hidden_sizes(hidden, heads, feats, mode):
     p = {k: v.clone().requires_grad_(True) for k, v in case["params"].items()}
     ref = po.pretrain_forward(p, cfg, case["tables"], case["batch"], training=True, nfr_inject=inj_cpu)
     ref["loss"].backward()
+    grms = max(float(v.grad.double().pow(2).mean().sqrt()) for v in p.values())
     for dtype in ("fp32", "bf16"):
         eng = make_engine(case, dtype=dtype)
         if mode == "token":
@@ -497,7 +498,11 @@ def test_modality_counts_at_wider_hidden_sizes(hidden, heads, feats, mode):
             a, b = g.float().cpu(), p[k].grad
             if dtype == "fp32":
                 scale = float(b.double().pow(2).mean().sqrt())
-                np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-3, atol=2e-3 * scale + 1e-9, err_msg=k)
+                # (key.bias gradients are exactly 0 in theory -- softmax shift invariance: absolute floor from the global scale)
+                np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-3, atol=2e-3 * scale + 1e-5 * grms, err_msg=k)
             elif k.startswith("bert.embeddings.") and (k.endswith("weight") or "feat_linear" in k):
+                if float(b.abs().max()) == 0.0:          # one modality: the softmax over a single score has no gradient
+                    assert float(a.abs().max()) <= 1e-6 * grms, k
+                    continue
                 cos = torch.nn.functional.cosine_similarity(a.reshape(-1), b.reshape(-1), dim=0).item()
                 assert cos > 0.99, (k, cos)
