@@ -41,6 +41,13 @@ __device__ __forceinline__ bf16x8 ld_rows(const bf16* base, int64_t ld, int row,
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return row < S ? v : z;
 }
+// FULL = every row exists (S is a compile-time multiple of 16): no clamp, no select.  A select on a loaded value is not free even
+// when it folds to "keep": under register pressure the compiler places it -- and the s_waitcnt vmcnt it needs -- BEFORE the loads
+// that follow in program order, which put a whole extra memory round trip at the start of the S = 64 backward kernel.
+template <bool FULL> __device__ __forceinline__ bf16x8 ld_rows_f(const bf16* base, int64_t ld, int row, int S, int col) {
+    if constexpr (FULL) return *(const bf16x8*)(base + (int64_t)row * ld + col);
+    else return ld_rows(base, ld, row, S, col);
+}
 // A operand (16 "c" rows x 32 k) of a product whose k index is a ROW of the row-major LDS tile
 // `tile` ([rows][DH] bf16): element e of lane (r, q) is tile[krow(q, e)][c0 + r].
 // PERM = true: krow = k0 + 16 (e >> 2) + 4 q + (e & 3)  (matches an accumulator tile used as B);
@@ -825,7 +832,16 @@ template <int DH, int NT> struct BwdSmemC : BwdSmem<DH, NT> {
     static constexpr int BYTES = 4 * B::TILE + (ALIAS ? 2 : 3) * B::IMG + 2 * 64 * 4;
 };
 
-template <int DH, int NT>
+#ifdef PMGT_COOP_PROF
+// cycles per interval of workgroup PMGT_COOP_PROF (a mid-grid index), per wave: loads issued | landed + tiles written | barrier |
+// first half | barrier(s) | second half + stores issued
+__device__ unsigned long long g_coop_prof[4][8];
+#define COOP_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == PMGT_COOP_PROF && lane == 0) g_coop_prof[wave][k_] = n_ - plast; plast = n_; } while (0)
+#else
+#define COOP_STAMP(k_) do { } while (0)
+#endif
+// FULL: S == 16 NT -- every bounds test is a compile-time constant (only the stores of an idle group are predicated off)
+template <int DH, int NT, bool FULL>
 __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_coop_kernel(AttnArgs a) {
     using SM = BwdSmemC<DH, NT>;
     constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2, G = CoopCfg<NT>::G;
@@ -833,6 +849,9 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
     constexpr int TP = DH * 2, IP = SP2 * 2;             // row pitches in bytes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+#ifdef PMGT_COOP_PROF
+    unsigned long long plast = __builtin_readcyclecounter();
+#endif
     const int ul = wave / NT, it = wave % NT;
     const int gidx = blockIdx.x * G + ul;
     const int S = a.S, H = a.H, d = H * DH;
@@ -852,8 +871,12 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
     const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
     bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
     const int64_t ld = 4 * d;
-    const int Sv = act ? S : 0;
+    const int Sv = FULL ? 16 * NT : (act ? S : 0);
+    const bool live = FULL ? act : true;                    // FULL: an idle group recomputes pair (0, 0), its stores are predicated off
     const float isq = rsqrtf((float)DH);
+    // the mask value of key `lane` first: the memory counter retires in order, so a load issued AFTER the tile loads would make its
+    // consumer wait for all of them
+    const float mval = a.mask ? a.mask[(int64_t)t * S + min(lane, S - 1)] : 1.f;
     const int x = 16 * it + r;                  // this lane's row (query i in the first half, key j in the second)
     auto trf = [&]<bool PERM>(const char* tile, int k0, int c0) {
         if constexpr (TSW) return tr_frag_swz<DH, PERM>(tile, k0, c0, r, q);
@@ -864,19 +887,20 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
     bf16x8 fq[KD], fo[KD], fko[KD], fco[KD], fk[NT][KD], fc[NT][KD], fv[NT][KD];
 #pragma unroll
     for (int ks = 0; ks < KD; ++ks) {
-        fq[ks] = ld_rows(X, ld, x, Sv, 32 * ks + 8 * q);
-        fko[ks] = ld_rows(X + d, ld, x, Sv, 32 * ks + 8 * q);
-        fco[ks] = ld_rows(X + 3 * d, ld, x, Sv, 32 * ks + 8 * q);
-        fo[ks] = ld_rows(DO, d, x, Sv, 32 * ks + 8 * q);
+        fq[ks] = ld_rows_f<FULL>(X, ld, x, Sv, 32 * ks + 8 * q);
+        fko[ks] = ld_rows_f<FULL>(X + d, ld, x, Sv, 32 * ks + 8 * q);
+        fco[ks] = ld_rows_f<FULL>(X + 3 * d, ld, x, Sv, 32 * ks + 8 * q);
+        fo[ks] = ld_rows_f<FULL>(DO, d, x, Sv, 32 * ks + 8 * q);
     }
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks) {
-            fk[jt][ks] = ld_rows(X + d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
-            fv[jt][ks] = ld_rows(X + 2 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
-            fc[jt][ks] = ld_rows(X + 3 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fk[jt][ks] = ld_rows_f<FULL>(X + d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fv[jt][ks] = ld_rows_f<FULL>(X + 2 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fc[jt][ks] = ld_rows_f<FULL>(X + 3 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
         }
+    COOP_STAMP(0);
     // own rows: inverse norm, mask term, and the four tiles
     float rho_x;
     {
@@ -888,10 +912,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
         ss = red_q<NT>(ss, false);
         rho_x = x < Sv ? rsqrtf(ss) : 0.f;
         if (q == 0) rho[x] = rho_x;
-        if (lane < 16) {
-            const int j = 16 * it + lane;
-            madd[j] = (j < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + j]) * -10000.f : 0.f;
-        }
+        if ((lane >> 4) == it) madd[lane] = lane < Sv ? (1.f - mval) * -10000.f : 0.f;
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks) {
             const int off = tile_off<TP, TSW>(x, (32 * ks + 8 * q) * 2);
@@ -914,7 +935,9 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
             }
         }
     }
+    COOP_STAMP(1);
     __syncthreads();
+    COOP_STAMP(2);
 
     // ---- first half: query tile `it`
     f32x4 a1[NT], a2[NT], dp[NT];
@@ -1037,9 +1060,10 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
                 dqv[u] = dq * isq;
                 dch[ct] = dc;
             }
-            store_row32(rowq + 32 * cp, dqv[0], dqv[1], q, x < Sv);
+            store_row32(rowq + 32 * cp, dqv[0], dqv[1], q, live && x < Sv);
         }
     }
+    COOP_STAMP(3);
     if constexpr (SM::ALIAS) {      // every wave is done with the K tile: the dS2^T image takes its place (SP2 == SP here: no padding columns)
         __syncthreads();
 #pragma unroll
@@ -1048,6 +1072,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
             for (int e = 0; e < 4; ++e) *(bf16*)(iS2 + image_off<IP, ISW>(16 * jt + 4 * q + e, x * 2)) = (bf16)a2[jt][e];
     }
     __syncthreads();
+    COOP_STAMP(4);
 
     // ---- second half: rows x of the images (x as key index)
     {
@@ -1080,8 +1105,8 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
                 const f32x4 ch = load4<bf16>((const bf16*)(tC + tile_off<TP, TSW>(x, (16 * ct + 4 * q) * 2)));
                 dt += (dch[ct][0] * ch[0] + dch[ct][1] * ch[1]) + (dch[ct][2] * ch[2] + dch[ct][3] * ch[3]);
             }
-            store_row32(rowx + 2 * d + 32 * cp, dvv[0], dvv[1], q, x < Sv);
-            store_row32(rowx + d + 32 * cp, dkv[0], dkv[1], q, x < Sv);
+            store_row32(rowx + 2 * d + 32 * cp, dvv[0], dvv[1], q, live && x < Sv);
+            store_row32(rowx + d + 32 * cp, dkv[0], dkv[1], q, live && x < Sv);
         }
         dt = red_q<NT>(dt, false);
 #pragma unroll
@@ -1090,13 +1115,14 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
             dch[ct] = (dch[ct] - ch * dt) * rho_x;
         }
 #pragma unroll
-        for (int cp = 0; cp < CT / 2; ++cp) store_row32(rowx + 3 * d + 32 * cp, dch[2 * cp], dch[2 * cp + 1], q, x < Sv);
+        for (int cp = 0; cp < CT / 2; ++cp) store_row32(rowx + 3 * d + 32 * cp, dch[2 * cp], dch[2 * cp + 1], q, live && x < Sv);
     }
+    COOP_STAMP(5);
 }
 
 // Forward, cooperative form: wave `it` of the NT waves of a (sequence, head) owns query tile it; the V tile is
 // shared through LDS (each wave stores its own 16 rows), everything else stays in registers.
-template <int DH, int NT>
+template <int DH, int NT, bool FULL>
 __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(AttnArgs a) {
     using SM = FwdSmem<DH, NT>;
     constexpr int KD = DH / 32, CT = DH / 16, KS = SM::SP2 / 32, SP = SM::SP, SP2 = SM::SP2, G = CoopCfg<NT>::G;
@@ -1113,22 +1139,24 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
     float* madd = rho + 64;
     const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
     const int64_t ld = 4 * d;
-    const int Sv = act ? S : 0;
+    const int Sv = FULL ? 16 * NT : (act ? S : 0);
+    const bool live = FULL ? act : true;
     const int x = 16 * it + r;
+    const float mval = a.mask ? a.mask[(int64_t)t * S + min(lane, S - 1)] : 1.f;      // first: see attn_bwd_coop_kernel
 
     bf16x8 fq[KD], fco[KD], fvo[KD], fk[NT][KD], fc[NT][KD];
 #pragma unroll
     for (int ks = 0; ks < KD; ++ks) {
-        fq[ks] = ld_rows(X, ld, x, Sv, 32 * ks + 8 * q);
-        fvo[ks] = ld_rows(X + 2 * d, ld, x, Sv, 32 * ks + 8 * q);
-        fco[ks] = ld_rows(X + 3 * d, ld, x, Sv, 32 * ks + 8 * q);
+        fq[ks] = ld_rows_f<FULL>(X, ld, x, Sv, 32 * ks + 8 * q);
+        fvo[ks] = ld_rows_f<FULL>(X + 2 * d, ld, x, Sv, 32 * ks + 8 * q);
+        fco[ks] = ld_rows_f<FULL>(X + 3 * d, ld, x, Sv, 32 * ks + 8 * q);
     }
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks) {
-            fk[jt][ks] = ld_rows(X + d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
-            fc[jt][ks] = ld_rows(X + 3 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fk[jt][ks] = ld_rows_f<FULL>(X + d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
+            fc[jt][ks] = ld_rows_f<FULL>(X + 3 * d, ld, 16 * jt + r, Sv, 32 * ks + 8 * q);
         }
     float rho_x;
     {
@@ -1140,10 +1168,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
         ss = red_q<NT>(ss, false);
         rho_x = x < Sv ? rsqrtf(ss) : 0.f;
         if (q == 0) rho[x] = rho_x;
-        if (lane < 16) {
-            const int j = 16 * it + lane;
-            madd[j] = (j < Sv && a.mask) ? (1.f - a.mask[(int64_t)t * S + j]) * -10000.f : 0.f;
-        }
+        if ((lane >> 4) == it) madd[lane] = lane < Sv ? (1.f - mval) * -10000.f : 0.f;
 #pragma unroll
         for (int ks = 0; ks < KD; ++ks) *(bf16x8*)(tV + x * (DH * 2) + (32 * ks + 8 * q) * 2) = fvo[ks];
         if (SP2 > SP && it == NT - 1) {
@@ -1218,7 +1243,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
                 const int j = 16 * jt + 4 * q + e;
                 const float p = beta * d1[e] * a1[jt][e] + omb * d2[e] * a2[jt][e];
                 a1[jt][e] = p;
-                if (a.probs && x < Sv && j < Sv) a.probs[(hbase + x) * S + j] = p;
+                if (a.probs && live && x < Sv && j < Sv) a.probs[(hbase + x) * S + j] = p;
             }
         }
     }
@@ -1235,7 +1260,7 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
     }
 #pragma unroll
     for (int cp = 0; cp < CT / 2; ++cp)
-        store_row32((bf16*)a.ctx + ((int64_t)t * S + min(x, S - 1)) * d + h * DH + 32 * cp, o[2 * cp], o[2 * cp + 1], q, x < Sv);
+        store_row32((bf16*)a.ctx + ((int64_t)t * S + min(x, S - 1)) * d + h * DH + 32 * cp, o[2 * cp], o[2 * cp + 1], q, live && x < Sv);
 }
 
 template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
@@ -1246,7 +1271,8 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
     if (!bwd && use_coop) {
         constexpr int G = CoopCfg<NT>::G;
         const size_t shmem = (size_t)FwdSmem<DH, NT>::BYTES * G;
-        hipLaunchKernelGGL((attn_fwd_coop_kernel<DH, NT>), dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);
+        if (a.S == 16 * NT) hipLaunchKernelGGL((attn_fwd_coop_kernel<DH, NT, true>), dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);
+        else hipLaunchKernelGGL((attn_fwd_coop_kernel<DH, NT, false>), dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);
         PMGT_LAUNCH_OK();
         return 0;
     }
@@ -1259,7 +1285,7 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
         if (use_coop) {
             constexpr int G = CoopCfg<NT>::G;
             const size_t shmem = (size_t)BwdSmemC<DH, NT>::BYTES * G;
-            auto kern = attn_bwd_coop_kernel<DH, NT>;
+            auto kern = a.S == 16 * NT ? attn_bwd_coop_kernel<DH, NT, true> : attn_bwd_coop_kernel<DH, NT, false>;
             if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             hipLaunchKernelGGL(kern, dim3(cdiv(groups, G)), dim3(CoopCfg<NT>::THREADS), shmem, st, a);
             PMGT_LAUNCH_OK();
@@ -1836,6 +1862,11 @@ int attn_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
 #ifdef PMGT_ABW_PROF
 extern "C" int pmgt_debug_abw_prof_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_abw_prof), sizeof(pmgt::g_abw_prof));
+}
+#endif
+#ifdef PMGT_COOP_PROF
+extern "C" int pmgt_debug_coop_prof_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_coop_prof), sizeof(pmgt::g_coop_prof));
 }
 #endif
 #ifdef PMGT_AB_PROF
