@@ -1120,6 +1120,272 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) __attribute__((amdgpu_waves_p
     COOP_STAMP(5);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, tile form (S = 16 NT exactly, an S x S image no larger than an S x DH tile; built for S = 64 / head size 64, the
+// C4 / C5 shapes).  Same arithmetic as attn_bwd_coop_kernel; what differs is how the operands reach the waves.  The cooperative
+// form has every wave load its own MFMA fragments from global memory: 37 loads per lane, each touching sixteen 64-byte halves
+// of 128-byte lines, the K / V / C rows four times per workgroup -- in-kernel stamps showed 5 600 - 9 300 cycles of a 26 000-cycle
+// workgroup life spent ISSUING them (the CU's address unit serves twelve such waves).  Here the workgroup reads each row of
+// Q, K, V, C and dO ONCE, as whole 128-byte lines (8 lanes per row, 10 loads per lane), stages them as five LDS tiles, and
+// every fragment -- row reads for the score products, transposing reads for the gradient products -- comes from LDS.
+// C stays RAW in its tile; the inverse norms are folded where C^ = C / |c| is meant: dS1 carries 1 / |c_j| into the first-half
+// product, its image 1 / |c_i| into the second-half one.  LDS: five tiles + the dS1 image (48.5 KB at S = 64: three workgroups per
+// CU); the P and dS2 images are written into the V and K tiles once every wave is done with those.
+// ------------------------------------------------------------------------------------------------
+template <int DH, int NT> struct BwdSmemT {
+    static constexpr int S = 16 * NT;
+    static constexpr int TILE = S * DH * 2, IMG = S * S * 2;
+    static constexpr int BYTES = 5 * TILE + IMG + 2 * 64 * 4;
+    static_assert(IMG <= TILE && NT % 2 == 0, "the images must fit the tiles they replace; S a multiple of 32");
+};
+
+template <int DH, int NT>
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_tiles_kernel(AttnArgs a) {
+    using SM = BwdSmemT<DH, NT>;
+    constexpr int S = SM::S, KD = DH / 32, CT = DH / 16, KS = S / 32;
+    constexpr bool TSW = DH == 64, ISW = S == 64;        // 128-byte rows: swizzled layouts (tile_off / image_off)
+    constexpr int TP = DH * 2, IP = S * 2;               // row pitches in bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int it = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int H = a.H, d = H * DH;
+    const int t = blockIdx.x / H, h = blockIdx.x % H;
+    char* tQ = smem;
+    char* tK = tQ + SM::TILE;
+    char* tV = tK + SM::TILE;
+    char* tO = tV + SM::TILE;
+    char* tC = tO + SM::TILE;
+    char* iS1 = tC + SM::TILE;
+    char* iP = tV;                  // after the first-half products
+    char* iS2 = tK;
+    float* rho = (float*)(iS1 + SM::IMG);
+    float* madd = rho + 64;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    const bf16* DO = (const bf16*)a.dctx + (int64_t)t * S * d + h * DH;
+    bf16* DX = (bf16*)a.dqkvc + (int64_t)t * S * 4 * d + h * DH;
+    const int64_t ld = 4 * d;
+    const float isq = rsqrtf((float)DH);
+    const float mval = a.mask ? a.mask[(int64_t)t * S + lane] : 1.f;      // first (the memory counter retires in order); S <= 64 lanes
+    const int x = 16 * it + r;                  // this lane's row (query i in the first half, key j in the second)
+    auto trf = [&]<bool PERM>(const char* tile, int k0, int c0) {
+        if constexpr (TSW) return tr_frag_swz<DH, PERM>(tile, k0, c0, r, q);
+        else return tr_frag<DH, PERM>(tile, k0, c0, r, q);
+    };
+
+    // ---- this wave's 16 rows of the five tiles: whole rows, CPR lanes each
+    {
+        constexpr int CPR = DH / 8, RPI = 64 / CPR, NI = 16 / RPI;
+        const int lr = lane / CPR, lc = lane % CPR;
+        bf16x8 gq[NI], gk[NI], gv[NI], gc[NI], go[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = 16 * it + RPI * i + lr;
+            const bf16* px = X + (int64_t)row * ld + lc * 8;
+            gq[i] = *(const bf16x8*)px;
+            gk[i] = *(const bf16x8*)(px + d);
+            gv[i] = *(const bf16x8*)(px + 2 * d);
+            gc[i] = *(const bf16x8*)(px + 3 * d);
+            go[i] = *(const bf16x8*)(DO + (int64_t)row * d + lc * 8);
+        }
+        if ((lane >> 4) == it) madd[lane] = lane < S ? (1.f - mval) * -10000.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = 16 * it + RPI * i + lr;
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = (float)gc[i][e]; ss = fmaf(c, c, ss); }
+#pragma unroll
+            for (int m = 1; m < CPR; m <<= 1) ss += __shfl_xor(ss, m);
+            if (lc == 0) rho[row] = rsqrtf(ss);
+            const int off = tile_off<TP, TSW>(row, lc * 16);
+            *(bf16x8*)(tQ + off) = gq[i];
+            *(bf16x8*)(tK + off) = gk[i];
+            *(bf16x8*)(tV + off) = gv[i];
+            *(bf16x8*)(tO + off) = go[i];
+            *(bf16x8*)(tC + off) = gc[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- first half: query tile `it`
+    const float rho_x = rho[x];
+    f32x4 a1[NT], a2[NT], dp[NT];
+    {
+        bf16x8 fq[KD], fco[KD], fo[KD];
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const int off = tile_off<TP, TSW>(x, (32 * ks + 8 * q) * 2);
+            fq[ks] = *(const bf16x8*)(tQ + off);
+            fco[ks] = *(const bf16x8*)(tC + off);
+            fo[ks] = *(const bf16x8*)(tO + off);
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1, x3 = x1;
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) {
+                const int off = tile_off<TP, TSW>(16 * jt + r, (32 * ks + 8 * q) * 2);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tC + off), fco[ks], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tK + off), fq[ks], x2, 0, 0, 0);
+                x3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tV + off), fo[ks], x3, 0, 0, 0);
+            }
+            a1[jt] = x1; a2[jt] = x2; dp[jt] = x3;
+        }
+    }
+    {
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 mj = *(const f32x4*)(madd + 16 * jt + 4 * q), rj = *(const f32x4*)(rho + 16 * jt + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const float v1 = 1.f - a1[jt][e] * (rho_x * rj[e]) + (x == j ? 1.f : 0.f) + mj[e];
+                const float v2 = a2[jt][e] * isq + mj[e];
+                a1[jt][e] = v1;
+                a2[jt][e] = v2;
+                m1 = fmaxf(m1, v1);
+                m2 = fmaxf(m2, v2);
+            }
+        }
+        m1 = red_q<NT>(m1, true);
+        m2 = red_q<NT>(m2, true);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e1 = __expf(a1[jt][e] - m1);
+                const float e2 = __expf(a2[jt][e] - m2);
+                a1[jt][e] = e1;
+                a2[jt][e] = e2;
+                s1 += e1;
+                s2 += e2;
+            }
+        s1 = red_q<NT>(s1, false);
+        s2 = red_q<NT>(s2, false);
+        const float i1 = __frcp_rn(s1), i2 = __frcp_rn(s2);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) { a1[jt] *= i1; a2[jt] *= i2; }
+    }
+    f32x4 pm[NT];
+    {   // softmax backward of both branches; the dS1^T image (rows scaled by 1 / |c_i|); P^T and dS2^T stay in registers for now
+        const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
+        const float beta = a.beta, omb = 1.f - a.beta;
+        const uint64_t hbase = ((uint64_t)t * H + h) * S;
+        float rd1 = 0.f, rd2 = 0.f;
+        f32x4 g1[NT], g2[NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            if (k1.on) {
+                drop_mul4(k1, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d1);
+                drop_mul4(k2, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float m1 = beta * d1[e], m2 = omb * d2[e];
+                const float x1 = m1 * dp[jt][e], x2 = m2 * dp[jt][e];
+                g1[jt][e] = x1;
+                g2[jt][e] = x2;
+                pm[jt][e] = m1 * a1[jt][e] + m2 * a2[jt][e];
+                rd1 = fmaf(a1[jt][e], x1, rd1);
+                rd2 = fmaf(a2[jt][e], x2, rd2);
+            }
+        }
+        rd1 = red_q<NT>(rd1, false);
+        rd2 = red_q<NT>(rd2, false);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 rj = *(const f32x4*)(rho + 16 * jt + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const float ds1 = a1[jt][e] * (g1[jt][e] - rd1);
+                a2[jt][e] = a2[jt][e] * (g2[jt][e] - rd2);
+                *(bf16*)(iS1 + image_off<IP, ISW>(j, x * 2)) = (bf16)(ds1 * rho_x);      // meets C_i in the second half: carries 1 / |c_i|
+                a1[jt][e] = ds1 * rj[e];                                                 // meets C_j below: carries 1 / |c_j|
+            }
+        }
+    }
+    // dQ^T and the accumulator-operand half of dC^T for this query tile (two 16-column blocks at a time: one 64-byte row store)
+    f32x4 dch[CT];
+    {
+        bf16x8 b2[KS], b1[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { b2[ks] = pack_col<NT>(a2, ks); b1[ks] = pack_col<NT>(a1, ks); }
+        bf16* rowq = DX + (int64_t)x * ld;
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) {
+            f32x4 dqv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ct = 2 * cp + u;
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dc = dq;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<true>(tK, 32 * ks, 16 * ct), b2[ks], dq, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<true>(tC, 32 * ks, 16 * ct), b1[ks], dc, 0, 0, 0);
+                }
+                dqv[u] = dq * isq;
+                dch[ct] = dc;
+            }
+            store_row32(rowq + 32 * cp, dqv[0], dqv[1], q, true);
+        }
+    }
+    __syncthreads();        // every wave is done with the K and V tiles: the dS2^T and P^T images take their places
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int io = image_off<IP, ISW>(16 * jt + 4 * q + e, x * 2);
+            *(bf16*)(iS2 + io) = (bf16)a2[jt][e];
+            *(bf16*)(iP + io) = (bf16)pm[jt][e];
+        }
+    __syncthreads();
+
+    // ---- second half: rows x of the images (x as key index)
+    {
+        bf16x8 bt[KS], bp[KS], bs[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = image_off<IP, ISW>(x, (32 * ks + 8 * q) * 2);
+            bt[ks] = *(const bf16x8*)(iS1 + off);
+            bp[ks] = *(const bf16x8*)(iP + off);
+            bs[ks] = *(const bf16x8*)(iS2 + off);
+        }
+        float dt = 0.f;
+        f32x4 chv[CT];
+        bf16* rowx = DX + (int64_t)x * ld;
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) {
+            f32x4 dvv[2], dkv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ct = 2 * cp + u;
+                f32x4 dc = dch[ct], dv = {0.f, 0.f, 0.f, 0.f}, dk = dv;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<false>(tC, 32 * ks, 16 * ct), bt[ks], dc, 0, 0, 0);
+                    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<false>(tO, 32 * ks, 16 * ct), bp[ks], dv, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trf.template operator()<false>(tQ, 32 * ks, 16 * ct), bs[ks], dk, 0, 0, 0);
+                }
+                dvv[u] = dv;
+                dkv[u] = dk * isq;
+                dch[ct] = -dc;       // dN = -dS1
+                chv[ct] = load4<bf16>((const bf16*)(tC + tile_off<TP, TSW>(x, (16 * ct + 4 * q) * 2))) * rho_x;        // C^_x
+                dt += (dch[ct][0] * chv[ct][0] + dch[ct][1] * chv[ct][1]) + (dch[ct][2] * chv[ct][2] + dch[ct][3] * chv[ct][3]);
+            }
+            store_row32(rowx + 2 * d + 32 * cp, dvv[0], dvv[1], q, true);
+            store_row32(rowx + d + 32 * cp, dkv[0], dkv[1], q, true);
+        }
+        dt = red_q<NT>(dt, false);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dch[ct] = (dch[ct] - chv[ct] * dt) * rho_x;
+#pragma unroll
+        for (int cp = 0; cp < CT / 2; ++cp) store_row32(rowx + 3 * d + 32 * cp, dch[2 * cp], dch[2 * cp + 1], q, true);
+    }
+}
+
 // Forward, cooperative form: wave `it` of the NT waves of a (sequence, head) owns query tile it; the V tile is
 // shared through LDS (each wave stores its own 16 rows), everything else stays in registers.
 template <int DH, int NT, bool FULL>
@@ -1282,6 +1548,20 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
         if (shmem > 64 * 1024) PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(kern, dim3(cdiv(groups, 4)), dim3(256), shmem, st, a);
     } else {
+        if constexpr (NT == 4 && DH == 64) {
+            if (use_coop && a.S == 16 * NT && !(a.opts & OPT_NO_TILE_ATTENTION_BWD)) {
+                auto kern = attn_bwd_tiles_kernel<DH, NT>;
+                constexpr int lds = BwdSmemT<DH, NT>::BYTES;
+                static bool attr_done = false;
+                if (!attr_done) {
+                    PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                    attr_done = true;
+                }
+                hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * NT), lds, st, a);
+                PMGT_LAUNCH_OK();
+                return 0;
+            }
+        }
         if (use_coop) {
             constexpr int G = CoopCfg<NT>::G;
             const size_t shmem = (size_t)BwdSmemC<DH, NT>::BYTES * G;

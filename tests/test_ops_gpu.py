@@ -393,7 +393,39 @@ def test_attention_dropout_forward_backward_consistent():
     assert 0.01 < zero_frac < 0.1        # both branches dropped together: ~p^2
 
 
-@pytest.mark.parametrize("S,H,dh", [(32, 4, 32), (48, 2, 64), (64, 2, 32)])
+def test_attention_bwd_tile_form_matches_the_cooperative_form():
+    """S = 64 / head size 64 (the C4 / C5 shapes): the tile form (rows staged once per workgroup as LDS tiles, raw C with the
+    inverse norms folded into dS1) against the cooperative form (per-wave fragment loads, normalised C tile) on the same inputs,
+    dropout and a ragged mask on; and both against the fp32 engine kernel."""
+    _lib, L = _setup()
+    T, S, H, dh, beta, p = 7, 64, 3, 64, 0.4, 0.15
+    d = H * dh
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(T, S, 4 * d, generator=g) * 0.7).cuda()
+    dctx = torch.randn(T, S, d, generator=g).cuda()
+    mask = torch.ones(T, S)
+    for t in range(1, T):
+        mask[t, 1 + (t * 11) % S:] = 0
+    md = mask.cuda()
+    rng = torch.tensor([7, 5], dtype=torch.int64, device="cuda")
+    xb, db = x.bfloat16(), dctx.bfloat16()
+    outs = {}
+    for name, opts in (("tile", []), ("coop", ["no_tile_attention_bwd"])):
+        L.use(*opts)
+        dx = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pmgt_op_attention_bwd(1, P(xb), P(md), P(db), P(dx), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+        assert torch.isfinite(dx.float()).all()
+        outs[name] = dx.float()
+    L.use()
+    assert rel_err(outs["tile"], outs["coop"]) < 1e-2
+    ref = torch.empty(T, S, 4 * d, device="cuda")
+    _lib.check(L.pmgt_op_attention_bwd(0, P(xb.float()), P(md), P(db.float()), P(ref), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+    for k in outs:
+        for m in range(4):          # dQ, dK, dV, dC blocks separately
+            assert rel_err(outs[k][..., m * d:(m + 1) * d], ref[..., m * d:(m + 1) * d]) < 3e-2, (k, m)
+
+
+@pytest.mark.parametrize("S,H,dh", [(32, 4, 32), (48, 2, 64), (64, 2, 32), (64, 2, 64)])
 def test_attention_mfma_dropout_consistent_and_matches_valu(S, H, dh):
     """bf16 MFMA attention: (a) with dropout on, forward output and dV are consistent with the reported
     (dropped) probabilities, i.e. backward regenerates the forward masks; (b) it agrees with the generic
