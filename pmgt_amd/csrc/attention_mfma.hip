@@ -1529,11 +1529,178 @@ __global__ __launch_bounds__(CoopCfg<NT>::THREADS) void attn_fwd_coop_kernel(Att
         store_row32((bf16*)a.ctx + ((int64_t)t * S + min(x, S - 1)) * d + h * DH + 32 * cp, o[2 * cp], o[2 * cp + 1], q, live && x < Sv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward, tile form (S = 16 NT exactly; built for S = 64 / head size 64): the counterpart of attn_bwd_tiles_kernel.  The
+// workgroup reads each row of Q, K, V, C once as whole 128-byte lines (8 loads per lane instead of 22 that touch sixteen half
+// lines each), stages four LDS tiles, and the score / context products take their fragments from there.  Same arithmetic as
+// attn_fwd_coop_kernel.  LDS 32.5 KB at S = 64: four workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+template <int DH, int NT> struct FwdSmemT {
+    static constexpr int S = 16 * NT;
+    static constexpr int TILE = S * DH * 2;
+    static constexpr int BYTES = 4 * TILE + 2 * 64 * 4;
+    static_assert(NT % 2 == 0, "S a multiple of 32");
+};
+
+template <int DH, int NT>
+__global__ __launch_bounds__(64 * NT) void attn_fwd_tiles_kernel(AttnArgs a) {
+    using SM = FwdSmemT<DH, NT>;
+    constexpr int S = SM::S, KD = DH / 32, CT = DH / 16, KS = S / 32;
+    constexpr bool TSW = DH == 64;
+    constexpr int TP = DH * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int it = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int H = a.H, d = H * DH;
+    const int t = blockIdx.x / H, h = blockIdx.x % H;
+    char* tQ = smem;
+    char* tK = tQ + SM::TILE;
+    char* tV = tK + SM::TILE;
+    char* tC = tV + SM::TILE;
+    float* rho = (float*)(tC + SM::TILE);
+    float* madd = rho + 64;
+    const bf16* X = (const bf16*)a.qkvc + (int64_t)t * S * 4 * d + h * DH;
+    const int64_t ld = 4 * d;
+    const float mval = a.mask ? a.mask[(int64_t)t * S + lane] : 1.f;      // first: the memory counter retires in order
+    const int x = 16 * it + r;
+    {
+        constexpr int CPR = DH / 8, RPI = 64 / CPR, NI = 16 / RPI;
+        const int lr = lane / CPR, lc = lane % CPR;
+        bf16x8 gq[NI], gk[NI], gv[NI], gc[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bf16* px = X + (int64_t)(16 * it + RPI * i + lr) * ld + lc * 8;
+            gq[i] = *(const bf16x8*)px;
+            gk[i] = *(const bf16x8*)(px + d);
+            gv[i] = *(const bf16x8*)(px + 2 * d);
+            gc[i] = *(const bf16x8*)(px + 3 * d);
+        }
+        if ((lane >> 4) == it) madd[lane] = lane < S ? (1.f - mval) * -10000.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = 16 * it + RPI * i + lr;
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = (float)gc[i][e]; ss = fmaf(c, c, ss); }
+#pragma unroll
+            for (int m = 1; m < CPR; m <<= 1) ss += __shfl_xor(ss, m);
+            if (lc == 0) rho[row] = rsqrtf(ss);
+            const int off = tile_off<TP, TSW>(row, lc * 16);
+            *(bf16x8*)(tQ + off) = gq[i];
+            *(bf16x8*)(tK + off) = gk[i];
+            *(bf16x8*)(tV + off) = gv[i];
+            *(bf16x8*)(tC + off) = gc[i];
+        }
+    }
+    __syncthreads();
+
+    const float rho_x = rho[x];
+    f32x4 a1[NT], a2[NT];
+    {
+        bf16x8 fq[KD], fco[KD];
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const int off = tile_off<TP, TSW>(x, (32 * ks + 8 * q) * 2);
+            fq[ks] = *(const bf16x8*)(tQ + off);
+            fco[ks] = *(const bf16x8*)(tC + off);
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f}, x2 = x1;
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) {
+                const int off = tile_off<TP, TSW>(16 * jt + r, (32 * ks + 8 * q) * 2);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tC + off), fco[ks], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tK + off), fq[ks], x2, 0, 0, 0);
+            }
+            a1[jt] = x1; a2[jt] = x2;
+        }
+    }
+    {
+        const float isq = rsqrtf((float)DH);
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 mj = *(const f32x4*)(madd + 16 * jt + 4 * q), rj = *(const f32x4*)(rho + 16 * jt + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 16 * jt + 4 * q + e;
+                const float v1 = 1.f - a1[jt][e] * (rho_x * rj[e]) + (x == j ? 1.f : 0.f) + mj[e];
+                const float v2 = a2[jt][e] * isq + mj[e];
+                a1[jt][e] = v1;
+                a2[jt][e] = v2;
+                m1 = fmaxf(m1, v1);
+                m2 = fmaxf(m2, v2);
+            }
+        }
+        m1 = red_q<NT>(m1, true);
+        m2 = red_q<NT>(m2, true);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e1 = __expf(a1[jt][e] - m1);
+                const float e2 = __expf(a2[jt][e] - m2);
+                a1[jt][e] = e1;
+                a2[jt][e] = e2;
+                s1 += e1;
+                s2 += e2;
+            }
+        s1 = red_q<NT>(s1, false);
+        s2 = red_q<NT>(s2, false);
+        const float i1 = __frcp_rn(s1), i2 = __frcp_rn(s2);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) { a1[jt] *= i1; a2[jt] *= i2; }
+    }
+    {   // mix + dropout -> P^T (in a1)
+        const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
+        const float beta = a.beta, omb = 1.f - a.beta;
+        const uint64_t hbase = ((uint64_t)t * H + h) * S;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            float d1[4] = {1.f, 1.f, 1.f, 1.f}, d2[4] = {1.f, 1.f, 1.f, 1.f};
+            if (k1.on) {
+                drop_mul4(k1, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d1);
+                drop_mul4(k2, (uint32_t)(hbase + x), (uint32_t)(4 * jt + q), d2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a1[jt][e] = beta * d1[e] * a1[jt][e] + omb * d2[e] * a2[jt][e];
+            if (a.probs) *(f32x4*)(a.probs + (hbase + x) * S + 16 * jt + 4 * q) = a1[jt];
+        }
+    }
+    bf16x8 pb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) pb[ks] = pack_col<NT>(a1, ks);
+    f32x4 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 fa;
+            if constexpr (TSW) fa = tr_frag_swz<DH, true>(tV, 32 * ks, 16 * ct, r, q);
+            else fa = tr_frag<DH, true>(tV, 32 * ks, 16 * ct, r, q);
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, pb[ks], o[ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int cp = 0; cp < CT / 2; ++cp)
+        store_row32((bf16*)a.ctx + ((int64_t)t * S + x) * d + h * DH + 32 * cp, o[2 * cp], o[2 * cp + 1], q, true);
+}
+
 template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
     const int groups = a.Tseq * a.H;
     // NT cooperating waves per (sequence, head) everywhere except S in 17..32 with head size 32, where the
     // one-wave form measures faster (464 vs 555 us backward at 98k pairs: the shared loads outweigh the occupancy)
     const bool use_coop = !(a.opts & OPT_WAVE_ATTENTION_BWD) && !(NT == 2 && DH == 32);
+    if constexpr (NT == 4 && DH == 64) {
+        if (!bwd && use_coop && a.S == 16 * NT && !(a.opts & OPT_NO_TILE_ATTENTION)) {
+            constexpr int lds = FwdSmemT<DH, NT>::BYTES;
+            hipLaunchKernelGGL((attn_fwd_tiles_kernel<DH, NT>), dim3(groups), dim3(64 * NT), lds, st, a);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
+    }
     if (!bwd && use_coop) {
         constexpr int G = CoopCfg<NT>::G;
         const size_t shmem = (size_t)FwdSmem<DH, NT>::BYTES * G;
@@ -1549,7 +1716,7 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
         hipLaunchKernelGGL(kern, dim3(cdiv(groups, 4)), dim3(256), shmem, st, a);
     } else {
         if constexpr (NT == 4 && DH == 64) {
-            if (use_coop && a.S == 16 * NT && !(a.opts & OPT_NO_TILE_ATTENTION_BWD)) {
+            if (use_coop && a.S == 16 * NT && !(a.opts & OPT_NO_TILE_ATTENTION)) {
                 auto kern = attn_bwd_tiles_kernel<DH, NT>;
                 constexpr int lds = BwdSmemT<DH, NT>::BYTES;
                 static bool attr_done = false;

@@ -1452,7 +1452,7 @@ static_assert(PMGT_OPT_TILE_GEMM == OPT_TILE_GEMM && PMGT_OPT_VALU_ATTENTION == 
               PMGT_OPT_NO_SHORTCUT == OPT_NO_SHORTCUT && PMGT_OPT_NO_FUSED_QKVC_ATTENTION == OPT_NO_FUSED_QKVC_ATTENTION && PMGT_OPT_NO_HEAD_MAJOR == OPT_NO_HEAD_MAJOR &&
               PMGT_OPT_NO_TABLE_PROJECTION == OPT_NO_TABLE_PROJECTION && PMGT_OPT_NO_SEGMENT_SUM == OPT_NO_SEGMENT_SUM && PMGT_OPT_CONSUMER_QUANT == OPT_CONSUMER_QUANT &&
               PMGT_OPT_NO_FUSED_ATTENTION_BWD == OPT_NO_FUSED_ATTENTION_BWD && PMGT_OPT_STORE_LN_INPUT == OPT_STORE_LN_INPUT && PMGT_OPT_EAGER_REDUCE == OPT_EAGER_REDUCE &&
-              PMGT_OPT_SIDE_STREAM_REDUCE == OPT_SIDE_STREAM_REDUCE && PMGT_OPT_UNFUSED_LN == OPT_UNFUSED_LN && PMGT_OPT_ONE_BUCKET == OPT_ONE_BUCKET && PMGT_OPT_SMALL_ARENA == OPT_SMALL_ARENA && PMGT_OPT_NO_ROLE_SPLIT_LN == OPT_NO_ROLE_SPLIT_LN && PMGT_OPT_NO_TILE_ATTENTION_BWD == OPT_NO_TILE_ATTENTION_BWD,
+              PMGT_OPT_SIDE_STREAM_REDUCE == OPT_SIDE_STREAM_REDUCE && PMGT_OPT_UNFUSED_LN == OPT_UNFUSED_LN && PMGT_OPT_ONE_BUCKET == OPT_ONE_BUCKET && PMGT_OPT_SMALL_ARENA == OPT_SMALL_ARENA && PMGT_OPT_NO_ROLE_SPLIT_LN == OPT_NO_ROLE_SPLIT_LN && PMGT_OPT_NO_TILE_ATTENTION == OPT_NO_TILE_ATTENTION,
               "include/pmgt_ops.h and csrc/common.h disagree on the option bits");
 static uint32_t option_bit(const char* key) {
     static const struct { const char* name; uint32_t bit; } tab[] = {
@@ -1460,7 +1460,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention_bwd", OPT_NO_TILE_ATTENTION_BWD}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;

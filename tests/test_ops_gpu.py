@@ -393,7 +393,7 @@ def test_attention_dropout_forward_backward_consistent():
     assert 0.01 < zero_frac < 0.1        # both branches dropped together: ~p^2
 
 
-def test_attention_bwd_tile_form_matches_the_cooperative_form():
+def test_attention_tile_forms_match_the_cooperative_forms():
     """S = 64 / head size 64 (the C4 / C5 shapes): the tile form (rows staged once per workgroup as LDS tiles, raw C with the
     inverse norms folded into dS1) against the cooperative form (per-wave fragment loads, normalised C tile) on the same inputs,
     dropout and a ragged mask on; and both against the fp32 engine kernel."""
@@ -410,7 +410,7 @@ def test_attention_bwd_tile_form_matches_the_cooperative_form():
     rng = torch.tensor([7, 5], dtype=torch.int64, device="cuda")
     xb, db = x.bfloat16(), dctx.bfloat16()
     outs = {}
-    for name, opts in (("tile", []), ("coop", ["no_tile_attention_bwd"])):
+    for name, opts in (("tile", []), ("coop", ["no_tile_attention"])):
         L.use(*opts)
         dx = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
         _lib.check(L.pmgt_op_attention_bwd(1, P(xb), P(md), P(db), P(dx), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
@@ -423,6 +423,21 @@ def test_attention_bwd_tile_form_matches_the_cooperative_form():
     for k in outs:
         for m in range(4):          # dQ, dK, dV, dC blocks separately
             assert rel_err(outs[k][..., m * d:(m + 1) * d], ref[..., m * d:(m + 1) * d]) < 3e-2, (k, m)
+    # forward: tile form against the cooperative form and the fp32 kernel, probabilities included
+    fo = {}
+    for name, opts in (("tile", []), ("coop", ["no_tile_attention"])):
+        L.use(*opts)
+        ctx = torch.full((T, S, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+        probs = torch.full((T, H, S, S), float("nan"), device="cuda")
+        _lib.check(L.pmgt_op_attention_fwd(1, P(xb), P(md), P(ctx), P(probs), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+        fo[name] = (ctx.float(), probs)
+    L.use()
+    assert rel_err(fo["tile"][0], fo["coop"][0]) < 1e-2 and rel_err(fo["tile"][1], fo["coop"][1]) < 1e-2
+    ctx32 = torch.empty(T, S, d, device="cuda")
+    probs32 = torch.empty(T, H, S, S, device="cuda")
+    _lib.check(L.pmgt_op_attention_fwd(0, P(xb.float()), P(md), P(ctx32), P(probs32), T, S, H, dh, beta, p, 11, 12, P(rng), stream()))
+    for k in fo:
+        assert rel_err(fo[k][0], ctx32) < 2e-2 and rel_err(fo[k][1], probs32) < 2e-2, k
 
 
 @pytest.mark.parametrize("S,H,dh", [(32, 4, 32), (48, 2, 64), (64, 2, 32), (64, 2, 64)])
