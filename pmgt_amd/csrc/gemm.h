@@ -46,6 +46,9 @@ int gemm_ws(const GemmWS& g, hipStream_t st);
 // 16-wave role-split form of the residual + LayerNorm mode at K = N = 256 (gemm_wsr.hip); gemm_ws dispatches to it
 bool gemm_wsr_ok(const GemmWS& g);
 int gemm_wsr(const GemmWS& g, hipStream_t st);
+// 12-wave role-split form of the plain / GELU / GELU' / residual modes at K = 512 (gemm_wsr.hip); gemm_ws dispatches to it
+bool gemm_wsr512_ok(const GemmWS& g);
+int gemm_wsr512(const GemmWS& g, hipStream_t st);
 
 // Partial weight gradients: slab[s][N1,N2] = sum over the s-th chunk of rows m of P[m,n1]*Q[m,n2]
 // ("TN": the reduction index is the row).  `slab_reduce` then sums the slabs in a fixed order.

@@ -433,6 +433,7 @@ int gemm_ws(const GemmWS& g, hipStream_t st) {
     PMGT_CHECK(gemm_ws_supported(g), -2, "gemm_ws: unsupported shape/epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
     PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0, -2, "gemm_ws: unaligned operands");
     if (ws_mode(g) == WS_RES_LN && gemm_wsr_ok(g)) return gemm_wsr(g, st);
+    if (ws_mode(g) != WS_RES_LN && gemm_wsr512_ok(g)) return gemm_wsr512(g, st);
     switch (g.K) {
         case 64: return launch_mode<2>(g, st);
         case 128: return launch_mode<4>(g, st);

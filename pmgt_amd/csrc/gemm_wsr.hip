@@ -241,4 +241,238 @@ int gemm_wsr(const GemmWS& g, hipStream_t st) {
     return 0;
 }
 
+
+// ================================================================================================
+// Role-split weight-stationary GEMM for K = 512 (the d = 512 shapes: Q|K|V|C projection, attention output, FFN1 / FFN2 and
+// their data gradients), epilogues: bias | bias + GELU (pre-activation kept) | GELU' of a saved pre-activation | bias + dropout +
+// residual.  gemm_ws_kernel<16, MODE> keeps a 256-column slab of W in 128 VGPRs per wave and alternates, in lockstep between
+// barriers, an MFMA phase (~4 800 cycles per 64-row tile) and an epilogue phase (~4 000) with the LDS-DMA of the next tile exposed
+// in between (in-kernel stamps: 10 000 cycles per tile, matrix pipe 37 - 41 % busy).  Here TWELVE waves per CU split the roles:
+//   waves 0-7  (GEMM role):     W columns 32 g .. 32 g + 31 of the slab in 128 VGPRs; the 32-row A tile of step t + 1 travels by LDS-DMA
+//                               (one 1-KB row per instruction, four per wave) while step t runs its 64 MFMAs per wave; the fp32 result
+//                               goes to staging buffer t & 1;
+//   waves 8-11 (epilogue role): the epilogue of step t - 1 from staging buffer (t - 1) & 1 (32 lanes per row, four passes of 8
+//                               rows), its operand (residual / pre-activation) prefetched a step ahead.
+// Three waves per SIMD leave 168 VGPRs each: the GEMM role fits with 32-row tiles (16 accumulator registers), which is also what
+// lets two A tiles and two staging buffers share the LDS (64 + 66.5 KB).  One s_barrier per step.  Same arithmetic per element in
+// the same order as gemm_ws_kernel<16, MODE> (bit-identical results).
+// ================================================================================================
+enum { W5_PLAIN = 0, W5_GELU = 1, W5_GELU_GRAD = 2, W5_RES = 3 };
+
+struct Wsr5Cfg {
+    static constexpr int TR = 32, ROWB = 1024, TILEB = TR * ROWB, NR = 2, ES = 256 + 4, STG = TR * ES * 4;
+    static constexpr int SMEM = NR * TILEB + 2 * STG;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_wsr512_kernel(GemmWS g) {
+    using C = Wsr5Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> (row-range slot x, column slab y); the slabs of one x sit on one XCD (ids b, b + 8, ...): their A re-reads hit its L2
+    const int ny = g.N / 256;
+    const int b = blockIdx.x;
+    const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
+    const int gx = gridDim.x / ny;
+    const int nb = y * 256;
+    const int num_mt = (g.M + C::TR - 1) / C::TR;
+    const int n = x < num_mt ? (num_mt - x + gx - 1) / gx : 0;      // steps of this workgroup: tiles x, x + gx, ...
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_wsr_t*)smem;
+    const uint32_t stg0 = lds0 + C::NR * C::TILEB;
+
+    if (wave < 8) {
+        // ================================================================ GEMM role
+        const int gw = wave, r = lane & 15, q = lane >> 4;
+        bf16x8 wf[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                wf[j][ks] = *(const bf16x8*)((const bf16*)g.B + (int64_t)(nb + 32 * gw + 16 * j + r) * g.ldb + 32 * ks + 8 * q);
+        // LDS-DMA of one A tile: wave gw moves rows 4 gw .. 4 gw + 3, one 1-KB row per instruction; LDS chunk slot `lane` of a row
+        // takes source chunk lane ^ (row & 15)
+        // (the per-lane part of the four source addresses is ONE register, lane ^ (4 gw & 15), XORed with p at the point of use: the
+        // compiler otherwise keeps four 64-bit addresses alive across the loop, spills them next to the 128 registers of W, and every
+        // reload waits with vmcnt(0) -- for the previous DMA)
+        const uint32_t l0 = (uint32_t)(lane ^ ((4 * gw) & 15));
+        auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+            const int mt = x + t * gx;
+            uint32_t lv = l0;
+            asm volatile("" : "+v"(lv));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = 4 * gw + p;
+                const int m = min(mt * C::TR + row, g.M - 1);
+                const char* rowp = (const char*)g.A + (int64_t)m * g.lda * 2;      // (wave-uniform)
+                const char* src = rowp + ((lv ^ (uint32_t)p) << 4);
+                __builtin_amdgcn_global_load_lds((gbl_void_wsr_t*)src, (lds_void_wsr_t*)(smem + slot * C::TILEB + row * C::ROWB), 16, 0, 0);
+            }
+        };
+        // fragment address of k-step 0 in row tile 0: row r, chunk slot q ^ r; k-step ks = XOR (ks << 6); row tile 1 = + 16 rows
+        const uint32_t fr0 = (uint32_t)(r * C::ROWB + ((q ^ r) << 4));
+        // staging address of acc[0][0][0]: row 4 q, column 32 gw + r
+        const uint32_t sw0 = (uint32_t)((4 * q * C::ES + 32 * gw + r) * 4);
+        if (0 < n) dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // W fragments and tile 0
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it <= n; ++it) {
+            if (it < n) {
+                if (it + 1 < n) dma(it + 1, (it + 1) & 1);      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
+                const uint32_t ab = lds0 + (uint32_t)((it & 1) * C::TILEB);
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    u32x4 fa[2];
+                    uint32_t f0 = fr0;
+                    asm volatile("" : "+v"(f0));                               // recomputed per k-step, not sixteen addresses kept in registers
+                    const uint32_t ad = (f0 ^ (uint32_t)(ks << 6)) + ab;       // XOR inside the row, then the tile base
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16384\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fa[0]), "=&v"(fa[1]) : "v"(ad) : "memory");
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), wf[j][ks], acc[i][j], 0, 0, 0);
+                }
+                // (inline-asm staging writes: the hazard recogniser does not put the wait states between an MFMA and an LDS instruction
+                // that reads its result there; the s_nop is tied to the four accumulator tiles)
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+                const uint32_t sb = stg0 + (uint32_t)((it & 1) * C::STG) + sw0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t ad = sb + (uint32_t)(((16 * i + e) * C::ES + 16 * j) * 4);
+                            asm volatile("ds_write_b32 %0, %1" :: "v"(ad), "v"(acc[i][j][e]) : "memory");
+                        }
+                // staging tile in LDS and the A tile of step it + 1 landed (for this wave) before the barrier
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // ==================================================================== epilogue role: 256 threads, 32 lanes per row, 8 rows per pass
+    const int te = tid - 512;
+    const int erow = te >> 5, ecol = (te & 31) * 8;
+    const DropKey dk = make_drop_key(g.drop);
+    bf16* Cp = (bf16*)g.C;
+    bf16* AUX = (bf16*)g.aux;
+    const bf16* PF = (MODE == W5_GELU_GRAD) ? (const bf16*)g.aux : (const bf16*)g.res;      // prefetched epilogue operand
+    const int64_t ldpf = (MODE == W5_GELU_GRAD) ? g.ldaux : g.ldr;
+    constexpr bool HAS_PF = MODE == W5_GELU_GRAD || MODE == W5_RES;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = g.bias ? g.bias[nb + ecol + e] : 0.f;
+    bf16x8 pf[4];
+    auto load_pf = [&](int t) __attribute__((always_inline)) {
+        const int mt = x + t * gx;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = min(mt * C::TR + erow + 8 * ps, g.M - 1);
+            pf[ps] = *(const bf16x8*)(PF + (int64_t)m * ldpf + nb + ecol);
+        }
+    };
+    if constexpr (HAS_PF) { if (0 < n) load_pf(0); }
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it <= n; ++it) {
+        if (it >= 1) {
+            const int tt = it - 1, mt = x + tt * gx;
+            const float* stage = (const float*)(smem + C::NR * C::TILEB + (tt & 1) * C::STG);
+            bf16x8 rv[4];
+            if constexpr (HAS_PF) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) rv[ps] = pf[ps];
+                if (tt + 1 < n) load_pf(tt + 1);      // the next step's operand rows travel under this step's arithmetic
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = erow + 8 * ps;
+                const int m = mt * C::TR + row;
+                const int ncol = nb + ecol;
+                if (m < g.M) {
+                    float v[8];
+                    const f32x4 s0 = *(const f32x4*)(stage + row * C::ES + ecol), s1 = *(const f32x4*)(stage + row * C::ES + ecol + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias[e];
+                    if constexpr (MODE == W5_GELU) {
+                        bf16x8 pre;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { pre[e] = (bf16)v[e]; v[e] = gelu_fast((float)pre[e]); }
+                        *(bf16x8*)(AUX + (int64_t)m * g.ldaux + ncol) = pre;
+                    } else if constexpr (MODE == W5_GELU_GRAD) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)rv[ps][e]);
+                    }
+                    if (MODE == W5_RES && dk.on) {
+                        float d0[4], d1[4];
+                        drop_mul4(dk, (uint32_t)m, (uint32_t)ncol >> 2, d0);
+                        drop_mul4(dk, (uint32_t)m, ((uint32_t)ncol >> 2) + 1, d1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] *= d0[e]; v[4 + e] *= d1[e]; }
+                    }
+                    if constexpr (MODE == W5_RES) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[ps][e];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                    *(bf16x8*)(Cp + (int64_t)m * g.ldc + ncol) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+static int wsr5_mode(const GemmWS& g) {
+    const bool drop = g.drop.p > 0.f;
+    if (g.epi == EPI_NONE && !g.res && !drop) return W5_PLAIN;
+    if (g.epi == EPI_GELU && !g.res && !drop) return W5_GELU;
+    if (g.epi == EPI_GELU_GRAD && !g.res && !drop) return W5_GELU_GRAD;
+    if (g.epi == EPI_NONE && g.res) return W5_RES;
+    return -1;
+}
+
+bool gemm_wsr512_ok(const GemmWS& g) {
+    const int mode = wsr5_mode(g);
+    return mode >= 0 && !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN)) && g.K == 512 && g.N % 256 == 0 && g.N >= 256 && g.M >= 8192 && g.a_rows == nullptr && g.m_dev == nullptr &&
+           g.q8 == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) && (g.aux == nullptr || g.ldaux % 8 == 0) &&
+           ((mode != W5_GELU && mode != W5_GELU_GRAD) || g.aux != nullptr) &&
+           ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 && ((uintptr_t)g.aux % 16) == 0;
+}
+
+template <int MODE> static int launch_wsr512(const GemmWS& g, hipStream_t st) {
+    auto kern = gemm_wsr512_kernel<MODE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Wsr5Cfg::SMEM));
+        attr_done = true;
+    }
+    const int ny = g.N / 256, num_mt = cdiv(g.M, Wsr5Cfg::TR);
+    const int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, one 12-wave workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(768), Wsr5Cfg::SMEM, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+int gemm_wsr512(const GemmWS& g, hipStream_t st) {
+    PMGT_CHECK(gemm_wsr512_ok(g), -2, "gemm_wsr512: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
+    switch (wsr5_mode(g)) {
+        case W5_PLAIN: return launch_wsr512<W5_PLAIN>(g, st);
+        case W5_GELU: return launch_wsr512<W5_GELU>(g, st);
+        case W5_GELU_GRAD: return launch_wsr512<W5_GELU_GRAD>(g, st);
+        default: return launch_wsr512<W5_RES>(g, st);
+    }
+}
+
 }  // namespace pmgt

@@ -511,6 +511,40 @@ def test_role_split_layernorm_gemm_is_bit_identical_to_the_streaming_kernel(M, d
         assert rel_err(outs[0][1], ref) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,epi,res,drop", [(9001, 512, 0, False, 0.0), (8192, 2048, 0, False, 0.0), (20000, 512, 1, False, 0.0),
+                                              (12345, 512, 2, False, 0.0), (9001, 512, 0, True, 0.1), (16384, 1024, 0, True, 0.0)])
+def test_role_split_k512_gemm_is_bit_identical_to_the_lockstep_kernel(M, N, epi, res, drop):
+    """K = 512 (the d = 512 shapes) from 8 192 rows on: the 12-wave role-split kernel (gemm_wsr512_kernel: 8 GEMM waves + 4 epilogue
+    waves, 32-row tiles) against gemm_ws_kernel<16, MODE> (option no_role_split_ln) -- same arithmetic per element in the same
+    order, so the outputs must be EQUAL, ragged last tile and dropout masks included; and against torch for the plain mode."""
+    _lib, L = _setup()
+    K = 512
+    g = torch.Generator().manual_seed(M + N + epi)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.1).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda().bfloat16() if res else None
+    aux_in = torch.randn(M, N, generator=g).cuda().bfloat16()
+    rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
+    outs = []
+    for opts in ((), ("no_role_split_ln",)):
+        L.use(*opts)
+        Cd = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        aux = aux_in.clone() if epi == 2 else torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pmgt_op_linear(1, P(A), K, P(W), K, P(Cd), N, M, N, K, P(bias), epi, P(aux) if epi else None, N,
+                                    P(R), N, drop, 33, P(rng), None, None, None, None, 1e-12, stream()))
+        torch.cuda.synchronize()
+        outs.append((Cd, aux))
+    L.use()
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epi == 1:
+        assert torch.isfinite(outs[0][1].float()).all() and torch.equal(outs[0][1], outs[1][1])
+    if epi == 0 and drop == 0.0:
+        ref = A.double().cpu() @ W.double().cpu().T + bias.double().cpu() + (R.double().cpu() if res else 0.0)
+        assert rel_err(outs[0][0], ref) < 1e-2
+
+
 @pytest.mark.parametrize("M,N,K,epi,res,drop,ln", [
     (4096, 256, 256, 0, True, 0.1, True),      # attn-out / FFN2 shape: dropout + residual + fused LayerNorm
     (1000, 256, 256, 1, False, 0.0, False),    # FFN1: GELU + pre-activation store, ragged M

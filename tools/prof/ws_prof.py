@@ -1,4 +1,5 @@
-"""Cycles per tile phase of gemm_ws_kernel (library built with -DPMGT_WS_PROF).  argv[1]: mode 0 plain, 1 gelu, 2 gelu', 3 res+drop, 4 res+drop+LN"""
+"""Cycles per tile phase of gemm_ws_kernel (library built with -DPMGT_WS_PROF).  argv[1]: mode 0 plain, 1 gelu, 2 gelu', 3 res+drop, 4 res+drop+LN;
+argv[2:5]: M N K (default 393216 256 256)"""
 import ctypes as C, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -6,7 +7,7 @@ from pmgt_amd import _lib
 L = _lib.ops()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-M, N, K = 12 * 1024 * 32, 256, 256
+M, N, K = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (12 * 1024 * 32, 256, 256)
 NS = 4
 As = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(NS)]
 W = torch.randn(N, K, device="cuda").bfloat16()
@@ -16,6 +17,7 @@ Xs = [torch.randn(M, N, device="cuda").bfloat16() for _ in range(NS)]
 lnos = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(NS)]
 stats = torch.empty(M, 2, device="cuda")
 g = torch.ones(N, device="cuda")
+if mode == 4: assert N == 256
 bias = torch.zeros(N, device="cuda")
 rng = torch.tensor([1, 2], dtype=torch.int64, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
