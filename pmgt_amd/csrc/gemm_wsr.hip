@@ -258,6 +258,14 @@ int gemm_wsr(const GemmWS& g, hipStream_t st) {
 // the same order as gemm_ws_kernel<16, MODE> (bit-identical results).
 // ================================================================================================
 enum { W5_PLAIN = 0, W5_GELU = 1, W5_GELU_GRAD = 2, W5_RES = 3 };
+#ifdef PMGT_W5_PROF
+// cycles per step of workgroup 40: [wave][interval] (GEMM role: DMA issue | fragments + MFMA | staging + waits | barrier; epilogue role:
+// work | barrier), slot 7 = steps
+__device__ unsigned long long g_w5_prof[12][8];
+#define W5_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc[k_] += n_ - plast; plast = n_; } while (0)
+#else
+#define W5_STAMP(k_) do { } while (0)
+#endif
 
 struct Wsr5Cfg {
     static constexpr int TR = 32, ROWB = 1024, TILEB = TR * ROWB, NR = 2, ES = 256 + 4, STG = TR * ES * 4;
@@ -280,6 +288,37 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int n = x < num_mt ? (num_mt - x + gx - 1) / gx : 0;      // steps of this workgroup: tiles x, x + gx, ...
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_wsr_t*)smem;
     const uint32_t stg0 = lds0 + C::NR * C::TILEB;
+#ifdef PMGT_W5_PROF
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long plast = 0;
+#endif
+
+    // Who moves the A tiles.  The plain epilogue leaves its four waves idle for 40 % of a step (in-kernel stamps: 2 050 cycles of
+    // work against 3 550 on the GEMM role's critical path, 400 - 650 of which are the issue of its four DMA pieces): there the EPILOGUE
+    // role issues the LDS-DMA of step t + 1 (eight rows per wave) and waits for it before the barrier.  The other epilogues are the
+    // longer role themselves (4 000 - 4 900 cycles: dropout / GELU arithmetic on four waves) and leave the DMA to the GEMM role.
+    constexpr bool EPI_DMA = MODE == W5_PLAIN;
+    constexpr int DR = EPI_DMA ? 8 : 4;                     // rows per DMA-issuing wave
+    const int dw = EPI_DMA ? wave - 8 : wave;              // its index among them
+    // LDS-DMA of one A tile: wave dw moves rows DR dw .. DR dw + DR - 1, one 1-KB row per instruction; LDS chunk slot `lane` of a row
+    // takes source chunk lane ^ (row & 15)
+    // (the per-lane part of the source addresses is ONE register, lane ^ (DR dw & 15), XORed with p at the point of use: the
+    // compiler otherwise keeps 64-bit addresses alive across the loop, spills them next to the 128 registers of W, and every
+    // reload waits with vmcnt(0) -- for the previous DMA)
+    const uint32_t l0 = (uint32_t)(lane ^ ((DR * dw) & 15));
+    auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+        const int mt = x + t * gx;
+        uint32_t lv = l0;
+        asm volatile("" : "+v"(lv));
+#pragma unroll
+        for (int p = 0; p < DR; ++p) {
+            const int row = DR * dw + p;
+            const int m = min(mt * C::TR + row, g.M - 1);
+            const char* rowp = (const char*)g.A + (int64_t)m * g.lda * 2;      // (wave-uniform)
+            const char* src = rowp + ((lv ^ (uint32_t)p) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_void_wsr_t*)src, (lds_void_wsr_t*)(smem + slot * C::TILEB + row * C::ROWB), 16, 0, 0);
+        }
+    };
 
     if (wave < 8) {
         // ================================================================ GEMM role
@@ -290,57 +329,52 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
                 wf[j][ks] = *(const bf16x8*)((const bf16*)g.B + (int64_t)(nb + 32 * gw + 16 * j + r) * g.ldb + 32 * ks + 8 * q);
-        // LDS-DMA of one A tile: wave gw moves rows 4 gw .. 4 gw + 3, one 1-KB row per instruction; LDS chunk slot `lane` of a row
-        // takes source chunk lane ^ (row & 15)
-        // (the per-lane part of the four source addresses is ONE register, lane ^ (4 gw & 15), XORed with p at the point of use: the
-        // compiler otherwise keeps four 64-bit addresses alive across the loop, spills them next to the 128 registers of W, and every
-        // reload waits with vmcnt(0) -- for the previous DMA)
-        const uint32_t l0 = (uint32_t)(lane ^ ((4 * gw) & 15));
-        auto dma = [&](int t, int slot) __attribute__((always_inline)) {
-            const int mt = x + t * gx;
-            uint32_t lv = l0;
-            asm volatile("" : "+v"(lv));
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int row = 4 * gw + p;
-                const int m = min(mt * C::TR + row, g.M - 1);
-                const char* rowp = (const char*)g.A + (int64_t)m * g.lda * 2;      // (wave-uniform)
-                const char* src = rowp + ((lv ^ (uint32_t)p) << 4);
-                __builtin_amdgcn_global_load_lds((gbl_void_wsr_t*)src, (lds_void_wsr_t*)(smem + slot * C::TILEB + row * C::ROWB), 16, 0, 0);
-            }
-        };
         // fragment address of k-step 0 in row tile 0: row r, chunk slot q ^ r; k-step ks = XOR (ks << 6); row tile 1 = + 16 rows
         const uint32_t fr0 = (uint32_t)(r * C::ROWB + ((q ^ r) << 4));
         // staging address of acc[0][0][0]: row 4 q, column 32 gw + r
         const uint32_t sw0 = (uint32_t)((4 * q * C::ES + 32 * gw + r) * 4);
-        if (0 < n) dma(0, 0);
+        if constexpr (!EPI_DMA) { if (0 < n) dma(0, 0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // W fragments and tile 0
         __builtin_amdgcn_s_barrier();
+#ifdef PMGT_W5_PROF
+        plast = __builtin_readcyclecounter();
+#endif
         for (int it = 0; it <= n; ++it) {
             if (it < n) {
-                if (it + 1 < n) dma(it + 1, (it + 1) & 1);      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
+                if constexpr (!EPI_DMA) { if (it + 1 < n) dma(it + 1, (it + 1) & 1); }      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
+                W5_STAMP(0);
                 const uint32_t ab = lds0 + (uint32_t)((it & 1) * C::TILEB);
                 f32x4 acc[2][2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    u32x4 fa[2];
+                u32x4 fa[2][2];      // [k-step parity][row tile]: the reads of k-step ks + 1 travel under the MFMAs of k-step ks
+                auto rd = [&](int ks) __attribute__((always_inline)) {
                     uint32_t f0 = fr0;
                     asm volatile("" : "+v"(f0));                               // recomputed per k-step, not sixteen addresses kept in registers
                     const uint32_t ad = (f0 ^ (uint32_t)(ks << 6)) + ab;       // XOR inside the row, then the tile base
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16384\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fa[0]), "=&v"(fa[1]) : "v"(ad) : "memory");
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16384" : "=&v"(fa[ks & 1][0]), "=&v"(fa[ks & 1][1]) : "v"(ad) : "memory");
+                };
+                rd(0);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    if (ks + 1 < 16) {
+                        rd(ks + 1);
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[ks & 1][0]), "+v"(fa[ks & 1][1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks & 1][0]), "+v"(fa[ks & 1][1]));
+                    }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), wf[j][ks], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][i]), wf[j][ks], acc[i][j], 0, 0, 0);
                 }
                 // (inline-asm staging writes: the hazard recogniser does not put the wait states between an MFMA and an LDS instruction
                 // that reads its result there; the s_nop is tied to the four accumulator tiles)
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+                W5_STAMP(1);
                 const uint32_t sb = stg0 + (uint32_t)((it & 1) * C::STG) + sw0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -353,9 +387,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         }
                 // staging tile in LDS and the A tile of step it + 1 landed (for this wave) before the barrier
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                W5_STAMP(2);
             }
             __builtin_amdgcn_s_barrier();
+            W5_STAMP(3);
         }
+#ifdef PMGT_W5_PROF
+        if (blockIdx.x == 40 && lane == 0) { for (int k_ = 0; k_ < 4; ++k_) g_w5_prof[wave][k_] = pacc[k_]; g_w5_prof[wave][7] = (unsigned long long)n; }
+#endif
         return;
     }
     // ==================================================================== epilogue role: 256 threads, 32 lanes per row, 8 rows per pass
@@ -380,10 +419,20 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     };
     if constexpr (HAS_PF) { if (0 < n) load_pf(0); }
+    if constexpr (EPI_DMA) {
+        if (0 < n) dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
+#ifdef PMGT_W5_PROF
+    plast = __builtin_readcyclecounter();
+#endif
     for (int it = 0; it <= n; ++it) {
+        if constexpr (EPI_DMA) { if (it + 1 < n) dma(it + 1, (it + 1) & 1); }      // first in the step: the stores below are younger
+        bool full_tile = false;
         if (it >= 1) {
             const int tt = it - 1, mt = x + tt * gx;
+            full_tile = mt * C::TR + C::TR <= g.M;
             const float* stage = (const float*)(smem + C::NR * C::TILEB + (tt & 1) * C::STG);
             bf16x8 rv[4];
             if constexpr (HAS_PF) {
@@ -430,8 +479,19 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
             }
         }
+        if constexpr (EPI_DMA) {
+            // the tile of step it + 1 has landed for this wave: the counter retires in order, and the four row stores of a FULL tile
+            // (every pass stores, for every lane) were issued after the DMA pieces -- they may stay in flight
+            if (full_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        W5_STAMP(0);
         __builtin_amdgcn_s_barrier();
+        W5_STAMP(1);
     }
+#ifdef PMGT_W5_PROF
+    if (blockIdx.x == 40 && lane == 0) { for (int k_ = 0; k_ < 2; ++k_) g_w5_prof[wave][k_] = pacc[k_]; g_w5_prof[wave][7] = (unsigned long long)n; }
+#endif
 }
 
 static int wsr5_mode(const GemmWS& g) {
@@ -476,3 +536,9 @@ int gemm_wsr512(const GemmWS& g, hipStream_t st) {
 }
 
 }  // namespace pmgt
+
+#ifdef PMGT_W5_PROF
+extern "C" int pmgt_debug_w5_prof_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_w5_prof), sizeof(pmgt::g_w5_prof));
+}
+#endif
