@@ -197,6 +197,17 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
     p = fmaf(p, t2, 3.186886549e+00f);
     return fmaf(p, t, 0.5f);
 }
+// bf16 mode: tanh(x) = 1 - 2 / (e^(2x) + 1) on the exp2 / rcp units (5 VALU operations, absolute error ~1e-7: far below the bf16
+// rounding of what it feeds) instead of libm's tanhf (~40 with two divergent branches): the modality-mix kernels evaluate it on every
+// element of every projected feature row and were VALU-bound on it in token mode (d = 512: 308 us forward for 0.8 GB).  The fp32
+// parity mode keeps tanhf.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+template <typename T> __device__ __forceinline__ float tanh_act(float x) {
+    if constexpr (sizeof(T) == 2) return tanh_fast(x); else return tanhf(x);
+}
 template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
     if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
 }

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
                 for (int f = 0; f < NF; ++f) {
                     ev[f][i] = load4<T>(E + f * d + 4 * ch);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) tv[f][e] = tanhf(ev[f][i][e]);
+                    for (int e = 0; e < 4; ++e) tv[f][e] = tanh_act<T>(ev[f][i][e]);
                 }
 #pragma unroll
                 for (int k = 0; k < NF; ++k) {
@@ -508,6 +508,18 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
         const int m = blockIdx.x * rpb + it * 4 + wave;
         if (m >= p.M) break;
         f32x4 df[NCH];
+        // the projected feature rows of token / node m: requested FIRST, so that they travel together with the LayerNorm operands
+        // instead of after the two reductions that depend on those (one memory round trip per row instead of two)
+        f32x4 ev[NW][NCH];
+        if constexpr (PHASE != 2) {
+            const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * NF * d;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = lane + 64 * i;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) ev[f][i] = ch < nch ? load4<T>(E + f * d + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
         if (PHASE != 1) {     // LayerNorm backward of token m -> df (gradient wrt the pre-LN sum)
             const float mean = p.stats[2 * (int64_t)m], rstd = p.stats[2 * (int64_t)m + 1];
             f32x4 g[NCH], xh[NCH];
@@ -557,22 +569,14 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
         if constexpr (PHASE != 2) {      // (token phase of the table mode: the mix is differentiated per node)
             // through f = sum_k a_k e_k
             float a[NF], da[NF];
-            f32x4 ev[NF][NCH];
-            const T* E = (const T*)p.E + (p.e_rows ? p.e_rows[m] : (int64_t)m) * NF * d;
 #pragma unroll
             for (int f = 0; f < NF; ++f) { a[f] = p.a[NF * (int64_t)m + f]; da[f] = 0.f; }
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int ch = lane + 64 * i;
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    if (ch < nch) {
-                        ev[f][i] = load4<T>(E + f * d + 4 * ch);
-                        da[f] += sum4(df[i] * ev[f][i]);
-                    } else {
-                        ev[f][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                }
+                for (int f = 0; f < NF; ++f)
+                    if (ch < nch) da[f] += sum4(df[i] * ev[f][i]);
             }
             float dot = 0.f;
 #pragma unroll
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(256) void embed_mix_bwd_kernel(EmbedMix p) {
                     for (int f = 0; f < NF; ++f) {
                         f32x4 tv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) tv[e] = tanhf(ev[f][i][e]);
+                        for (int e = 0; e < 4; ++e) tv[e] = tanh_act<T>(ev[f][i][e]);
                         f32x4 back = wa[0][f][i] * dz[0];
 #pragma unroll
                         for (int k = 0; k < NF; ++k) {
