@@ -255,7 +255,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         const int row = 16 * (AI * wave + j) + (lane >> 2);
         const int ch = (lane & 3) ^ nt_swz(row);
         const int m = min(m0 + row, g.M - 1);
-        asrc[j] = (const char*)g.A + (int64_t)m * g.lda * 2 + ch * 16;
+        // (row gather: token m reads row a_rows[m] of A -- the per-token feature projection straight from the frozen table; the
+        // row pointer is per lane anyway and lives in registers for the whole K loop)
+        const int64_t arow = g.a_rows ? g.a_rows[m] : (int64_t)m;
+        asrc[j] = (const char*)g.A + arow * g.lda * 2 + ch * 16;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -643,7 +646,7 @@ static bool nt_big_ok(const GemmNT& g) {
     // fewer than ~96 tiles of 256 rows leave most of the 256 CUs idle: the 128 x 128 tile then wins (dX = dQKVC W at B = 32 targets,
     // M = 12 288, K = 1 024, N = 256: 48 big tiles 32.5 us, 192 small ones 22.6 us; equal at M = 24 576)
     if ((int64_t)cdiv(g.M, 256) * cdiv(g.N, 256) < 96) return false;
-    return !(g.opts & OPT_TILE_GEMM) && g.a_rows == nullptr && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 128 == 0 && g.K % 32 == 0 &&
+    return !(g.opts & OPT_TILE_GEMM) && g.m_dev == nullptr && !g.res_gather && g.M >= 4096 && g.N % 128 == 0 && g.K % 32 == 0 &&
            g.K >= 128 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
            (g.aux == nullptr || g.ldaux % 8 == 0) && ((uintptr_t)g.C % 16) == 0 && (g.res == nullptr || ((uintptr_t)g.res % 16) == 0) &&
            (g.aux == nullptr || ((uintptr_t)g.aux % 16) == 0) && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0);

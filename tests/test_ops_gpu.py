@@ -61,6 +61,32 @@ def test_gemm_nt_plain(dt, M, N, K):
     assert rel_err(Cd, ref) < tol(dt), rel_err(Cd, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(24600, 512, 1536), (30000, 256, 768)])
+def test_gemm_nt_big_tile_row_gather(M, N, K):
+    """The per-token feature projection (token mode: A = rows of the frozen table picked by node id, written into a column block of
+    a wider buffer): 256 x 256 tile with the row gather in its LDS-DMA addresses, against the 128 x 128 tile kernel and fp64."""
+    _lib, L = _setup()
+    g = torch.Generator().manual_seed(M + K)
+    R = 5000
+    table = torch.randn(R, K, generator=g).cuda().bfloat16()
+    rows = torch.randint(0, R, (M,), generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda()
+    outs = []
+    for opts in ((), ("tile_gemm",)):
+        L.use(*opts)
+        E = torch.full((M, 2 * N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        Cv = E[:, N:]                      # second column block, row stride 2 N
+        _lib.check(L.pmgt_op_gemm_nt(1, P(table), K, P(rows), P(W), K, C.c_void_p(Cv.data_ptr()), 2 * N, M, N, K, P(bias), 0, None, 0, None, 0,
+                                     0.0, 0, None, None, stream()))
+        assert torch.isnan(E[:, :N].float()).all()           # the neighbouring block is untouched
+        outs.append(E[:, N:].float())
+    L.use()
+    assert rel_err(outs[0], outs[1]) < 5e-3
+    ref = table.double().cpu()[rows.cpu()] @ W.double().cpu().T + bias.double().cpu()
+    assert rel_err(outs[0], ref) < 1e-2
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("K", [72, 96, 256])
 def test_gemm_nt_epilogues_and_gather(dt, K):
