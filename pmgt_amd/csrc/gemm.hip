@@ -1176,8 +1176,13 @@ __device__ __forceinline__ int tn_f5(int row) { return (row & 3) | (((row >> 3) 
 // cycles per k-step phase of gemm_tn_big_kernel: [block slot][wave][0 vmcnt wait | 1 barrier | 2 DMA issue | 3 LDS reads + MFMA]
 __device__ unsigned int g_tn_prof[2][8][4];
 #endif
+// GATHER: Q rows are picked by q_rows[m] (the token-mode feature-projection weight gradient: Q = the frozen table).  The row indices
+// of a stage travel ahead of it by LDS-DMA into a small ring (each wave fetches the 32 indices itself: no cross-wave dependency), are
+// read at the END of the step before the one that issues the stage's data DMA, and the data pieces carry per-lane source rows.
+template <bool GATHER>
 __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_rows) {
     constexpr int BKM = 32, ROWB = 512, STAGE = 2 * BKM * ROWB, NST = 4;     // 32 KiB per stage (P + Q)
+    constexpr int IDX_SLOTS = 8, IDX_BYTES = BKM * 8, IDX_AHEAD = 7;         // index ring (GATHER): after the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tn1 = (g.N1 + 255) / 256, tn2 = (g.N2 + 255) / 256, tiles = tn1 * tn2;
     const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
@@ -1226,7 +1231,10 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
         sq0[j] = (const char*)g.Q + ((int64_t)(mbeg + row) * g.ldq + cq) * 2;
     }
     const int64_t stp = (int64_t)BKM * g.ldp * 2, stq = (int64_t)BKM * g.ldq * 2;
-    auto issue = [&](int kt) {
+    uint32_t qcol[2];                 // GATHER: byte column of this lane's chunk inside a Q row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) qcol[j] = (uint32_t)((n2_0 + (((lane & 31) ^ (tn_f5(rowj[j]) << 1)) * 8)) * 2);
+    auto issue = [&](int kt, uint32_t q0, uint32_t q1) {
         const int mb = mbeg + kt * BKM;
         char* st = smem + (kt & (NST - 1)) * STAGE;
         const bool full = mb + BKM <= mend;          // (uniform) every row of the stage exists
@@ -1234,15 +1242,47 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
         for (int j = 0; j < 2; ++j) {
             const bool in = full || mb + rowj[j] < mend;
             const char* sp = (in && okp[j]) ? sp0[j] + kt * stp : zero;
-            const char* sq = (in && okq[j]) ? sq0[j] + kt * stq : zero;
+            const char* sq;
+            if constexpr (GATHER) sq = (in && okq[j]) ? (const char*)g.Q + (int64_t)(j == 0 ? q0 : q1) * g.ldq * 2 + qcol[j] : zero;
+            else sq = (in && okq[j]) ? sq0[j] + kt * stq : zero;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (4 * wave + 2 * j) * ROWB), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + BKM * ROWB + (4 * wave + 2 * j) * ROWB), 16, 0, 0);
         }
     };
+    // index DMA of stage kt: lane l fetches dword l of q_rows[mb .. mb + 32) (clamped inside the array); its own rows' indices sit at
+    // byte 8 (4 wave + 2 j + (lane >> 5)) of the slot (low dword: node ids are far below 2^31)
+    char* idx_ring = smem + NST * STAGE;
+    auto issue_idx = [&](int kt) {
+        const int64_t m = min((int64_t)mbeg + (int64_t)kt * BKM + (lane >> 1), (int64_t)g.M - 1);
+        const char* src = (const char*)(g.q_rows + m) + 4 * (lane & 1);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(idx_ring + (kt & (IDX_SLOTS - 1)) * IDX_BYTES), 4, 0, 0);
+    };
+    const uint32_t idx_off = (uint32_t)((4 * wave + (lane >> 5)) * 8);      // row of j = 0; j = 1 is 2 rows (16 B) further
+    auto read_idx = [&](int kt, uint32_t& q0, uint32_t& q1) __attribute__((always_inline)) {
+        const uint32_t ia = lds_base + (uint32_t)(NST * STAGE + (kt & (IDX_SLOTS - 1)) * IDX_BYTES) + idx_off;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(ia) : "memory");
+    };
     const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+    uint32_t qn0 = 0, qn1 = 0;        // GATHER: row indices of the stage whose data DMA the NEXT step issues
+    if constexpr (GATHER) {
+        if (nk > 0) {
+#pragma unroll
+            for (int kt = 0; kt < IDX_AHEAD; ++kt) issue_idx(kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                uint32_t q0, q1;
+                read_idx(kt, q0, q1);
+                if (kt < nk) issue(kt, q0, q1);
+            }
+            read_idx(3, qn0, qn1);
+        }
+    } else {
+        if (nk > 0) issue(0, 0, 0);
+        if (nk > 1) issue(1, 0, 0);
+        if (nk > 2) issue(2, 0, 0);
+    }
     // per-lane byte offsets of the fragment reads inside a stage (row = 8 q + (r >> 2); +4 rows = +2048 B)
     uint32_t offa[8], offb[4];
     {
@@ -1269,11 +1309,28 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
     for (int kt = 0; kt < nk; ++kt) {
         TN_STAMP(3);
         const int younger = min(2, nk - 1 - kt);
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (GATHER) {
+            // 4 data pieces per younger stage + the index DMAs of the last min(kt, 2) steps (one per step, issued after the barrier
+            // below for every kt, also past the end: clamped reads)
+            switch (4 * younger + min(kt, 2)) {
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         TN_STAMP(0);
         __builtin_amdgcn_s_barrier();
+        if constexpr (GATHER) issue_idx(kt + IDX_AHEAD);
         TN_STAMP(1);
         TN_STAMP(2);
         const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
@@ -1341,9 +1398,12 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
             // the next stage's DMA goes out while the matrix pipe works through the MFMAs queued above: its address
             // arithmetic costs VALU issue slots only (ring slot (kt + 3) % 4 was last read in step kt - 1, and every wave
             // has passed this step's barrier)
-            if (i == 3 && kt + 3 < nk) issue(kt + 3);
+            if (i == 3 && kt + 3 < nk) issue(kt + 3, qn0, qn1);
         }
+        // GATHER: the indices of stage kt + 4 (their DMA went out at step kt - 3: the wait at the top of this step covered it)
+        if constexpr (GATHER) read_idx(kt + 4, qn0, qn1);
     }
+    if constexpr (GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // trailing index DMAs must land before the LDS is released
 #ifdef PMGT_TN_PROF
     TN_STAMP(3);
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
@@ -1423,17 +1483,19 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (g.q_rows == nullptr && g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm, g.opts) &&
-            g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm, g.opts)) {
-            constexpr int smem = 4 * 2 * 32 * 512;
+        if (g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm, g.opts) && g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm, g.opts) &&
+            (g.q_rows == nullptr || g.M >= 1)) {
+            constexpr int smem = 4 * 2 * 32 * 512 + 8 * 32 * 8;      // stage ring + index ring
             static bool attr_set = false;
             if (!attr_set) {
-                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
                 attr_set = true;
             }
             const int tiles256 = (g.N1 / 256) * (g.N2 / 256);
             int chunk256 = cdiv(cdiv(std::max(g.M, 1), g.splits), 32) * 32;
-            hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
+            if (g.q_rows) hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
+            else hipLaunchKernelGGL(gemm_tn_big_kernel<false>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
             PMGT_LAUNCH_OK();
             return 0;
         }
