@@ -440,6 +440,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int ps = 0; ps < 4; ++ps) rv[ps] = pf[ps];
                 if (tt + 1 < n) load_pf(tt + 1);      // the next step's operand rows travel under this step's arithmetic
             }
+            // the four passes' staging rows are read up front: ONE LDS round trip per step for a role that has a single wave per SIMD
+            // (nothing else of its own to issue while a read is in flight)
+            f32x4 sv[4][2];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                sv[ps][0] = *(const f32x4*)(stage + (erow + 8 * ps) * C::ES + ecol);
+                sv[ps][1] = *(const f32x4*)(stage + (erow + 8 * ps) * C::ES + ecol + 4);
+            }
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = erow + 8 * ps;
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int ncol = nb + ecol;
                 if (m < g.M) {
                     float v[8];
-                    const f32x4 s0 = *(const f32x4*)(stage + row * C::ES + ecol), s1 = *(const f32x4*)(stage + row * C::ES + ecol + 4);
+                    const f32x4 s0 = sv[ps][0], s1 = sv[ps][1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
 #pragma unroll
