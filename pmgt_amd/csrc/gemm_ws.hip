@@ -263,13 +263,15 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                 }
-                bf16x8 o;
+                if (!(MODE == WS_RES_LN && g.skip_c)) {      // (LayerNorm input not stored: not rounded either -- see gemm_wsr.hip)
+                    bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
+                    for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
 #ifdef PMGT_WS_ABL_NO_C
-                if (g.M < 0)
+                    if (g.M < 0)
 #endif
-                if (!(MODE == WS_RES_LN && g.skip_c)) *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
+                    *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -280,9 +282,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                 for (int e = 0; e < 8; ++e) s += v[e];
                 s = sum_lanes32(s);
                 const float mean = s * (1.f / 256.f);
-                float ss = 0.f;
+                float ss = 0.f, tc[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
+                for (int e = 0; e < 8; ++e) { tc[e] = v[e] - mean; ss = fmaf(tc[e], tc[e], ss); }
                 ss = sum_lanes32(ss);
                 // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequences (~40 VALU instructions per row pass in an epilogue that
                 // in-kernel stamps show VALU-bound: 5.4k / 9.1k cycles per tile on the older / younger wave of a SIMD)
@@ -297,8 +299,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
                     const f32x4 b0 = *(const f32x4*)(cvec + 512 + ecol), b1 = *(const f32x4*)(cvec + 512 + ecol + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o[e] = (bf16)((v[e] - mean) * rstd * g0[e] + b0[e]);
-                        o[4 + e] = (bf16)((v[4 + e] - mean) * rstd * g1[e] + b1[e]);
+                        o[e] = (bf16)(tc[e] * rstd * g0[e] + b0[e]);
+                        o[4 + e] = (bf16)(tc[4 + e] * rstd * g1[e] + b1[e]);
                     }
 #ifdef PMGT_WS_ABL_NO_LNO
                     if (g.M < 0)

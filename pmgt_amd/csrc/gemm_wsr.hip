@@ -24,8 +24,18 @@ struct WsrCfg {
     static constexpr int SMEM = NR * TILEB + 2 * STG;
 };
 
+#ifdef PMGT_W5_PROF
+__device__ unsigned long long g_w2_prof[16][8];
+#define W2_STAMP(k_) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc[k_] += n_ - plast; plast = n_; } while (0)
+#else
+#define W2_STAMP(k_) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
     using C = WsrCfg;
+#ifdef PMGT_W5_PROF
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long plast = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,10 +82,14 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
             if (t < n) dma(t, t);
         wait_tiles(min(C::NR - 2, n - 1));      // tile 0 has landed for this wave (the W loads are older and drain first)
         __builtin_amdgcn_s_barrier();
+#ifdef PMGT_W5_PROF
+        plast = __builtin_readcyclecounter();
+#endif
         for (int it = 0; it <= n; ++it) {
             if (it < n) {
                 const int slot = it % C::NR;
                 if (it + C::NR - 1 < n) dma(it + C::NR - 1, (it + C::NR - 1) % C::NR);      // that slot held tile it - 1: every wave's reads of it drained before the last barrier
+                W2_STAMP(0);
                 const uint32_t ab = lds0 + (uint32_t)(slot * C::TILEB);
                 f32x4 acc[2][2];
 #pragma unroll
@@ -106,6 +120,7 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 // and an LDS instruction that reads its result there -- without them every row 4 q + 0 carried a stale value)
                 // (tied to the four accumulator tiles: every MFMA is issued before it, every staging write after it)
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+                W2_STAMP(1);
                 // fp32 tile -> staging buffer it & 1: element (row 16 i + 4 q + e, column 32 gw + 16 j + r)
                 const uint32_t sb = stg0 + (uint32_t)((it & 1) * C::STG) + sw0;
 #pragma unroll
@@ -121,9 +136,14 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 // for this wave (issued a whole step ago; the pieces of step it + 2 stay in flight)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (it + 1 < n) wait_tiles(min(it + C::NR - 1, n - 1) - (it + 1));
+                W2_STAMP(2);
             }
             __builtin_amdgcn_s_barrier();
+            W2_STAMP(3);
         }
+#ifdef PMGT_W5_PROF
+        if (blockIdx.x == 40 && lane == 0) { for (int k_ = 0; k_ < 4; ++k_) g_w2_prof[wave][k_] = pacc[k_]; g_w2_prof[wave][7] = (unsigned long long)n; }
+#endif
         return;
     }
     // ==================================================================== epilogue role: 512 threads, 32 lanes per row, 16 rows per pass
@@ -151,6 +171,9 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
     };
     if (0 < n) load_pf(0);
     __builtin_amdgcn_s_barrier();
+#ifdef PMGT_W5_PROF
+    plast = __builtin_readcyclecounter();
+#endif
     for (int it = 0; it <= n; ++it) {
         if (it >= 1) {
             const int tt = it - 1, mt = x + tt * gx;
@@ -175,25 +198,29 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[ps][e];
-                bf16x8 o;
+                // the LayerNorm input is stored (then LN sees the bf16 values the backward re-reads) -- or it is not (the backward
+                // works from the LayerNorm OUTPUT): then it is not rounded either, 16 of the epilogue's ~190 vector instructions per pass
+                if (!g.skip_c) {
+                    bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what a stored C would hold (rows past M: clamped inputs, never stored)
-                if (ok && !g.skip_c) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ecol) = o;
+                    for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // (rows past M: clamped inputs, never stored)
+                    if (ok) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ecol) = o;
+                }
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[e];
                 s = sum_lanes32(s);
                 const float mean = s * (1.f / 256.f);
-                float ss = 0.f;
+                float ss = 0.f, tc[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; ss = fmaf(t, t, ss); }
+                for (int e = 0; e < 8; ++e) { tc[e] = v[e] - mean; ss = fmaf(tc[e], tc[e], ss); }
                 ss = sum_lanes32(ss);
                 const float rstd = __builtin_amdgcn_rsqf(ss * (1.f / 256.f) + g.ln_eps);
                 if (ok) {
                     if ((te & 31) == 0) *(float2*)(g.ln_stats + 2 * (int64_t)m) = make_float2(mean, rstd);
                     bf16x8 y;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = (bf16)((v[e] - mean) * rstd * gam[e] + bet[e]);
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16)(tc[e] * rstd * gam[e] + bet[e]);
                     *(bf16x8*)(LNO + (int64_t)m * g.ldc + ecol) = y;
                     if (g.q8) {      // (uniform) fp8 mode: the row additionally as e4m3 + one scale, for the next layer's fp8 projection (fp8.h contract)
 #pragma unroll
@@ -216,8 +243,13 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 }
             }
         }
+        W2_STAMP(0);
         __builtin_amdgcn_s_barrier();
+        W2_STAMP(1);
     }
+#ifdef PMGT_W5_PROF
+    if (blockIdx.x == 40 && lane == 0) { for (int k_ = 0; k_ < 2; ++k_) g_w2_prof[wave][k_] = pacc[k_]; g_w2_prof[wave][7] = (unsigned long long)n; }
+#endif
 }
 
 bool gemm_wsr_ok(const GemmWS& g) {
@@ -548,5 +580,8 @@ int gemm_wsr512(const GemmWS& g, hipStream_t st) {
 #ifdef PMGT_W5_PROF
 extern "C" int pmgt_debug_w5_prof_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_w5_prof), sizeof(pmgt::g_w5_prof));
+}
+extern "C" int pmgt_debug_w2_prof_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmgt::g_w2_prof), sizeof(pmgt::g_w2_prof));
 }
 #endif
