@@ -31,7 +31,7 @@ extern "C" {
 #define PMGT_OPT_UNFUSED_LN (1u << 13)               /* "unfused_ln": LayerNorm as its own launch after the streaming GEMM */
 #define PMGT_OPT_ONE_BUCKET (1u << 14)               /* "one_bucket": the gradient-ready callback fires once per backward pass (whole buffer) */
 #define PMGT_OPT_SMALL_ARENA (1u << 15)              /* "small_arena": (test) partial-sum arena sized for one producer: a batched reduction per producer */
-#define PMGT_OPT_NO_ROLE_SPLIT_LN (1u << 16)         /* "no_role_split_ln": residual + LayerNorm GEMMs (K = N = 256) on the 8-wave streaming kernel instead of gemm_wsr.hip (bit-identical) */
+#define PMGT_OPT_NO_ROLE_SPLIT_LN (1u << 16)         /* "no_role_split_ln": the 8-wave lockstep streaming kernels instead of the role-split ones of gemm_wsr.hip (K = N = 256 residual + LayerNorm; K = 512 plain / GELU / GELU' / residual) -- bit-identical results */
 #define PMGT_OPT_NO_TILE_ATTENTION (1u << 17)        /* "no_tile_attention": S = 64 / head size 64 attention on the cooperative kernels (per-wave fragment loads) instead of the tile forms */
 
 /* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */

@@ -302,7 +302,7 @@ enum PathOpt : uint32_t {
     OPT_UNFUSED_LN = 1u << 13,          // LayerNorm as its own launch after the streaming GEMM
     OPT_ONE_BUCKET = 1u << 14,          // gradient-ready callback once per backward pass instead of per layer
     OPT_SMALL_ARENA = 1u << 15,         // test: the partial-sum arena holds ONE producer's regions, so every take flushes the previous ones
-    OPT_NO_ROLE_SPLIT_LN = 1u << 16,    // residual + LayerNorm GEMMs stay on the 8-wave streaming kernel (no 16-wave role-split form)
+    OPT_NO_ROLE_SPLIT_LN = 1u << 16,    // streaming GEMMs stay on the 8-wave lockstep kernels (no role-split forms: K = N = 256 residual + LayerNorm, K = 512)
     OPT_NO_TILE_ATTENTION = 1u << 17,   // S = 64 / head size 64 attention: the cooperative kernels (per-wave fragment loads from global memory) instead of the tile forms
 };
 
