@@ -263,15 +263,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                 }
-                if (!(MODE == WS_RES_LN && g.skip_c)) {      // (LayerNorm input not stored: not rounded either -- see gemm_wsr.hip)
-                    bf16x8 o;
+                bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
+                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what backward re-reads
 #ifdef PMGT_WS_ABL_NO_C
-                    if (g.M < 0)
+                if (g.M < 0)
 #endif
-                    *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
-                }
+                if (!(MODE == WS_RES_LN && g.skip_c)) *(bf16x8*)(Cp + (int64_t)m * g.ldc + n) = o;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;

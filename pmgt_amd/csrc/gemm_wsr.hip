@@ -198,14 +198,10 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[ps][e];
-                // the LayerNorm input is stored (then LN sees the bf16 values the backward re-reads) -- or it is not (the backward
-                // works from the LayerNorm OUTPUT): then it is not rounded either, 16 of the epilogue's ~190 vector instructions per pass
-                if (!g.skip_c) {
-                    bf16x8 o;
+                bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // (rows past M: clamped inputs, never stored)
-                    if (ok) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ecol) = o;
-                }
+                for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }   // LN sees what a stored C would hold: the same values whether or not it is stored (rows past M: clamped inputs, never stored)
+                if (ok && !g.skip_c) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ecol) = o;
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[e];
