@@ -32,6 +32,7 @@ extern "C" {
 #define PMGT_OPT_ONE_BUCKET (1u << 14)               /* "one_bucket": the gradient-ready callback fires once per backward pass (whole buffer) */
 #define PMGT_OPT_SMALL_ARENA (1u << 15)              /* "small_arena": (test) partial-sum arena sized for one producer: a batched reduction per producer */
 #define PMGT_OPT_NO_ROLE_SPLIT_LN (1u << 16)         /* "no_role_split_ln": the 8-wave lockstep streaming kernels instead of the role-split ones of gemm_wsr.hip (K = N = 256 residual + LayerNorm; K = 512 plain / GELU / GELU' / residual) -- bit-identical results */
+#define PMGT_OPT_UNFUSED_LN_BWD (1u << 18)           /* "unfused_ln_bwd": LayerNorm backward as its own launch behind the data-gradient GEMM that produces its dy (default, bf16 / hidden 256: epilogue of that GEMM) */
 #define PMGT_OPT_NO_TILE_ATTENTION (1u << 17)        /* "no_tile_attention": S = 64 / head size 64 attention on the cooperative kernels (per-wave fragment loads) instead of the tile forms */
 
 /* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
@@ -75,6 +76,15 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
                    uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
                    const float* ln_beta, float ln_eps, uint32_t path_opts, void* stream);
+/* dy = A B^T + residual, then the backward of the LayerNorm whose OUTPUT is y (x^ = (y - beta) / gamma; stats = its {mean, rstd}
+ * rows): dx, dx_drop = dx * dropout mask (optional), dgamma | dbeta | column sums of the bf16 dx_drop (or dx) [3 N].  bf16.  One launch
+ * where the role-split streaming kernel (K = N = 256, M >= 8192) or the 256 x 256 tile with the LayerNorm-backward phase (N = 256,
+ * K % 64 == 0, >= 96 tiles) applies, else GEMM -> dy_tmp [M, N] -> LayerNorm backward (autograd through BertSelfOutput /
+ * BertOutput, pmgt/pmgt/modeling_pmgt.py:293-294,322-325,332,371).  part: scratch of max(256, ceil(M / 64)) * 3 N floats. */
+int pmgt_op_linear_ln_bwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* residual, int64_t ldr,
+                          const void* y, const float* stats, const float* gamma, const float* beta, void* dy_tmp, void* dx, void* dx_drop,
+                          float drop_p, uint32_t drop_site, const uint64_t* rng, float* part, float* dgamma_dbeta_dbias,
+                          uint32_t path_opts, void* stream);
 /* Fused Q|K|V|C projection + attention forward (bf16; S = 32, dh = 32, hidden 128 or 256; returns -3 otherwise):
  * x [n_seq*S, d], w [4d, d] (rows q | k | v | c), bias [4d] fp32 -> qkvc [n_seq*S, 4d], ctx [n_seq*S, d]. */
 int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,

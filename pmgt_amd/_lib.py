@@ -61,7 +61,7 @@ HIP_SYMBOLS = [
 ]
 OPS_SYMBOLS = [
     "pmgt_op_gemm_nt", "pmgt_op_gemm_tn_slab_elems", "pmgt_op_gemm_tn", "pmgt_op_gemm_tn_bias", "pmgt_op_colsum",
-    "pmgt_op_layernorm_fwd", "pmgt_op_layernorm_bwd", "pmgt_op_linear", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd",
+    "pmgt_op_layernorm_fwd", "pmgt_op_layernorm_bwd", "pmgt_op_linear", "pmgt_op_linear_ln_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd",
     "pmgt_op_qkvc_attention_fwd", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts",
     "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8", "pmgt_op_qkvc_attention_fwd_f8",
 ]
@@ -69,7 +69,7 @@ OPS_SYMBOLS = [
 OPT = {k: 1 << i for i, k in enumerate((
     "tile_gemm", "valu_attention", "wave_attention_bwd", "no_shortcut", "no_fused_qkvc_attention", "no_head_major",
     "no_table_projection", "no_segment_sum", "consumer_quant", "no_fused_attention_bwd", "store_ln_input", "eager_reduce",
-    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena", "no_role_split_ln", "no_tile_attention"))}
+    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena", "no_role_split_ln", "no_tile_attention", "unfused_ln_bwd"))}
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
     "pmgt_sampler_context", "pmgt_sampler_batch", "pmgt_sampler_batch_mt", "pmgt_sampler_max_pairs",
@@ -137,6 +137,7 @@ def hip():
     L.pmgt_engine_set_option.argtypes = [vp, C.c_char_p, i]
     L.pmgt_engine_get_option.argtypes = [vp, C.c_char_p]
     L.pmgt_op_linear.argtypes = [i, vp, i64, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, vp, vp, vp, f, u32, vp]
+    L.pmgt_op_linear_ln_bwd.argtypes = [vp, i64, vp, i64, i, i, i, vp, i64, vp, vp, vp, vp, vp, vp, vp, f, u32, vp, vp, vp, u32, vp]
     L.pmgt_op_attention_fwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]
     L.pmgt_op_attention_bwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]
     L.pmgt_op_attention_bwd_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, f, f, u32, u32, vp, i, vp]
@@ -156,7 +157,7 @@ class Ops:
     """The library as the per-kernel tests and profiling tools call it: every pmgt_op_* entry that takes a `path_opts` bit
     mask (include/pmgt_ops.h) gets it from `self.path` (an int, or option names through `use`), so call sites read as the
     kernel's own argument list.  Everything else passes straight through to the CDLL."""
-    _BEFORE_STREAM = {"pmgt_op_gemm_nt", "pmgt_op_gemm_tn", "pmgt_op_gemm_tn_bias", "pmgt_op_linear", "pmgt_op_attention_fwd",
+    _BEFORE_STREAM = {"pmgt_op_gemm_nt", "pmgt_op_gemm_tn", "pmgt_op_gemm_tn_bias", "pmgt_op_linear", "pmgt_op_linear_ln_bwd", "pmgt_op_attention_fwd",
                       "pmgt_op_attention_bwd"}
     _LAST = {"pmgt_op_gemm_tn_slab_elems"}
 

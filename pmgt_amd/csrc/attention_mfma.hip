@@ -1719,11 +1719,7 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
             if (use_coop && a.S == 16 * NT && !(a.opts & OPT_NO_TILE_ATTENTION)) {
                 auto kern = attn_bwd_tiles_kernel<DH, NT>;
                 constexpr int lds = BwdSmemT<DH, NT>::BYTES;
-                static bool attr_done = false;
-                if (!attr_done) {
-                    PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                    attr_done = true;
-                }
+                PMGT_SMEM_ATTR((const void*)kern, lds);
                 hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * NT), lds, st, a);
                 PMGT_LAUNCH_OK();
                 return 0;
@@ -2280,11 +2276,7 @@ bool attn_bwd_wgrad_supported(const AttnBwdWg& w) {
 template <int KT> static int launch_abw(const AttnBwdWg& w, hipStream_t st) {
     using C = AbwCfg<KT>;
     auto kern = attn_bwd_wgrad_kernel<KT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-        attr_done = true;
-    }
+    PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int gx = attn_bwd_wgrad_parts(w.a.H);
     hipLaunchKernelGGL(kern, dim3(gx * w.a.H), dim3(1024), C::SMEM, st, w);
     PMGT_LAUNCH_OK();

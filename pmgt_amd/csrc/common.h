@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace pmgt {
 
 typedef __bf16 bf16;
@@ -32,6 +34,19 @@ void set_error(const char* fmt, ...);
             ::pmgt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,   \
                               __LINE__);                                                          \
             return -100;                                                                          \
+        }                                                                                         \
+    } while (0)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: set once per (call site, device) -- one bit per
+// device ordinal; two threads racing on the first launch both set it (idempotent)
+#define PMGT_SMEM_ATTR(kern, bytes)                                                               \
+    do {                                                                                          \
+        static std::atomic<uint64_t> done__{0};                                                   \
+        int dev__ = 0;                                                                            \
+        PMGT_HIP(hipGetDevice(&dev__));                                                           \
+        const uint64_t bit__ = 1ull << (dev__ & 63);                                              \
+        if (!(done__.load(std::memory_order_acquire) & bit__)) {                                  \
+            PMGT_HIP(hipFuncSetAttribute((kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            done__.fetch_or(bit__, std::memory_order_release);                                    \
         }                                                                                         \
     } while (0)
 #define PMGT_LAUNCH_OK()                                                                          \
@@ -304,6 +319,7 @@ enum PathOpt : uint32_t {
     OPT_SMALL_ARENA = 1u << 15,         // test: the partial-sum arena holds ONE producer's regions, so every take flushes the previous ones
     OPT_NO_ROLE_SPLIT_LN = 1u << 16,    // streaming GEMMs stay on the 8-wave lockstep kernels (no role-split forms: K = N = 256 residual + LayerNorm, K = 512)
     OPT_NO_TILE_ATTENTION = 1u << 17,   // S = 64 / head size 64 attention: the cooperative kernels (per-wave fragment loads from global memory) instead of the tile forms
+    OPT_UNFUSED_LN_BWD = 1u << 18,      // LayerNorm backward as its own launch behind the data-gradient GEMM that produces its dy
 };
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -99,6 +99,12 @@ struct pmgt_engine {
     std::vector<hipEvent_t> sync_ev;
     size_t sync_next = 0;
     uint32_t opts = 0;        // PathOpt bits (pmgt_engine_set_option): per engine, read by every dispatch decision below
+    // pmgt_encode_train -> pmgt_encode_backward are two calls over one workspace: the backward re-derives which buffers the forward
+    // filled (head-major Q|K|V|C, unstored LayerNorm inputs, table mode ...) from the options, so it must see the SAME options.
+    // The forward records its option bits per workspace; a backward over that workspace under different bits is refused
+    // (it would read buffers the forward never wrote).  Bits that only move reductions / callbacks do not count.
+    static constexpr uint32_t SCHED_OPTS = OPT_EAGER_REDUCE | OPT_SIDE_STREAM_REDUCE | OPT_ONE_BUCKET | OPT_SMALL_ARENA;
+    std::map<const void*, uint32_t> fwd_opts;
     bool overlap() const { return (opts & OPT_SIDE_STREAM_REDUCE) != 0; }     // partial-sum reductions on the side stream (see SideReduce): measured neutral, opt-in
     // data-parallel exchange: called when a contiguous range of the flat gradient buffer is final in stream order
     pmgt_grad_ready_fn grad_cb = nullptr;
@@ -831,6 +837,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     float* G = t->grads;
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
     const bool dd = train && pd > 0.f;
+    bool ln2_done = false;      // this layer's LN2 backward ran inside the previous iteration's last GEMM
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = e->layers[l];
         LayerBufs<T>& lb = b.layer[l];
@@ -848,9 +855,12 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         T* gD = sc ? b.c_bD : b.bD;
         T* gbig = sc ? b.c_big : b.big;
         const bool ln1_from_y = ln_from_y_applies<T>(e, Mt, d, sc), ln2_from_y = ln_from_y_applies<T>(e, Mt, I, sc);      // as the forward decided
-        // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output)
-        RUN(ln_bwd_reduce<T>(e, b, gA, ln2_from_y ? tb.hout : tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d,
-                             dropcfg(t, train, pd, l, SITE_FO), mdev, G + o.ln2g, acc, st, ln2_from_y ? P + o.ln2b : nullptr));                                              // dgamma | dbeta | db2
+        // LN2 backward: gA -> gB (residual branch), gC (masked: gradient of the FFN2 dense output) -- unless it already ran as the
+        // epilogue of the layer above's dX = dQKVC W (below): gB / gC are then in place and gA was never written
+        if (!ln2_done)
+            RUN(ln_bwd_reduce<T>(e, b, gA, ln2_from_y ? tb.hout : tb.fo_pre, tb.stats2, P + o.ln2g, gB, dd ? gC : nullptr, Mt, d,
+                                 dropcfg(t, train, pd, l, SITE_FO), mdev, G + o.ln2g, acc, st, ln2_from_y ? P + o.ln2b : nullptr));                                          // dgamma | dbeta | db2
+        ln2_done = false;
         const T* dY2 = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
@@ -860,15 +870,34 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
         RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1));
-        {   // du = dff W1 + residual branch
+        bool ln1_fused = false;
+        if constexpr (sizeof(T) == 2) {
+            // du = dff W1 + residual branch, and the LN1 backward of du in the same launch (the role-split streaming kernel's epilogue
+            // role: du never reaches HBM; dx overwrites the residual branch in place, row tile by row tile)
             GemmWS g; g.opts = e->opts;
-            g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gD; g.ldc = d; g.m_dev = mdev;
+            g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gB; g.ldc = d; g.m_dev = mdev;
             g.M = Mt; g.N = d; g.K = I; g.res = gB; g.ldr = d;
-            RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
+            g.lnb_y = tb.u; g.lnb_ldy = d; g.lnb_stats = tb.stats1; g.lnb_gamma = P + o.ln1g; g.lnb_beta = P + o.ln1b;
+            g.lnb_dx_drop = dd ? gC : nullptr; g.lnb_lddx = d; g.lnb_drop = dropcfg(t, train, pd, l, SITE_AO);
+            if (ln1_from_y && b.defer && gemm_wsr_lnb_ok(g)) {
+                const int parts = gemm_wsr_lnb_parts(Mt);
+                RUN(take_partials<T>(e, b, (int64_t)parts * 3 * d, &g.lnb_part, st));
+                RUNP("bwd.dgrad_ffn1_lnb", gemm_wsr_lnb(g, st));
+                RUN(queue_reduce<T>(e, b, g.lnb_part, parts, 3 * d, G + o.ln1g, acc, st));                                                                                 // dgamma | dbeta | dbo
+                ln1_fused = true;
+            }
         }
-        // LN1 backward
-        RUN(ln_bwd_reduce<T>(e, b, gD, ln1_from_y ? tb.u : tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d,
-                             dropcfg(t, train, pd, l, SITE_AO), mdev, G + o.ln1g, acc, st, ln1_from_y ? P + o.ln1b : nullptr));                                              // dgamma | dbeta | dbo
+        if (!ln1_fused) {
+            {   // du = dff W1 + residual branch
+                GemmWS g; g.opts = e->opts;
+                g.A = gbig; g.lda = I; g.B = b.mirror + o.mW1T; g.ldb = I; g.C = gD; g.ldc = d; g.m_dev = mdev;
+                g.M = Mt; g.N = d; g.K = I; g.res = gB; g.ldr = d;
+                RUN(linear<T>(e, "bwd.dgrad_ffn1", g, st));
+            }
+            // LN1 backward
+            RUN(ln_bwd_reduce<T>(e, b, gD, ln1_from_y ? tb.u : tb.ao_pre, tb.stats1, P + o.ln1g, gB, dd ? gC : nullptr, Mt, d,
+                                 dropcfg(t, train, pd, l, SITE_AO), mdev, G + o.ln1g, acc, st, ln1_from_y ? P + o.ln1b : nullptr));                                          // dgamma | dbeta | dbo
+        }
         const T* dYo = dd ? gC : gB;
         RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
         {   // dctx = dYo Wo
@@ -938,7 +967,27 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             GemmNT g; g.opts = e->opts;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + (b.qkvc_hm ? o.mWqkvcT_hm : o.mWqkvcT); g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
             g.M = M; g.N = d; g.K = 4 * d; g.res = sc ? nullptr : b.bB; g.ldr = d;
-            RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
+            bool with_ln = false;
+            if constexpr (sizeof(T) == 2) {
+                // d hin is the gradient of layer l - 1's output LayerNorm (BertOutput): its backward runs on the tile's rows behind the
+                // main loop of this GEMM (N = 256 = whole rows per workgroup), d hin never reaches HBM; dx overwrites the residual branch
+                // in place (b.bB), the masked copy goes to b.bC -- exactly what the next iteration's LN2 step would have left there
+                if (l >= 1 && !sc && b.defer && ln_from_y_applies<T>(e, M, I, false)) {
+                    const LayerOff& on = e->layers[l - 1];
+                    GemmNT f = g;
+                    f.C = b.bB;
+                    f.lnb_y = b.layer[l - 1].hout; f.lnb_ldy = d; f.lnb_stats = b.layer[l - 1].stats2; f.lnb_gamma = P + on.ln2g; f.lnb_beta = P + on.ln2b;
+                    f.lnb_dx_drop = dd ? b.bC : nullptr; f.lnb_lddx = d; f.lnb_drop = dropcfg(t, train, pd, l - 1, SITE_FO);
+                    if (gemm_nt_lnb_ok(f)) {
+                        const int parts = gemm_nt_lnb_parts(M);
+                        RUN(take_partials<T>(e, b, (int64_t)parts * 3 * d, &f.lnb_part, st));
+                        RUNP("bwd.dgrad_qkvc_lnb", gemm_nt_lnb(f, st));
+                        RUN(queue_reduce<T>(e, b, f.lnb_part, parts, 3 * d, G + on.ln2g, acc, st));                                                                        // dgamma | dbeta | db2 of layer l - 1
+                        with_ln = ln2_done = true;
+                    }
+                }
+            }
+            if (!with_ln) RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
             if (sc) RUN(scatter_rows<T>(gB, b.need_rows, b.need_cnt, Mt, d, b.bA, st, true));
         }
     }
@@ -1137,6 +1186,8 @@ static int encode_train(pmgt_engine* e, const pmgt_tensors* t, const int64_t* id
     carve<T>(e, c, b, Tseq, S, 1, true);
     PMGT_CHECK(c.cur <= ws_bytes, -4, "workspace too small: need %lld bytes, got %lld", (long long)c.cur, (long long)ws_bytes);
     const int64_t M = (int64_t)Tseq * S;
+    if (e->fwd_opts.size() > 64) e->fwd_opts.clear();      // (callers that never run the backward: keep the table small)
+    e->fwd_opts[ws] = e->opts & ~pmgt_engine::SCHED_OPTS;
     PMGT_HIP(hipMemcpyAsync(b.rng_snap, t->rng_state, 16, hipMemcpyDeviceToDevice, st));
     if (ids) PMGT_HIP(hipMemcpyAsync(b.ids, ids, M * 8, hipMemcpyDeviceToDevice, st));
     PMGT_HIP(hipMemcpyAsync(b.mask, mask, M * 4, hipMemcpyDeviceToDevice, st));
@@ -1153,6 +1204,12 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* co
                            int Tseq, int S, void* ws, int64_t ws_bytes, int flags, hipStream_t st) {
     const bool train = flags & PMGT_FLAG_TRAINING, acc = flags & PMGT_FLAG_ACCUMULATE;
     PMGT_CHECK(Tseq > 0 && S > 0 && d_last != nullptr, -2, "encode_backward: empty input");
+    {
+        auto itr = e->fwd_opts.find(ws);
+        PMGT_CHECK(itr == e->fwd_opts.end() || itr->second == (e->opts & ~pmgt_engine::SCHED_OPTS), -5,
+                   "encode_backward: engine options changed since the forward pass over this workspace (0x%x -> 0x%x): the backward would "
+                   "read buffers the forward did not write; run the forward again", itr->second, e->opts & ~pmgt_engine::SCHED_OPTS);
+    }
     Carver c(ws);
     Bufs<T> b;
     carve<T>(e, c, b, Tseq, S, 1, true);
@@ -1460,7 +1517,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;
@@ -1496,6 +1553,33 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PMGT_DTYPE_BF16) return linear<bf16>(e, "op.linear", g, st);
     return linear<float>(e, "op.linear", g, st);
+}
+
+int pmgt_op_linear_ln_bwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* residual, int64_t ldr,
+                          const void* y, const float* stats, const float* gamma, const float* beta, void* dy_tmp, void* dx, void* dx_drop,
+                          float drop_p, uint32_t drop_site, const uint64_t* rng, float* part, float* dgamma_dbeta_dbias,
+                          uint32_t path_opts, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GemmWS g; g.opts = path_opts;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = dx; g.ldc = N; g.M = M; g.N = N; g.K = K; g.res = residual; g.ldr = ldr;
+    g.lnb_y = y; g.lnb_ldy = N; g.lnb_stats = stats; g.lnb_gamma = gamma; g.lnb_beta = beta;
+    g.lnb_dx_drop = dx_drop; g.lnb_lddx = N; g.lnb_drop = DropCfg{rng, rng ? drop_p : 0.f, drop_site};
+    g.lnb_part = part;
+    pmgt_engine dummy;
+    const pmgt_engine* e = &dummy;
+    if (gemm_wsr_lnb_ok(g)) {
+        RUN(gemm_wsr_lnb(g, st));
+        return slab_reduce(part, gemm_wsr_lnb_parts(M), 3 * N, dgamma_dbeta_dbias, false, st);
+    }
+    if (gemm_nt_lnb_ok(g)) {
+        RUN(gemm_nt_lnb(g, st));
+        return slab_reduce(part, gemm_nt_lnb_parts(M), 3 * N, dgamma_dbeta_dbias, false, st);
+    }
+    // the two-launch form: dy through HBM, then the standalone LayerNorm backward with x^ from the output
+    g.C = dy_tmp;
+    RUN(linear<bf16>(e, "op.linear", g, st));
+    RUN(ln_bwd<bf16>((const bf16*)dy_tmp, (const bf16*)y, stats, gamma, (bf16*)dx, (bf16*)dx_drop, part, M, N, DropCfg{nullptr, 0.f, 0}, g.lnb_drop, st, nullptr, beta));
+    return slab_reduce(part, ln_bwd_parts(M), 3 * N, dgamma_dbeta_dbias, false, st);
 }
 
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S, int H,

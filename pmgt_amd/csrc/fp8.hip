@@ -310,11 +310,7 @@ int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
                "gemm_nt_f8: bias / scale vectors must be 16-byte aligned");
     if (f8_big_ok(g) && !(g.opts & OPT_TILE_GEMM)) {
         constexpr int smem = 4 * (256 + 256) * 64;
-        static bool attr_set = false;
-        if (!attr_set) {
-            PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_f8_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
-        }
+        PMGT_SMEM_ATTR((const void*)gemm_nt_f8_big_kernel, smem);
         hipLaunchKernelGGL(gemm_nt_f8_big_kernel, dim3(cdiv(cdiv(g.M, 256), 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
         PMGT_LAUNCH_OK();
         return 0;

@@ -21,9 +21,26 @@ struct GemmNT {
     const void* res = nullptr; int64_t ldr = 0;   // residual added last (same dtype as C)
     bool res_gather = false;           // residual row = a_rows[m] (compacted-row GEMMs)
     const int* m_dev = nullptr;        // optional device-side row count (<= M)
+    // LayerNorm-BACKWARD epilogue (gemm_wsr_lnb: K = N = 256 streaming form; gemm_nt_lnb: the 256 x 256 tile at N = 256): the GEMM
+    // result (+ residual) is the gradient dy of a LayerNorm whose OUTPUT y the forward kept (lnb_gamma / lnb_beta: its parameters;
+    // lnb_stats: its {mean, rstd} rows; x^ = (y - beta) / gamma).  C receives dx = LN'(dy), lnb_dx_drop (optional) dx times the
+    // dropout mask lnb_drop of the dense layer in front of that LayerNorm, lnb_part one [3][N] partial per workgroup:
+    // dgamma | dbeta | column sums of the bf16-rounded dx_drop (or dx).  dy never reaches HBM.
+    const void* lnb_y = nullptr; int64_t lnb_ldy = 0;
+    const float* lnb_stats = nullptr;
+    const float* lnb_gamma = nullptr;
+    const float* lnb_beta = nullptr;
+    void* lnb_dx_drop = nullptr; int64_t lnb_lddx = 0;
+    DropCfg lnb_drop = {nullptr, 0.f, 0};
+    float* lnb_part = nullptr;
     uint32_t opts = 0;                 // PathOpt bits of the calling engine (OPT_TILE_GEMM: register-staged 128 x 128 tile only)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
+// the 256 x 256 LDS-DMA tile with the LayerNorm-backward phase behind its main loop (lnb_* fields; bf16, N = 256, K % 64 == 0);
+// partials: [gemm_nt_lnb_parts(M)][3][256]
+bool gemm_nt_lnb_ok(const GemmNT& g);
+int gemm_nt_lnb_parts(int M);
+int gemm_nt_lnb(const GemmNT& g, hipStream_t st);
 
 // Weight-stationary streaming variant for K <= 256 in bf16 (gemm_ws.hip); optional fused LayerNorm of the
 // output row when N == 256: ln_out = LN(C) with C the (bf16-rounded) epilogue result, stats = {mean, rstd}.
@@ -46,6 +63,10 @@ int gemm_ws(const GemmWS& g, hipStream_t st);
 // 16-wave role-split form of the residual + LayerNorm mode at K = N = 256 (gemm_wsr.hip); gemm_ws dispatches to it
 bool gemm_wsr_ok(const GemmWS& g);
 int gemm_wsr(const GemmWS& g, hipStream_t st);
+// the same GEMM role with the LayerNorm-backward epilogue (lnb_* fields); partials: [gemm_wsr_lnb_parts(M)][3][256]
+bool gemm_wsr_lnb_ok(const GemmWS& g);
+int gemm_wsr_lnb_parts(int M);
+int gemm_wsr_lnb(const GemmWS& g, hipStream_t st);
 // 12-wave role-split form of the plain / GELU / GELU' / residual modes at K = 512 (gemm_wsr.hip); gemm_ws dispatches to it
 bool gemm_wsr512_ok(const GemmWS& g);
 int gemm_wsr512(const GemmWS& g, hipStream_t st);

@@ -230,9 +230,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT g) {
 // cycles of gemm_nt_big_kernel: [block slot][wave][0 vmcnt wait | 1 barrier | 2 DMA issue | 3 LDS reads + MFMA | 4 prologue | 5 epilogue]
 __device__ unsigned int g_nt_prof[2][8][6];
 #endif
-template <int BN, int NW>
+// LNB (BN = 256 only): the tile holds whole rows of an N = 256 output that is the gradient dy of a LayerNorm (GemmNT::lnb_*): behind
+// the main loop the workgroup runs that LayerNorm's backward on its 256 rows (see the phase below) instead of storing dy.
+template <int BN, int NW, bool LNB = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
     typedef bf16 T;
+    static_assert(!LNB || BN == 256, "LayerNorm-backward phase: whole rows in the tile");
     constexpr int BM = 256, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = BN == 256 ? 4 : 3;
     constexpr int WN = BN / 64, AI = 16 / NW, BI = BN / 16 / NW, PER = AI + BI;     // DMA instructions per wave per stage
     static_assert(NW / WN == 2, "two wave rows of 128 output rows each");
@@ -521,6 +524,141 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         }
     };
     constexpr bool SWAPPED = BN == 256;             // accumulator layout of the main loop above (see there)
+    if constexpr (LNB) {
+        // ---- dy = acc + residual (the direct epilogue's register layout: lane (r, q) owns 8 consecutive columns of row 16 i + r per
+        // block pair) goes to LDS as a bf16 [256][256] image -- 128 KB, exactly the ring; 16-byte chunk c of row R sits in slot
+        // c ^ (R & 31): sixteen consecutive rows of one chunk column (a ds_write_b128 of 16 lanes) hit sixteen different slots, and
+        // a row read back by 32 lanes is one permuted 512-byte line.  (bf16: what the two-launch form rounds dy to on its way through HBM.)
+        const int cb = ((q & 1) << 4) | ((q & 2) << 2);          // q = 0, 1, 2, 3 -> columns 0, 16, 8, 24 of the 32-column pair
+        const int ncol = wn * 64 + cb;
+        {
+            u32x4 rr[8][2];
+            if (R) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = min(m0 + wm * 128 + 16 * i + r, g.M - 1);
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) rr[i][pr] = *(const u32x4*)(R + (int64_t)m * g.ldr + ncol + 32 * pr);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wm * 128 + 16 * i + r;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    f32x4 a = acc[i][2 * pr], b = acc[i][2 * pr + 1];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+                                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+                    if (R) {
+                        const bf16x8 rv8 = __builtin_bit_cast(bf16x8, rr[i][pr]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] += (float)rv8[e]; b[e] += (float)rv8[4 + e]; }
+                    }
+                    const bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+                    const int ch = (ncol + 32 * pr) >> 3;
+                    *(bf16x8*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)) = o;
+                }
+            }
+        }
+        // ---- LayerNorm backward of the tile's rows: 32 lanes per row, 8 columns per lane, sixteen passes of 16 rows.  The rows of the
+        // LayerNorm OUTPUT y and rstd travel eight passes ahead (requested before the barrier: the first ones arrive under the LDS round
+        // trip), each slot refilled as soon as its pass has converted it.
+        __builtin_amdgcn_sched_barrier(0);      // (the requests below must not be scheduled into the block above: its accumulators and residual rows fill the register file)
+        const int erow = tid >> 5, ecl = (tid & 31) * 8;
+        const char* Yp = (const char*)g.lnb_y;
+        char* DX = (char*)g.C;
+        char* DXD = (char*)g.lnb_dx_drop;
+        const uint32_t ld2 = (uint32_t)g.ldc * 2u, ec2 = (uint32_t)ecl * 2u;      // equal leading dimensions, < 4 GB each (host)
+        constexpr int PFD = 8;      // passes in flight (40 VGPRs)
+        bf16x8 yv[PFD];
+        float rs[PFD];
+        auto load_y = [&](int p) __attribute__((always_inline)) {
+            const uint32_t m = (uint32_t)min(m0 + 16 * p + erow, g.M - 1);
+            yv[p % PFD] = *(const bf16x8*)(Yp + (m * ld2 + ec2));
+            rs[p % PFD] = *(const float*)((const char*)g.lnb_stats + (m * 8u + 4u));
+        };
+#pragma unroll
+        for (int p = 0; p < PFD; ++p) load_y(p);
+        const DropKey lk = make_drop_key(g.lnb_drop);
+        float gam[8], nbet[8], igam[8], dgam[8], dbet[8], dbia[8];      // x^ = y / gamma - beta / gamma
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gam[e] = g.lnb_gamma[ecl + e];
+            igam[e] = gam[e] != 0.f ? __builtin_amdgcn_rcpf(gam[e]) : 0.f;      // (a dead channel: the host guard stores LayerNorm inputs instead, engine.py)
+            nbet[e] = -g.lnb_beta[ecl + e] * igam[e];
+            dgam[e] = dbet[e] = dbia[e] = 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int row = 16 * p + erow;
+            const int m = m0 + row;
+            const bool ok = m < g.M;
+            const bf16x8 dyv = *(const bf16x8*)(smem + row * 512 + (((tid & 31) ^ (row & 31)) << 4));
+            float v[8], xh[8], gg[8];
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xh[e] = fmaf((float)yv[p % PFD][e], igam[e], nbet[e]);
+            const float rsp = rs[p % PFD];
+            __builtin_amdgcn_sched_barrier(0);      // (the refill targets the registers converted above)
+            if (p + PFD < 16) load_y(p + PFD);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = ok ? (float)dyv[e] : 0.f;      // rows past M (clamped operands): no term in any sum, nothing stored
+                gg[e] = v[e] * gam[e];
+                dgam[e] = fmaf(v[e], xh[e], dgam[e]);
+                dbet[e] += v[e];
+                sg += gg[e];
+                sgx = fmaf(gg[e], xh[e], sgx);
+            }
+            sg = sum_lanes32(sg) * (1.f / 256.f);
+            sgx = sum_lanes32(sgx) * (1.f / 256.f);
+            float o[8];
+            bf16x8 ob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = (gg[e] - sg - xh[e] * sgx) * rsp; ob[e] = (bf16)o[e]; }
+            const uint32_t off = (uint32_t)m * ld2 + ec2;
+            if (ok) *(bf16x8*)(DX + off) = ob;
+            if (DXD) {      // (uniform)
+                if (lk.on) {
+                    float d0[4], d1[4];
+                    drop_mul4(lk, (uint32_t)m, (uint32_t)ecl >> 2, d0);
+                    drop_mul4(lk, (uint32_t)m, ((uint32_t)ecl >> 2) + 1, d1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] *= d0[e]; o[4 + e] *= d1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (bf16)o[e];
+                if (ok) *(bf16x8*)(DXD + off) = ob;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dbia[e] += (float)ob[e];      // column sum of what the GEMMs behind it will read
+            // the running sums are pinned here, pass by pass: the predicated stores above split the unrolled passes into basic blocks,
+            // and the compiler otherwise SINKS all sixteen passes' terms into the block behind the last one (their operands alive, or
+            // spilled, until then: 96 VGPRs of scratch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(dgam[e]), "+v"(dbet[e]), "+v"(dbia[e]));
+            __builtin_amdgcn_sched_barrier(0);      // one pass at a time
+        }
+        __syncthreads();      // every wave is done with the dy image
+        float* red = (float*)smem;      // [16][768]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[erow * 768 + ecl + e] = dgam[e];
+            red[erow * 768 + 256 + ecl + e] = dbet[e];
+            red[erow * 768 + 512 + ecl + e] = dbia[e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 768; idx += 512) {
+            float a = 0.f;
+#pragma unroll
+            for (int rr2 = 0; rr2 < 16; ++rr2) a += red[rr2 * 768 + idx];
+            g.lnb_part[(int64_t)m_tile * 768 + idx] = a;
+        }
+        return;
+    }
     if constexpr (SWAPPED) {
         if (g.epi == EPI_NONE && !dk.on) {
             // ---- direct epilogue (bias / residual only: the data-gradient GEMMs): no LDS staging, no barriers.  Blocks (j, j + 1)
@@ -652,6 +790,24 @@ static bool nt_big_ok(const GemmNT& g) {
            (g.aux == nullptr || ((uintptr_t)g.aux % 16) == 0) && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0);
 }
 
+// ---- dy = A W^T + res (K > 512: dX = dQKVC W) followed by the LayerNorm backward of dy in the same launch
+int gemm_nt_lnb_parts(int M) { return cdiv(M, 256); }
+bool gemm_nt_lnb_ok(const GemmNT& g) {
+    return nt_big_ok(g) && !(g.opts & OPT_UNFUSED_LN_BWD) && g.N == 256 && g.K % 64 == 0 && g.a_rows == nullptr && g.epi == EPI_NONE && g.bias == nullptr &&
+           g.drop.p == 0.f && g.lnb_y != nullptr && g.lnb_stats != nullptr && g.lnb_gamma != nullptr && g.lnb_beta != nullptr &&
+           (g.res == nullptr || g.ldr == g.ldc) && g.lnb_ldy == g.ldc && (g.lnb_dx_drop == nullptr || g.lnb_lddx == g.ldc) &&
+           (int64_t)g.M * g.ldc * 2 < (int64_t)1 << 32 && ((uintptr_t)g.lnb_y % 16) == 0 && ((uintptr_t)g.lnb_dx_drop % 16) == 0 &&
+           ((uintptr_t)g.lnb_stats % 8) == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
+}
+int gemm_nt_lnb(const GemmNT& g, hipStream_t st) {
+    PMGT_CHECK(gemm_nt_lnb_ok(g) && g.lnb_part != nullptr, -2, "gemm_nt_lnb: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
+    constexpr int smem = 4 * (256 + 256) * 64;
+    PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8, true>), smem);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8, true>), dim3(cdiv(cdiv(g.M, 256), 8) * 8), dim3(512), smem, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
     if (g.M <= 0 || g.N <= 0) return 0;
@@ -671,19 +827,11 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
             const int nm = cdiv(g.M, 256);
             if (g.N % 256 == 0 && g.K % 64 == 0) {      // (K % 64: the 256-wide tile walks k-steps in pairs)
                 constexpr int smem = 4 * (256 + 256) * 64;
-                static bool attr_set = false;
-                if (!attr_set) {
-                    PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_big_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                    attr_set = true;
-                }
+                PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8>), smem);
                 hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8>), dim3(cdiv(nm, 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
             } else {
                 constexpr int smem = 3 * (256 + 128) * 64;
-                static bool attr_set = false;
-                if (!attr_set) {
-                    PMGT_HIP(hipFuncSetAttribute((const void*)gemm_nt_big_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                    attr_set = true;
-                }
+                PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<128, 4>), smem);
                 hipLaunchKernelGGL((gemm_nt_big_kernel<128, 4>), dim3(cdiv(nm, 8) * 8 * (g.N / 128)), dim3(256), smem, st, g);
             }
             PMGT_LAUNCH_OK();
@@ -1486,12 +1634,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
         if (g.zeros != nullptr && tn_big_shape(g.M, g.N1, g.N2, bkm, g.opts) && g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm, g.opts) &&
             (g.q_rows == nullptr || g.M >= 1)) {
             constexpr int smem = 4 * 2 * 32 * 512 + 8 * 32 * 8;      // stage ring + index ring
-            static bool attr_set = false;
-            if (!attr_set) {
-                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_set = true;
-            }
+            PMGT_SMEM_ATTR((const void*)gemm_tn_big_kernel<false>, smem); PMGT_SMEM_ATTR((const void*)gemm_tn_big_kernel<true>, smem);
             const int tiles256 = (g.N1 / 256) * (g.N2 / 256);
             int chunk256 = cdiv(cdiv(std::max(g.M, 1), g.splits), 32) * 32;
             if (g.q_rows) hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
@@ -1506,11 +1649,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
             } else {
                 PMGT_CHECK(g.M >= 1, -2, "gemm_tn: gather needs at least one row");
                 constexpr size_t smem = ring + 8 * 32 * 8;
-                static bool attr_set = false;
-                if (!attr_set) {
-                    PMGT_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                    attr_set = true;
-                }
+                PMGT_SMEM_ATTR((const void*)gemm_tn_dma_kernel<true>, (int)smem);
                 hipLaunchKernelGGL(gemm_tn_dma_kernel<true>, grid, dim3(256), smem, st, g, chunk);
             }
             PMGT_LAUNCH_OK();

@@ -392,11 +392,7 @@ template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st
         if (ws_form(MODE) == 2) {
             using C = WsCfg<KS, 4>;
             auto kern = gemm_ws2_kernel<KS, MODE>;
-            static bool attr_done = false;
-            if (!attr_done) {
-                PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-                attr_done = true;
-            }
+            PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
             const int num_mt = cdiv(g.M, C::TR);
             const int gx = std::max(8, std::min(512 / ny, num_mt) / 8 * 8);      // two workgroups per CU
             hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(C::NT), C::SMEM, st, g);
@@ -406,11 +402,7 @@ template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st
     }
     using C = WsCfg<KS, 8>;
     auto kern = gemm_ws_kernel<KS, MODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-        attr_done = true;
-    }
+    PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int num_mt = cdiv(g.M, 64);
     int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, ~one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(512), C::SMEM, st, g);

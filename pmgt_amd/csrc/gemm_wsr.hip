@@ -30,6 +30,8 @@ __device__ unsigned long long g_w2_prof[16][8];
 #else
 #define W2_STAMP(k_) do { } while (0)
 #endif
+// LNB = false: the forward form above.  LNB = true: the LayerNorm-BACKWARD epilogue (see the role below) on the same GEMM role.
+template <bool LNB>
 __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
     using C = WsrCfg;
 #ifdef PMGT_W5_PROF
@@ -144,11 +146,125 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
 #ifdef PMGT_W5_PROF
         if (blockIdx.x == 40 && lane == 0) { for (int k_ = 0; k_ < 4; ++k_) g_w2_prof[wave][k_] = pacc[k_]; g_w2_prof[wave][7] = (unsigned long long)n; }
 #endif
+        if constexpr (LNB) __builtin_amdgcn_s_barrier();      // the epilogue role's column-sum exchange (one more barrier of the workgroup)
         return;
     }
     // ==================================================================== epilogue role: 512 threads, 32 lanes per row, 16 rows per pass
     const int te = tid - 512;
     const int erow = te >> 5, ecol = (te & 31) * 8;
+    if constexpr (LNB) {
+        // ---- LayerNorm backward of the row the GEMM role just produced: dy = A W^T + res is the gradient of a LayerNorm OUTPUT y the
+        // forward kept (x^ = (y - beta) / gamma, rowops.h), so  dx = rstd (dy gamma - mean(dy gamma) - x^ mean(dy gamma x^))  leaves as
+        // C (the residual branch) and, times the dropout mask of the dense layer in front of that LayerNorm, as lnb_dx_drop (what its
+        // weight / data gradient GEMMs read); dy itself never reaches HBM.  dgamma | dbeta | dbias (column sums of dy x^, dy and the
+        // bf16-rounded dx_drop) are carried in registers for the life of the workgroup: one [3][256] partial per workgroup.
+        // (one 32-bit byte offset per row serves all four row-major operands: the host requires equal leading dimensions and < 4 GB
+        // each, so every access is  scalar base + 32-bit lane offset  and no 64-bit lane addresses are kept alive)
+        const char* R = (const char*)g.res;
+        const char* Y = (const char*)g.lnb_y;
+        char* DX = (char*)g.C;
+        char* DXD = (char*)g.lnb_dx_drop;
+        const uint32_t ldb2 = (uint32_t)g.ldc * 2u, ecol2 = (uint32_t)ecol * 2u;
+        const DropKey dk = make_drop_key(g.lnb_drop);
+        float gam[8], nbet[8], igam[8], dgam[8], dbet[8], dbia[8];      // x^ = y / gamma - beta / gamma
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gam[e] = g.lnb_gamma[ecol + e];
+            igam[e] = gam[e] != 0.f ? __builtin_amdgcn_rcpf(gam[e]) : 0.f;      // (a dead channel: the host guard stores LayerNorm inputs instead, engine.py)
+            nbet[e] = -g.lnb_beta[ecol + e] * igam[e];
+            dgam[e] = dbet[e] = dbia[e] = 0.f;
+        }
+        // residual / y / rstd of this lane's two rows of a tile, loaded a whole step ahead: the registers of pass ps are refilled for
+        // step t + 1 right after pass ps of step t has converted them (no second register set: sixteen waves leave 128 VGPRs each)
+        bf16x8 pfr[2], pfy[2];
+        float pfs[2];
+        auto load_pf = [&](int t, int ps) __attribute__((always_inline)) {
+            const uint32_t m = (uint32_t)min((x + t * gx) * C::TR + erow + 16 * ps, g.M - 1);
+            const uint32_t off = m * ldb2 + ecol2;
+            pfr[ps] = *(const bf16x8*)(R + off);
+            pfy[ps] = *(const bf16x8*)(Y + off);
+            pfs[ps] = *(const float*)((const char*)g.lnb_stats + (m * 8u + 4u));
+        };
+        load_pf(0, 0); load_pf(0, 1);      // (row indices are clamped: valid addresses even for a workgroup without tiles)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();      // the GEMM role's step 0 (this role trails it by one step: same number of barriers)
+        for (int tt = 0; tt < n; ++tt) {
+            {
+                const int mt = x + tt * gx;
+                const float* stage = (const float*)(smem + C::NR * C::TILEB + (tt & 1) * C::STG);
+                const int tnext = min(tt + 1, n - 1);      // unconditional refill (the last step re-reads its own rows): no branch in the loop body
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int row = erow + 16 * ps;
+                    const int m = mt * C::TR + row;
+                    const bool ok = m < g.M;
+                    const f32x4 s0 = *(const f32x4*)(stage + row * C::ES + ecol), s1 = *(const f32x4*)(stage + row * C::ES + ecol + 4);
+                    float v[8], xh[8], gg[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = s0[e] + (float)pfr[ps][e]; v[4 + e] = s1[e] + (float)pfr[ps][4 + e]; }
+                    if (!ok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 0.f;      // rows past M (clamped operands): no term in any sum, nothing stored
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xh[e] = fmaf((float)pfy[ps][e], igam[e], nbet[e]);
+                    const float rs = pfs[ps];
+                    __builtin_amdgcn_sched_barrier(0);        // (the refill must not be scheduled above the conversions: it targets their registers)
+                    load_pf(tnext, ps);                       // the next step's rows travel under the rest of this step
+                    __builtin_amdgcn_sched_barrier(0);
+                    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        gg[e] = v[e] * gam[e];
+                        dgam[e] = fmaf(v[e], xh[e], dgam[e]);
+                        dbet[e] += v[e];
+                        sg += gg[e];
+                        sgx = fmaf(gg[e], xh[e], sgx);
+                    }
+                    sg = sum_lanes32(sg) * (1.f / 256.f);
+                    sgx = sum_lanes32(sgx) * (1.f / 256.f);
+                    float o[8];
+                    bf16x8 ob;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { o[e] = (gg[e] - sg - xh[e] * sgx) * rs; ob[e] = (bf16)o[e]; }
+                    const uint32_t off = (uint32_t)m * ldb2 + ecol2;
+                    if (ok) *(bf16x8*)(DX + off) = ob;
+                    if (DXD) {      // (uniform)
+                        if (dk.on) {
+                            float d0[4], d1[4];
+                            drop_mul4(dk, (uint32_t)m, (uint32_t)ecol >> 2, d0);
+                            drop_mul4(dk, (uint32_t)m, ((uint32_t)ecol >> 2) + 1, d1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { o[e] *= d0[e]; o[4 + e] *= d1[e]; }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ob[e] = (bf16)o[e];
+                        if (ok) *(bf16x8*)(DXD + off) = ob;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dbia[e] += (float)ob[e];      // column sum of what the GEMMs behind it will read
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---- the sixteen row groups' column sums -> one [3][256] partial of this workgroup (the staging buffers are free: every
+        // epilogue wave is past the loop's last barrier)
+        float* red = (float*)(smem + C::NR * C::TILEB);      // [16][768]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[erow * 768 + ecol + e] = dgam[e];
+            red[erow * 768 + 256 + ecol + e] = dbet[e];
+            red[erow * 768 + 512 + ecol + e] = dbia[e];
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int idx = te; idx < 768; idx += 512) {
+            float a = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) a += red[rr * 768 + idx];
+            g.lnb_part[(int64_t)blockIdx.x * 768 + idx] = a;
+        }
+        return;
+    }
     const DropKey dk = make_drop_key(g.drop);
     bf16* Cp = (bf16*)g.C;
     const bf16* R = (const bf16*)g.res;
@@ -257,14 +373,32 @@ bool gemm_wsr_ok(const GemmWS& g) {
 
 int gemm_wsr(const GemmWS& g, hipStream_t st) {
     PMGT_CHECK(gemm_wsr_ok(g), -2, "gemm_wsr: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)gemm_wsr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WsrCfg::SMEM));
-        attr_done = true;
-    }
+    PMGT_SMEM_ATTR((const void*)gemm_wsr_kernel<false>, WsrCfg::SMEM);
     const int num_mt = cdiv(g.M, WsrCfg::TR);
     const int gx = std::max(8, std::min(256, num_mt) / 8 * 8);      // one 16-wave workgroup per CU
-    hipLaunchKernelGGL(gemm_wsr_kernel, dim3(gx), dim3(1024), WsrCfg::SMEM, st, g);
+    hipLaunchKernelGGL(gemm_wsr_kernel<false>, dim3(gx), dim3(1024), WsrCfg::SMEM, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// ---- dy = A W^T + res followed by the LayerNorm backward of dy, in one launch (K = N = 256): the data-gradient GEMM in front of a
+// LayerNorm site whose input the forward did not store.  One [3][256] partial (dgamma | dbeta | dbias) per workgroup.
+int gemm_wsr_lnb_parts(int M) {
+    const int num_mt = cdiv(M, WsrCfg::TR);
+    return std::max(8, std::min(256, num_mt) / 8 * 8);
+}
+bool gemm_wsr_lnb_ok(const GemmWS& g) {
+    return !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN | OPT_UNFUSED_LN_BWD)) && g.K == 256 && g.N == 256 && g.M >= 8192 && g.epi == EPI_NONE && g.bias == nullptr &&
+           g.drop.p == 0.f && g.res != nullptr && g.lnb_y != nullptr && g.lnb_stats != nullptr && g.lnb_gamma != nullptr && g.lnb_beta != nullptr &&
+           g.a_rows == nullptr && g.m_dev == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.ldr == g.ldc && g.lnb_ldy == g.ldc &&
+           (g.lnb_dx_drop == nullptr || g.lnb_lddx == g.ldc) && (int64_t)g.M * g.ldc * 2 < (int64_t)1 << 32 &&
+           ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 &&
+           ((uintptr_t)g.lnb_y % 16) == 0 && ((uintptr_t)g.lnb_dx_drop % 16) == 0 && ((uintptr_t)g.lnb_stats % 8) == 0;
+}
+int gemm_wsr_lnb(const GemmWS& g, hipStream_t st) {
+    PMGT_CHECK(gemm_wsr_lnb_ok(g) && g.lnb_part != nullptr, -2, "gemm_wsr_lnb: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
+    PMGT_SMEM_ATTR((const void*)gemm_wsr_kernel<true>, WsrCfg::SMEM);
+    hipLaunchKernelGGL(gemm_wsr_kernel<true>, dim3(gemm_wsr_lnb_parts(g.M)), dim3(1024), WsrCfg::SMEM, st, g);
     PMGT_LAUNCH_OK();
     return 0;
 }
@@ -549,11 +683,7 @@ bool gemm_wsr512_ok(const GemmWS& g) {
 
 template <int MODE> static int launch_wsr512(const GemmWS& g, hipStream_t st) {
     auto kern = gemm_wsr512_kernel<MODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Wsr5Cfg::SMEM));
-        attr_done = true;
-    }
+    PMGT_SMEM_ATTR((const void*)kern, Wsr5Cfg::SMEM);
     const int ny = g.N / 256, num_mt = cdiv(g.M, Wsr5Cfg::TR);
     const int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, one 12-wave workgroup per CU
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(768), Wsr5Cfg::SMEM, st, g);

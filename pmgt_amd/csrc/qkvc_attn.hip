@@ -737,11 +737,7 @@ bool qkvc_attn_supported(const QkvcAttn& a) {
 template <int KS, int F8> static int launch_qa2(const QkvcAttn& a, hipStream_t st) {
     using C = QaCfg2<KS, F8>;
     auto kern = qkvc_attn_fwd2_kernel<KS, F8>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-        attr_done = true;
-    }
+    PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int ny = a.H / 2;
     const int gx = std::max(8, std::min(512 / ny, a.Tseq) / 8 * 8);       // two workgroups per CU
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(256), C::SMEM, st, a);
@@ -752,11 +748,7 @@ template <int KS, int F8> static int launch_qa2(const QkvcAttn& a, hipStream_t s
 template <int KS> static int launch_qa3(const QkvcAttn& a, hipStream_t st) {
     using C = QaCfg3<KS>;
     auto kern = qkvc_attn_fwd3_kernel<KS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PMGT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
-        attr_done = true;
-    }
+    PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int ny = a.H / 2;
     const int gx = std::max(8, std::min(256 / ny, a.Tseq) / 8 * 8);       // one 16-wave workgroup per CU
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(1024), C::SMEM, st, a);

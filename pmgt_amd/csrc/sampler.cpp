@@ -106,6 +106,40 @@ struct MT19937 {
     }
 };
 
+// ---- generator of the THREADED entry (per-target streams; no reference stream to reproduce there: the reference samples
+// sequentially from the global np.random, which is what MT19937 above restates).  xoshiro256++ seeded by splitmix64 from
+// (base seed, item counter): one 64-bit output per uniform instead of two tempered MT words -- the Mersenne Twister was a third
+// of the CPU time of a context (1 312 words for its 656 weighted draws), and the live input pipeline is bound by exactly that
+// CPU time on a 16-CPU share.  Same algorithm, same distributions (53-bit uniforms, masked-rejection bounded integers).
+struct Xoshiro256pp {
+    uint64_t s[4];
+    static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    void seed(uint64_t base, uint64_t ctr) {
+        uint64_t z = base * 0xD1342543DE82EF95ull + 0x9E3779B97F4A7C15ull * (ctr + 1);
+        for (int i = 0; i < 4; ++i) {      // splitmix64
+            z += 0x9E3779B97F4A7C15ull;
+            uint64_t t = z;
+            t = (t ^ (t >> 30)) * 0xBF58476D1CE4E5B9ull;
+            t = (t ^ (t >> 27)) * 0x94D049BB133111EBull;
+            s[i] = t ^ (t >> 31);
+        }
+    }
+    inline uint64_t next64() {
+        const uint64_t r = rotl(s[0] + s[3], 23) + s[0], t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    inline double next_double() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+    inline uint64_t interval(uint64_t max) {      // uniform integer in [0, max]
+        if (max == 0) return 0;
+        uint64_t mask = max;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        uint64_t v;
+        while ((v = (next64() >> 11) & mask) > max) {}
+        return v;
+    }
+};
+
 // numpy pairwise summation (DOUBLE_pairwise_sum) — the order np.sum uses on a contiguous 1-D array
 double pairwise_sum(const double* a, int64_t n) {
     if (n < 8) {
@@ -217,11 +251,9 @@ struct pmgt_sampler {
     // re-creating them per call costs more than the sampling itself on million-node graphs)
     std::mutex pool_mu;
     std::vector<std::unique_ptr<Scratch>> pool;
-    // staging of the threaded entry (private slot of max_pairs rows per target), kept across calls under stage_mu
+    // first pair row of every target of a threaded call (kept across calls; one threaded call at a time per handle)
     std::mutex stage_mu;
-    std::vector<int64_t> st_pid;
-    std::vector<float> st_pmk, st_lab;
-    std::vector<int> st_cnt;
+    std::vector<int64_t> st_off;
     WorkerPool workers;               // declared last: destroyed (joined) first
     // sorted adjacency for the negative-sampling membership test
     std::vector<int64_t> sorted_idx;
@@ -236,8 +268,10 @@ struct pmgt_sampler {
 
 namespace {
 
-// pmgt/pmgt/datasets.py:14-53
-int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* ids, float* mask) {
+// pmgt/pmgt/datasets.py:14-53.  R = the uniform source: the sequential entries pass the numpy legacy stream (bit-exact with the
+// reference), the threaded entry a per-target xoshiro stream.
+template <class R>
+int sample_context(const pmgt_sampler* s, Scratch& sc, R& rng, int64_t target, int64_t* ids, float* mask) {
     const int depth = (int)s->hops.size();
     const int S = s->max_ctx + 1;
     if (target < 2 || target >= s->n_nodes + 2) { set_err("target id %lld out of range", (long long)target); return -2; }
@@ -268,7 +302,7 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
             const int nd = size < 64 ? size : 64;
             for (int r0 = 0; r0 < size; r0 += nd) {
                 const int nb_ = size - r0 < nd ? size - r0 : nd;
-                for (int r = 0; r < nb_; ++r) us[r] = sc.rng.next_double();
+                for (int r = 0; r < nb_; ++r) us[r] = rng.next_double();
                 for (int r = 0; r < nb_; ++r) {
                     const double u = us[r];
                     // searchsorted(cdf, u, side='right') = first index with cdf[i] > u.  cdf[dg - 1] is exactly 1 > u, so the scan
@@ -345,10 +379,11 @@ int sample_context(const pmgt_sampler* s, Scratch& sc, int64_t target, int64_t* 
 int max_pairs(const pmgt_sampler* s, int mode) { return mode == 0 ? s->max_total : (mode == 1 ? 2 : 0); }
 
 // PMGTDataset.__getitem__ (pmgt/pmgt/datasets.py:113-165); returns number of pairs or <0
-int sample_item(const pmgt_sampler* s, Scratch& sc, int64_t target, int mode, int64_t* tgt_ids, float* tgt_mask,
+template <class R>
+int sample_item(const pmgt_sampler* s, Scratch& sc, R& rng, int64_t target, int mode, int64_t* tgt_ids, float* tgt_mask,
                 int64_t* pair_ids, float* pair_mask, float* labels) {
     const int S = s->max_ctx + 1;
-    int rc = sample_context(s, sc, target, tgt_ids, tgt_mask);
+    int rc = sample_context(s, sc, rng, target, tgt_ids, tgt_mask);
     if (rc < 0) return rc;
     if (mode == 2) return 0;
     const int k = mode == 0 ? (s->max_total - s->min_neg) : 1;
@@ -358,7 +393,7 @@ int sample_item(const pmgt_sampler* s, Scratch& sc, int64_t target, int mode, in
     sc.perm.resize(dg);
     for (int64_t i = 0; i < dg; ++i) sc.perm[i] = i;
     for (int64_t i = dg - 1; i >= 1; --i) {
-        const int64_t j = (int64_t)sc.rng.interval((uint64_t)i);
+        const int64_t j = (int64_t)rng.interval((uint64_t)i);
         std::swap(sc.perm[i], sc.perm[j]);
     }
     int64_t pos_nodes[64];
@@ -366,7 +401,7 @@ int sample_item(const pmgt_sampler* s, Scratch& sc, int64_t target, int mode, in
     for (int i = 0; i < npos; ++i) pos_nodes[i] = s->indices[b + sc.perm[i]];
     int np_ = 0;
     for (int i = 0; i < npos; ++i, ++np_) {
-        rc = sample_context(s, sc, pos_nodes[i], pair_ids + (int64_t)np_ * S, pair_mask + (int64_t)np_ * S);
+        rc = sample_context(s, sc, rng, pos_nodes[i], pair_ids + (int64_t)np_ * S, pair_mask + (int64_t)np_ * S);
         if (rc < 0) return rc;
         labels[np_] = 1.f;
     }
@@ -374,25 +409,18 @@ int sample_item(const pmgt_sampler* s, Scratch& sc, int64_t target, int mode, in
     int64_t neg_nodes[64];
     if (nneg > 64) { set_err("too many negatives"); return -5; }
     for (int i = 0; i < nneg; ++i) {       // datasets.py:173-180 (all negatives are drawn before their contexts)
-        int64_t cand = (int64_t)sc.rng.interval((uint64_t)(s->n_nodes - 1)) + 2;
-        while (s->is_neighbor(target, cand)) cand = (int64_t)sc.rng.interval((uint64_t)(s->n_nodes - 1)) + 2;
+        int64_t cand = (int64_t)rng.interval((uint64_t)(s->n_nodes - 1)) + 2;
+        while (s->is_neighbor(target, cand)) cand = (int64_t)rng.interval((uint64_t)(s->n_nodes - 1)) + 2;
         neg_nodes[i] = cand;
     }
     for (int i = 0; i < nneg; ++i, ++np_) {
-        rc = sample_context(s, sc, neg_nodes[i], pair_ids + (int64_t)np_ * S, pair_mask + (int64_t)np_ * S);
+        rc = sample_context(s, sc, rng, neg_nodes[i], pair_ids + (int64_t)np_ * S, pair_mask + (int64_t)np_ * S);
         if (rc < 0) return rc;
         labels[np_] = 0.f;
     }
     return np_;
 }
 
-inline uint32_t mix_seed(uint64_t base, uint64_t ctr) {   // splitmix64 -> 32-bit MT seed
-    uint64_t z = base + 0x9E3779B97F4A7C15ull * (ctr + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z ^ (z >> 32));
-}
 
 }  // namespace
 
@@ -464,7 +492,7 @@ double pmgt_sampler_random_sample(pmgt_sampler* s) { return s->main.rng.next_dou
 int64_t pmgt_sampler_randint(pmgt_sampler* s, int64_t n) { return (int64_t)s->main.rng.interval((uint64_t)(n - 1)); }
 
 int pmgt_sampler_context(pmgt_sampler* s, int64_t target, int64_t* ids, float* mask) {
-    return sample_context(s, s->main, target, ids, mask);
+    return sample_context(s, s->main, s->main.rng, target, ids, mask);
 }
 
 int pmgt_sampler_batch(pmgt_sampler* s, const int64_t* targets, int n, int mode, int64_t* tgt_ids, float* tgt_mask,
@@ -472,7 +500,7 @@ int pmgt_sampler_batch(pmgt_sampler* s, const int64_t* targets, int n, int mode,
     const int S = s->max_ctx + 1;
     int64_t tot = 0;
     for (int i = 0; i < n; ++i) {
-        const int rc = sample_item(s, s->main, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
+        const int rc = sample_item(s, s->main, s->main.rng, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
                                    pair_ids ? pair_ids + tot * S : nullptr, pair_mask ? pair_mask + tot * S : nullptr,
                                    labels ? labels + tot : nullptr);
         if (rc < 0) return rc;
@@ -488,14 +516,26 @@ int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mo
     const int S = s->max_ctx + 1, mp = max_pairs(s, mode);
     if (n <= 0) return 0;
     n_threads = std::max(1, std::min(n_threads, n));
-    // every target samples into a private slot of max_pairs rows, then the rows are compacted in order
+    // The number of pair rows of a target depends on its degree only (datasets.py:128-147: min(k, deg) positives, then
+    // max(min_neg, max_total - positives) negatives), so every target's first output row is known BEFORE sampling: the workers
+    // write straight into the caller's arrays.  (The staged form -- private slots, then a sequential compaction of ~4 MB per
+    // 1 024-target batch on the calling thread -- sat on the critical path of the live input pipeline.)
     std::lock_guard<std::mutex> stage_lock(s->stage_mu);
-    if (s->st_pid.size() < (size_t)n * mp * S) { s->st_pid.resize((size_t)n * mp * S); s->st_pmk.resize((size_t)n * mp * S); }
-    if (s->st_lab.size() < (size_t)n * mp) s->st_lab.resize((size_t)n * mp);
-    s->st_cnt.assign(n, 0);
-    std::vector<int64_t>& pid = s->st_pid;
-    std::vector<float>&pmk = s->st_pmk, &lab = s->st_lab;
-    std::vector<int>& cnt = s->st_cnt;
+    std::vector<int64_t>& off = s->st_off;
+    off.resize((size_t)n + 1);
+    off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        int c = 0;
+        const int64_t t = targets[i];
+        if (mode != 2 && t >= 2 && t < s->n_nodes + 2) {
+            const int64_t dg = s->deg(t);
+            const int k = mode == 0 ? (s->max_total - s->min_neg) : 1;
+            const int npos = (int)std::min<int64_t>(k, dg);
+            c = npos + (mode == 0 ? std::max(s->min_neg, s->max_total - npos) : 1);
+        }
+        off[i + 1] = off[i] + c;      // (an invalid target contributes no rows; its worker reports the error)
+    }
+    (void)mp;
     std::atomic<int> next(0), fail(0);
     std::vector<std::string> errs(n_threads);
     const std::function<void(int)> work = [&](int tid) {
@@ -513,11 +553,14 @@ int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mo
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n || fail.load()) break;
-            sc.rng.seed(mix_seed(base_seed, counter + counter_stride * (uint64_t)i));
-            const int rc = sample_item(s, sc, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
-                                       pid.data() + (size_t)i * mp * S, pmk.data() + (size_t)i * mp * S, lab.data() + (size_t)i * mp);
+            Xoshiro256pp rng;
+            rng.seed(base_seed, counter + counter_stride * (uint64_t)i);
+            const int64_t o = off[i];
+            const int rc = sample_item(s, sc, rng, targets[i], mode, tgt_ids + (int64_t)i * S, tgt_mask + (int64_t)i * S,
+                                       pair_ids ? pair_ids + o * S : nullptr, pair_mask ? pair_mask + o * S : nullptr, labels ? labels + o : nullptr);
             if (rc < 0) { errs[tid] = g_err; fail.store(rc); break; }
-            cnt[i] = rc;
+            if (rc != (int)(off[i + 1] - o)) { errs[tid] = "internal: pair count differs from its degree formula"; fail.store(-6); break; }
+            if (num_pairs) num_pairs[i] = rc;
         }
     };
     s->workers.run(n_threads, work);
@@ -525,17 +568,7 @@ int pmgt_sampler_batch_mt(pmgt_sampler* s, const int64_t* targets, int n, int mo
         for (auto& e : errs) if (!e.empty()) { set_err("%s", e.c_str()); break; }
         return fail.load();
     }
-    int64_t tot = 0;
-    for (int i = 0; i < n; ++i) {
-        if (cnt[i] > 0) {
-            memcpy(pair_ids + tot * S, pid.data() + (size_t)i * mp * S, sizeof(int64_t) * cnt[i] * S);
-            memcpy(pair_mask + tot * S, pmk.data() + (size_t)i * mp * S, sizeof(float) * cnt[i] * S);
-            memcpy(labels + tot, lab.data() + (size_t)i * mp, sizeof(float) * cnt[i]);
-        }
-        if (num_pairs) num_pairs[i] = cnt[i];
-        tot += cnt[i];
-    }
-    return (int)tot;
+    return (int)off[n];
 }
 
 int pmgt_train_valid_split(int64_t n_nodes, double valid_size, uint32_t seed, int64_t* train_out, int64_t* valid_out) {

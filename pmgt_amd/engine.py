@@ -110,18 +110,23 @@ class Engine:
     # harmless for the reference's initialisation (gamma = 1, beta = 0) and anything near it, not for a checkpoint whose LayerNorm has
     # |beta| >> |gamma| in some channel.  Loading parameters checks that ratio and falls back to stored inputs ("store_ln_input").
     LN_CARRIER_MAX_RATIO = 8.0
+    LN_CARRIER_MIN_GAMMA = 1e-6
 
     def check_layernorm_carrier(self) -> float:
-        """max over the encoder's LayerNorm channels of |beta| / |gamma| (channels with gamma == 0 are handled exactly by the
-        kernel and skipped); above LN_CARRIER_MAX_RATIO the engine switches to stored LayerNorm inputs."""
+        """max over the encoder's LayerNorm channels of |beta| / |gamma|; above LN_CARRIER_MAX_RATIO -- or with a channel whose
+        gamma is (nearly) zero, where x^ cannot be recovered from the output at all -- the engine switches to stored LayerNorm
+        inputs.  Called wherever parameters arrive in bulk (load_params, the modules' load_state_dict), by the Trainer every
+        `check_carrier_every` optimizer steps and before a step is captured into a graph."""
         worst = 0.0
         for e in self.entries:
             if e["name"].endswith("LayerNorm.weight") and "encoder.layer" in e["name"]:
                 g = self.view(e["name"]).abs()
                 b = self.view(e["name"][:-len("weight")] + "bias").abs()
-                nz = g > 0
-                if bool(nz.any()):
-                    worst = max(worst, float((b[nz] / g[nz]).max()))
+                tiny = g < self.LN_CARRIER_MIN_GAMMA
+                if bool(tiny.any()):
+                    worst = float("inf")
+                    break
+                worst = max(worst, float((b / g).max()))
         if worst > self.LN_CARRIER_MAX_RATIO and not self.get_option("store_ln_input"):
             import warnings
             warnings.warn(f"pmgt_amd: LayerNorm |beta / gamma| reaches {worst:.1f}: x^ from the LayerNorm output would lose "
@@ -131,6 +136,10 @@ class Engine:
 
     # ---- path options (include/pmgt_ops.h): state of THIS engine, not of the process ----------------
     def set_option(self, key: str, value) -> None:
+        if getattr(self, "_live_graphs", 0) > 0 and bool(value) != self.get_option(key):
+            # a captured step keeps the kernels it was captured with, while the workspace would be re-carved for the new option
+            raise RuntimeError(f"pmgt_amd: option {key!r} cannot change while a captured step of this engine is alive "
+                               "(drop the replay handle first)")
         _lib.check(self.lib.pmgt_engine_set_option(self.h, key.encode(), 1 if value else 0))
         self.__dict__.pop("_ws_bytes", None)          # workspace carving depends on some options
 

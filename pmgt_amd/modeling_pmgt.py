@@ -133,6 +133,11 @@ class PMGTModel(PMGTPretrainedModel):
         if engine is None:
             self._init_weights()
 
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = super().load_state_dict(state_dict, strict=strict)      # writes the engine's parameters through the Parameter views
+        self.engine.check_layernorm_carrier()
+        return out
+
     def forward(self, *input_feat_embeds, attention_mask=None, head_mask=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None):
         first = input_feat_embeds[0]

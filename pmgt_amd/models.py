@@ -158,8 +158,9 @@ class PMGT(PMGTPretrainedModel):
         self.engine.set_tables(*[emb.weight for emb in self.feat_embeddings.children()])
 
     def load_state_dict(self, state_dict, strict: bool = True):
-        out = super().load_state_dict(state_dict, strict=strict)
+        out = super().load_state_dict(state_dict, strict=strict)      # writes the engine's parameters through the Parameter views
         self.engine.set_tables(*[emb.weight for emb in self.feat_embeddings.children()])
+        self.engine.check_layernorm_carrier()
         return out
 
     def forward(self, target_node_inputs, pair_node_inputs=None, num_pairs=None, labels=None, output_attentions=None,

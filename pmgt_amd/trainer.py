@@ -27,7 +27,7 @@ class Trainer:
     def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
                  random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True,
-                 buckets: str = "layer", check_carrier_every: int = 0):
+                 buckets: str = "layer", check_carrier_every: int = 200):
         self.engine = engine
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
@@ -37,7 +37,8 @@ class Trainer:
         self.last_loss = None
         self._micro = 0
         # every N optimizer steps re-check that the LayerNorm parameters still allow x^ = (y - beta) / gamma from the bf16 output
-        # (Engine.check_layernorm_carrier: one small device -> host read per LayerNorm; 0 = only when parameters are loaded)
+        # (Engine.check_layernorm_carrier: one small device -> host read per LayerNorm; 0 = only when parameters are loaded or a
+        # step is captured)
         self.check_carrier_every = int(check_carrier_every)
         self._opt_steps = 0
         # world_size > 1: per-bucket all-reduce started from the engine's gradient-ready hook while the backward pass of
@@ -109,6 +110,9 @@ class Trainer:
         the gradient all-reduce is not captured."""
         assert self.world_size == 1 and self.accum == 1, "capture covers the single-GPU, non-accumulating step"
         dev = self.engine.device
+        # replays never run the Python-side guard: decide "x^ from the LayerNorm output or from stored inputs" once, on the
+        # parameters as they are now, before the kernels are frozen into the graph
+        self.engine.check_layernorm_carrier()
         st = torch.cuda.Stream(device=dev)
         st.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(st):
@@ -129,6 +133,10 @@ class Trainer:
             graph.replay()
             self.last_loss = loss
             return loss
+        import weakref
+        eng = self.engine
+        eng._live_graphs = getattr(eng, "_live_graphs", 0) + 1      # Engine.set_option refuses changes while a captured step lives
+        weakref.finalize(graph, lambda: setattr(eng, "_live_graphs", eng._live_graphs - 1))
         replay.graph = graph
         replay.outputs = outputs          # loss / logits / nfr_count the replays write (kept alive with the graph)
         return replay

@@ -755,3 +755,67 @@ def test_gemm_nt_big_tile_epilogues(M, N, K):
     assert rel_err(Cd, C2.double()) < 1e-3
     kept = ((Cd.double() - rounded(res, tdt).cuda()).abs() > 1e-6).double().mean().item()
     assert abs(kept - 0.75) < 0.02
+
+
+@pytest.mark.parametrize("M,K,drop", [(8192, 256, 0.1), (8193, 256, 0.0), (9000, 256, 0.1), (65537, 256, 0.1), (12288, 256, 0.0), (300000, 256, 0.1),
+                                      (24577, 1024, 0.1), (24576, 1024, 0.0), (100001, 1024, 0.1), (30000, 512, 0.1), (393216, 1024, 0.1)])
+def test_layernorm_backward_in_the_data_gradient_epilogue(M, K, drop):
+    """dy = A W^T + residual followed by the backward of a LayerNorm whose OUTPUT y the forward kept (x^ = (y - beta) / gamma):
+    gemm_wsr_kernel<true> (K = 256: epilogue role of the streaming kernel) and gemm_nt_big_kernel<256, 8, true> (larger K: a phase
+    behind the tile's main loop) do both in one launch, dy never reaches HBM; checked against the two-launch form
+    (streaming GEMM -> dy in bf16 -> ln_bwd_kernel) and against fp64 autograd through torch's layer_norm
+    (BertSelfOutput / BertOutput backward, pmgt/pmgt/modeling_pmgt.py:293-294,322-325).  Ragged M, one and many steps per workgroup."""
+    _lib, L = _setup()
+    N = 256
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda().bfloat16()
+    R = torch.randn(M, N, generator=g).cuda().bfloat16()
+    x = torch.randn(M, N, generator=g) * 1.5 + 0.3                      # the LayerNorm's input (never given to the kernels)
+    gam = (1 + 0.1 * torch.randn(N, generator=g))
+    bet = (0.1 * torch.randn(N, generator=g))
+    xd = x.double().requires_grad_(True)
+    gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(xd, (N,), gd, bd, 1e-12)
+    y = yref.detach().float().cuda().bfloat16()
+    mean = x.double().mean(1)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-12)
+    stats = torch.stack([mean, rstd], 1).float().cuda().contiguous()
+    gamd, betd = gam.cuda(), bet.cuda()
+    rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
+    outs = []
+    for opts in ((), ("unfused_ln_bwd",)):
+        L.use(*opts)
+        dx = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        dxd = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        tmp = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        part = torch.empty(max(256, (M + 63) // 64) * 3 * N, device="cuda")
+        dgb = torch.full((3 * N,), float("nan"), device="cuda")
+        _lib.check(L.pmgt_op_linear_ln_bwd(P(A), K, P(W), K, M, N, K, P(R), N, P(y), P(stats), P(gamd), P(betd), P(tmp), P(dx), P(dxd),
+                                           drop, 35, P(rng), P(part), P(dgb), stream()))
+        torch.cuda.synchronize()
+        outs.append((dx, dxd, dgb))
+    L.use()
+    (dx, dxd, dgb), (dx2, dxd2, dgb2) = outs
+    assert torch.isfinite(dx.float()).all() and torch.isfinite(dxd.float()).all() and torch.isfinite(dgb).all()
+    # fused vs two-launch: the only differences are dy kept in fp32 instead of rounded to bf16 and the order of the row sums
+    assert rel_err(dx, dx2.float()) < 1.5e-2
+    # (the two-launch form sums bf16-rounded dy: ~2^-9 sqrt(M) |dy| of noise on column sums of size ~sqrt(M) |dy|)
+    assert rel_err(dgb[:N], dgb2[:N]) < 1e-2 and rel_err(dgb[N:2 * N], dgb2[N:2 * N]) < 1e-2 and rel_err(dgb[2 * N:], dgb2[2 * N:]) < 1e-2
+    keep = dxd2 != 0
+    if drop > 0:
+        assert abs(float(keep.float().mean()) - (1 - drop)) < 0.01
+        assert float(((dxd != 0) == keep).float().mean()) > 0.9999      # the same dropout mask (up to exact zeros of dx)
+    # against fp64 autograd: dy = A W^T + R, x^ from the bf16 y (the carrier error of engine.py's guard is part of the tolerance)
+    dy = A.double().cpu() @ W.double().cpu().T + R.double().cpu()
+    yref.backward(dy)
+    assert rel_err(dx, xd.grad) < 3e-2
+    # (K > 256: the tile form passes dy to its LayerNorm phase as bf16 -- what the two-launch form rounds it to in HBM)
+    assert rel_err(dgb[:N], gd.grad) < 1.5e-2
+    assert rel_err(dgb[N:2 * N], bd.grad) < (1e-3 if K == 256 else 5e-3)
+    assert rel_err(dgb[2 * N:], dxd.double().sum(0)) < 1e-4               # the dense bias gradient = column sums of what was stored
+    if drop > 0:
+        scale = 1.0 / (1.0 - drop)
+        assert rel_err(dxd, (dx.double().cpu() * scale).to(torch.bfloat16).double() * keep.double().cpu()) < 1e-2
+    else:
+        assert torch.equal(dx, dxd)

@@ -153,3 +153,65 @@ def test_layernorm_carrier_guard_switches_to_stored_inputs():
     assert eng.get_option("store_ln_input")
     out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, want_hidden=False)
     assert np.isfinite(out["loss"].item()) and torch.isfinite(eng.grads).all()
+
+
+def test_module_load_state_dict_runs_the_layernorm_carrier_guard():
+    """Round-3 advisor finding: PMGT.load_state_dict writes a checkpoint through the Parameter views and never went through
+    Engine.load_params, so a checkpoint with |beta / gamma| >> 1 (or gamma == 0) trained on x^ recovered from the bf16 output."""
+    from tests.test_surface_gpu import build
+    case = gu.model_case("m3")
+    model = build(case, dtype="bf16")
+    assert not model.engine.get_option("store_ln_input")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["bert.encoder.layer.0.attention.output.LayerNorm.weight"][3] = 0.0       # a dead channel: x^ is not recoverable from y at all
+    with pytest.warns(UserWarning, match="store_ln_input"):
+        model.load_state_dict(sd)
+    assert model.engine.get_option("store_ln_input")
+    # the encoder module on its own engine takes the same route
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.modeling_pmgt import PMGTModel
+    enc = PMGTModel(PMGTConfig(**case["cfg"]), dtype="bf16")
+    esd = {k: v.clone() for k, v in enc.state_dict().items()}
+    esd["encoder.layer.1.output.LayerNorm.weight"][5] = 1e-3
+    esd["encoder.layer.1.output.LayerNorm.bias"][5] = 1.0
+    with pytest.warns(UserWarning, match="store_ln_input"):
+        enc.load_state_dict(esd)
+    assert enc.engine.get_option("store_ln_input")
+
+
+def test_backward_refuses_options_changed_since_the_forward():
+    """Round-3 advisor finding: the backward re-derives which buffers the forward filled from the CURRENT options; a flip between
+    pmgt_encode_train and pmgt_encode_backward read never-written buffers.  Now the forward's bits are remembered per workspace."""
+    case = gu.model_case("m3")
+    eng = make_engine(case, dtype="bf16")
+    tgt = case["batch"][1]
+    ids, mask = tgt["node_ids"].cuda(), tgt["attention_mask"].cuda()
+    last, state = eng.encode_train(ids=ids, attention_mask=mask, training=True)
+    eng.set_option("store_ln_input", 1)
+    with pytest.raises(RuntimeError, match="options changed since the forward"):
+        eng.encode_backward(state, torch.ones_like(last))
+    eng.set_option("store_ln_input", 0)                  # back to what the forward saw: accepted
+    eng.encode_backward(state, torch.ones_like(last))
+    eng.set_option("eager_reduce", 1)                    # scheduling-only bits do not count
+    last, state = eng.encode_train(ids=ids, attention_mask=mask, training=True)
+    eng.set_option("eager_reduce", 0)
+    eng.encode_backward(state, torch.ones_like(last))
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.grads).all()
+
+
+def test_options_are_frozen_while_a_captured_step_lives():
+    import gc
+    from pmgt_amd.trainer import Trainer
+    case = gu.model_case("m3")
+    eng = make_engine(case, dtype="bf16")
+    tr = Trainer(eng, lr=1e-3, max_grad_norm=5.0)
+    replay = tr.capture_step(dev_batch(case["batch"]), warmup=1)
+    replay()
+    eng.set_option("store_ln_input", 0)                  # no change: fine
+    with pytest.raises(RuntimeError, match="captured step"):
+        eng.set_option("store_ln_input", 1)
+    torch.cuda.synchronize()
+    del replay
+    gc.collect()
+    eng.set_option("store_ln_input", 1)                  # the graph is gone
