@@ -35,6 +35,13 @@ extern "C" {
 #define PMGT_OPT_UNFUSED_LN_BWD (1u << 18)           /* "unfused_ln_bwd": LayerNorm backward as its own launch behind the data-gradient GEMM that produces its dy (default, bf16 / hidden 256: epilogue of that GEMM) */
 #define PMGT_OPT_NO_TILE_ATTENTION (1u << 17)        /* "no_tile_attention": S = 64 / head size 64 attention on the cooperative kernels (per-wave fragment loads) instead of the tile forms */
 
+/* ---- which kernel families the calling thread has launched since the last reset (test instrumentation: a parity test at a given
+ * size only covers a kernel if the dispatcher actually picked it).  Families: gemm_wsr, gemm_wsr_lnb, gemm_wsr512, gemm_ws, nt_big,
+ * nt_big_gather, nt_big_128, nt_lnb, nt_tile, tn_big, tn_big_gather, tn_dma, tn_dma_gather, tn_tile, attn_tiles_fwd, attn_tiles_bwd,
+ * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile.  Unknown name: -1. */
+void pmgt_launch_trace_reset(void);
+int64_t pmgt_launch_trace_count(const char* family);
+
 /* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
 /* per-row absmax e4m3 quantisation (weights per output channel, activations per token): scale[r] = max|row| / 448 */
 int pmgt_op_quant_rows_e4m3(int src_dtype, const void* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd,

@@ -1696,6 +1696,7 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
     if constexpr (NT == 4 && DH == 64) {
         if (!bwd && use_coop && a.S == 16 * NT && !(a.opts & OPT_NO_TILE_ATTENTION)) {
             constexpr int lds = FwdSmemT<DH, NT>::BYTES;
+            note_launch(LT_ATTN_TILES_FWD);
             hipLaunchKernelGGL((attn_fwd_tiles_kernel<DH, NT>), dim3(groups), dim3(64 * NT), lds, st, a);
             PMGT_LAUNCH_OK();
             return 0;
@@ -1720,6 +1721,7 @@ template <int DH, int NT> static int launch_mfma(const AttnArgs& a, bool bwd, hi
                 auto kern = attn_bwd_tiles_kernel<DH, NT>;
                 constexpr int lds = BwdSmemT<DH, NT>::BYTES;
                 PMGT_SMEM_ATTR((const void*)kern, lds);
+                note_launch(LT_ATTN_TILES_BWD);
                 hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * NT), lds, st, a);
                 PMGT_LAUNCH_OK();
                 return 0;
@@ -1799,6 +1801,16 @@ __device__ unsigned long long g_abw_prof[16][8];
 #define ABW_STAMP(k_) do { } while (0)
 #endif
 
+// PMGT_ABW_MARK (tools/isa_mix.py builds with it): comment lines in the ISA that name the role / phase the following instructions
+// belong to -- the per-role, per-phase instruction-mix table under profiles/.  No instruction is emitted for a marker.
+#ifdef PMGT_ABW_MARK
+#define ABW_MARK(txt) asm volatile("; ABW_MARK " txt ::: "memory")
+#define ABW_MARK2(txt, a_, b_) asm volatile("; ABW_MARK " txt " it=%0 br=%1" :: "n"(a_), "n"(b_) : "memory")
+#else
+#define ABW_MARK(txt) do { } while (0)
+#define ABW_MARK2(txt, a_, b_) do { } while (0)
+#endif
+
 template <int KT> struct AbwCfg {
     static constexpr int D = 16 * KT;                 // hidden size (256 or 128)
     static constexpr int XROW = D * 2;                // bytes per row of x
@@ -1862,6 +1874,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
     float* rho = (float*)(scr + 8192);
     float* madd = rho + 32;
     const int x = 16 * IT + r;
+    ABW_MARK2("attn I1.fragments+norms", IT, BR);
     // ---- I1: fragments from the tiles; branch 1: inverse norms of C and the mask term (log2 domain, shifted by its maximum)
     bf16x8 fown, kc[2], fv[2], fo;      // own Q rows (branch 2) | K or C rows of all keys | V rows of all keys | own dO rows
     if (BR == 2) fown = *(const bf16x8*)(gin + abw_g_addr(x, 16 * q));
@@ -1893,6 +1906,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         if ((lane >> 4) == IT) madd[lane & 31] = (mv - mm) * L2E;      // each tile's cosine wave writes 16 of the 32 entries
     }
     // scores (transposed: key on (q, e), query on r) do not depend on the other waves: start the matrix pipe before the barrier
+    ABW_MARK2("attn I1.scores_mfma", IT, BR);
     f32x4 sc[2], dp[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
@@ -1906,6 +1920,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fo, z, 0, 0, 0);
     }
     bar(0);
+    ABW_MARK2("attn I2.softmax", IT, BR);
     // ---- I2: first half, query tile IT: this branch's softmax and its backward
     f32x4 rj[2];
     {
@@ -1936,6 +1951,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) sc[jt] *= inv;
     }
+    ABW_MARK2("attn I2.dropout+softmax_bwd+images", IT, BR);
     {
         const float cw = (BR == 1 ? a.beta : 1.f - a.beta) * kd.scale;      // branch weight x dropout scale
         const uint32_t hrow = (uint32_t)((((uint64_t)t * a.H + h) * 32) + x);
@@ -1964,6 +1980,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
             if (BR == 1) sc[jt] *= rj[jt];                       // ... and C^_j in the first half (sum over keys j): 1 / |c_j| per key
         }
     }
+    ABW_MARK2("attn I2.dq_or_dc_half_mfma", IT, BR);
     // branch 2: dQ^T; branch 1: the accumulator-operand half of dC^T -- both for this query tile
     f32x4 dch[2];
     {
@@ -1980,6 +1997,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         }
     }
     bar(2);
+    ABW_MARK2("attn I3.dv", IT, BR);
     // ---- I3: second half, key tile IT (x is the key index now).  dV^T = dO^T (P1 + P2) is split between the two branch waves
     // (16 columns each): the cosine wave also has dC, the dot-product wave dK.
     {
@@ -1991,6 +2009,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp2, dv, 0, 0, 0);                      // P = P1 + P2 meets in the accumulator
         *(bf16x4*)(gout + abw_g_addr(x, 128 + (16 * CV + 4 * q) * 2)) = pack4(dv);              // dV block
     }
+    ABW_MARK2("attn I3.dk_or_dc", IT, BR);
     if (BR == 2) {
         const bf16x8 bs = abw_tr_img(iS, 16 * IT, r, q);
 #pragma unroll
@@ -2017,6 +2036,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
             *(bf16x4*)(gout + abw_g_addr(x, 192 + (16 * ct + 4 * q) * 2)) = pack4((dch[ct] - chv[ct] * dt) * rho_x);    // dC block
     }
     bar(4);
+    ABW_MARK2("attn end", IT, BR);
 }
 
 // ---- GEMM-wave LDS access (inline asm: see the header) ----------------------------------------------------------------
@@ -2163,8 +2183,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     };
     for (int i = 0; i <= nsteps + 1; ++i) {
         const int sg = i - 2;                     // the step whose results are consumed in this iteration
+        ABW_MARK("gemm A.kstep0");
         if (sg >= 0) kstep(sg, 0);
         bar(0);
+        ABW_MARK("gemm B.dma");
 #ifndef PMGT_ABW_NO_DMA
         {
             // LDS-DMA of this iteration: 52 (d = 256) one-KB instructions, fixed shares per GEMM wave, straight-line code:
@@ -2207,6 +2229,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             }
         }
 #endif
+        ABW_MARK("gemm B.copy_out");
 #ifndef PMGT_ABW_NO_COPY
         if (sg >= 0) {          // copy the finished dQ|dK|dV|dC tile to HBM: 64 rows x 16 chunks of 16 bytes, 2 per lane
             const uint32_t gb = lds0 + out_tile(sg);
@@ -2229,6 +2252,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         }
 #endif
         bar(2);
+        ABW_MARK("gemm C.kstep1");
         if (sg >= 0) kstep(sg, 1);
         // This wave's DMAs have landed.  vmcnt retires loads and stores in issue order, and the two copy-out stores of a FULL tile
         // (no store instruction skipped by an all-false row predicate) were issued after the DMAs: they may stay in flight -- waiting for
@@ -2239,6 +2263,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar(4);
+        ABW_MARK("gemm loop_end");
     }
 #ifdef PMGT_ABW_PROF
     if (blockIdx.x == 0 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_abw_prof[wave][k_] = pacc[k_]; g_abw_prof[wave][7] = (unsigned long long)nsteps; }
@@ -2278,6 +2303,7 @@ template <int KT> static int launch_abw(const AttnBwdWg& w, hipStream_t st) {
     auto kern = attn_bwd_wgrad_kernel<KT>;
     PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int gx = attn_bwd_wgrad_parts(w.a.H);
+    note_launch(LT_ATTN_BWD_WGRAD);
     hipLaunchKernelGGL(kern, dim3(gx * w.a.H), dim3(1024), C::SMEM, st, w);
     PMGT_LAUNCH_OK();
     return 0;

@@ -59,6 +59,16 @@ void set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+// ---- which kernel families a call chain launched (test instrumentation: per host thread, no effect on the launches) ---------
+// The dispatchers pick a kernel by shape; a parity test at a given size is only a test of the kernel it believes it covers if that
+// kernel actually ran.  Each dispatcher notes the family it launches; tests read the counts through pmgt_launch_trace_count().
+enum LaunchTag {
+    LT_GEMM_WSR = 0, LT_GEMM_WSR_LNB, LT_GEMM_WSR512, LT_GEMM_WS, LT_NT_BIG, LT_NT_BIG_GATHER, LT_NT_BIG_128, LT_NT_LNB, LT_NT_TILE,
+    LT_TN_BIG, LT_TN_BIG_GATHER, LT_TN_DMA, LT_TN_DMA_GATHER, LT_TN_TILE, LT_ATTN_TILES_FWD, LT_ATTN_TILES_BWD, LT_QKVC_ATTN_FWD,
+    LT_ATTN_BWD_WGRAD, LT_F8_BIG, LT_F8_TILE, LT_COUNT
+};
+void note_launch(int tag);
+
 // ---- scalar conversions -----------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }

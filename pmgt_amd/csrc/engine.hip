@@ -31,6 +31,13 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local int64_t g_launch_count[LT_COUNT] = {};
+void note_launch(int tag) { if (tag >= 0 && tag < LT_COUNT) ++g_launch_count[tag]; }
+static const char* const g_launch_names[LT_COUNT] = {
+    "gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_tile",
+    "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
+    "attn_bwd_wgrad", "f8_big", "f8_tile"};
+
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // Optional per-phase timers: HIP events recorded on the launch stream around each group of kernels.
@@ -1528,6 +1535,13 @@ int pmgt_engine_set_option(pmgt_engine* e, const char* key, int value) {
     PMGT_CHECK(bit != 0, -2, "pmgt_engine_set_option: unknown option '%s'", key ? key : "(null)");
     e->opts = value ? (e->opts | bit) : (e->opts & ~bit);
     return 0;
+}
+void pmgt_launch_trace_reset(void) { for (auto& c : g_launch_count) c = 0; }
+int64_t pmgt_launch_trace_count(const char* family) {
+    for (int i = 0; i < LT_COUNT; ++i)
+        if (family && strcmp(family, g_launch_names[i]) == 0) return g_launch_count[i];
+    set_error("pmgt_launch_trace_count: unknown kernel family '%s'", family ? family : "(null)");
+    return -1;
 }
 int pmgt_engine_get_option(const pmgt_engine* e, const char* key) {
     PMGT_CHECK(e != nullptr, -2, "pmgt_engine_get_option: NULL engine");

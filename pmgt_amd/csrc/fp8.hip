@@ -311,11 +311,13 @@ int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
     if (f8_big_ok(g) && !(g.opts & OPT_TILE_GEMM)) {
         constexpr int smem = 4 * (256 + 256) * 64;
         PMGT_SMEM_ATTR((const void*)gemm_nt_f8_big_kernel, smem);
+        note_launch(LT_F8_BIG);
         hipLaunchKernelGGL(gemm_nt_f8_big_kernel, dim3(cdiv(cdiv(g.M, 256), 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
         PMGT_LAUNCH_OK();
         return 0;
     }
     const int num_n = cdiv(g.N, 128), num_m = cdiv(g.M, 128);
+    note_launch(LT_F8_TILE);
     hipLaunchKernelGGL(gemm_nt_f8_kernel, dim3(8 * num_n * cdiv(num_m, 8)), dim3(256), 0, st, g);
     PMGT_LAUNCH_OK();
     return 0;

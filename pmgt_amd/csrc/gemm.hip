@@ -803,6 +803,7 @@ int gemm_nt_lnb(const GemmNT& g, hipStream_t st) {
     PMGT_CHECK(gemm_nt_lnb_ok(g) && g.lnb_part != nullptr, -2, "gemm_nt_lnb: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
     constexpr int smem = 4 * (256 + 256) * 64;
     PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8, true>), smem);
+    note_launch(LT_NT_LNB);
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8, true>), dim3(cdiv(cdiv(g.M, 256), 8) * 8), dim3(512), smem, st, g);
     PMGT_LAUNCH_OK();
     return 0;
@@ -828,16 +829,19 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
             if (g.N % 256 == 0 && g.K % 64 == 0) {      // (K % 64: the 256-wide tile walks k-steps in pairs)
                 constexpr int smem = 4 * (256 + 256) * 64;
                 PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8>), smem);
+                note_launch(g.a_rows ? LT_NT_BIG_GATHER : LT_NT_BIG);
                 hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8>), dim3(cdiv(nm, 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
             } else {
                 constexpr int smem = 3 * (256 + 128) * 64;
                 PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<128, 4>), smem);
+                note_launch(LT_NT_BIG_128);
                 hipLaunchKernelGGL((gemm_nt_big_kernel<128, 4>), dim3(cdiv(nm, 8) * 8 * (g.N / 128)), dim3(256), smem, st, g);
             }
             PMGT_LAUNCH_OK();
             return 0;
         }
     }
+    note_launch(LT_NT_TILE);
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(grid), dim3(256), 0, st, g);
     PMGT_LAUNCH_OK();
     return 0;
@@ -1637,6 +1641,7 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
             PMGT_SMEM_ATTR((const void*)gemm_tn_big_kernel<false>, smem); PMGT_SMEM_ATTR((const void*)gemm_tn_big_kernel<true>, smem);
             const int tiles256 = (g.N1 / 256) * (g.N2 / 256);
             int chunk256 = cdiv(cdiv(std::max(g.M, 1), g.splits), 32) * 32;
+            note_launch(g.q_rows ? LT_TN_BIG_GATHER : LT_TN_BIG);
             if (g.q_rows) hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
             else hipLaunchKernelGGL(gemm_tn_big_kernel<false>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
             PMGT_LAUNCH_OK();
@@ -1645,17 +1650,20 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
         if (!(g.opts & OPT_TILE_GEMM) && g.zeros != nullptr) {
             constexpr size_t ring = 4 * 2 * 32 * 256;
             if (g.q_rows == nullptr) {
+                note_launch(LT_TN_DMA);
                 hipLaunchKernelGGL((gemm_tn_dma_kernel<false, 8>), grid, dim3(512), ring, st, g, chunk);
             } else {
                 PMGT_CHECK(g.M >= 1, -2, "gemm_tn: gather needs at least one row");
                 constexpr size_t smem = ring + 8 * 32 * 8;
                 PMGT_SMEM_ATTR((const void*)gemm_tn_dma_kernel<true>, (int)smem);
+                note_launch(LT_TN_DMA_GATHER);
                 hipLaunchKernelGGL(gemm_tn_dma_kernel<true>, grid, dim3(256), smem, st, g, chunk);
             }
             PMGT_LAUNCH_OK();
             return 0;
         }
     }
+    note_launch(LT_TN_TILE);
     hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(256), 0, st, g, chunk);
     PMGT_LAUNCH_OK();
     return 0;

@@ -395,6 +395,7 @@ template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st
             PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
             const int num_mt = cdiv(g.M, C::TR);
             const int gx = std::max(8, std::min(512 / ny, num_mt) / 8 * 8);      // two workgroups per CU
+            note_launch(LT_GEMM_WS);
             hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(C::NT), C::SMEM, st, g);
             PMGT_LAUNCH_OK();
             return 0;
@@ -405,6 +406,7 @@ template <int KS, int MODE> static int launch_ws(const GemmWS& g, hipStream_t st
     PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int num_mt = cdiv(g.M, 64);
     int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, ~one workgroup per CU
+    note_launch(LT_GEMM_WS);
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(512), C::SMEM, st, g);
     PMGT_LAUNCH_OK();
     return 0;

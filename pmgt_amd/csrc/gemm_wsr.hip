@@ -376,6 +376,7 @@ int gemm_wsr(const GemmWS& g, hipStream_t st) {
     PMGT_SMEM_ATTR((const void*)gemm_wsr_kernel<false>, WsrCfg::SMEM);
     const int num_mt = cdiv(g.M, WsrCfg::TR);
     const int gx = std::max(8, std::min(256, num_mt) / 8 * 8);      // one 16-wave workgroup per CU
+    note_launch(LT_GEMM_WSR);
     hipLaunchKernelGGL(gemm_wsr_kernel<false>, dim3(gx), dim3(1024), WsrCfg::SMEM, st, g);
     PMGT_LAUNCH_OK();
     return 0;
@@ -398,6 +399,7 @@ bool gemm_wsr_lnb_ok(const GemmWS& g) {
 int gemm_wsr_lnb(const GemmWS& g, hipStream_t st) {
     PMGT_CHECK(gemm_wsr_lnb_ok(g) && g.lnb_part != nullptr, -2, "gemm_wsr_lnb: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
     PMGT_SMEM_ATTR((const void*)gemm_wsr_kernel<true>, WsrCfg::SMEM);
+    note_launch(LT_GEMM_WSR_LNB);
     hipLaunchKernelGGL(gemm_wsr_kernel<true>, dim3(gemm_wsr_lnb_parts(g.M)), dim3(1024), WsrCfg::SMEM, st, g);
     PMGT_LAUNCH_OK();
     return 0;
@@ -686,6 +688,7 @@ template <int MODE> static int launch_wsr512(const GemmWS& g, hipStream_t st) {
     PMGT_SMEM_ATTR((const void*)kern, Wsr5Cfg::SMEM);
     const int ny = g.N / 256, num_mt = cdiv(g.M, Wsr5Cfg::TR);
     const int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, one 12-wave workgroup per CU
+    note_launch(LT_GEMM_WSR512);
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(768), Wsr5Cfg::SMEM, st, g);
     PMGT_LAUNCH_OK();
     return 0;

@@ -740,6 +740,7 @@ template <int KS, int F8> static int launch_qa2(const QkvcAttn& a, hipStream_t s
     PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int ny = a.H / 2;
     const int gx = std::max(8, std::min(512 / ny, a.Tseq) / 8 * 8);       // two workgroups per CU
+    note_launch(LT_QKVC_ATTN_FWD);
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(256), C::SMEM, st, a);
     PMGT_LAUNCH_OK();
     return 0;
@@ -751,6 +752,7 @@ template <int KS> static int launch_qa3(const QkvcAttn& a, hipStream_t st) {
     PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int ny = a.H / 2;
     const int gx = std::max(8, std::min(256 / ny, a.Tseq) / 8 * 8);       // one 16-wave workgroup per CU
+    note_launch(LT_QKVC_ATTN_FWD);
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(1024), C::SMEM, st, a);
     PMGT_LAUNCH_OK();
     return 0;

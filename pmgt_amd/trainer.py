@@ -144,27 +144,42 @@ class Trainer:
     # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
     def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3,
                  stall_timeout_s: float = 120.0):
+        """Training steps fed by the live host pipeline (the reference: a DataLoader over PMGTDataset, pmgt/pmgt/trainer.py:84-105):
+        ONE producer thread runs the threaded C++ sampler into a pinned host slot and issues the slot's async H2D copies on a
+        side stream into that slot's PRE-ALLOCATED device buffers (no allocator call, no record_stream on the step's path); the
+        launch thread orders each step behind its copies with one event and hands the slot back with a completion event."""
         eng = self.engine
         dev = eng.device
         copy_stream = torch.cuda.Stream(device=dev)
         slots = [sampler.alloc(batch_size, MODE_TRAIN, pinned=True) for _ in range(depth)]
+        dslots = [{k: torch.empty_like(v, device=dev) for k, v in sl.items()} for sl in slots]
         n = len(node_ids)
-        t_sample = [0.0]
+        t_sample, t_wait, t_copy = [0.0], [0.0], [0.0]
 
         def produce(step, slot, done):
+            ts = time.perf_counter()
             if done is not None:
-                done.synchronize()     # the pinned slot may be refilled once the step that read its copies is done
+                done.synchronize()     # the slot (pinned + device buffers) may be refilled once the step that read it is done
             lo = (step * batch_size) % max(n - batch_size, 1)
             tg = np.resize(node_ids[lo:], batch_size)
-            ts = time.perf_counter()
+            t1 = time.perf_counter()
             tgt, pair, num_pairs, labels = sampler.batch(tg, MODE_TRAIN, out=slots[slot], threads=threads,
                                                         base_seed=7, counter=step * batch_size)
-            t_sample[0] += time.perf_counter() - ts
+            t2 = time.perf_counter()
+            P = int(pair["node_ids"].shape[0])
+            d = dslots[slot]
             with torch.cuda.stream(copy_stream):
-                cu = lambda dct: {k: v.to(dev, non_blocking=True) for k, v in dct.items()}
-                b = (cu(tgt), cu(pair), num_pairs.to(dev, non_blocking=True), labels.to(dev, non_blocking=True))
+                for k, cnt in (("tgt_ids", batch_size), ("tgt_mask", batch_size), ("pair_ids", P), ("pair_mask", P),
+                               ("num_pairs", batch_size), ("labels", P)):
+                    d[k][:cnt].copy_(slots[slot][k][:cnt], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
+            b = ({"node_ids": d["tgt_ids"][:batch_size], "attention_mask": d["tgt_mask"][:batch_size]},
+                 {"node_ids": d["pair_ids"][:P], "attention_mask": d["pair_mask"][:P]}, d["num_pairs"][:batch_size], d["labels"][:P])
+            t3 = time.perf_counter()
+            t_wait[0] += t1 - ts
+            t_sample[0] += t2 - t1
+            t_copy[0] += t3 - t2
             return b, ev
 
         pipe = ProducerPipeline(produce, steps, depth, stall_timeout_s=stall_timeout_s)
@@ -172,26 +187,37 @@ class Trainer:
         t_start = time.perf_counter()
         t0 = None
         pipe.start()
+        # GPU-side view of the pipeline: events around every step on the launch stream; the gap between one step's end and the
+        # next step's start is time the GPU had nothing of this stream to run (input not there yet, or the launch thread late)
+        ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t_launch = 0.0
         try:
-            for slot, (b, ev) in pipe:
+            for i, (slot, (b, ev)) in enumerate(pipe):
                 if t0 is None:
                     t0 = time.perf_counter()       # sustained rate: the clock starts when the first batch is there (the fill is reported)
+                tl = time.perf_counter()
                 torch.cuda.current_stream().wait_event(ev)
+                ev_a[i].record()
                 self.train_step(b)
-                for v in list(b[0].values()) + list(b[1].values()) + [b[2], b[3]]:
-                    v.record_stream(torch.cuda.current_stream())      # allocated on the copy stream, read on this one
-                done = torch.cuda.Event()
-                done.record()
-                pipe.release(slot, done)   # the launch thread does not wait for the GPU: the producer does, before it refills
+                ev_b[i].record()
+                pipe.release(slot, ev_b[i])   # the launch thread does not wait for the GPU: the producer does, before it refills
+                t_launch += time.perf_counter() - tl
         finally:
             torch.cuda.synchronize()
             pipe.close()
         el = time.perf_counter() - t0
+        idle = sum(ev_b[i - 1].elapsed_time(ev_a[i]) for i in range(1, steps))
+        busy = sum(ev_a[i].elapsed_time(ev_b[i]) for i in range(steps))
         return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
                 "pipeline_fill_ms": round((t0 - t_start) * 1e3, 3),
                 "sampler_threads": threads, "steps": steps, "pipeline_depth": depth,
-                "sampler_ms_per_batch": round(t_sample[0] / steps * 1e3, 3),
-                "launch_thread_idle_ms_per_step": round(pipe.starved_s / steps * 1e3, 3)}
+                "gpu_step_ms": round(busy / steps, 3),
+                "gpu_idle_ms_per_step": round(idle / max(steps - 1, 1), 3),
+                "launch_thread_busy_ms_per_step": round(t_launch / steps * 1e3, 3),
+                "launch_thread_waiting_for_input_ms_per_step": round(pipe.starved_s / steps * 1e3, 3),
+                "producer_ms_per_batch": {"sampling": round(t_sample[0] / steps * 1e3, 3), "h2d_issue": round(t_copy[0] / steps * 1e3, 3),
+                                          "waiting_for_a_free_slot": round(t_wait[0] / steps * 1e3, 3)}}
 
 
 class PipelineError(RuntimeError):

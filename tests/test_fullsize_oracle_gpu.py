@@ -266,3 +266,67 @@ def test_smallest_and_odd_batches_match_the_oracle(B, dtype):
     np.testing.assert_allclose(got["logits"].cpu().numpy(), want["logits"].numpy(), rtol=0, atol=2e-4 if dtype == "fp32" else 3e-2)
     np.testing.assert_allclose(got["last_hidden_state"].float().cpu().numpy(), want["last_hidden_state"].numpy(), rtol=0,
                                atol=2e-4 if dtype == "fp32" else 8e-2)
+
+
+def launch_counts(names):
+    from pmgt_amd import _lib
+    L = _lib.hip()
+    return {n: int(L.pmgt_launch_trace_count(n.encode())) for n in names}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("mode", ["table", "token"])
+def test_hidden_512_kernels_at_benchmark_token_counts_match_the_oracle(mode):
+    """The d = 512 kernels the C4 / C5 bench lines time, at a token count where the dispatchers actually pick them: L = 2, H = 8,
+    d = I = 512, S = 64, B = 96 targets -> M = 73 728 tokens (gemm_wsr512_kernel needs M >= 8 192, gemm_tn_big_kernel M >= 65 536,
+    the 256 x 256 NT tile >= 96 tiles; the B = 4 cases above run the 128 x 128 tiles and the lockstep streaming kernel).  fp32, bf16
+    and fp8 engines against the oracle (32-target chunks, recombined exactly), in table mode (20 000 nodes: projection per node,
+    segment sums) and in token mode (100 000 nodes: row-gathered 256 x 256 NT / TN tiles on the feature tables); the launch trace
+    proves which kernel families ran.  Reference math: pmgt/pmgt/models.py:56-176, modeling_pmgt.py:420-534."""
+    from pmgt_amd import _lib
+    n, e = (20_000, 240_000) if mode == "table" else (100_000, 1_200_000)
+    S, B = 64, 96
+    case = make_case(n, e, dict(hidden_size=512, num_attention_heads=8, num_hidden_layers=2, intermediate_size=512), S, B, seed=41)
+    M = 12 * B * S
+    assert M >= 65536 and ((n + 2) * 2 <= M) == (mode == "table")
+    g = torch.Generator().manual_seed(11)
+    tabs = []
+    for f in case["cfg"]["feat_hidden_sizes"]:
+        t = torch.randn(n + 2, f, generator=g).to(torch.bfloat16).float()       # bf16-representable: every engine sees the same values
+        t[:2] = 0
+        tabs.append(t)
+    refs = {}
+
+    def oracle(fp8_tables=None):
+        key = "fp8" if fp8_tables is not None else "plain"
+        if key not in refs:
+            c = dict(case)
+            if fp8_tables is not None:
+                c["cfg"] = dict(case["cfg"], fp8=True)
+            refs[key] = run_oracle_chunked(c, fp8_tables if fp8_tables is not None else tabs, chunk=32)
+        return refs[key]
+
+    L = _lib.hip()
+    fams = ("gemm_wsr512", "tn_big", "tn_big_gather", "nt_big", "nt_big_gather", "attn_tiles_fwd", "attn_tiles_bwd", "f8_big", "gemm_ws", "nt_tile", "tn_tile")
+    for dtype in ("fp32", "bf16", "fp8"):
+        L.pmgt_launch_trace_reset()
+        eng, out = run_engine(case, dtype, [t.numpy() for t in tabs])
+        ran = launch_counts(fams)
+        if dtype != "fp32":
+            # the kernels of the C4 / C5 bench lines, not their small-M stand-ins
+            # (the last layer's dense blocks run on the compacted rows the loss reads: small-M kernels by design)
+            # (fp8: the Q|K|V|C projections run on the fp8 tiles, and the FFN2 launch that also emits the next layer's e4m3 rows
+            #  stays on the lockstep streaming kernel)
+            assert ran["gemm_wsr512"] >= (5 if dtype == "fp8" else 6) and ran["tn_big"] >= 4 and ran["nt_big"] >= 2, ran
+            assert ran["attn_tiles_fwd"] >= 1 and ran["attn_tiles_bwd"] >= 1, ran
+            if mode == "token" and dtype == "bf16":
+                assert ran["nt_big_gather"] == 2 and ran["tn_big_gather"] == 2, ran   # feature projection + its weight gradient on table rows
+            if dtype == "fp8":
+                assert ran["f8_big"] >= 2, ran
+        if dtype == "fp8":
+            p, ref = oracle([t.cpu() for t in eng.dequantized_tables()])
+        else:
+            p, ref = oracle()
+        compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tabs])[0])
+        del eng, out
+        torch.cuda.empty_cache()

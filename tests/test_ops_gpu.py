@@ -819,3 +819,34 @@ def test_layernorm_backward_in_the_data_gradient_epilogue(M, K, drop):
         assert rel_err(dxd, (dx.double().cpu() * scale).to(torch.bfloat16).double() * keep.double().cpu()) < 1e-2
     else:
         assert torch.equal(dx, dxd)
+
+
+@pytest.mark.parametrize("opts", [(), ("no_tile_attention",)])
+def test_attention_tile_forms_match_the_oracle_restatement(opts):
+    """S = 64 / head size 64 / H = 8 (the C4 / C5 attention shape, d = 512): forward output, probabilities and dQ | dK | dV | dC of the
+    tile form (and of the cooperative form it replaced) against the fp64 autograd restatement of
+    pmgt/pmgt/modeling_pmgt.py:420-534 -- not against another kernel of this library; ragged masks, beta != 0.5."""
+    _lib, L = _setup()
+    T, S, H, dh, beta = 9, 64, 8, 64, 0.3
+    d = H * dh
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(T, S, 4 * d, generator=g) * 0.7)
+    dctx = torch.randn(T, S, d, generator=g)
+    mask = torch.ones(T, S)
+    for t in range(1, T):
+        mask[t, 1 + (t * 13) % S:] = 0
+    xb, db, md = x.cuda().bfloat16(), dctx.cuda().bfloat16(), mask.cuda()
+    xr = xb.double().cpu().requires_grad_(True)
+    ctx_ref, w_ref = _attn_ref(xr, mask.double(), H, beta)
+    ctx_ref.backward(db.double().cpu())
+    L.use(*opts)
+    ctx = torch.full((T, S, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    probs = torch.full((T, H, S, S), float("nan"), device="cuda")
+    _lib.check(L.pmgt_op_attention_fwd(1, P(xb), P(md), P(ctx), P(probs), T, S, H, dh, beta, 0.0, 11, 12, None, stream()))
+    dx = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.pmgt_op_attention_bwd(1, P(xb), P(md), P(db), P(dx), T, S, H, dh, beta, 0.0, 11, 12, None, stream()))
+    L.use()
+    assert rel_err(ctx, ctx_ref.detach()) < 2e-2
+    assert rel_err(probs, w_ref.detach()) < 2e-2
+    for m in range(4):          # dQ, dK, dV, dC blocks separately (their scales differ)
+        assert rel_err(dx[..., m * d:(m + 1) * d], xr.grad[..., m * d:(m + 1) * d]) < 3e-2, m
