@@ -257,8 +257,10 @@ def main():
     from pmgt_amd.parallel import shard_indices
     share = host_cpu_share()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    # sampler workers per rank: this rank's part of the CPU share minus two CPUs for the launch thread and the runtime's
-    threads = args.sampler_threads or int(max(2, min(32, share / max(local_world, 1) - 2)))
+    # sampler workers per rank: this rank's part of the CPU share minus three CPUs for the launch thread, the producer thread and the runtime's
+    # (three, not two: tools/e2e_sweep.py on a 16-CPU share -- 13 workers leave the launch thread, the producer thread and the HIP runtime's
+    #  own threads a CPU each; with 14 the sampler is 5 % faster per batch and the pipeline no better)
+    threads = args.sampler_threads or int(max(2, min(32, share / max(local_world, 1) - 3)))
     sampler = MCNSampler(graph, max_ctx_neigh=S - 1)
     # DistributedSampler semantics (what PL injects, pmgt/base_trainer.py:309-322): rank r takes r::W of one seeded permutation
     shard = shard_indices(nodes, rank, world, seed=0, epoch=0) + 2
@@ -442,7 +444,8 @@ def main():
     # (at N > 1 only on request: the data-parallel numbers the driver collects are the pre-staged `value`; the multi-rank live pipeline
     # has only been rehearsed over gloo on one GPU)
     if not args.no_end_to_end and (world == 1 or args.end_to_end):
-        e2e = trainer.run_live(sampler, shard, B, steps=min(args.steps, 30), threads=threads)
+        trainer.run_live(sampler, shard, B, steps=6, threads=threads)      # untimed: pinned slots, device slots and the worker pool exist, pages touched
+        e2e = trainer.run_live(sampler, shard, B, steps=max(min(args.steps, 40), 10), threads=threads)
         if world > 1:
             tt = torch.tensor([e2e["ms_per_step"]], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

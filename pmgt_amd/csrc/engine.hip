@@ -309,6 +309,7 @@ template <typename T> struct Bufs {
     int rcap = 0;
     int64_t* need_rows = nullptr;
     int* need_cnt = nullptr;
+    int* need_inv = nullptr;      // [M] token row -> compact row or -1 (the residual of the shortcut layer, read by the fused dX + LayerNorm-backward tile)
     LayerBufs<T> ctail;
     T *c_dh = nullptr, *c_bB = nullptr, *c_bC = nullptr, *c_bD = nullptr, *c_big = nullptr;
 };
@@ -418,6 +419,7 @@ static void carve(const pmgt_engine* e, Carver& c, Bufs<T>& b, int Tseq, int S, 
     b.rcap = (int)R;
     b.need_rows = c.get<int64_t>(R);
     b.need_cnt = c.get<int>(4);
+    b.need_inv = c.get<int>(M);
     b.ctail.qkvc = nullptr; b.ctail.ctx = nullptr;
     b.ctail.ao_pre = c.get<T>(R * d);
     b.ctail.stats1 = c.get<float>(R * 2);
@@ -979,10 +981,13 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                 // d hin is the gradient of layer l - 1's output LayerNorm (BertOutput): its backward runs on the tile's rows behind the
                 // main loop of this GEMM (N = 256 = whole rows per workgroup), d hin never reaches HBM; dx overwrites the residual branch
                 // in place (b.bB), the masked copy goes to b.bC -- exactly what the next iteration's LN2 step would have left there
-                if (l >= 1 && !sc && b.defer && ln_from_y_applies<T>(e, M, I, false)) {
+                // (shortcut layer: its residual branch exists on the compacted rows only -- read through the inverse row map instead of
+                //  being scattered into d hin by a launch of its own behind the GEMM)
+                if (l >= 1 && b.defer && ln_from_y_applies<T>(e, M, I, false) && (!sc || b.need_inv != nullptr)) {
                     const LayerOff& on = e->layers[l - 1];
                     GemmNT f = g;
                     f.C = b.bB;
+                    if (sc) { f.res = gB; f.ldr = d; f.lnb_res_inv = b.need_inv; }
                     f.lnb_y = b.layer[l - 1].hout; f.lnb_ldy = d; f.lnb_stats = b.layer[l - 1].stats2; f.lnb_gamma = P + on.ln2g; f.lnb_beta = P + on.ln2b;
                     f.lnb_dx_drop = dd ? b.bC : nullptr; f.lnb_lddx = d; f.lnb_drop = dropcfg(t, train, pd, l - 1, SITE_FO);
                     if (gemm_nt_lnb_ok(f)) {
@@ -994,8 +999,10 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                     }
                 }
             }
-            if (!with_ln) RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
-            if (sc) RUN(scatter_rows<T>(gB, b.need_rows, b.need_cnt, Mt, d, b.bA, st, true));
+            if (!with_ln) {
+                RUNP("bwd.dgrad_qkvc", gemm_nt<T>(g, st));
+                if (sc) RUN(scatter_rows<T>(gB, b.need_rows, b.need_cnt, Mt, d, b.bA, st, true));
+            }
         }
     }
     // embeddings
@@ -1105,7 +1112,7 @@ static int pretrain_step(pmgt_engine* e, const pmgt_tensors* t, const pmgt_batch
     // Training fast path: the caller does not ask for last_hidden_state, so the last layer's attn-out/FFN blocks
     // only run on the rows the loss reads (compact order: B target CLS, P pair CLS, masked rows).
     const bool sc = train && !(e->opts & OPT_NO_SHORTCUT) && o->last_hidden == nullptr;
-    if (sc) RUN(build_need_rows(B, Pn, S, b.nfr_rows, b.nfr_count, b.need_rows, b.need_cnt, st));
+    if (sc) RUN(build_need_rows(B, Pn, S, b.nfr_rows, b.nfr_count, b.need_rows, b.need_cnt, st, b.need_inv, (int64_t)Tseq * S));
     RUN(encoder_forward<T>(e, t, b, Tseq, S, b.ids, nullptr, b.mask, train, (T*)nullptr, (float*)nullptr, st, sc, B + Pn));
     T* hL = sc ? b.ctail.hout : b.layer[e->L - 1].hout;
     T* dhL = sc ? b.c_dh : b.bA;

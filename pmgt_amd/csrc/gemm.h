@@ -33,6 +33,9 @@ struct GemmNT {
     void* lnb_dx_drop = nullptr; int64_t lnb_lddx = 0;
     DropCfg lnb_drop = {nullptr, 0.f, 0};
     float* lnb_part = nullptr;
+    // gemm_nt_lnb only: the residual lives in COMPACT row order -- row m of the output adds row lnb_res_inv[m] of `res`, or nothing
+    // where lnb_res_inv[m] < 0 (last-layer shortcut: the residual branch exists on the rows the loss read only)
+    const int* lnb_res_inv = nullptr;
     uint32_t opts = 0;                 // PathOpt bits of the calling engine (OPT_TILE_GEMM: register-staged 128 x 128 tile only)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);

@@ -536,9 +536,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
             if (R) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int m = min(m0 + wm * 128 + 16 * i + r, g.M - 1);
+                    int m = min(m0 + wm * 128 + 16 * i + r, g.M - 1);
+                    if (g.lnb_res_inv) m = g.lnb_res_inv[m];      // (uniform branch) compact residual: its row, or < 0 = none
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) rr[i][pr] = *(const u32x4*)(R + (int64_t)m * g.ldr + ncol + 32 * pr);
+                    for (int pr = 0; pr < 2; ++pr)
+                        rr[i][pr] = m >= 0 ? *(const u32x4*)(R + (int64_t)m * g.ldr + ncol + 32 * pr) : (u32x4){0u, 0u, 0u, 0u};
                 }
             }
 #pragma unroll
@@ -795,7 +797,7 @@ int gemm_nt_lnb_parts(int M) { return cdiv(M, 256); }
 bool gemm_nt_lnb_ok(const GemmNT& g) {
     return nt_big_ok(g) && !(g.opts & OPT_UNFUSED_LN_BWD) && g.N == 256 && g.K % 64 == 0 && g.a_rows == nullptr && g.epi == EPI_NONE && g.bias == nullptr &&
            g.drop.p == 0.f && g.lnb_y != nullptr && g.lnb_stats != nullptr && g.lnb_gamma != nullptr && g.lnb_beta != nullptr &&
-           (g.res == nullptr || g.ldr == g.ldc) && g.lnb_ldy == g.ldc && (g.lnb_dx_drop == nullptr || g.lnb_lddx == g.ldc) &&
+           (g.res == nullptr || g.ldr == g.ldc) && (g.lnb_res_inv == nullptr || g.res != nullptr) && g.lnb_ldy == g.ldc && (g.lnb_dx_drop == nullptr || g.lnb_lddx == g.ldc) &&
            (int64_t)g.M * g.ldc * 2 < (int64_t)1 << 32 && ((uintptr_t)g.lnb_y % 16) == 0 && ((uintptr_t)g.lnb_dx_drop % 16) == 0 &&
            ((uintptr_t)g.lnb_stats % 8) == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
 }

@@ -41,8 +41,9 @@ template <typename T> int nfr_diff(const NfrDiffArgs& a, hipStream_t st);
 template <typename T>
 int scatter_rows(const T* src, const int64_t* rows, const int* count, int cap, int d, T* dst, hipStream_t st, bool add = false);
 // rows the loss reads from the last layer: CLS of the B targets, CLS of the P pairs, then the masked rows
+// `inv` (optional, [n_tokens] ints): filled with the inverse map token row -> compact row, -1 for rows that are not needed
 int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
-                    hipStream_t st);
+                    hipStream_t st, int* inv = nullptr, int64_t n_tokens = 0);
 struct FeatSizes { int nf; int F[MAX_FEATS]; };
 int loss_finish(const float* gsr_part, int B, const float* sse_part, int nparts, const int* count, FeatSizes fs,
                 bool with_nfr, float* out, hipStream_t st, int* count_out = nullptr);

@@ -346,17 +346,24 @@ template int scatter_rows<float>(const float*, const int64_t*, const int*, int, 
 template int scatter_rows<bf16>(const bf16*, const int64_t*, const int*, int, int, bf16*, hipStream_t, bool);
 
 __global__ void build_need_rows_kernel(int B, int P, int S, const int64_t* __restrict__ nfr_rows,
-                                       const int* __restrict__ nfr_count, int64_t* __restrict__ rows, int* __restrict__ count) {
+                                       const int* __restrict__ nfr_count, int64_t* __restrict__ rows, int* __restrict__ count,
+                                       int* __restrict__ inv) {
     const int n = *nfr_count;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < B + P) rows[i] = (int64_t)i * S;              // CLS token of sequence i (targets, then pairs)
-    else if (i < B + P + n) rows[i] = nfr_rows[i - B - P];
+    int64_t row = -1;
+    if (i < B + P) row = (int64_t)i * S;              // CLS token of sequence i (targets, then pairs)
+    else if (i < B + P + n) row = nfr_rows[i - B - P];
+    if (row >= 0) {
+        rows[i] = row;
+        if (inv) inv[row] = i;                            // token row -> compact row (the caller filled `inv` with -1)
+    }
     if (i == 0) *count = B + P + n;
 }
 int build_need_rows(int B, int P, int S, const int64_t* nfr_rows, const int* nfr_count, int64_t* rows, int* count,
-                    hipStream_t st) {
+                    hipStream_t st, int* inv, int64_t n_tokens) {
     const int cap = B + P + B * (S - 1 > 0 ? S - 1 : 1);
-    hipLaunchKernelGGL(build_need_rows_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, st, B, P, S, nfr_rows, nfr_count, rows, count);
+    if (inv) PMGT_HIP(hipMemsetAsync(inv, 0xFF, (size_t)n_tokens * sizeof(int), st));
+    hipLaunchKernelGGL(build_need_rows_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, st, B, P, S, nfr_rows, nfr_count, rows, count, inv);
     PMGT_LAUNCH_OK();
     return 0;
 }

@@ -113,9 +113,9 @@ def test_bench_control_flow_is_symmetric_across_ranks():
     tail = ast.unparse(main.body[-1])
     assert tail.index("dist.barrier()") < tail.index("dist.destroy_process_group()"), tail
     assert "shard_indices(nodes, rank, world" in src and "RandomState(0).permutation" not in src
-    # the rank-0-only blocks are the print and the CPU baseline
+    # the rank-0-only blocks are the print, the CPU baseline and the extra single-GPU workloads (child processes; N = 1 only)
     r0 = [ast.unparse(n) for n in ast.walk(main) if isinstance(n, ast.If) and ast.unparse(n.test).startswith("rank == 0")]
-    assert all(("print(" in b or "cpu_baseline" in b) for b in r0), r0
+    assert all(("print(" in b or "cpu_baseline" in b or "extra_workloads" in b) for b in r0), r0
 
 
 def test_bench_gpus_flag_starts_its_own_ranks_and_refuses_a_mismatch():
