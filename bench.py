@@ -444,8 +444,12 @@ def main():
     # (at N > 1 only on request: the data-parallel numbers the driver collects are the pre-staged `value`; the multi-rank live pipeline
     # has only been rehearsed over gloo on one GPU)
     if not args.no_end_to_end and (world == 1 or args.end_to_end):
-        trainer.run_live(sampler, shard, B, steps=6, threads=threads)      # untimed: pinned slots, device slots and the worker pool exist, pages touched
-        e2e = trainer.run_live(sampler, shard, B, steps=max(min(args.steps, 40), 10), threads=threads)
+        # untimed pass first: pinned slots, device slots and the worker pool exist, pages touched, and (N = 1) the step is captured once
+        # per slot -- the timed pass replays it with one launch per step (a launch thread that loses its CPU mid-step on a shared
+        # host otherwise shows up as GPU idle time inside the step)
+        live_graphs = world == 1
+        trainer.run_live(sampler, shard, B, steps=6, threads=threads, graphs=live_graphs)
+        e2e = trainer.run_live(sampler, shard, B, steps=max(min(args.steps, 40), 10), threads=threads, graphs=live_graphs)
         if world > 1:
             tt = torch.tensor([e2e["ms_per_step"]], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

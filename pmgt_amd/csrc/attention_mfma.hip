@@ -1919,24 +1919,6 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         sc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[jt], BR == 1 ? kc[IT] : fown, z1, 0, 0, 0);
         dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fo, z, 0, 0, 0);
     }
-    // dropout multipliers of this wave's eight (query, key) elements: branch weight x dropout scale, or 0 where dropped -- they depend on
-    // (sequence, head, row, key) only.  The dot-product wave draws them HERE, in front of the barrier it reaches 600 cycles before the
-    // cosine wave (in-kernel stamps: its first interval is 840 cycles against 1 310), instead of in the second interval, where it is the
-    // slower of the two and the SIMD's vector issue is saturated (profiles/r04/abw_instruction_mix.md: 24 integer + 8 compare + 8 select
-    // instructions per wave and step move out of that interval).  The cosine wave, the pole of the first interval, keeps them behind it.
-    const float cw = (BR == 1 ? a.beta : 1.f - a.beta) * kd.scale;      // branch weight x dropout scale
-    f32x4 mval[2];
-    auto draw_mval = [&]() __attribute__((always_inline)) {
-        const uint32_t hrow = (uint32_t)((((uint64_t)t * a.H + h) * 32) + x);
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            bool kp[4] = {true, true, true, true};
-            if (kd.on) drop_keep4(kd, hrow, (uint32_t)(4 * jt + q), kp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mval[jt][e] = kp[e] ? cw : 0.f;
-        }
-    };
-    if (BR == 2) draw_mval();
     bar(0);
     ABW_MARK2("attn I2.softmax", IT, BR);
     // ---- I2: first half, query tile IT: this branch's softmax and its backward
@@ -1971,15 +1953,18 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
     }
     ABW_MARK2("attn I2.dropout+softmax_bwd+images", IT, BR);
     {
-        if (BR == 1) draw_mval();
+        const float cw = (BR == 1 ? a.beta : 1.f - a.beta) * kd.scale;      // branch weight x dropout scale
+        const uint32_t hrow = (uint32_t)((((uint64_t)t * a.H + h) * 32) + x);
         float rd = 0.f;
         f32x4 gr[2], pm[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
+            bool kp[4] = {true, true, true, true};
+            if (kd.on) drop_keep4(kd, hrow, (uint32_t)(4 * jt + q), kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                gr[jt][e] = mval[jt][e] * dp[jt][e];
-                pm[jt][e] = mval[jt][e] * sc[jt][e];
+                gr[jt][e] = kp[e] ? cw * dp[jt][e] : 0.f;
+                pm[jt][e] = kp[e] ? cw * sc[jt][e] : 0.f;
                 rd = fmaf(sc[jt][e], gr[jt][e], rd);
             }
         }

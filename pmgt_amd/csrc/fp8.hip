@@ -296,6 +296,192 @@ __global__ __launch_bounds__(512) void gemm_nt_f8_big_kernel(GemmF8 g) {
     }
 }
 
+
+// ================================================================================================
+// Role-split weight-stationary fp8 GEMM for K = 512 (the d = 512 Q|K|V|C projection of the fp8 mode, N = 2048): the e4m3 twin of
+// gemm_wsr512_kernel<W5_PLAIN> (gemm_wsr.hip).  Twelve waves per CU:
+//   waves 0-7  (GEMM role):     e4m3 W columns 32 g .. 32 g + 31 of a 256-column slab in 64 VGPRs (half of what bf16 takes); per 32-row
+//                               A tile 16 block-scaled MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: 4 k-steps of 128) into
+//                               the fp32 staging buffer of the step;
+//   waves 8-11 (epilogue role): LDS-DMA of the NEXT tile (32 rows x 512 e4m3 bytes: four 1-KB pieces per wave), and the epilogue of the
+//                               previous step: acc * (wscale[n] * xscale[m]) + bias -> bf16, 16-byte row-contiguous stores.
+// The 256 x 256 fp8 tile this replaces for that shape re-stages W through LDS for every 256 rows and ran at 496 us per launch against
+// 251 us for the bf16 role-split kernel: the mode that exists to be faster was slower (profiles/r03).  One s_barrier per step.
+// LDS: two A tiles (2 x 16 KB) + two staging buffers (2 x 33 KB).
+// ================================================================================================
+struct Wsr8Cfg {
+    static constexpr int TR = 32, ROWB = 512, TILEB = TR * ROWB, NR = 2, ES = 256 + 4, STG = TR * ES * 4;
+    static constexpr int SMEM = NR * TILEB + 2 * STG;
+};
+typedef __attribute__((address_space(3))) void lds_void_f8_t;
+typedef __attribute__((address_space(1))) const void gbl_void_f8_t;
+
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_wsr512_f8_kernel(GemmF8 g) {
+    using C = Wsr8Cfg;
+    typedef int i32x8_t __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> (row-range slot x, column slab y); the slabs of one x sit on one XCD (ids b, b + 8, ...): their A re-reads hit its L2
+    const int ny = g.N / 256;
+    const int b = blockIdx.x;
+    const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
+    const int gx = gridDim.x / ny;
+    const int nb = y * 256;
+    const int num_mt = (g.M + C::TR - 1) / C::TR;
+    const int n = x < num_mt ? (num_mt - x + gx - 1) / gx : 0;      // steps of this workgroup: tiles x, x + gx, ...
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_f8_t*)smem;
+    const uint32_t stg0 = lds0 + C::NR * C::TILEB;
+
+    if (wave < 8) {
+        // ================================================================ GEMM role
+        const int gw = wave, r = lane & 15, q = lane >> 4;
+        i32x8_t wf[2][4];      // [column tile][k-step]: lane (r, q) holds k = 128 ks + 32 q .. + 31 of W row nb + 32 gw + 16 j + r
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const char* wp = (const char*)g.B + (int64_t)(nb + 32 * gw + 16 * j + r) * g.ldb + 128 * ks + 32 * q;
+                const u32x4 lo = *(const u32x4*)wp, hi = *(const u32x4*)(wp + 16);
+                wf[j][ks] = (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
+        // fragment address of k-step 0, first 16-byte half, row tile 0: row r, chunk slot (2 q) ^ (r & 15); second half = XOR 16,
+        // k-step ks = XOR (ks << 7) (chunk bits 3, 4), row tile 1 = + 16 rows
+        const uint32_t fr0 = (uint32_t)(r * C::ROWB + (((2 * q) ^ (r & 15)) << 4));
+        const uint32_t sw0 = (uint32_t)((4 * q * C::ES + 32 * gw + r) * 4);      // staging address of acc[0][0][0]: row 4 q, column 32 gw + r
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // W fragments
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it <= n; ++it) {
+            if (it < n) {
+                const uint32_t ab = lds0 + (uint32_t)((it & 1) * C::TILEB);
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                u32x4 fa[2][2][2];      // [k-step parity][row tile][16-byte half]
+                auto rd = [&](int ks) __attribute__((always_inline)) {
+                    uint32_t f0 = fr0;
+                    asm volatile("" : "+v"(f0));
+                    const uint32_t ad = (f0 ^ (uint32_t)(ks << 7)) + ab, ad1 = ad ^ 16u;
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192"
+                                 : "=&v"(fa[ks & 1][0][0]), "=&v"(fa[ks & 1][0][1]), "=&v"(fa[ks & 1][1][0]), "=&v"(fa[ks & 1][1][1])
+                                 : "v"(ad), "v"(ad1) : "memory");
+                };
+                rd(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4) {
+                        rd(ks + 1);
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[ks & 1][0][0]), "+v"(fa[ks & 1][0][1]), "+v"(fa[ks & 1][1][0]), "+v"(fa[ks & 1][1][1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks & 1][0][0]), "+v"(fa[ks & 1][0][1]), "+v"(fa[ks & 1][1][0]), "+v"(fa[ks & 1][1][1]));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const u32x4 lo = fa[ks & 1][i][0], hi = fa[ks & 1][i][1];
+                        const i32x8_t af = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, wf[j][ks], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    }
+                }
+                // (inline-asm staging writes: the hazard recogniser does not put the wait states between an MFMA and an LDS instruction
+                // that reads its result there; the s_nop is tied to the four accumulator tiles)
+                asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+                const uint32_t sb = stg0 + (uint32_t)((it & 1) * C::STG) + sw0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t ad = sb + (uint32_t)(((16 * i + e) * C::ES + 16 * j) * 4);
+                            asm volatile("ds_write_b32 %0, %1" :: "v"(ad), "v"(acc[i][j][e]) : "memory");
+                        }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging tile in LDS before the barrier
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // ==================================================================== epilogue role: 256 threads, 32 lanes per row, 8 rows per pass; also the DMA engine
+    const int te = tid - 512, dw = wave - 8;
+    const int erow = te >> 5, ecol = (te & 31) * 8;
+    // LDS-DMA of one A tile: wave dw moves rows 8 dw .. 8 dw + 7 as four 1-KB pieces (two 512-byte rows each); LDS chunk slot `lane & 31` of a
+    // row takes source chunk slot ^ (row & 15)
+    auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+        const int mt = x + t * gx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = 8 * dw + 2 * p + (lane >> 5);
+            const int m = min(mt * C::TR + row, g.M - 1);
+            const char* src = (const char*)g.A + (int64_t)m * g.lda + (((lane & 31) ^ (row & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_void_f8_t*)src, (lds_void_f8_t*)(smem + slot * C::TILEB + (8 * dw + 2 * p) * C::ROWB), 16, 0, 0);
+        }
+    };
+    bf16* Cp = (bf16*)g.C;
+    float bias[8], wsc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias[e] = g.bias ? g.bias[nb + ecol + e] : 0.f;
+        wsc[e] = g.b_row_scale ? g.b_row_scale[nb + ecol + e] : 1.f;
+    }
+    float pfx[4];      // dequantisation scales of this lane's four rows of the next tile
+    auto load_xs = [&](int t) __attribute__((always_inline)) {
+        const int mt = x + t * gx;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = min(mt * C::TR + erow + 8 * ps, g.M - 1);
+            pfx[ps] = g.a_row_scale ? g.a_row_scale[m] : g.a_scale;
+        }
+    };
+    load_xs(0);
+    if (0 < n) dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it <= n; ++it) {
+        if (it + 1 < n) dma(it + 1, (it + 1) & 1);      // first in the step: that slot held tile it - 1, every read of it drained before the last barrier
+        bool full_tile = false;
+        if (it >= 1) {
+            const int tt = it - 1, mt = x + tt * gx;
+            full_tile = mt * C::TR + C::TR <= g.M;
+            const float* stage = (const float*)(smem + C::NR * C::TILEB + (tt & 1) * C::STG);
+            const float xs[4] = {pfx[0], pfx[1], pfx[2], pfx[3]};
+            load_xs(min(tt + 1, max(n - 1, 0)));      // unconditional (clamped): the next step's row scales travel under this step's arithmetic
+            f32x4 sv[4][2];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                sv[ps][0] = *(const f32x4*)(stage + (erow + 8 * ps) * C::ES + ecol);
+                sv[ps][1] = *(const f32x4*)(stage + (erow + 8 * ps) * C::ES + ecol + 4);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int m = mt * C::TR + erow + 8 * ps;
+                if (m < g.M) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (bf16)(sv[ps][0][e] * (wsc[e] * xs[ps]) + bias[e]);
+                        o[4 + e] = (bf16)(sv[ps][1][e] * (wsc[4 + e] * xs[ps]) + bias[4 + e]);
+                    }
+                    *(bf16x8*)(Cp + (int64_t)m * g.ldc + nb + ecol) = o;
+                }
+            }
+        }
+        // the tile of step it + 1 has landed for this wave: the counter retires in order, and a FULL tile's four row stores (every pass
+        // stores, for every lane) were issued after the DMA pieces -- they may stay in flight (the row-scale loads only add to the margin)
+        if (full_tile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+static bool f8_wsr512_ok(const GemmF8& g) {
+    return !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN)) && g.K == 512 && g.N % 256 == 0 && g.N >= 256 && g.M >= 8192 && g.a_rows == nullptr && g.m_dev == nullptr &&
+           g.lda % 16 == 0 && g.ldb % 16 == 0 && g.ldc % 8 == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
+}
+
 static bool f8_big_ok(const GemmF8& g) {
     return g.a_rows == nullptr && g.m_dev == nullptr && g.M >= 4096 && g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128 && g.lda % 16 == 0 &&
            g.ldb % 16 == 0 && g.ldc % 8 == 0 && ((uintptr_t)g.C % 16) == 0;
@@ -308,6 +494,15 @@ int gemm_nt_f8(const GemmF8& g, hipStream_t st) {
     PMGT_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 8) == 0, -2, "gemm_nt_f8: unaligned operands");
     PMGT_CHECK((g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0) && (g.b_row_scale == nullptr || ((uintptr_t)g.b_row_scale % 16) == 0), -2,
                "gemm_nt_f8: bias / scale vectors must be 16-byte aligned");
+    if (f8_wsr512_ok(g)) {
+        PMGT_SMEM_ATTR((const void*)gemm_wsr512_f8_kernel, Wsr8Cfg::SMEM);
+        const int ny = g.N / 256, num_mt = cdiv(g.M, Wsr8Cfg::TR);
+        const int gx = std::max(8, std::min(256 / ny, num_mt) / 8 * 8);      // multiple of 8 row slots, one 12-wave workgroup per CU
+        note_launch(LT_F8_WSR512);
+        hipLaunchKernelGGL(gemm_wsr512_f8_kernel, dim3(gx * ny), dim3(768), Wsr8Cfg::SMEM, st, g);
+        PMGT_LAUNCH_OK();
+        return 0;
+    }
     if (f8_big_ok(g) && !(g.opts & OPT_TILE_GEMM)) {
         constexpr int smem = 4 * (256 + 256) * 64;
         PMGT_SMEM_ATTR((const void*)gemm_nt_f8_big_kernel, smem);

@@ -63,7 +63,14 @@ __device__ unsigned int g_ws_prof[2][8][8];
 #endif
 
 template <int KS, int MODE, int NW>
-__device__ __forceinline__ void gemm_ws_body(const GemmWS& g) {
+__device__ __forceinline__ void gemm_ws_body(const GemmWS& g_) {
+    // device-side row count (compacted rows of the last-layer shortcut): the grid is sized for the host bound g_.M, the row loop for
+    // min(M, *m_dev); a workgroup without rows leaves before its first barrier
+    GemmWS g = g_;
+    if (g_.m_dev) {
+        g.M = min(g_.M, *g_.m_dev);
+        if (g.M <= 0) return;
+    }
     constexpr bool HAS_PF = MODE == WS_GELU_GRAD || MODE == WS_RES || MODE == WS_RES_LN;
     using C = WsCfg<KS, NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -368,7 +375,7 @@ static int ws_mode(const GemmWS& g) {
 }
 
 bool gemm_ws_supported(const GemmWS& g) {
-    return ws_mode(g) >= 0 && g.a_rows == nullptr && g.m_dev == nullptr && g.K % 32 == 0 && g.K >= 64 && g.K <= 512 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
+    return ws_mode(g) >= 0 && g.a_rows == nullptr && g.K % 32 == 0 && g.K >= 64 && g.K <= 512 && (g.K & (g.K - 1)) == 0 && g.N % 8 == 0 && g.N >= 8 &&
            g.M >= 64 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) &&
            (g.aux == nullptr || g.ldaux % 8 == 0);
 }

@@ -34,6 +34,10 @@ __device__ unsigned long long g_w2_prof[16][8];
 template <bool LNB>
 __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
     using C = WsrCfg;
+    if (g.m_dev) {      // device-side row count (see gemm_ws_body): uniform over the workgroup, taken before any barrier
+        g.M = min(g.M, *g.m_dev);
+        if (g.M <= 0) return;
+    }
 #ifdef PMGT_W5_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long plast = 0;
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(1024) void gemm_wsr_kernel(GemmWS g) {
 
 bool gemm_wsr_ok(const GemmWS& g) {
     return !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN | OPT_UNFUSED_LN)) && g.K == 256 && g.N == 256 && g.M >= 8192 && g.epi == EPI_NONE && g.res != nullptr && g.ln_out != nullptr && g.ln_stats != nullptr &&
-           g.a_rows == nullptr && g.m_dev == nullptr && (g.q8 == nullptr || (g.q8_scale != nullptr && ((uintptr_t)g.q8 % 8) == 0)) && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.ldr % 8 == 0 &&
+           g.a_rows == nullptr && (g.q8 == nullptr || (g.q8_scale != nullptr && ((uintptr_t)g.q8 % 8) == 0)) && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && g.ldr % 8 == 0 &&
            ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 &&
            ((uintptr_t)g.ln_out % 16) == 0 && ((uintptr_t)g.ln_stats % 8) == 0;
 }
@@ -439,6 +443,10 @@ struct Wsr5Cfg {
 template <int MODE>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_wsr512_kernel(GemmWS g) {
     using C = Wsr5Cfg;
+    if (g.m_dev) {      // device-side row count (see gemm_ws_body)
+        g.M = min(g.M, *g.m_dev);
+        if (g.M <= 0) return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -677,7 +685,7 @@ static int wsr5_mode(const GemmWS& g) {
 
 bool gemm_wsr512_ok(const GemmWS& g) {
     const int mode = wsr5_mode(g);
-    return mode >= 0 && !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN)) && g.K == 512 && g.N % 256 == 0 && g.N >= 256 && g.M >= 8192 && g.a_rows == nullptr && g.m_dev == nullptr &&
+    return mode >= 0 && !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN)) && g.K == 512 && g.N % 256 == 0 && g.N >= 256 && g.M >= 8192 && g.a_rows == nullptr &&
            g.q8 == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) && (g.aux == nullptr || g.ldaux % 8 == 0) &&
            ((mode != W5_GELU && mode != W5_GELU_GRAD) || g.aux != nullptr) &&
            ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 && ((uintptr_t)g.aux % 16) == 0;

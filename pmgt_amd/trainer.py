@@ -101,7 +101,7 @@ class Trainer:
         return loss
 
     # ---- the whole step as ONE hipGraph ---------------------------------------------------------------------------
-    def capture_step(self, batch, warmup: int = 2):
+    def capture_step(self, batch, warmup: int = 2, capture_error_mode: str = "global"):
         """Captures train_step(batch) (mask -> forward -> losses -> backward -> clip + AdamW) into a hipGraph and
         returns `replay()`: the library never syncs or allocates and keeps every data-dependent count (masked rows,
         dropout step, AdamW step) on the device, so the captured launches stay valid step after step.  New batches
@@ -122,7 +122,7 @@ class Trainer:
             graph = torch.cuda.CUDAGraph()
             self._capturing = True        # the graph gets an output set of its own: replays keep writing it, eager steps never do
             try:
-                with torch.cuda.graph(graph, stream=st):
+                with torch.cuda.graph(graph, stream=st, capture_error_mode=capture_error_mode):
                     loss = self.train_step(batch)
                     outputs = self.last_outputs
             finally:
@@ -143,16 +143,25 @@ class Trainer:
 
     # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
     def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3,
-                 stall_timeout_s: float = 120.0):
+                 stall_timeout_s: float = 120.0, graphs: bool = False):
         """Training steps fed by the live host pipeline (the reference: a DataLoader over PMGTDataset, pmgt/pmgt/trainer.py:84-105):
         ONE producer thread runs the threaded C++ sampler into a pinned host slot and issues the slot's async H2D copies on a
         side stream into that slot's PRE-ALLOCATED device buffers (no allocator call, no record_stream on the step's path); the
-        launch thread orders each step behind its copies with one event and hands the slot back with a completion event."""
+        launch thread orders each step behind its copies with one event and hands the slot back with a completion event.
+        graphs=True: the step is captured once per slot over that slot's device buffers (train-mode batches have a fixed shape: every
+        target brings max_total_samples pairs) and replayed -- ONE launch per step, so a launch thread that loses its CPU for a
+        millisecond in the middle of a step's ~70 launches (a shared host) no longer shows up as GPU idle time inside the step."""
         eng = self.engine
         dev = eng.device
         copy_stream = torch.cuda.Stream(device=dev)
-        slots = [sampler.alloc(batch_size, MODE_TRAIN, pinned=True) for _ in range(depth)]
-        dslots = [{k: torch.empty_like(v, device=dev) for k, v in sl.items()} for sl in slots]
+        # the slots (pinned host + device buffers) live as long as the trainer: a second pass over the same shapes re-uses them -- and, with
+        # graphs=True, the steps captured over them
+        skey = (id(sampler), batch_size, depth)
+        cache = self.__dict__.setdefault("_live_slots", {})
+        if skey not in cache:
+            sl = [sampler.alloc(batch_size, MODE_TRAIN, pinned=True) for _ in range(depth)]
+            cache[skey] = (sl, [{k: torch.empty_like(v, device=dev) for k, v in s_.items()} for s_ in sl])
+        slots, dslots = cache[skey]
         n = len(node_ids)
         t_sample, t_wait, t_copy = [0.0], [0.0], [0.0]
 
@@ -192,6 +201,7 @@ class Trainer:
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         t_launch = 0.0
+        replays = self.__dict__.setdefault("_live_replays", {})       # (slot buffers, shape) -> captured step, kept across calls
         try:
             for i, (slot, (b, ev)) in enumerate(pipe):
                 if t0 is None:
@@ -199,7 +209,16 @@ class Trainer:
                 tl = time.perf_counter()
                 torch.cuda.current_stream().wait_event(ev)
                 ev_a[i].record()
-                self.train_step(b)
+                key = (b[0]["node_ids"].data_ptr(), tuple(b[0]["node_ids"].shape), tuple(b[1]["node_ids"].shape)) if graphs else None
+                if graphs and key in replays:
+                    self.last_loss = replays[key]()
+                elif graphs and self.world_size == 1 and self.accum == 1:
+                    # first batch of this slot: record the step (nothing executes during capture), then replay it like every later one.
+                    # thread_local: the producer thread keeps issuing its own copies / event waits while this thread captures
+                    replays[key] = self.capture_step(b, warmup=0, capture_error_mode="thread_local")
+                    self.last_loss = replays[key]()
+                else:
+                    self.train_step(b)
                 ev_b[i].record()
                 pipe.release(slot, ev_b[i])   # the launch thread does not wait for the GPU: the producer does, before it refills
                 t_launch += time.perf_counter() - tl
@@ -211,7 +230,7 @@ class Trainer:
         busy = sum(ev_a[i].elapsed_time(ev_b[i]) for i in range(steps))
         return {"nodes_per_s": round(steps * batch_size / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
                 "pipeline_fill_ms": round((t0 - t_start) * 1e3, 3),
-                "sampler_threads": threads, "steps": steps, "pipeline_depth": depth,
+                "sampler_threads": threads, "steps": steps, "pipeline_depth": depth, "graph_replay": bool(graphs),
                 "gpu_step_ms": round(busy / steps, 3),
                 "gpu_idle_ms_per_step": round(idle / max(steps - 1, 1), 3),
                 "launch_thread_busy_ms_per_step": round(t_launch / steps * 1e3, 3),

@@ -76,7 +76,8 @@ def _rand_e4m3(shape, g, spread=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 1536), (77, 40, 48), (1000, 256, 768), (513, 1024, 256),
-                                   (4100, 512, 512), (8192, 2048, 512), (5000, 256, 192)])      # last three: the 256 x 256 LDS-DMA tile
+                                   (4100, 512, 512), (8192, 2048, 512), (5000, 256, 192),       # these three: the 256 x 256 LDS-DMA tile (8192 rows, no gather: role split)
+                                   (9001, 512, 512), (40000, 2048, 512)])                       # K = 512, M >= 8192, no gather: the role-split streaming kernel (ragged M, many steps)
 @pytest.mark.parametrize("gather", [False, True])
 def test_gemm_nt_f8(M, N, K, gather):
     """C = (A8 B8^T) sa sb + bias on v_mfma_f32_16x16x32_fp8_fp8.  Random (asymmetric) e4m3 operands: every product is
@@ -107,6 +108,11 @@ def test_gemm_nt_f8(M, N, K, gather):
     assert torch.isfinite(Cd.float()).all()
     err = (Cd.double().cpu() - ref).abs()
     assert (err <= 1.02 * 2 ** -8 * ref.abs() + 4e-5 * mag).all(), float((err / (ref.abs() + 1e-9)).max())
+    if K == 512 and M >= 8192 and N % 256 == 0 and not gather:      # the shape of the d = 512 Q|K|V|C projection: its own kernel must be the one that ran
+        H = _lib.hip()
+        H.pmgt_launch_trace_reset()
+        _lib.check(L.pmgt_op_gemm_nt_f8(P(A8d), K, None, P(sad), 1.0, P(B8d), K, P(sbd), P(Cd), N, M, N, K, P(bd), None, stream()))
+        assert H.pmgt_launch_trace_count(b"f8_wsr512") == 1 and H.pmgt_launch_trace_count(b"f8_big") == 0
     # device-side row count: rows beyond it are not written
     if not gather:
         Cd.fill_(7.0)

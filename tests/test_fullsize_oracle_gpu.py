@@ -307,7 +307,7 @@ def test_hidden_512_kernels_at_benchmark_token_counts_match_the_oracle(mode):
         return refs[key]
 
     L = _lib.hip()
-    fams = ("gemm_wsr512", "tn_big", "tn_big_gather", "nt_big", "nt_big_gather", "attn_tiles_fwd", "attn_tiles_bwd", "f8_big", "gemm_ws", "nt_tile", "tn_tile")
+    fams = ("gemm_wsr512", "tn_big", "tn_big_gather", "nt_big", "nt_big_gather", "attn_tiles_fwd", "attn_tiles_bwd", "f8_big", "f8_wsr512", "gemm_ws", "nt_tile", "tn_tile")
     for dtype in ("fp32", "bf16", "fp8"):
         L.pmgt_launch_trace_reset()
         eng, out = run_engine(case, dtype, [t.numpy() for t in tabs])
@@ -321,8 +321,8 @@ def test_hidden_512_kernels_at_benchmark_token_counts_match_the_oracle(mode):
             assert ran["attn_tiles_fwd"] >= 1 and ran["attn_tiles_bwd"] >= 1, ran
             if mode == "token" and dtype == "bf16":
                 assert ran["nt_big_gather"] == 2 and ran["tn_big_gather"] == 2, ran   # feature projection + its weight gradient on table rows
-            if dtype == "fp8":
-                assert ran["f8_big"] >= 2, ran
+            if dtype == "fp8":      # Q|K|V|C projections on the role-split e4m3 kernel; table mode: the whole-table feature projection on the 256 x 256 e4m3 tile
+                assert ran["f8_wsr512"] >= 2 and (mode == "token" or ran["f8_big"] >= 2), ran
         if dtype == "fp8":
             p, ref = oracle([t.cpu() for t in eng.dequantized_tables()])
         else:

@@ -46,8 +46,9 @@ print(json.dumps({"cpu_share": host_cpu_share(), "prestaged_ms_per_step": round(
 for rep in range(reps):
     for dp in depths:
         for th in threads:
-            r = trainer.run_live(sampler, shard, B, steps=steps, threads=th, depth=dp)
-            print(json.dumps({"rep": rep, "threads": th, "depth": dp, "vs_prestaged": round(pre / r["ms_per_step"], 4), "ms_per_step": r["ms_per_step"],
+          for gr in (False, True):
+            r = trainer.run_live(sampler, shard, B, steps=steps, threads=th, depth=dp, graphs=gr)
+            print(json.dumps({"rep": rep, "threads": th, "depth": dp, "graphs": gr, "launch_ms": r["launch_thread_busy_ms_per_step"], "vs_prestaged": round(pre / r["ms_per_step"], 4), "ms_per_step": r["ms_per_step"],
                               "gpu_idle_ms_per_step": r["gpu_idle_ms_per_step"], "gpu_step_ms": r["gpu_step_ms"],
                               "producer": r["producer_ms_per_batch"]}), flush=True)
 pre2 = time_steps(trainer, staged, steps=30, warmup=5) * 1e3

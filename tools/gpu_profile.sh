@@ -7,8 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH_ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-phase-profile --no-end-to-end --no-batch-sweep ${BENCH_EXTRA:-}"
-PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-phase-profile --no-end-to-end --no-batch-sweep ${BENCH_EXTRA:-}"
+BENCH_ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-phase-profile --no-end-to-end --no-batch-sweep --no-extra-workloads ${BENCH_EXTRA:-}"
+PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-phase-profile --no-end-to-end --no-batch-sweep --no-extra-workloads ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py $BENCH_ARGS > $OUT/kt_bench.json 2> $OUT/kt.err
 python3 $REPO/tools/summarize_rocprof.py stats $OUT/kt > $OUT/kernel_stats.txt 2>&1
 # counters in their own passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
@@ -16,6 +16,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_write.err
 python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_fetch FETCH_SIZE > $OUT/pmc_fetch.txt 2>&1
 python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_write WRITE_SIZE > $OUT/pmc_write.txt 2>&1
+# the same two counters over SIX steps: the whole-step traffic is the DIFFERENCE of the two runs divided by the three extra steps
+# (tools/make_traffic.py), so that set-up kernels -- launched once, or a multiple of the step count -- never count as step traffic
+PMC_ARGS_B="--steps 5 --warmup 1 --no-cpu-baseline --no-phase-profile --no-end-to-end --no-batch-sweep --no-extra-workloads ${BENCH_EXTRA:-}"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_b -- python3 $REPO/bench.py $PMC_ARGS_B > /dev/null 2> $OUT/pmc_fetch_b.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_b -- python3 $REPO/bench.py $PMC_ARGS_B > /dev/null 2> $OUT/pmc_write_b.err
+python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_fetch_b FETCH_SIZE > $OUT/pmc_fetch_6steps.txt 2>&1
+python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_write_b WRITE_SIZE > $OUT/pmc_write_6steps.txt 2>&1
+rm -rf $OUT/pmc_fetch_b $OUT/pmc_write_b
 # matrix-pipe and vector-ALU occupancy per kernel over the same step (SQ counters, one group per pass):
 #   matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES); VALU / MFMA instruction counts
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_sq1.err

@@ -12,6 +12,8 @@ import re
 import sys
 
 PHASE_KERNELS = {           # bench.py phase name -> substring of the kernel that dominates it
+    "bwd.dgrad_qkvc_lnb": "gemm_nt_big_kernelILi256ELi8ELb1",
+    "bwd.dgrad_ffn1_lnb": "gemm_wsr_kernelILb1",
     "fwd.qkvc_attention": "qkvc_attn_fwd",
     "bwd.attention": "attn_bwd_mfma_kernel",
     "bwd.attention_wgrad": "attn_bwd_wgrad_kernel",
@@ -32,16 +34,26 @@ def parse(path, counts=None):
     return rows
 
 
-PMC_STEPS = 3        # tools/gpu_profile.sh runs the counter passes with --steps 2 --warmup 1
+PMC_STEPS = 3        # tools/gpu_profile.sh runs the counter passes with --steps 2 --warmup 1 ...
+PMC_STEPS_B = 6      # ... and once more with --steps 5 --warmup 1 (the *_6steps.txt summaries)
 
 
 def main():
     prefix = sys.argv[1]
     nf, nw = {}, {}
     fetch, write = parse(prefix + "_pmc_fetch_size.txt", nf), parse(prefix + "_pmc_write_size.txt", nw)
-    # the whole step: every pmgt kernel's dispatches x its average, per training step (one-off setup kernels of the process -- table
-    # casts, parameter init -- are launched once and do not belong to a step: only kernels launched a multiple of PMC_STEPS times count)
-    step_kib = sum((2.0 * fetch[k] * nf[k] + write.get(k, 0.0) * nw.get(k, 0)) / PMC_STEPS for k in fetch if nf[k] % PMC_STEPS == 0)
+    # the whole step = (counter totals of the six-step run - totals of the three-step run) / 3: set-up kernels of the process (table
+    # casts, parameter init, the first mirror) are launched equally often in both runs and cancel, whatever their launch count
+    six_f, six_w = prefix + "_pmc_fetch_size_6steps.txt", prefix + "_pmc_write_size_6steps.txt"
+    if os.path.exists(six_f) and os.path.exists(six_w):
+        nf6, nw6 = {}, {}
+        fetch6, write6 = parse(six_f, nf6), parse(six_w, nw6)
+        tot = lambda v, n, w: sum(w * v[k] * n[k] for k in v)
+        step_kib = ((tot(fetch6, nf6, 2.0) + tot(write6, nw6, 1.0)) - (tot(fetch, nf, 2.0) + tot(write, nw, 1.0))) / (PMC_STEPS_B - PMC_STEPS)
+        step_how = "difference of the six-step and the three-step counter runs / 3"
+    else:       # older profile sets: dispatches per step = floor(launch count / steps of the run) for every kernel
+        step_kib = sum(2.0 * fetch[k] * (nf[k] // PMC_STEPS) + write.get(k, 0.0) * (nw.get(k, 0) // PMC_STEPS) for k in fetch)
+        step_how = "launch count // 3 dispatches of every kernel per step (three-step counter run)"
     phases = {}
     for ph, sub in PHASE_KERNELS.items():
         kf = next((k for k in fetch if sub in k), None)
@@ -74,6 +86,7 @@ def main():
                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
         "correction": "HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE; counters in KiB",
         "step_hbm_gb": round(step_kib * 1024.0 / 1e9, 2),
+        "step_hbm_gb_method": step_how,
         "phases": phases,
     }
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
