@@ -686,7 +686,8 @@ static int wsr5_mode(const GemmWS& g) {
 bool gemm_wsr512_ok(const GemmWS& g) {
     const int mode = wsr5_mode(g);
     return mode >= 0 && !(g.opts & (OPT_TILE_GEMM | OPT_NO_ROLE_SPLIT_LN)) && g.K == 512 && g.N % 256 == 0 && g.N >= 256 && g.M >= 8192 && g.a_rows == nullptr &&
-           g.q8 == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) && (g.aux == nullptr || g.ldaux % 8 == 0) &&
+           // (q8: the e4m3 copy of the LayerNorm OUTPUT -- at N = 512 written by the LayerNorm launch behind this GEMM, not by its epilogue)
+           g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 8 == 0 && (g.res == nullptr || g.ldr % 8 == 0) && (g.aux == nullptr || g.ldaux % 8 == 0) &&
            ((mode != W5_GELU && mode != W5_GELU_GRAD) || g.aux != nullptr) &&
            ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.res % 16) == 0 && ((uintptr_t)g.aux % 16) == 0;
 }
