@@ -421,8 +421,11 @@ def main():
             if Bx == B:
                 continue
             st_x = stage(Bx, 4, ctr0=10 ** 6)
-            ms = time_steps(trainer, st_x, steps=30, warmup=5) * 1e3
-            ent = {"nodes_per_s": round(Bx / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+            # eager launches at these sizes are ~100 kernels of 5 - 30 us: a launch thread that shares its host with other tenants shows up
+            # directly (one pass measured 2.3 ms where its neighbours measured 1.26), so: the best of three passes of 30 steps, all three reported
+            runs = [time_steps(trainer, st_x, steps=30, warmup=5) * 1e3 for _ in range(3)]
+            ms = min(runs)
+            ent = {"nodes_per_s": round(Bx / ms * 1e3, 1), "ms_per_step": round(ms, 4), "ms_per_step_passes": [round(r, 4) for r in runs]}
             try:
                 replay = trainer.capture_step(st_x[0])
                 for _ in range(3):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/rNN/README.md (per-kernel table) from a committed profile set.  Usage: tools/make_profile_readme.py profiles/r03/a"""
+"""profiles/rNN/README.md (per-kernel table) from a committed profile set, followed by the hand-written profiles/rNN/NOTES.md when there
+is one.  Usage: tools/make_profile_readme.py profiles/r04/a"""
 import json
 import os
 import re
@@ -30,11 +31,10 @@ def main():
     out = [
         "# %s -- one MI355X, C2 (7 252 nodes, L4 H8 d256 S32), bf16, B = 1 024, dropout 0.1\n" % os.path.dirname(pre),
         "Files: `a_kernel_stats.txt` (`rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3`: 13 steps), `a_pmc_*.txt` (separate "
-        "`--pmc` passes of 3 steps: FETCH_SIZE / WRITE_SIZE in KiB per launch; SQ counters), `a_bench_*.json` (bench lines: default C2, C3 "
+        "`--pmc` passes of 3 steps, and of 6 steps for `*_6steps.txt`: FETCH_SIZE / WRITE_SIZE in KiB per launch; SQ counters), `a_bench_*.json` (bench lines: default C2, C3 "
         "graph, C4 / C5 shapes, C2 in fp8 mode, a 4-rank gloo rehearsal on one GPU), `a_kernel_stats_B32.txt` / `_B256.txt` (the "
-        "reference's own batch sizes), `macro_tile_experiment.txt` (kernel designs that were measured and not kept), `library_gemm_comparison.txt` "
-        "(hipBLASLt / rocBLAS through torch at the engine's GEMM shapes). Collected by `tools/gpu_collect.sh` -> "
-        "`tools/gpu_profile.sh`; `profiles/traffic.json` comes from this set (`tools/make_traffic.py`), this file from `tools/make_profile_readme.py`.\n",
+        "reference's own batch sizes). Collected by `tools/gpu_collect.sh` -> `tools/gpu_profile.sh`; `profiles/traffic.json` comes from this set "
+        "(`tools/make_traffic.py`), the tables of this file from `tools/make_profile_readme.py`, the notes behind them from `NOTES.md`.\n",
         "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md). Matrix pipe busy = "
         "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES).\n",
         "| kernel | launches / step | avg us | ms / step | HBM MB / launch | TB/s | matrix pipe busy | VALU per MFMA |", "|---|---|---|---|---|---|---|---|"]
@@ -47,8 +47,9 @@ def main():
         out.append(f"| `{name[:48]}` | {calls / steps:.1f} | {avg:.1f} | {tms / steps:.3f} | {'%.0f' % mb if mb else '-'} | "
                    f"{'%.2f' % (mb / avg) if mb else '-'} | {'%.2f' % (b / (4 * c)) if c else '-'} | "
                    f"{'%.1f' % (valu[k][1] / mf[k][1]) if k in mf and mf[k][1] > 0 else '-'} |")
+    how = tr.get("step_hbm_gb_method", "every kernel's dispatches x its average, per step")
     out.append(f"\nWhole step: {sum(v[1] for v in ks.values()) / steps:.2f} ms of kernel time under the profiler, **{tr['step_hbm_gb']} GB of HBM "
-               f"traffic per step** by the counters (every kernel's dispatches x its average, per step).\n")
+               f"traffic per step** by the counters ({how}).\n")
     # ---- C4 shapes (10^6 nodes, L6 d512 S64, B = 256): same passes with BENCH_EXTRA="--workload c4 --batch 256"
     c4 = pre + "_kernel_stats_c4shapes_B256.txt"
     if os.path.exists(c4):
@@ -82,6 +83,9 @@ def main():
                        f"{'%.1f' % (v4[k][1] / m4[k][1]) if k in m4 and m4[k][1] > 0 else '-'} | "
                        f"{'%.2f' % (la[k][1] / c) if k in la and c else '-'} | {'%.2f' % (lc[k][1] / la[k][1]) if k in la and la[k][1] > 0 else '-'} |")
         out.append(f"\nWhole step: {sum(v[1] for v in ks4.values()) / steps:.2f} ms of kernel time under the profiler, {tot_gb:.1f} GB of HBM traffic per step.\n")
+    notes = os.path.join(os.path.dirname(pre), "NOTES.md")
+    if os.path.exists(notes):
+        out.append(open(notes).read())
     open(os.path.join(os.path.dirname(pre), "README.md"), "w").write("\n".join(out))
     print("\n".join(out[4:16]))
 

@@ -12,12 +12,12 @@ import re
 import sys
 
 PHASE_KERNELS = {           # bench.py phase name -> substring of the kernel that dominates it
-    "bwd.dgrad_qkvc_lnb": "gemm_nt_big_kernelILi256ELi8ELb1",
-    "bwd.dgrad_ffn1_lnb": "gemm_wsr_kernelILb1",
+    "bwd.dgrad_qkvc_lnb": "gemm_nt_big_kernel<256, 8, true>",
+    "bwd.dgrad_ffn1_lnb": "gemm_wsr_kernel<true>",
     "fwd.qkvc_attention": "qkvc_attn_fwd",
     "bwd.attention": "attn_bwd_mfma_kernel",
     "bwd.attention_wgrad": "attn_bwd_wgrad_kernel",
-    "bwd.dgrad_qkvc": "gemm_nt_big_kernel",
+    "bwd.dgrad_qkvc": "gemm_nt_big_kernel<256, 8, false>",
     "bwd.wgrad_qkvc": "gemm_tn_big_kernel",
     "bwd.layernorm": "ln_bwd_kernel",
 }
