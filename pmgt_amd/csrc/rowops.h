@@ -15,8 +15,10 @@ int ln_fwd(const T* x, T* y, float* stats, const float* gamma, const float* beta
 // that fed the residual sum).  Partials go to `part` ([ln_bwd_parts(M)][3][d] floats): dgamma, dbeta and
 // dbias = column sum of dx_drop (or dx): the bias gradient of the dense layer in front of the LayerNorm.
 // `beta_y` != NULL: `x` is the LayerNorm OUTPUT y (what the next sublayer reads anyway) and x^ = (y - beta) / gamma -- the forward
-// pass then never stores the pre-LayerNorm sum (1U of HBM writes per LayerNorm).  Only rstd of `stats` is read; a channel with
-// gamma == 0 gets x^ = 0 (its output is constant).
+// pass then never stores the pre-LayerNorm sum (1U of HBM writes per LayerNorm).  Only rstd of `stats` is read.  A channel with
+// gamma == 0 carries no information about x^ in y: the kernels use x^ = 0 there only to stay finite -- the host guard
+// (Engine.check_layernorm_carrier) never lets that form run on such parameters: it switches the engine to stored LayerNorm inputs when a
+// gamma is (nearly) zero or |beta / gamma| > 8.
 template <typename T>
 int ln_bwd(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_drop, float* part,
            int M, int d, DropCfg in_drop, DropCfg out_drop, hipStream_t st, const int* m_dev = nullptr, const float* beta_y = nullptr);
