@@ -1860,25 +1860,55 @@ __device__ __forceinline__ bf16x8 abw_tr_img(const char* img, int c0, int r, int
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// One step of an attention wave: pair = rows [0, 32) of `gin` (Q|K|V|C, 256-byte rows) / `oin` (dO, 64-byte rows), query / key
-// tile IT, softmax branch BR; results into `gout`; `scr` = the pair's images and norms; `mraw` = raw mask value of key (lane & 31);
-// `bar(k)` = the workgroup barrier.
-template <int IT, int BR, typename Bar>
-__device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& kd, bool act, float mraw, int t, int h, const char* gin,
-                                              const char* oin, char* gout, char* scr, int r, int q, int lane, Bar bar) {
+// One step of an attention wave, as three PHASES separated by the workgroup's barriers: pair = rows [0, 32) of `gin` (Q|K|V|C, 256-byte rows) /
+// `oin` (dO, 64-byte rows), query / key tile IT, softmax branch BR; results into `gout`; `scr` = the pair's images and norms.
+//   phase 1: fragments from the tiles, inverse norms of C + mask term (cosine wave), score and dP = dO V^T MFMAs
+//   phase 2: this branch's softmax, dropout, softmax backward, dS / P images; dQ (dot-product wave) or the accumulator half of dC (cosine wave)
+//   phase 3: key tile IT: dV, dK (dot-product wave) or dC (cosine wave)
+// Phase k + 1 reads what the OTHER waves of the pair wrote in phase k, so consecutive phases of a pair sit on either side of a barrier.  What a
+// wave carries between phases is explicit (AbwCarry): the kernel runs the two pairs of a step ONE INTERVAL APART (pair 1 is in phase k - 1
+// while pair 0 is in phase k), so the waves that share a SIMD -- w and w + 4: same tile and branch, the two pairs -- are never both in the
+// instruction-heavy second phase.
+struct AbwStep {      // (wave-uniform) what a phase needs to know about its step
+    const char* gin;
+    const char* oin;
+    char* gout;
+    int t;            // sequence (clamped into the tensor), for the dropout row index
+    bool act;         // the sequence exists
+};
+struct AbwCarry {
+    f32x4 sc[2], dp[2];      // phase 1 -> 2: raw scores and dP of this wave's query tile against both key tiles
+    f32x4 dch[2];            // phase 2 -> 3 (cosine wave): accumulator half of dC^T
+    float rho_x, ss;         // phase 1 -> 2 -> 3 (cosine wave): 1 / |c_x| (0 for a sequence that does not exist), |c_x|^2
+    f32x4 mval[2];           // phase 1 -> 2 (dot-product wave): dropout multipliers of its eight (query, key) elements
+};
+
+// dropout multipliers of a wave's eight (query, key) elements: branch weight x dropout scale, or 0 where dropped -- a function of (sequence,
+// head, row, key) only
+template <int BR>
+__device__ __forceinline__ void abw_draw_mval(const AttnArgs& a, const DropKey& kd, int t, int h, int x, int q, f32x4 (&mval)[2]) {
+    const float cw = (BR == 1 ? a.beta : 1.f - a.beta) * kd.scale;
+    const uint32_t hrow = (uint32_t)((((uint64_t)t * a.H + h) * 32) + x);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        bool kp[4] = {true, true, true, true};
+        if (kd.on) drop_keep4(kd, hrow, (uint32_t)(4 * jt + q), kp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mval[jt][e] = kp[e] ? cw : 0.f;
+    }
+}
+
+template <int IT, int BR>
+__device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, float mraw, int h, char* scr, int r, int q, int lane) {
     constexpr float L2E = 1.4426950408889634f;
-    constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
-    char* iS = scr + (BR == 1 ? 0 : 2048);               // dS1 (rows scaled by 1 / |c_i|) | dS2
-    char* iP1 = scr + 4096;
-    char* iP2 = scr + 6144;
     float* rho = (float*)(scr + 8192);
     float* madd = rho + 32;
     const int x = 16 * IT + r;
+    const char* gin = st.gin;
     ABW_MARK2("attn I1.fragments+norms", IT, BR);
-    // ---- I1: fragments from the tiles; branch 1: inverse norms of C and the mask term (log2 domain, shifted by its maximum)
     bf16x8 fown, kc[2], fv[2], fo;      // own Q rows (branch 2) | K or C rows of all keys | V rows of all keys | own dO rows
     if (BR == 2) fown = *(const bf16x8*)(gin + abw_g_addr(x, 16 * q));
-    fo = *(const bf16x8*)(oin + abw_o_addr(x, 16 * q));
+    fo = *(const bf16x8*)(st.oin + abw_o_addr(x, 16 * q));
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         kc[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, (BR == 1 ? 192 : 64) + 16 * q));
@@ -1892,7 +1922,7 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
             ss = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, ss, false);
         }
         ss = red_q<2>(ss, false);
-        rho_x = act ? __builtin_amdgcn_rsqf(ss) : 0.f;
+        rho_x = st.act ? __builtin_amdgcn_rsqf(ss) : 0.f;
         if (q == 0) rho[x] = rho_x;
         // the mask term sits with the cosine wave: the dot-product wave reads one fragment more, and the in-kernel stamps showed its
         // first interval at 1 340 cycles against 770 here with the mask term over there
@@ -1905,9 +1935,10 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         mm = red_q<2>(mm, true);
         if ((lane >> 4) == IT) madd[lane & 31] = (mv - mm) * L2E;      // each tile's cosine wave writes 16 of the 32 entries
     }
-    // scores (transposed: key on (q, e), query on r) do not depend on the other waves: start the matrix pipe before the barrier
+    cy.rho_x = rho_x;
+    cy.ss = ss;
+    // scores (transposed: key on (q, e), query on r) do not depend on the other waves: the matrix pipe starts before the barrier
     ABW_MARK2("attn I1.scores_mfma", IT, BR);
-    f32x4 sc[2], dp[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
@@ -1916,12 +1947,29 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
             for (int e = 0; e < 4; ++e) z1[e] = (4 * q + e == r) ? -ss : 0.f;      // "+ I": |c_i|^2 rho_i^2 = 1 on the diagonal
         }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        sc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[jt], BR == 1 ? kc[IT] : fown, z1, 0, 0, 0);
-        dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fo, z, 0, 0, 0);
+        cy.sc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[jt], BR == 1 ? kc[IT] : fown, z1, 0, 0, 0);
+        cy.dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fo, z, 0, 0, 0);
     }
-    bar(0);
+    // The dot-product wave draws its dropout multipliers HERE, behind its MFMAs: it reaches the barrier long before the cosine wave (stamps:
+    // 840 against 1 310 cycles), while its second phase is the longer of the two.  The cosine wave, the pole of this phase, draws them in phase 2.
+    if (BR == 2) abw_draw_mval<BR>(a, kd, st.t, h, x, q, cy.mval);
+}
+
+template <int IT, int BR>
+__device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, int h, char* scr, int r, int q) {
+    constexpr float L2E = 1.4426950408889634f;
+    constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
+    char* iS = scr + (BR == 1 ? 0 : 2048);               // dS1 (rows scaled by 1 / |c_i|) | dS2
+    char* iP1 = scr + 4096;
+    char* iP2 = scr + 6144;
+    const float* rho = (const float*)(scr + 8192);
+    const float* madd = rho + 32;
+    const int x = 16 * IT + r;
+    const float rho_x = cy.rho_x;
+    f32x4 (&sc)[2] = cy.sc;
+    f32x4 (&dp)[2] = cy.dp;
     ABW_MARK2("attn I2.softmax", IT, BR);
-    // ---- I2: first half, query tile IT: this branch's softmax and its backward
+    // first half, query tile IT: this branch's softmax and its backward
     f32x4 rj[2];
     {
         const float fac = BR == 1 ? -rho_x * L2E : ISQ * L2E;
@@ -1947,24 +1995,21 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
                 sum += sc[jt][e];
             }
         sum = red_q<2>(sum, false);
-        const float inv = act ? __builtin_amdgcn_rcpf(sum) : 0.f;
+        const float inv = st.act ? __builtin_amdgcn_rcpf(sum) : 0.f;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) sc[jt] *= inv;
     }
     ABW_MARK2("attn I2.dropout+softmax_bwd+images", IT, BR);
     {
-        const float cw = (BR == 1 ? a.beta : 1.f - a.beta) * kd.scale;      // branch weight x dropout scale
-        const uint32_t hrow = (uint32_t)((((uint64_t)t * a.H + h) * 32) + x);
+        if (BR == 1) abw_draw_mval<BR>(a, kd, st.t, h, x, q, cy.mval);
         float rd = 0.f;
         f32x4 gr[2], pm[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            bool kp[4] = {true, true, true, true};
-            if (kd.on) drop_keep4(kd, hrow, (uint32_t)(4 * jt + q), kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                gr[jt][e] = kp[e] ? cw * dp[jt][e] : 0.f;
-                pm[jt][e] = kp[e] ? cw * sc[jt][e] : 0.f;
+                gr[jt][e] = cy.mval[jt][e] * dp[jt][e];
+                pm[jt][e] = cy.mval[jt][e] * sc[jt][e];
                 rd = fmaf(sc[jt][e], gr[jt][e], rd);
             }
         }
@@ -1982,28 +2027,38 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
     }
     ABW_MARK2("attn I2.dq_or_dc_half_mfma", IT, BR);
     // branch 2: dQ^T; branch 1: the accumulator-operand half of dC^T -- both for this query tile
-    f32x4 dch[2];
     {
         const bf16x8 bs = pack_col<2>(sc, 0);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (BR == 2) {
-                const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(gin, 64, 16 * ct, r, q), bs, z, 0, 0, 0);     // K block
-                *(bf16x4*)(gout + abw_g_addr(x, (16 * ct + 4 * q) * 2)) = pack4(dq * ISQ);      // dQ block: columns 0..31
+                const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(st.gin, 64, 16 * ct, r, q), bs, z, 0, 0, 0);     // K block
+                *(bf16x4*)(st.gout + abw_g_addr(x, (16 * ct + 4 * q) * 2)) = pack4(dq * ISQ);      // dQ block: columns 0..31
             } else {
-                dch[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(gin, 192, 16 * ct, r, q), bs, z, 0, 0, 0);          // C block
+                cy.dch[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(st.gin, 192, 16 * ct, r, q), bs, z, 0, 0, 0);        // C block
             }
         }
     }
-    bar(2);
+}
+
+template <int IT, int BR>
+__device__ __forceinline__ void abw_phase3(const AbwStep& st, AbwCarry& cy, char* scr, int r, int q) {
+    constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
+    const char* iS = scr + (BR == 1 ? 0 : 2048);
+    const char* iP1 = scr + 4096;
+    const char* iP2 = scr + 6144;
+    const int x = 16 * IT + r;           // the KEY index now
+    const char* gin = st.gin;
+    char* gout = st.gout;
+    const float rho_x = cy.rho_x;
     ABW_MARK2("attn I3.dv", IT, BR);
-    // ---- I3: second half, key tile IT (x is the key index now).  dV^T = dO^T (P1 + P2) is split between the two branch waves
-    // (16 columns each): the cosine wave also has dC, the dot-product wave dK.
+    // second half, key tile IT.  dV^T = dO^T (P1 + P2) is split between the two branch waves (16 columns each): the cosine wave also has
+    // dC, the dot-product wave dK.
     {
         constexpr int CV = BR == 1 ? 0 : 1;
         const bf16x8 bp1 = abw_tr_img(iP1, 16 * IT, r, q), bp2 = abw_tr_img(iP2, 16 * IT, r, q);
-        const bf16x8 ao = abw_tr_o(oin, 16 * CV, r, q);
+        const bf16x8 ao = abw_tr_o(st.oin, 16 * CV, r, q);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp1, z, 0, 0, 0);
         dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp2, dv, 0, 0, 0);                      // P = P1 + P2 meets in the accumulator
@@ -2021,10 +2076,10 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
     } else {
         const bf16x8 bt = abw_tr_img(iS, 16 * IT, r, q);
         float dt = 0.f;
-        f32x4 chv[2];
+        f32x4 chv[2], dch[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x4 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<false>(gin, 192, 16 * ct, r, q), bt, dch[ct], 0, 0, 0);
+            const f32x4 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<false>(gin, 192, 16 * ct, r, q), bt, cy.dch[ct], 0, 0, 0);
             const int gc = (16 * ct + 4 * q) * 2;
             dch[ct] = -dc;           // dN = -dS1
             chv[ct] = load4<bf16>((const bf16*)(gin + abw_g_addr(x, 192 + gc))) * rho_x;        // C^_x
@@ -2035,7 +2090,6 @@ __device__ __forceinline__ void abw_attention(const AttnArgs& a, const DropKey& 
         for (int ct = 0; ct < 2; ++ct)
             *(bf16x4*)(gout + abw_g_addr(x, 192 + (16 * ct + 4 * q) * 2)) = pack4((dch[ct] - chv[ct] * dt) * rho_x);    // dC block
     }
-    bar(4);
     ABW_MARK2("attn end", IT, BR);
 }
 
@@ -2115,26 +2169,89 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             const int t = min(seq_of(s), a.Tseq - 1);
             return a.mask ? a.mask[(int64_t)t * 32 + (lane & 31)] : 1.f;
         };
-        float mnext = mask_of(0);
-        for (int i = 0; i <= nsteps + 1; ++i) {
-            const int s = i - 1;
-            if (s >= 0 && s < nsteps) {
-                const int t = seq_of(s);
-                const bool act = t < a.Tseq;
-                const int tc = min(t, a.Tseq - 1);
-                const char* gin = smem + in_tile(s) + ul * (32 * 256);
-                char* gout = smem + out_tile(s) + ul * (32 * 256);
-                const char* oin = smem + C::O0 + (s & 1) * C::OB + ul * (32 * 64);
-                const float mraw = mnext;
-                mnext = mask_of(s + 1);
-                if (role == 0) abw_attention<0, 1>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
-                else if (role == 1) abw_attention<0, 2>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
-                else if (role == 2) abw_attention<1, 1>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
-                else abw_attention<1, 2>(a, kd, act, mraw, tc, h, gin, oin, gout, scr, r, q, lane, bar);
+        auto step_of = [&](int s) {      // (uniform) tiles and sequence of this wave's pair in step s
+            AbwStep st;
+            const int t = seq_of(s);
+            st.act = t < a.Tseq;
+            st.t = min(t, a.Tseq - 1);
+            st.gin = smem + in_tile(s) + ul * (32 * 256);
+            st.gout = smem + out_tile(s) + ul * (32 * 256);
+            st.oin = smem + C::O0 + (s & 1) * C::OB + ul * (32 * 64);
+            return st;
+        };
+        // Pair 0 runs the three phases of step i - 1 in the three intervals of iteration i.  Pair 1 runs ONE INTERVAL LATER: phase 3 of step
+        // i - 2 | phase 1 of step i - 1 | phase 2 of step i - 1.  Every tile it reads or writes allows that without a change to the ring or to
+        // the GEMM role: the in-tile and dO slot of step s are overwritten by the DMA of step s + 2, issued after the FIRST barrier of
+        // iteration s + 2 (pair 1's last read of them is before it); the out-tile rows 32..63 of step s are first consumed by the copy-out
+        // (second interval of iteration s + 2) and by k-step 1 (third interval), both after pair 1's phase 3.  What it buys: the two attention
+        // waves of a SIMD (w and w + 4: same tile and branch, the two pairs) are never both in the instruction-heavy second phase -- the
+        // interval that was 2 360 of a step's 5 810 cycles with both of them in it (profiles/r04/abw_interval_stamps.txt).
+        auto run = [&](auto ITc, auto BRc) __attribute__((always_inline)) {
+            constexpr int IT = decltype(ITc)::value, BR = decltype(BRc)::value;
+            AbwCarry cy;
+            cy.rho_x = 0.f; cy.ss = 0.f;
+#pragma unroll
+            for (int k_ = 0; k_ < 2; ++k_) cy.sc[k_] = cy.dp[k_] = cy.dch[k_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float mnext = mask_of(0);
+#ifdef PMGT_ABW_LOCKSTEP
+            const bool late = false;      // (A/B build of tools/prof: the option below as a compile-time constant)
+#else
+            const bool late = ul == 1 && !(a.opts & OPT_LOCKSTEP_ATTENTION_BWD);      // (uniform)
+#endif
+            if (!late) {
+                for (int i = 0; i <= nsteps + 1; ++i) {
+                    const int s = i - 1;
+                    const bool on = s >= 0 && s < nsteps;
+                    AbwStep st = step_of(on ? s : 0);
+#ifdef PMGT_ABW_NO_ATTN
+                    const bool on_ = false;      // (ablation build: the attention role only keeps the barriers; results are garbage)
+#else
+                    const bool on_ = on;
+#endif
+                    if (on_) {
+                        const float mraw = mnext;
+                        mnext = mask_of(s + 1);
+                        abw_phase1<IT, BR>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                    }
+                    bar(0);
+                    if (on_) abw_phase2<IT, BR>(a, kd, st, cy, h, scr, r, q);
+                    bar(2);
+                    if (on_) abw_phase3<IT, BR>(st, cy, scr, r, q);
+                    bar(4);
+                }
             } else {
-                bar(0); bar(2); bar(4);
+                for (int i = 0; i <= nsteps + 1; ++i) {
+                    const int s3 = i - 2, s1 = i - 1;
+#ifdef PMGT_ABW_NO_ATTN
+                    if (false) {
+#else
+                    if (s3 >= 0 && s3 < nsteps) {
+#endif
+                        const AbwStep st3 = step_of(s3);
+                        abw_phase3<IT, BR>(st3, cy, scr, r, q);
+                    }
+                    bar(0);
+#ifdef PMGT_ABW_NO_ATTN
+                    const bool on = false;
+#else
+                    const bool on = s1 >= 0 && s1 < nsteps;
+#endif
+                    AbwStep st = step_of(on ? s1 : 0);
+                    if (on) {
+                        const float mraw = mnext;
+                        mnext = mask_of(s1 + 1);
+                        abw_phase1<IT, BR>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                    }
+                    bar(2);
+                    if (on) abw_phase2<IT, BR>(a, kd, st, cy, h, scr, r, q);
+                    bar(4);
+                }
             }
-        }
+        };
+        if (role == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        else if (role == 1) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        else if (role == 2) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
 #ifdef PMGT_ABW_PROF
         if (blockIdx.x == 0 && lane == 0) { for (int k_ = 0; k_ < 6; ++k_) g_abw_prof[wave][k_] = pacc[k_]; g_abw_prof[wave][7] = (unsigned long long)nsteps; }
 #endif
@@ -2170,79 +2287,131 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             aa[u] = gb + (32 * ks + fr_) * 256 + (((2 * (4 * gn + u)) ^ fk_) << 4) + fhalf;
             ab[u] = xb + (32 * ks + fr_) * C::XROW + (((2 * (C::KQ * gk + (u % C::KQ))) ^ fk_) << 4) + fhalf;
         }
-        abw_read_frags<4 * 256>(aa, fa);
-        abw_read_frags<4 * C::XROW>(ab, fb);
+        // All sixteen transposing reads of the k-step go out back to back (x fragments first), and the MFMAs of dQKVC fragment nt start as
+        // soon as ITS two reads have landed (LDS returns in order: lgkmcnt counts down): ONE LDS round trip per k-step instead of two
+        // serialised ones.  (Ablation, profiles/r04: the GEMM role alone -- no attention work at all -- takes 458 of the launch's 552 us,
+        // its two k-steps 194 of them: this role, not the attention arithmetic, is the pole of the kernel.)
+        u32x2 tb[8], ta[8];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\t"
+            "ds_read_b64_tr_b16 %1, %16 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\t"
+            "ds_read_b64_tr_b16 %3, %17 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\t"
+            "ds_read_b64_tr_b16 %5, %18 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\t"
+            "ds_read_b64_tr_b16 %7, %19 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %8, %20\n\t"
+            "ds_read_b64_tr_b16 %9, %20 offset:%25\n\t"
+            "ds_read_b64_tr_b16 %10, %21\n\t"
+            "ds_read_b64_tr_b16 %11, %21 offset:%25\n\t"
+            "ds_read_b64_tr_b16 %12, %22\n\t"
+            "ds_read_b64_tr_b16 %13, %22 offset:%25\n\t"
+            "ds_read_b64_tr_b16 %14, %23\n\t"
+            "ds_read_b64_tr_b16 %15, %23 offset:%25"
+            : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7]),
+              "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]), "=&v"(ta[7])
+            : "v"(ab[0]), "v"(ab[1]), "v"(ab[2]), "v"(ab[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "n"(4 * C::XROW), "n"(4 * 256)
+            : "memory");
+        // the x fragments and dQKVC fragment 0 have landed when at most 6 reads are outstanding
+        asm volatile("s_waitcnt lgkmcnt(6)"
+                     : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(tb[4]), "+v"(tb[5]), "+v"(tb[6]), "+v"(tb[7]), "+v"(ta[0]), "+v"(ta[1]));
 #pragma unroll
-        for (int u = 0; u < C::KQ; ++u)
+        for (int u = 0; u < 4; ++u) fb[u] = __builtin_bit_cast(bf16x8, (u32x4){tb[2 * u][0], tb[2 * u][1], tb[2 * u + 1][0], tb[2 * u + 1][1]});
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ta[2]), "+v"(ta[3]));
+            if (nt == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ta[4]), "+v"(ta[5]));
+            if (nt == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[6]), "+v"(ta[7]));
+            fa[nt] = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * nt][0], ta[2 * nt][1], ta[2 * nt + 1][0], ta[2 * nt + 1][1]});
+#pragma unroll
+            for (int u = 0; u < C::KQ; ++u) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
+        }
         // bias gradient = column sums of the tile: one more product against all-ones; this wave sums n tile 4 gn + (gk & 3)
         const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
         const bf16x8 fsel = (gk & 3) == 0 ? fa[0] : ((gk & 3) == 1 ? fa[1] : ((gk & 3) == 2 ? fa[2] : fa[3]));
         accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fsel, ones, accb, 0, 0, 0);
     };
-    for (int i = 0; i <= nsteps + 1; ++i) {
-        const int sg = i - 2;                     // the step whose results are consumed in this iteration
-        ABW_MARK("gemm A.kstep0");
-        if (sg >= 0) kstep(sg, 0);
-        bar(0);
-        ABW_MARK("gemm B.dma");
-#ifndef PMGT_ABW_NO_DMA
-        {
-            // LDS-DMA of this iteration: 52 (d = 256) one-KB instructions, fixed shares per GEMM wave, straight-line code:
-            //   x rows of step i - 1 (RPI rows per instruction; x is only needed when that step's results are consumed, one iteration
-            //   from now, so it travels one iteration behind the attention inputs and two x tiles suffice): wave g takes rows 8 g ..;
-            //   Q|K|V|C rows of the head for step i, 4 rows per instruction: wave g takes rows 8 g .. 8 g + 7;
-            //   dO rows of step i, 16 per instruction: waves 0 - 3.
-            // Per-lane address = two loop-invariant registers XOR / plus wave-uniform terms (the swizzle key of a row splits into a
-            // lane part and a row-block part): ~4 VALU instructions per DMA instead of ~12 -- the vector ALU belongs to the attention waves.
-            const int m0 = 64 * (xs + i * gx), m0x = m0 - 64 * gx;
-            constexpr int RPI = 1024 / C::XROW, LPR = 64 / RPI;
-            if (i >= 1 && i - 1 < nsteps) {
-                char* xb = smem + ((i - 1) & 1) * C::XB;
+    // LDS-DMA: 52 (d = 256) one-KB instructions per iteration, fixed shares per GEMM wave, straight-line code.  Per-lane address = two
+    // loop-invariant registers XOR / plus wave-uniform terms (the swizzle key of a row splits into a lane part and a row-block part): ~4 VALU
+    // instructions per DMA instead of ~12.
+    //   x rows of step i - 1 (RPI rows per instruction): wave g takes rows 8 g ..  They are only needed when that step's results are consumed,
+    //   one iteration from now, and their tile was last read in the third interval of the previous iteration: they go out FIRST in the
+    //   iteration, in front of k-step 0 (round 3 issued all pieces behind the first barrier: a burst of 7 per wave in the interval that also
+    //   carries the copy-out; ablation: without its DMAs the launch takes 454 us instead of 552).
+    auto dma_x = [&](int i) __attribute__((always_inline)) {
+        const int m0x = 64 * (xs + (i - 1) * gx);
+        constexpr int RPI = 1024 / C::XROW;
+        if (i >= 1 && i - 1 < nsteps) {
+            char* xb = smem + ((i - 1) & 1) * C::XB;
 #pragma unroll
-                for (int j = 0; j < 8 / RPI; ++j) {
-                    const int row0 = 8 * g + RPI * j;                            // (uniform) rows row0 .. row0 + RPI - 1, lane -> row0 + lane / LPR
-                    const int mrow = min(m0x + row0, M - RPI);                    // (uniform) whole instruction clamped into the tensor
-                    // abw_f(row0 + lane / LPR) = abw_f(row0) ^ abw_f(lane / LPR): row0 is a multiple of RPI, lane / LPR < RPI <= 4 (bits 0, 1)
-                    const uint32_t off = (uint32_t)mrow * (uint32_t)w.ldx * 2u + dx_row + ((dx_chunk ^ (uint32_t)abw_f(row0)) << 4);
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)w.x + (size_t)off), (lds_void_t*)(xb + row0 * C::XROW), 16, 0, 0);
-                }
-            }
-            if (i < nsteps) {
-                char* gt = smem + in_tile(i);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int row0 = 8 * g + 4 * j;
-                    const int mrow = min(m0 + row0, M - 4);
-                    const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);          // source chunk of the head's 256 bytes
-                    const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
-                    const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
-                }
-                if (g < 4) {
-                    const int row0 = 16 * g, row = row0 + (lane >> 2), c = (lane & 3) ^ abw_kt(row);
-                    const uint32_t m = (uint32_t)min(m0 + row, M - 1);
-                    const char* src = (const char*)a.dctx + (size_t)((m * (uint32_t)D + (uint32_t)(h * 32 + c * 8)) * 2u);
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + C::O0 + (i & 1) * C::OB + row0 * 64), 16, 0, 0);
-                }
+            for (int j = 0; j < 8 / RPI; ++j) {
+                const int row0 = 8 * g + RPI * j;                            // (uniform) rows row0 .. row0 + RPI - 1, lane -> row0 + lane / LPR
+                const int mrow = min(m0x + row0, M - RPI);                    // (uniform) whole instruction clamped into the tensor
+                // abw_f(row0 + lane / LPR) = abw_f(row0) ^ abw_f(lane / LPR): row0 is a multiple of RPI, lane / LPR < RPI <= 4 (bits 0, 1)
+                const uint32_t off = (uint32_t)mrow * (uint32_t)w.ldx * 2u + dx_row + ((dx_chunk ^ (uint32_t)abw_f(row0)) << 4);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)w.x + (size_t)off), (lds_void_t*)(xb + row0 * C::XROW), 16, 0, 0);
             }
         }
+    };
+    //   Q|K|V|C rows of the head for step i, 4 rows per instruction: wave g takes rows 8 g .. 8 g + 7; dO rows of step i, 16 per instruction:
+    //   waves 0 - 3.  Their ring slots are read by the attention waves until the first barrier of this iteration (pair 1 runs an interval late).
+    auto dma_attn = [&](int i) __attribute__((always_inline)) {
+        const int m0 = 64 * (xs + i * gx);
+        if (i < nsteps) {
+            char* gt = smem + in_tile(i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row0 = 8 * g + 4 * j;
+                const int mrow = min(m0 + row0, M - 4);
+                const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);          // source chunk of the head's 256 bytes
+                const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
+                const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
+            }
+            if (g < 4) {
+                const int row0 = 16 * g, row = row0 + (lane >> 2), c = (lane & 3) ^ abw_kt(row);
+                const uint32_t m = (uint32_t)min(m0 + row, M - 1);
+                const char* src = (const char*)a.dctx + (size_t)((m * (uint32_t)D + (uint32_t)(h * 32 + c * 8)) * 2u);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + C::O0 + (i & 1) * C::OB + row0 * 64), 16, 0, 0);
+            }
+        }
+    };
+    for (int i = 0; i <= nsteps + 1; ++i) {
+        const int sg = i - 2;                     // the step whose results are consumed in this iteration
+        ABW_MARK("gemm A.dma_x+kstep0");
+#ifndef PMGT_ABW_NO_DMA
+        dma_x(i);
 #endif
-        ABW_MARK("gemm B.copy_out");
-#ifndef PMGT_ABW_NO_COPY
-        if (sg >= 0) {          // copy the finished dQ|dK|dV|dC tile to HBM: 64 rows x 16 chunks of 16 bytes, 2 per lane
+#ifndef PMGT_ABW_NO_GEMM
+        if (sg >= 0) kstep(sg, 0);
+#endif
+        bar(0);
+        ABW_MARK("gemm B.copy_out+dma");
+        // copy-out of the finished dQ|dK|dV|dC tile (64 rows x 16 chunks of 16 bytes, 2 per lane): its two LDS reads go out first and
+        // travel under the issue of the attention-input DMAs; the stores follow
+        u32x4 v[2];
+        bool copy = false;
+#if !defined(PMGT_ABW_NO_COPY) && !defined(PMGT_ABW_NO_GEMM)
+        copy = sg >= 0;
+#endif
+        int lc = lane;
+        asm volatile("" : "+v"(lc));
+        if (copy) {
             const uint32_t gb = lds0 + out_tile(sg);
-            u32x4 v[2];
             uint32_t ad[2];
-            int lc = lane;
-            asm volatile("" : "+v"(lc));
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
                 ad[p] = gb + row * 256 + ((c ^ abw_f(row)) << 4);
             }
-            abw_read128x2(ad[0], ad[1], v);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
+        }
+#ifndef PMGT_ABW_NO_DMA
+        dma_attn(i);
+#endif
+        if (copy) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]) :: "memory");
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
@@ -2250,15 +2419,16 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                 if (m < M) *(u32x4*)((char*)a.dqkvc + (size_t)(((uint32_t)m * 4u * D + (uint32_t)(hoff + (c >> 2) * ms + (c & 3) * 8)) * 2u)) = v[p];
             }
         }
-#endif
         bar(2);
         ABW_MARK("gemm C.kstep1");
+#ifndef PMGT_ABW_NO_GEMM
         if (sg >= 0) kstep(sg, 1);
+#endif
         // This wave's DMAs have landed.  vmcnt retires loads and stores in issue order, and the two copy-out stores of a FULL tile
         // (no store instruction skipped by an all-false row predicate) were issued after the DMAs: they may stay in flight -- waiting for
         // their acknowledgement as well put a store round trip on every iteration's critical path.
 #ifndef PMGT_ABW_WAIT_STORES
-        if (sg >= 0 && 64 * (xs + sg * gx) + 64 <= M) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (copy && 64 * (xs + sg * gx) + 64 <= M) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

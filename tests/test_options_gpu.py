@@ -215,3 +215,24 @@ def test_options_are_frozen_while_a_captured_step_lives():
     del replay
     gc.collect()
     eng.set_option("store_ln_input", 1)                  # the graph is gone
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_attention_backward_pairs_one_interval_apart_is_bit_identical_to_lockstep(dropout):
+    """The fused attention backward runs the two (sequence, head) pairs of a step one barrier interval apart (pair 1 in phase k - 1 while
+    pair 0 is in phase k); `lockstep_attention_bwd` keeps both in the same phase.  Same arithmetic per element, different schedule:
+    every gradient must agree BIT FOR BIT, with an odd number of sequences (a last step with one live pair) and with dropout."""
+    case = gu.model_case("m3")          # d = 256, H = 8, S = 32
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    outs = []
+    for lock in (0, 1):
+        eng = make_engine(case, dtype="bf16", hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+        eng.set_option("lockstep_attention_bwd", lock)
+        eng.profile_begin()
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+        assert "bwd.attention_wgrad" in eng.profile_end()
+        torch.cuda.synchronize()
+        outs.append((out["loss"].item(), eng.grads.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.isfinite(outs[0][1]).all() and torch.equal(outs[0][1], outs[1][1])
