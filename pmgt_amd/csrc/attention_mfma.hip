@@ -2355,21 +2355,27 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         }
     };
     //   Q|K|V|C rows of the head for step i, 4 rows per instruction: wave g takes rows 8 g .. 8 g + 7; dO rows of step i, 16 per instruction:
-    //   waves 0 - 3.  Their ring slots are read by the attention waves until the first barrier of this iteration (pair 1 runs an interval late).
-    auto dma_attn = [&](int i) __attribute__((always_inline)) {
+    //   waves 0 - 3.  Rows 0..31 of these tiles belong to pair 0, whose last read of the slot's previous occupant is in the THIRD interval of
+    //   the previous iteration: their pieces are EARLY (first interval, with the x rows) and have to land by the end of this iteration.  Rows
+    //   32..63 belong to pair 1, which runs an interval late: their pieces are LATE (second interval) and have to land by the first barrier
+    //   of the NEXT iteration.  Either way a piece has a whole step to arrive (round 3: issue behind the first barrier, wait before the
+    //   third -- two thirds of a step, about the loaded HBM latency).
+    auto dma_attn = [&](int i, bool early) __attribute__((always_inline)) {
         const int m0 = 64 * (xs + i * gx);
         if (i < nsteps) {
-            char* gt = smem + in_tile(i);
+            if ((g < 4) == early) {
+                char* gt = smem + in_tile(i);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row0 = 8 * g + 4 * j;
-                const int mrow = min(m0 + row0, M - 4);
-                const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);          // source chunk of the head's 256 bytes
-                const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
-                const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    const int row0 = 8 * g + 4 * j;
+                    const int mrow = min(m0 + row0, M - 4);
+                    const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);          // source chunk of the head's 256 bytes
+                    const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
+                    const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
+                }
             }
-            if (g < 4) {
+            if (g < 4 && (g < 2) == early) {
                 const int row0 = 16 * g, row = row0 + (lane >> 2), c = (lane & 3) ^ abw_kt(row);
                 const uint32_t m = (uint32_t)min(m0 + row, M - 1);
                 const char* src = (const char*)a.dctx + (size_t)((m * (uint32_t)D + (uint32_t)(h * 32 + c * 8)) * 2u);
@@ -2377,19 +2383,47 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             }
         }
     };
+    // vector-memory operations of this wave per iteration, in issue order: [E: early pieces] [L: x rows, late pieces] [2 copy-out stores]
+    const int attnE = (g < 4 ? 2 : 0) + (g < 2 ? 1 : 0), attnL = (g >= 4 ? 2 : 0) + ((g == 2 || g == 3) ? 1 : 0);      // (uniform)
+    auto wait_vm = [](int n) __attribute__((always_inline)) {      // s_waitcnt vmcnt(n) as an immediate; n <= 9 here
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        }
+    };
+#ifdef PMGT_ABW_LOCKSTEP
+    const bool lock = true;
+#else
+    const bool lock = (a.opts & OPT_LOCKSTEP_ATTENTION_BWD) != 0;      // (uniform) both pairs in the same phase: every piece is due at the END of its iteration
+#endif
+    int prev_tail = 0;       // operations issued BEHIND the late pieces in the previous iteration (its full tile's 2 stores), -1 = do not count on any
     for (int i = 0; i <= nsteps + 1; ++i) {
         const int sg = i - 2;                     // the step whose results are consumed in this iteration
-        ABW_MARK("gemm A.dma_x+kstep0");
+        ABW_MARK("gemm A.dma_early+kstep0");
+        int nE = 0;
 #ifndef PMGT_ABW_NO_DMA
-        dma_x(i);
+        dma_attn(i, true);
+        nE = i < nsteps ? attnE : 0;
 #endif
 #ifndef PMGT_ABW_NO_GEMM
         if (sg >= 0) kstep(sg, 0);
 #endif
+        // the LATE pieces of the previous iteration (pair 1's rows of this iteration's attention inputs) have landed for this wave: vmcnt retires in
+        // issue order, and only that iteration's copy-out stores and this iteration's early pieces were issued behind them (a smaller count
+        // than the true one only waits longer)
+        if (!lock) wait_vm(prev_tail >= 0 ? min(prev_tail + nE, 9) : 0);
         bar(0);
-        ABW_MARK("gemm B.copy_out+dma");
+        ABW_MARK("gemm B.copy_out+dma_late");
         // copy-out of the finished dQ|dK|dV|dC tile (64 rows x 16 chunks of 16 bytes, 2 per lane): its two LDS reads go out first and
-        // travel under the issue of the attention-input DMAs; the stores follow
+        // travel under the issue of the late DMA pieces; the stores follow
         u32x4 v[2];
         bool copy = false;
 #if !defined(PMGT_ABW_NO_COPY) && !defined(PMGT_ABW_NO_GEMM)
@@ -2407,9 +2441,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             }
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
         }
+        // (the x rows go out HERE, not with the early pieces: stamps of the first form showed the GEMM waves at 1 970 cycles in the first
+        // interval -- seven DMA issues in front of k-step 0 -- against 630 - 860 in this one)
+        int nL = 0;
 #ifndef PMGT_ABW_NO_DMA
-        dma_attn(i);
+        dma_x(i);                       // issued BEFORE the late pieces: the wait that closes the iteration lets only those (and the stores) stay in flight
+        dma_attn(i, false);
+        nL = i < nsteps ? attnL : 0;
 #endif
+        const bool full = copy && 64 * (xs + sg * gx) + 64 <= M;      // (uniform) no store instruction skipped by an all-false row predicate
         if (copy) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]) :: "memory");
 #pragma unroll
@@ -2424,14 +2464,19 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
 #ifndef PMGT_ABW_NO_GEMM
         if (sg >= 0) kstep(sg, 1);
 #endif
-        // This wave's DMAs have landed.  vmcnt retires loads and stores in issue order, and the two copy-out stores of a FULL tile
-        // (no store instruction skipped by an all-false row predicate) were issued after the DMAs: they may stay in flight -- waiting for
-        // their acknowledgement as well put a store round trip on every iteration's critical path.
+        // This iteration's EARLY pieces have landed (x rows: needed an iteration from now; pair 0's rows: at the next barrier).  Behind them
+        // in issue order: the late pieces and, for a full tile, the two copy-out stores -- they stay in flight (waiting for the stores'
+        // acknowledgement as well put a store round trip on every iteration's critical path).
 #ifndef PMGT_ABW_WAIT_STORES
-        if (copy && 64 * (xs + sg * gx) + 64 <= M) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (full) wait_vm(lock ? 2 : nL + 2);
+        else if (!copy) wait_vm(lock ? 0 : nL);
         else
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vm(0);
+        prev_tail = full ? 2 : (!copy ? 0 : -1);
+#ifdef PMGT_ABW_WAIT_STORES
+        prev_tail = -1;
+#endif
         bar(4);
         ABW_MARK("gemm loop_end");
     }

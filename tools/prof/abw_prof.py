@@ -3,7 +3,9 @@ w = work of the role in the interval, b = its wait at the barrier that closes it
 import ctypes as C, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from pmgt_amd import _lib
+from pmgt_amd import _lib, _build
+if len(sys.argv) > 1:          # a library of its own (built with -DPMGT_ABW_PROF), e.g. build/abl/abw3_PROF.so
+    _build.hip_lib_path = lambda: os.path.abspath(sys.argv[1])
 L = _lib.ops()
 P = lambda t: C.c_void_p(t.data_ptr())
 T, S, H, dh = 12288, 32, 8, 32
