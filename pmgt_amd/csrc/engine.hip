@@ -514,6 +514,12 @@ static int build_mirrors(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b
 
 // whether encoder_forward takes the fused projection + attention kernel (and, in training, stores Q|K|V|C head-major):
 // a pure function of the configuration, the shape and the debug switches, so a separate backward call can re-derive it
+// Table mode with per-node segment sums at hidden size 256 in bf16: the token phase of the embedding runs embed_tok8_*_kernel, which do not
+// store the pre-LayerNorm sum (forward and backward take the same decision from the same engine state: encode_backward refuses changed options)
+template <typename T>
+static inline bool embed_recomputes(const pmgt_engine* e, bool table_mode) {
+    return table_mode && !(e->opts & OPT_NO_SEGMENT_SUM) && e->d == 256 && sizeof(T) == 2;
+}
 template <typename T>
 static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool want_probs) {
     if (sizeof(T) != 2 || (e->opts & (OPT_NO_FUSED_QKVC_ATTENTION | OPT_TILE_GEMM | OPT_VALU_ATTENTION)) || want_probs) return false;
@@ -583,7 +589,7 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             T* F_all = b.E + n_rows * NF * d;                // fits: (N + 2) * (NF + 1) d <= M * max(NF, 2) d
             m.phase = 1; m.M = (int)n_rows; m.E = b.E; m.pre = F_all;
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
-            m.phase = 2; m.M = M; m.E = F_all; m.e_rows = ids; m.pre = b.emb_pre;
+            m.phase = 2; m.M = M; m.E = F_all; m.e_rows = ids; m.pre = embed_recomputes<T>(e, true) ? nullptr : b.emb_pre;
             if (pq) { m.q8 = b.x8; m.q8_scale = b.xscale; }
             RUNP("fwd.embed_mix", embed_mix_fwd<T>(m, st));
         } else {
@@ -1019,6 +1025,9 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             // per-node backward of the modality mix, whose dE [N+2, NF d] is the P operand of the weight-gradient GEMMs.
             const int n_rows = (int)t->n_nodes + 2;
             m.phase = 2; m.M = M; m.dh0 = b.bA; m.pre = b.emb_pre; m.dF = b.bB;
+            if (embed_recomputes<T>(e, true)) {      // the forward kept F_all [n_rows, d] behind the projected table instead of the per-token sum
+                m.pre = nullptr; m.E = b.E + (int64_t)n_rows * NF * d; m.e_rows = b.ids; m.pos = P + e->pos; m.role = P + e->role;
+            }
             if (b.defer) RUN(take_partials<T>(e, b, (int64_t)embed_bwd_parts(M) * pe, &m.part, st));
             RUNP("bwd.embed_mix", embed_mix_bwd<T>(m, st));
             if (b.defer) RUN(queue_reduce<T>(e, b, m.part, embed_bwd_parts(M), pe, G + e->ln_g, acc, st));

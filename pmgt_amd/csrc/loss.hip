@@ -121,27 +121,40 @@ __global__ __launch_bounds__(1024) void nfr_compact_kernel(const int64_t* __rest
     __shared__ int wcnt[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = B * S;
     int base = 0;
-    for (int s0 = 0, it = 0; s0 < n; s0 += 1024, ++it) {
-        const int i = s0 + tid;
-        const int64_t t = i < n ? tgt_full[i] : -1;
-        const bool hit = t >= 0;
-        const unsigned long long m = __ballot(hit);
-        const int below = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[it & 1][wave] = __popcll(m);
-        __syncthreads();                      // (double-buffered counters: one barrier per slab)
-        int woff = 0, tot = 0;
+    // eight slabs of 1024 positions are requested together: with one load per slab iteration the kernel was 32 serialised memory round trips
+    // (28 us at B = 1024, at the head of every step)
+    for (int g0 = 0, it = 0; g0 < n; g0 += 8 * 1024) {
+        int64_t tv[8];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int c = wcnt[it & 1][w];
-            woff += w < wave ? c : 0;
-            tot += c;
+        for (int u = 0; u < 8; ++u) {
+            const int i = g0 + 1024 * u + tid;
+            tv[u] = i < n ? tgt_full[i] : -1;
         }
-        if (hit) {
-            const int k = base + woff + below;
-            rows[k] = (int64_t)seq_off * S + i;
-            tids[k] = t;
+#pragma unroll
+        for (int u = 0; u < 8; ++u, ++it) {
+            const int s0 = g0 + 1024 * u;
+            if (s0 >= n) break;                   // (uniform)
+            const int i = s0 + tid;
+            const int64_t t = tv[u];
+            const bool hit = t >= 0;
+            const unsigned long long m = __ballot(hit);
+            const int below = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[it & 1][wave] = __popcll(m);
+            __syncthreads();                      // (double-buffered counters: one barrier per slab)
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int c = wcnt[it & 1][w];
+                woff += w < wave ? c : 0;
+                tot += c;
+            }
+            if (hit) {
+                const int k = base + woff + below;
+                rows[k] = (int64_t)seq_off * S + i;
+                tids[k] = t;
+            }
+            base += tot;
         }
-        base += tot;
     }
     if (tid == 0) *count = base;
 }

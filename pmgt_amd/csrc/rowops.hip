@@ -381,72 +381,237 @@ __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(EmbedMix p) {
     }
 }
 
-// Token phase of the table mode at d = 256 (the bench shape), FOUR rows per wave: the generic kernel above gives a wave one row
-// -- node id -> mixed row F[id] -> LayerNorm -> stores is one dependent chain of two memory round trips, and 32 resident waves
-// per CU keep 32 rows x 1.5 KB in flight (3.3 TB/s measured).  Here the four ids, then the four rows, are loaded back to back
-// before anything is consumed.  Same arithmetic in the same order as the token phase of embed_mix_fwd_kernel (bit-identical outputs).
+// Token phase of the table-mode embedding at hidden size 256 (bf16): x = F_all[ids[m]] + pos[s] + role[s > 0] -> LayerNorm -> dropout, and its
+// backward.  A row is 32 lanes x 16 bytes; a wave task = positions (2 pp, 2 pp + 1) of TOK_R consecutive sequences: the position and role rows
+// (fp32, 2 KB per token when read per row -- four times the bytes of the gathered row, all through L2) are read once per task, and the TOK_R
+// row pairs' loads are in flight together.  `pre` == NULL (what the engine passes): the pre-LayerNorm sum is not stored -- the backward
+// recomputes it from the same three rows (F_all is 3.7 MB and stays in L2) with the same operations, so both passes see the same bf16 values
+// (1U of writes and 1U of reads less per step).
+constexpr int TOK_R = 4;
+__device__ __forceinline__ float half_sum(float v) {       // sum over the 32 lanes of this half of the wave
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float half_max(float v) {
+    v = dpp_max<0xB1>(v);
+    v = dpp_max<0x4E>(v);
+    v = dpp_max<0x141>(v);
+    v = dpp_max<0x140>(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+struct TokTask {
+    int q0, s;          // first sequence, position of this half-wave
+    bool sv;            // the position exists (odd S: the last pair has one)
+};
+__host__ __device__ inline int tok_tasks(int M, int S) { return ((S + 1) >> 1) * ((M / S + TOK_R - 1) / TOK_R); }
+__device__ __forceinline__ TokTask tok_task(int w, int S, int hs) {
+    const int npp = (S + 1) >> 1;
+    TokTask t;
+    t.q0 = (w / npp) * TOK_R;
+    t.s = 2 * (w % npp) + hs;
+    t.sv = t.s < S;
+    if (!t.sv) t.s = S - 1;
+    return t;
+}
+// the pre-LayerNorm sum of one row as the forward rounds it (x: 8 gathered bf16; ps / rl: position and role rows, fp32)
+__device__ __forceinline__ void tok_sum(const bf16x8& x, const f32x4 (&ps)[2], const f32x4 (&rl)[2], float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)x[j] * 1.f + ps[j >> 2][j & 3] + rl[j >> 2][j & 3];
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void embed_tok4_fwd_kernel(EmbedMix p) {
-    constexpr int R = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = (blockIdx.x * 4 + wave) * R;
-    if (m0 >= p.M) return;
-    constexpr int d = 256;
+__global__ __launch_bounds__(256) void embed_tok8_fwd_kernel(EmbedMix p) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int R = TOK_R, d = 256;
+    const int lane = threadIdx.x & 63, hl = lane & 31, hs = lane >> 5;
+    const int S = p.S, Tq = p.M / S;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= tok_tasks(p.M, S)) return;
+    const TokTask tk = tok_task(w, S, hs);
     int64_t er[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) er[k] = p.e_rows[min(m0 + k, p.M - 1)];
-    f32x4 x[R];
+    for (int k = 0; k < R; ++k) er[k] = p.e_rows[(int64_t)min(tk.q0 + k, Tq - 1) * S + tk.s];
+    bf16x8 x[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) x[k] = load4<T>((const T*)p.E + er[k] * d + 4 * lane);
+    for (int k = 0; k < R; ++k) x[k] = *(const bf16x8*)((const bf16*)p.E + er[k] * d + 8 * hl);
+    f32x4 ps[2], rl[2], gam[2], bet[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        ps[c] = *(const f32x4*)(p.pos + (int64_t)tk.s * d + 8 * hl + 4 * c);
+        rl[c] = *(const f32x4*)(p.role + (tk.s > 0 ? d : 0) + 8 * hl + 4 * c);
+        gam[c] = *(const f32x4*)(p.gamma + 8 * hl + 4 * c);
+        bet[c] = *(const f32x4*)(p.beta + 8 * hl + 4 * c);
+    }
     const DropKey dk = make_drop_key(p.drop);
-    const f32x4 gam = *(const f32x4*)(p.gamma + 4 * lane), bet = *(const f32x4*)(p.beta + 4 * lane);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const int m = m0 + k;
-        if (m >= p.M) break;
-        const int s = m % p.S;
-        f32x4 v = x[k] * 1.f + *(const f32x4*)(p.pos + (int64_t)s * d + 4 * lane) + *(const f32x4*)(p.role + (s > 0 ? d : 0) + 4 * lane);
-        store4<T>((T*)p.pre + (int64_t)m * d + 4 * lane, v);
+        const bool ok = tk.sv && tk.q0 + k < Tq;           // (uniform over the half-wave; every lane runs the reductions)
+        const int64_t m = (int64_t)min(tk.q0 + k, Tq - 1) * S + tk.s;
+        float v[8];
+        tok_sum(x[k], ps, rl, v);
+        if (p.pre && ok) {
+            bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = to_f<T>(from_f<T>(v[e]));
-        const float mean = wave_sum(sum4(v)) / (float)d;
-        const f32x4 t = v - mean;
-        const float rstd = 1.f / sqrtf(wave_sum(sum4(t * t)) / (float)d + p.eps);
-        if (lane == 0) { p.stats[2 * (int64_t)m] = mean; p.stats[2 * (int64_t)m + 1] = rstd; }
-        f32x4 o = (v - mean) * rstd * gam + bet;
-        if (dk.on) {
-            float dm[4];
-            drop_mul4(dk, (uint32_t)m, (uint32_t)lane, dm);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= dm[e];
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+            *(bf16x8*)((bf16*)p.pre + m * d + 8 * hl) = o;
         }
-        store4<T>((T*)p.h0 + (int64_t)m * d + 4 * lane, o);
-        if (p.q8) {
-            f32x4 oq;
-            float mx = 0.f;
+        float sm = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { oq[e] = to_f<T>(from_f<T>(o[e])); mx = fmaxf(mx, fabsf(oq[e])); }
-            mx = wave_max(mx);
+        for (int j = 0; j < 8; ++j) { v[j] = (float)(bf16)v[j]; sm += v[j]; }
+        const float mean = half_sum(sm) / (float)d;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] -= mean; sq += v[j] * v[j]; }
+        const float rstd = 1.f / sqrtf(half_sum(sq) / (float)d + p.eps);
+        if (hl == 0 && ok) { p.stats[2 * m] = mean; p.stats[2 * m + 1] = rstd; }
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[j] * rstd * gam[j >> 2][j & 3] + bet[j >> 2][j & 3];
+        if (dk.on) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float dm[4];
+                drop_mul4(dk, (uint32_t)m, (uint32_t)(2 * hl + c), dm);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * c + e] *= dm[e];
+            }
+        }
+        bf16x8 ob;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ob[j] = (bf16)o[j];
+        if (ok) *(bf16x8*)((bf16*)p.h0 + m * d + 8 * hl) = ob;
+        if (p.q8) {
+            float oq[8], mx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { oq[j] = (float)ob[j]; mx = fmaxf(mx, fabsf(oq[j])); }
+            mx = half_max(mx);
             const float inv = mx > 0.f ? E4M3_MAX / mx : 1.f;
-            if (lane == 0) p.q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
-            int w = 0;
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[0] * inv, -E4M3_MAX, E4M3_MAX),
-                                                __builtin_amdgcn_fmed3f(oq[1] * inv, -E4M3_MAX, E4M3_MAX), w, false);
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[2] * inv, -E4M3_MAX, E4M3_MAX),
-                                                __builtin_amdgcn_fmed3f(oq[3] * inv, -E4M3_MAX, E4M3_MAX), w, true);
-            *(int*)((char*)p.q8 + (int64_t)m * d + 4 * lane) = w;
+            if (hl == 0 && ok) p.q8_scale[m] = mx > 0.f ? mx / E4M3_MAX : 1.f;
+            int wq[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                int w_ = 0;
+                w_ = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[4 * c] * inv, -E4M3_MAX, E4M3_MAX),
+                                                     __builtin_amdgcn_fmed3f(oq[4 * c + 1] * inv, -E4M3_MAX, E4M3_MAX), w_, false);
+                w_ = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(oq[4 * c + 2] * inv, -E4M3_MAX, E4M3_MAX),
+                                                     __builtin_amdgcn_fmed3f(oq[4 * c + 3] * inv, -E4M3_MAX, E4M3_MAX), w_, true);
+                wq[c] = w_;
+            }
+            if (ok) *(int2*)((char*)p.q8 + m * d + 8 * hl) = make_int2(wq[0], wq[1]);
         }
     }
+}
+
+// LayerNorm backward of the same rows: dF = LN'(dh0 * dropout mask), dgamma / dbeta partials per workgroup ([embed_part_elems]: the dWa / dba
+// part is zero, as in the generic token phase).  Tasks are dealt round-robin over the grid of embed_bwd_parts(M) workgroups.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tok8_bwd_kernel(EmbedMix p) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    extern __shared__ float red[];       // embed_part_elems(d, NF) floats
+    constexpr int R = TOK_R, d = 256;
+    const int lane = threadIdx.x & 63, hl = lane & 31, hs = lane >> 5, wave = threadIdx.x >> 6;
+    const int S = p.S, Tq = p.M / S;
+    const int ntask = tok_tasks(p.M, S);
+    const DropKey ik = make_drop_key(p.drop);
+    f32x4 gam[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) gam[c] = *(const f32x4*)(p.gamma + 8 * hl + 4 * c);
+    float dgam[8], dbet[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dgam[j] = dbet[j] = 0.f;
+    for (int w = blockIdx.x * 4 + wave; w < ntask; w += gridDim.x * 4) {
+        const TokTask tk = tok_task(w, S, hs);
+        int64_t er[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) er[k] = p.e_rows[(int64_t)min(tk.q0 + k, Tq - 1) * S + tk.s];
+        bf16x8 x[R], dy[R];
+        float mean[R], rstd[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int64_t m = (int64_t)min(tk.q0 + k, Tq - 1) * S + tk.s;
+            x[k] = *(const bf16x8*)((const bf16*)p.E + er[k] * d + 8 * hl);
+            dy[k] = *(const bf16x8*)((const bf16*)p.dh0 + m * d + 8 * hl);
+            mean[k] = p.stats[2 * m];
+            rstd[k] = p.stats[2 * m + 1];
+        }
+        f32x4 ps[2], rl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ps[c] = *(const f32x4*)(p.pos + (int64_t)tk.s * d + 8 * hl + 4 * c);
+            rl[c] = *(const f32x4*)(p.role + (tk.s > 0 ? d : 0) + 8 * hl + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool ok = tk.sv && tk.q0 + k < Tq;
+            const int64_t m = (int64_t)min(tk.q0 + k, Tq - 1) * S + tk.s;
+            float v[8], g[8], dyv[8];
+            tok_sum(x[k], ps, rl, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dyv[j] = ok ? (float)dy[k][j] : 0.f;
+            if (ik.on) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float dm[4];
+                    drop_mul4(ik, (uint32_t)m, (uint32_t)(2 * hl + c), dm);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dyv[4 * c + e] *= dm[e];
+                }
+            }
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = ((float)(bf16)v[j] - mean[k]) * rstd[k];      // x^
+                g[j] = dyv[j] * gam[j >> 2][j & 3];
+                dgam[j] += dyv[j] * v[j];
+                dbet[j] += dyv[j];
+                sg += g[j];
+                sgx += g[j] * v[j];
+            }
+            sg = half_sum(sg) * (1.f / (float)d);
+            sgx = half_sum(sgx) * (1.f / (float)d);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((g[j] - sg - v[j] * sgx) * rstd[k]);
+            if (ok) *(bf16x8*)((bf16*)p.dF + m * d + 8 * hl) = o;
+        }
+    }
+    // workgroup sums through LDS, half-wave after half-wave (fixed order): dgamma | dbeta
+    for (int hw = 0; hw < 8; ++hw) {
+        if (wave == (hw >> 1) && hs == (hw & 1)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float* dg = red + 8 * hl + j;
+                dg[0] = (hw > 0 ? dg[0] : 0.f) + dgam[j];
+                dg[d] = (hw > 0 ? dg[d] : 0.f) + dbet[j];
+            }
+        }
+        __syncthreads();
+    }
+    const int n_out = embed_part_elems(d, p.nf);
+    float* out = p.part + (int64_t)blockIdx.x * n_out;
+    for (int i = threadIdx.x; i < n_out; i += 256) out[i] = i < 2 * d ? red[i] : 0.f;
 }
 
 template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st) {
     if (e.M <= 0) return 0;
     PMGT_CHECK(e.d % 4 == 0 && e.d <= 1024, -2, "embed_mix_fwd: hidden size %d must be a multiple of 4 and <= 1024", e.d);
-    if (e.phase == 2 && e.d == 256 && e.e_rows != nullptr && sizeof(T) == 2) {
-        hipLaunchKernelGGL((embed_tok4_fwd_kernel<T>), dim3(cdiv(e.M, 16)), dim3(256), 0, st, e);
-        PMGT_LAUNCH_OK();
-        return 0;
+    if constexpr (sizeof(T) == 2) {
+        if (e.phase == 2 && e.d == 256 && e.e_rows != nullptr) {
+            PMGT_CHECK(e.S > 0 && e.M % e.S == 0, -2, "embed_mix_fwd: %d tokens are not whole sequences of %d", e.M, e.S);
+            const int tasks = tok_tasks(e.M, e.S);
+            hipLaunchKernelGGL((embed_tok8_fwd_kernel<T>), dim3(cdiv(tasks, 4)), dim3(256), 0, st, e);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
     }
+    PMGT_CHECK(e.phase != 2 || e.pre != nullptr, -2, "embed_mix_fwd: the token phase at hidden size %d stores the pre-LayerNorm sum", e.d);
     PMGT_CHECK(e.nf >= 1 && e.nf <= 4, -2, "embed_mix_fwd: %d modalities (1 .. 4 are built)", e.nf);
     dim3 grid(cdiv(e.M, 4)), block(256);
 #define PMGT_EMB_FWD_NF(PH, NF_)                                                                                  \
@@ -647,6 +812,16 @@ template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st) {
     PMGT_CHECK(e.nf >= 1 && e.nf <= 4, -2, "embed_mix_bwd: %d modalities (1 .. 4 are built)", e.nf);
     dim3 grid(embed_bwd_parts(e.M)), block(256);
     const size_t lds = (size_t)embed_part_elems(e.d, e.nf) * sizeof(float);
+    if (e.phase == 2 && e.pre == nullptr) {      // the pre-LayerNorm sum is recomputed (what embed_tok8_fwd_kernel's callers pass)
+        if constexpr (sizeof(T) == 2) {
+            PMGT_CHECK(e.d == 256 && e.e_rows != nullptr && e.E != nullptr && e.pos != nullptr && e.role != nullptr && e.S > 0 && e.M % e.S == 0, -2,
+                       "embed_mix_bwd: recomputed pre-LayerNorm sum needs the table-mode token phase at hidden size 256 (d=%d)", e.d);
+            hipLaunchKernelGGL((embed_tok8_bwd_kernel<T>), grid, block, lds, st, e);
+            PMGT_LAUNCH_OK();
+            return 0;
+        }
+        PMGT_CHECK(false, -2, "embed_mix_bwd: fp32 stores the pre-LayerNorm sum");
+    }
 #define PMGT_EMB_BWD_NF(PH, NF_)                                                                                  \
     do {                                                                                                          \
         if (e.d <= 256) hipLaunchKernelGGL((embed_mix_bwd_kernel<T, 1, PH, NF_>), grid, block, lds, st, e);       \
