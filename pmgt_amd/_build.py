@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-HIP_SOURCES = ["gemm.hip", "gemm_ws.hip", "gemm_wsr.hip", "fp8.hip", "rowops.hip", "attention.hip", "attention_mfma.hip", "qkvc_attn.hip", "segsum.hip", "loss.hip", "optim.hip", "engine.hip"]
+HIP_SOURCES = ["gemm.hip", "gemm_ws.hip", "gemm_wsr.hip", "gemm_rowln.hip", "fp8.hip", "rowops.hip", "attention.hip", "attention_mfma.hip", "qkvc_attn.hip", "segsum.hip", "loss.hip", "optim.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs (no v_accvgpr_read moves before every VALU
 # use of a result: -7 % VALU instructions in the attention backward, which is VALU-issue-bound)

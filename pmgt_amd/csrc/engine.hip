@@ -36,7 +36,7 @@ void note_launch(int tag) { if (tag >= 0 && tag < LT_COUNT) ++g_launch_count[tag
 static const char* const g_launch_names[LT_COUNT] = {
     "gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_tile",
     "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
-    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512"};
+    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln"};
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -487,6 +487,10 @@ static inline bool ln_from_y_applies(const pmgt_engine* e, int Mt, int K, bool c
 template <typename T>
 static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
+        if (g.ln_out && gemm_rowln_ok(g)) {      // N = 512: whole rows in one workgroup, LayerNorm in the epilogue (gemm_rowln.hip)
+            RUNP(name, gemm_rowln(g, st));
+            return 0;
+        }
         if (!(g.opts & OPT_TILE_GEMM) && gemm_ws_supported(g)) {
             PMGT_CHECK(!g.skip_c || gemm_ws_fuses_ln(g), -2, "linear: skip_c needs the fused-LayerNorm form");
             RUNP(name, gemm_ws(g, st));
@@ -512,14 +516,15 @@ static int build_mirrors(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>& b
     return 0;
 }
 
-// whether encoder_forward takes the fused projection + attention kernel (and, in training, stores Q|K|V|C head-major):
-// a pure function of the configuration, the shape and the debug switches, so a separate backward call can re-derive it
 // Table mode with per-node segment sums at hidden size 256 in bf16: the token phase of the embedding runs embed_tok8_*_kernel, which do not
 // store the pre-LayerNorm sum (forward and backward take the same decision from the same engine state: encode_backward refuses changed options)
 template <typename T>
 static inline bool embed_recomputes(const pmgt_engine* e, bool table_mode) {
     return table_mode && !(e->opts & OPT_NO_SEGMENT_SUM) && e->d == 256 && sizeof(T) == 2;
 }
+
+// whether encoder_forward takes the fused projection + attention kernel (and, in training, stores Q|K|V|C head-major):
+// a pure function of the configuration, the shape and the debug switches, so a separate backward call can re-derive it
 template <typename T>
 static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool want_probs) {
     if (sizeof(T) != 2 || (e->opts & (OPT_NO_FUSED_QKVC_ATTENTION | OPT_TILE_GEMM | OPT_VALU_ATTENTION)) || want_probs) return false;

@@ -74,6 +74,11 @@ int gemm_wsr_lnb(const GemmWS& g, hipStream_t st);
 bool gemm_wsr512_ok(const GemmWS& g);
 int gemm_wsr512(const GemmWS& g, hipStream_t st);
 
+// Full-row tile at N = 512 (gemm_rowln.hip): C = dropout(A W^T + bias) + res and ln_out = LayerNorm(C) in one launch (tile 128 x 512, LDS-DMA
+// ring; bf16); linear() dispatches to it before gemm_ws.  skip_c as above.
+bool gemm_rowln_ok(const GemmWS& g);
+int gemm_rowln(const GemmWS& g, hipStream_t st);
+
 // Partial weight gradients: slab[s][N1,N2] = sum over the s-th chunk of rows m of P[m,n1]*Q[m,n2]
 // ("TN": the reduction index is the row).  `slab_reduce` then sums the slabs in a fixed order.
 struct GemmTN {

@@ -184,6 +184,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmWS& g_) {
             if (mt + 2 * gx < num_mt) gload(mt + 2 * gx, P);
         }
         WS_STAMP(1);
+        // K = 512 form: this tile's LDS-DMA (issued behind the previous step's second barrier) must have landed for EVERY wave before
+        // anyone reads fragments.  An explicit wait: __syncthreads() only orders what the memory model makes the compiler wait for, and
+        // the unrolled loop's back edge reached this barrier with lgkmcnt(0) alone (rows of the incoming tile still in flight: wrong and
+        // run-to-run different outputs on some boxes, tests/test_ops_gpu.py::test_role_split_k512_*).
+        if constexpr (C::DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         WS_STAMP(2);
         // 4-wave form: ONE tile in flight in registers (the W fragments take 128 of the 256): loaded here, at the start of the

@@ -579,7 +579,11 @@ def test_role_split_k512_gemm_is_bit_identical_to_the_lockstep_kernel(M, N, epi,
     (640, 128, 128, 0, True, 0.0, True),       # d = 128: streaming kernel, LayerNorm unfused
     (500, 64, 64, 1, False, 0.0, False),
     (100, 264, 256, 0, False, 0.0, False),     # N not a multiple of the slab
-    (5000, 512, 512, 0, True, 0.1, True),      # d = 512 (C4 shapes): K = 512 form (one LDS buffer, A tile by LDS-DMA), LayerNorm unfused
+    (5000, 512, 512, 0, True, 0.1, True),      # d = 512 (C4 shapes): full-row tile with the LayerNorm in its epilogue (gemm_rowln.hip), ragged M
+    (4097, 512, 512, 0, True, 0.0, True),      # ... one row in the last tile, no dropout: also against fp64
+    (4100, 512, 512, 0, False, 0.0, True),     # ... no residual
+    (8192, 512, 2048, 0, True, 0.1, True),     # ... FFN2 with I = 4 d (K = 2048)
+    (3000, 512, 512, 0, True, 0.1, True),      # below the full-row form's size: K = 512 streaming form, LayerNorm unfused
     (3001, 512, 512, 1, False, 0.0, False),    # ... GELU
     (2000, 512, 512, 2, False, 0.0, False),    # ... GELU'
     (4096, 2048, 512, 0, False, 0.0, False),   # ... eight column slabs
@@ -599,15 +603,19 @@ def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, 
     aux_in = torch.randn(M, N, generator=g).cuda().bfloat16()
     rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
     outs = []
+    H = _lib.hip()
     for force in (0, 1):
         L.use(*(['tile_gemm'] if force else []))
         Cd = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         aux = aux_in.clone() if epi == 2 else torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         lno = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if ln else None
         stats = torch.zeros(M, 2, device="cuda") if ln else None
+        H.pmgt_launch_trace_reset()
         _lib.check(L.pmgt_op_linear(1, P(A), K, P(W), K, P(Cd), N, M, N, K, P(bias), epi, P(aux) if epi else None, N,
                                     P(R), N, drop, 33, P(rng), P(lno), P(stats), P(gam) if ln else None, P(bet) if ln else None,
                                     1e-12, stream()))
+        # the full-row form runs exactly where the docstring of gemm_rowln.hip says (N = 512 with a LayerNorm behind it, M >= 4096)
+        assert H.pmgt_launch_trace_count(b"gemm_rowln") == (1 if (not force and ln and N == 512 and M >= 4096) else 0)
         outs.append((Cd.float(), aux.float(), None if lno is None else lno.float(), stats))
     ws, tile = outs
     assert rel_err(ws[0], tile[0]) < 1e-2

@@ -236,3 +236,59 @@ def test_attention_backward_pairs_one_interval_apart_is_bit_identical_to_lockste
         outs.append((out["loss"].item(), eng.grads.clone()))
     assert outs[0][0] == outs[1][0]
     assert torch.isfinite(outs[0][1]).all() and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("S,Tq,dropout", [(31, 7, 0.0), (32, 5, 0.1), (9, 13, 0.1)])
+def test_embedding_sum_is_recomputed_in_the_backward_at_ragged_shapes(S, Tq, dropout):
+    """Table mode at hidden size 256 in bf16: the token phase of the embedding (embed_tok8_fwd/bwd_kernel: two positions x four sequences per
+    wave) does not store its pre-LayerNorm sum, the backward recomputes it from the mixed row + position + role rows
+    (pmgt/pmgt/modeling_pmgt.py:199-208).  An odd S leaves the last pair's second half-wave without a position, a sequence count that
+    is not a multiple of four leaves row slots empty: both must neither write nor count.  Checked against the per-token path
+    (no_segment_sum: generic kernels, stored sum) and against the fp32 engine."""
+    from oracle import pmgt_oracle as po
+    n = 40
+    cfg = po.default_cfg(hidden_size=256, num_attention_heads=8, num_hidden_layers=1, intermediate_size=256, hidden_dropout_prob=dropout,
+                         attention_probs_dropout_prob=0.0)
+    case = dict(cfg=cfg, params=po.synth_params(cfg, 7), tables=po.synth_tables(n, cfg["feat_hidden_sizes"], 8), n_nodes=n)
+    g = torch.Generator().manual_seed(100 * S + Tq)
+    ids = torch.randint(2, n + 2, (Tq, S), generator=g)
+    mask = torch.ones(Tq, S)
+    ids[1, S - 3:] = 0
+    mask[1, S - 3:] = 0
+    w = torch.randn(Tq, S, 256, generator=g)
+    res = {}
+    for key, dtype, off in (("tok8", "bf16", 0), ("per_token", "bf16", 1), ("f32", "fp32", 0)):
+        eng = make_engine(case, dtype=dtype)
+        eng.set_option("no_segment_sum", off)
+        eng.view("bert.embeddings.LayerNorm.weight").copy_((0.7 + 0.6 * torch.rand(256, generator=torch.Generator().manual_seed(3))).cuda())
+        eng.view("bert.embeddings.LayerNorm.bias").copy_((0.2 * torch.randn(256, generator=torch.Generator().manual_seed(4))).cuda())
+        nbytes = int(eng.lib.pmgt_workspace_bytes(eng.h, Tq, S, 1, 1))
+        poison = torch.full((nbytes // 4 + 1,), float("nan"), device="cuda")      # (a read of a never-written buffer shows up as NaN)
+        torch.cuda.synchronize()
+        del poison
+        last, state = eng.encode_train(ids=ids.cuda(), attention_mask=mask.cuda(), training=dropout > 0)
+        eng.grads.fill_(float("nan"))
+        eng.encode_backward(state, w.cuda().to(last.dtype))
+        torch.cuda.synchronize()
+        n_bert = eng.entry("nfr_loss.projections.0.weight")["offset"]
+        assert torch.isfinite(eng.grads[:n_bert]).all() and torch.isfinite(last.float()).all(), key
+        res[key] = (last.float().clone(), eng.grads[:n_bert].clone(), eng)
+    # same dropout masks (same seed, step, site, row, column) in both bf16 paths: they differ by summation order only
+    assert float((res["tok8"][0] - res["per_token"][0]).abs().max()) < 8e-2
+    cos = torch.nn.functional.cosine_similarity(res["tok8"][1], res["per_token"][1], dim=0).item()
+    assert cos > 0.999, cos
+    eng = res["tok8"][2]
+    for k in ("bert.embeddings.LayerNorm.weight", "bert.embeddings.LayerNorm.bias", "bert.embeddings.position_embeddings.weight",
+              "bert.embeddings.role_embeddings.weight", "bert.embeddings.feat_linear.0.weight"):
+        e = eng.entry(k)
+        a = res["tok8"][1][e["offset"]: e["offset"] + e["numel"]]
+        b = res["per_token"][1][e["offset"]: e["offset"] + e["numel"]]
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 2e-2, (k, rel)
+        if k.startswith("bert.embeddings.position"):       # rows of positions >= S get no gradient at all
+            assert float(a.view(*e["shape"])[S:].abs().max()) == 0.0
+        if dropout == 0.0:
+            c = res["f32"][1][e["offset"]: e["offset"] + e["numel"]]
+            assert ((a - c).norm() / c.norm()).item() < 3e-2, k
+    if dropout == 0.0:
+        assert float((res["tok8"][0] - res["f32"][0]).abs().max()) < 8e-2
