@@ -120,7 +120,7 @@ struct pmgt_engine {
     void grad_ready(int64_t off, int64_t numel) const { if (grad_cb && numel > 0) grad_cb(grad_cb_user, off, numel); }
     hipEvent_t next_sync() {
         if (sync_ev.empty()) {
-            sync_ev.resize(64);
+            sync_ev.resize(256);
             for (auto& ev : sync_ev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         }
         return sync_ev[sync_next++ % sync_ev.size()];
@@ -271,6 +271,11 @@ template <typename T> struct Bufs {
     float* xscale = nullptr;   //           [M]
     T *E, *emb_pre, *h0;
     hipEvent_t sort_done = nullptr;   // set when the token sort of this step already runs on the side stream
+    // dense weight gradients of a layer on the side stream (option side_stream_wgrad; nothing in the data-gradient chain depends on them): side_last
+    // = "this wgrad has finished" (the caller waits for it before a launch that overwrites its operands), side_pending = something on the
+    // side stream has written arena regions since the last join
+    bool side_wgrad = false, side_pending = false;
+    hipEvent_t side_last = nullptr;
     bool qkvc_hm = false;   // Q|K|V|C (and its gradient) are stored head-major (fused forward + one-wave MFMA backward)
     bool e_by_id = false;   // E holds the projection of the whole table (rows = node ids) instead of one row per token
     float *a, *emb_stats;
@@ -735,7 +740,22 @@ struct SideReduce {
 };
 
 template <typename T>
+static int join_side_wgrads(const pmgt_engine* e, Bufs<T>& b, hipStream_t main) {
+    if (!b.side_pending) return 0;
+    pmgt_engine* em = const_cast<pmgt_engine*>(e);
+    hipEvent_t ev = em->next_sync();
+    PMGT_HIP(hipEventRecord(ev, em->side));
+    PMGT_HIP(hipStreamWaitEvent(main, ev, 0));
+    b.side_pending = false;
+    return 0;
+}
+static inline int wait_event(hipStream_t st, hipEvent_t ev) {
+    if (ev) PMGT_HIP(hipStreamWaitEvent(st, ev, 0));
+    return 0;
+}
+template <typename T>
 static int flush_reduces(const pmgt_engine* e, Bufs<T>& b, hipStream_t st) {
+    RUN(join_side_wgrads<T>(e, b, st));      // the slabs of side-stream weight gradients are complete before anything sums them
     if (!b.pend.empty()) RUNP("bwd.slab_reduce", multi_reduce(b.pend.data(), (int)b.pend.size(), st));
     b.pend.clear();
     b.arena_cur = 0;          // later producers are stream-ordered behind the launch that read the arena
@@ -765,6 +785,7 @@ static int queue_reduce(const pmgt_engine* e, Bufs<T>& b, const float* src, int 
     for (const ReduceJob& j : b.pend)
         if (j.dst == dst) {       // two sums into one destination must not share a launch: the second one reads the first one's result
             // (the arena keeps its contents: only the job list is run)
+            RUN(join_side_wgrads<T>(e, b, st));
             RUNP("bwd.slab_reduce", multi_reduce(b.pend.data(), (int)b.pend.size(), st));
             b.pend.clear();
             break;
@@ -777,9 +798,14 @@ static int queue_reduce(const pmgt_engine* e, Bufs<T>& b, const float* src, int 
 template <typename T>
 static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm, int64_t ldp, const T* Qm, int64_t ldq, const int64_t* q_rows,
                  int M, int m_for_splits, int N1, int N2, float* dst, bool acc, const int* m_dev, hipStream_t main,
-                 float* bias_dst = nullptr, int perm_d = 0, int perm_dh = 0, float q_f8_scale = 0.f) {
+                 float* bias_dst = nullptr, int perm_d = 0, int perm_dh = 0, float q_f8_scale = 0.f, bool side_ok = false) {
+    b.side_last = nullptr;
     if (b.defer) {
         hipStream_t st = main;
+        // side stream: forked behind everything `main` has launched so far (the operands are final there); phase timers bracket launches on
+        // `main`, so a profiled step keeps the weight gradients in line
+        const bool side = side_ok && b.side_wgrad && !e->prof.on;
+        pmgt_engine* em = const_cast<pmgt_engine*>(e);
         GemmTN g; g.opts = e->opts;
         g.P = Pm; g.ldp = ldp; g.Q = Qm; g.ldq = ldq; g.q_rows = q_rows; g.M = M; g.N1 = N1; g.N2 = N2;
         g.m_dev = m_dev; g.zeros = e->zeros; g.perm_d = perm_d; g.perm_dh = perm_dh;
@@ -787,7 +813,19 @@ static int wgrad(const char* name, const pmgt_engine* e, Bufs<T>& b, const T* Pm
         g.splits = gemm_tn_pick_splits(m_for_splits, N1, N2, gemm_tn_bkm<T>(), e->opts);
         g.bias_slab = nullptr;
         RUN(take_partials2<T>(e, b, (int64_t)g.splits * N1 * N2, &g.slab, (int64_t)g.splits * N1, bias_dst ? &g.bias_slab : nullptr, main));
-        RUNP(name, gemm_tn<T>(g, main));
+        hipStream_t ws = main;
+        if (side) {
+            hipEvent_t ev = em->next_sync();
+            PMGT_HIP(hipEventRecord(ev, main));
+            PMGT_HIP(hipStreamWaitEvent(em->side, ev, 0));
+            ws = em->side;
+        }
+        RUNP(name, gemm_tn<T>(g, ws));
+        if (side) {
+            b.side_last = em->next_sync();
+            PMGT_HIP(hipEventRecord(b.side_last, em->side));
+            b.side_pending = true;
+        }
         RUN(queue_reduce<T>(e, b, g.slab, g.splits, (int64_t)N1 * N2, dst, acc, main));
         if (bias_dst) RUN(queue_reduce<T>(e, b, g.bias_slab, g.splits, N1, bias_dst, acc, main));
         return 0;
@@ -853,6 +891,11 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                             int n_cls_only = 0, bool whole_buffer = false) {
     const int d = e->d, I = e->I, L = e->L, H = e->H, NF = e->NF;
     const int M = Tseq * S;
+    // dense weight gradients next to the data-gradient chain (side stream): opt-in.  Measured at the bench model (profiles/r04/NOTES.md section 9):
+    // B = 32 1.25 -> 1.32 ms, B = 256 3.12 -> 3.14, B = 1 024 9.24 -> 9.45 eager, worse still under graph replay -- a fork / join through events
+    // costs more than a 10 - 25 us weight gradient overlaps.
+    b.side_wgrad = b.defer && e->side != nullptr && (e->opts & OPT_SIDE_STREAM_WGRAD);
+    b.side_pending = false;
     const float* P = t->params;
     float* G = t->grads;
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
@@ -882,14 +925,17 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                                  dropcfg(t, train, pd, l, SITE_FO), mdev, G + o.ln2g, acc, st, ln2_from_y ? P + o.ln2b : nullptr));                                          // dgamma | dbeta | db2
         ln2_done = false;
         const T* dY2 = dd ? gC : gB;
-        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st));
+        RUN(wgrad<T>("bwd.wgrad_ffn2", e, b, dY2, d, tb.g, I, nullptr, Mt, msp, d, I, G + o.W2, acc, mdev, st, nullptr, 0, 0, 0.f, true));
+        const hipEvent_t w2_done = b.side_last;      // (side stream) waited for before dY2 is overwritten
         {   // d ff_pre = (dY2 W2) * gelu'(ff_pre)
             GemmWS g; g.opts = e->opts;
             g.A = dY2; g.lda = d; g.B = b.mirror + o.mW2T; g.ldb = d; g.C = gbig; g.ldc = I; g.m_dev = mdev;
             g.M = Mt; g.N = I; g.K = d; g.epi = EPI_GELU_GRAD; g.aux = tb.ff_pre; g.ldaux = I;
             RUN(linear<T>(e, "bwd.dgrad_ffn2", g, st));
         }
-        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1));
+        RUN(wgrad<T>("bwd.wgrad_ffn1", e, b, gbig, I, tb.u, d, nullptr, Mt, msp, I, d, G + o.W1, acc, mdev, st, G + o.b1, 0, 0, 0.f, true));
+        const hipEvent_t w1_done = b.side_last;      // ... before d ff_pre (gbig / b.big) is overwritten
+        RUN(wait_event(st, w2_done));                // the launches below write the residual-branch / masked-gradient buffers dY2 lives in
         bool ln1_fused = false;
         if constexpr (sizeof(T) == 2) {
             // du = dff W1 + residual branch, and the LN1 backward of du in the same launch (the role-split streaming kernel's epilogue
@@ -919,7 +965,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                                  dropcfg(t, train, pd, l, SITE_AO), mdev, G + o.ln1g, acc, st, ln1_from_y ? P + o.ln1b : nullptr));                                          // dgamma | dbeta | dbo
         }
         const T* dYo = dd ? gC : gB;
-        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st));
+        RUN(wgrad<T>("bwd.wgrad_attn_out", e, b, dYo, d, lb.ctx, d, rows, Mt, msp, d, d, G + o.Wo, acc, mdev, st, nullptr, 0, 0, 0.f, true));
+        // (its operands -- dYo, ctx -- are next overwritten behind the flush below, which joins the side stream)
         {   // dctx = dYo Wo
             GemmWS g; g.opts = e->opts;
             g.A = dYo; g.lda = d; g.B = b.mirror + o.mWoT; g.ldb = d; g.C = gD; g.ldc = d; g.M = Mt; g.N = d; g.K = d; g.m_dev = mdev;
@@ -931,6 +978,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             PMGT_HIP(hipMemsetAsync(b.bD, 0, (size_t)M * d * sizeof(T), st));
             RUN(scatter_rows<T>(gD, b.need_rows, b.need_cnt, Mt, d, b.bD, st));
         }
+        RUN(wait_event(st, w1_done));                // the attention backward writes dQ|dK|dV|dC into the buffer d ff_pre lived in
         bool fused_bw = false;
         {
             AttnArgs a; a.opts = e->opts;
@@ -1545,7 +1593,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;

@@ -292,3 +292,30 @@ def test_embedding_sum_is_recomputed_in_the_backward_at_ragged_shapes(S, Tq, dro
             assert ((a - c).norm() / c.norm()).item() < 3e-2, k
     if dropout == 0.0:
         assert float((res["tok8"][0] - res["f32"][0]).abs().max()) < 8e-2
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_side_stream_weight_gradients_are_bit_identical_to_in_line_ones(dtype):
+    """Option side_stream_wgrad: the dense weight-gradient GEMMs of a layer run on the engine's side stream next to the data-gradient chain
+    (fork behind their operands' producers, joined before a launch overwrites an operand and before anything sums their slabs).  Same
+    kernels, same slabs, same reduction order: gradients and the updated parameters must be EQUAL to the in-line schedule's, step after
+    step (a missing wait shows up as a difference or a NaN here).  Opt-in: it measured slower (profiles/r04/NOTES.md section 9)."""
+    case = gu.model_case("m3")
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = {}
+    for key, on in (("side", 1), ("inline", 0)):
+        eng = make_engine(case, dtype=dtype, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        eng.set_option("side_stream_wgrad", on)
+        gs = []
+        for step in range(3):
+            eng.grads.fill_(float("nan"))
+            out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+            gs.append(eng.grads.clone())
+            eng.optimizer_step(lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
+        torch.cuda.synchronize()
+        res[key] = (gs, eng.params.clone(), out["loss"].item())
+    for a, b in zip(res["side"][0], res["inline"][0]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+    assert torch.equal(res["side"][1], res["inline"][1]) and res["side"][2] == res["inline"][2]
