@@ -75,7 +75,7 @@ bool gemm_wsr512_ok(const GemmWS& g);
 int gemm_wsr512(const GemmWS& g, hipStream_t st);
 
 // Full-row tile at N = 512 (gemm_rowln.hip): C = dropout(A W^T + bias) + res and ln_out = LayerNorm(C) in one launch (tile 128 x 512, LDS-DMA
-// ring; bf16); linear() dispatches to it before gemm_ws.  skip_c as above.
+// ring; bf16; C is always stored); linear() dispatches to it before gemm_ws.
 bool gemm_rowln_ok(const GemmWS& g);
 int gemm_rowln(const GemmWS& g, hipStream_t st);
 

@@ -10,7 +10,7 @@
 // residual rows are requested during the last two k-steps; x = bf16(dropout(acc + bias) + res) -- the rounding the two-launch form
 // applies on its way through HBM, so both forms normalise the same values; row statistics as per-wave (mean, M2) pairs over 64 columns
 // combined across the eight waves through 8 KB of LDS (Chan's formula: no E[x^2] - mean^2 cancellation); y = (x - mean) rstd gamma + beta.
-// `skip_c`: the pre-LayerNorm sum is not stored (the backward then takes x^ from y: rowops.h).
+// The pre-LayerNorm sum C is always stored: the d = 512 LayerNorm backward reads it (the x^-from-the-output form is a d = 256 path).
 #include <type_traits>
 
 #include "gemm.h"
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void gemm_rowln512_kernel(GemmWS g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { o[e] = (bf16)v[e]; v[e] = (float)o[e]; }
 #ifndef PMGT_RL_NO_C
-            if (!g.skip_c && m < g.M) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ncol + 32 * pr) = o;
+            if (m < g.M) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ncol + 32 * pr) = o;
 #endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm_rowln512_kernel(GemmWS g) {
 bool gemm_rowln_ok(const GemmWS& g) {
     return !(g.opts & (OPT_TILE_GEMM | OPT_UNFUSED_LN)) && g.N == RL_BN && g.K % 32 == 0 && g.K >= 64 && g.M >= 4096 && g.a_rows == nullptr &&
            !g.res_gather && g.epi == EPI_NONE && g.ln_out != nullptr && g.ln_stats != nullptr && g.ln_gamma != nullptr && g.ln_beta != nullptr &&
-           g.q8 == nullptr && g.lda % 8 == 0 && g.ldb % 8 == 0 && (g.skip_c || (g.C != nullptr && g.ldc % 8 == 0 && ((uintptr_t)g.C % 16) == 0)) &&
+           g.q8 == nullptr && !g.skip_c && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.C != nullptr && g.ldc % 8 == 0 && ((uintptr_t)g.C % 16) == 0 &&
            (g.res == nullptr || (g.ldr % 8 == 0 && ((uintptr_t)g.res % 16) == 0)) && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 &&
            ((uintptr_t)g.ln_out % 16) == 0 && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0) && ((uintptr_t)g.ln_gamma % 16) == 0 &&
            ((uintptr_t)g.ln_beta % 16) == 0 && ((uintptr_t)g.ln_stats % 8) == 0;
