@@ -349,7 +349,12 @@ def main():
         "allreduce": None,
     }
     if world > 1:
-        out["allreduce"] = measure_allreduce(trainer, eng, dev)
+        # (a side measurement: every rank enters it, and a failure inside it must not cost the line its headline numbers; a collective that
+        #  raises does so on every rank at the same call, so the ranks stay in step)
+        try:
+            out["allreduce"] = measure_allreduce(trainer, eng, dev)
+        except Exception as ex:      # noqa: BLE001
+            out["allreduce"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     flops_node = train_flops_per_node(d, I, L, S)
     out["train_gflop_per_node"] = round(flops_node / 1e9, 3)
@@ -522,8 +527,8 @@ def measure_allreduce(trainer, eng, dev):
     if not sent:
         sent = [(0, eng.n_params)]
     scratch = torch.zeros_like(eng.grads)
-    avg = dist.get_backend() == "nccl"
-    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    from pmgt_amd.parallel import backend_averages
+    op = dist.ReduceOp.AVG if backend_averages(scratch.device) else dist.ReduceOp.SUM
     reps = 10
     for _ in range(2):
         for off, n in sent:

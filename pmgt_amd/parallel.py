@@ -19,13 +19,34 @@ def world():
     return 0, 1
 
 
+_AVG_OK = None
+
+
+def backend_averages(device) -> bool:
+    """Whether the process group reduces with ReduceOp.AVG.  gloo has none; on "nccl" (= RCCL on ROCm) it is tried ONCE with a one-element
+    collective -- every rank reaches this at the same point of its first exchange -- and a build that refuses the op (PyTorch raises before
+    anything is sent) falls back to SUM and a division, like gloo.  RCCL has never run this code in the dev loop: the driver's multi-GPU
+    tier must not die on a capability assumption."""
+    global _AVG_OK
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl":
+        return False
+    if _AVG_OK is None:
+        try:
+            dist.all_reduce(torch.ones(1, device=device), op=dist.ReduceOp.AVG)
+            _AVG_OK = True
+        except (RuntimeError, ValueError, NotImplementedError):
+            _AVG_OK = False
+    return _AVG_OK
+
+
 def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """In-place average of a flat buffer over all ranks (DDP gradient semantics)."""
     import torch.distributed as dist
     rank, ws = world()
     if ws == 1:
         return flat
-    if dist.get_backend() == "nccl":
+    if backend_averages(flat.device):
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
     else:                       # gloo has no AVG
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -58,7 +79,7 @@ class BucketedAllReduce:
     def _send(self, offset: int, numel: int):
         import torch.distributed as dist
         sl = self.flat[offset: offset + numel]
-        avg = dist.get_backend() == "nccl"
+        avg = backend_averages(sl.device)
         work = dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self._pending.append((work, sl, avg))
         self._elems += numel
