@@ -35,6 +35,7 @@ extern "C" {
 #define PMGT_OPT_UNFUSED_LN_BWD (1u << 18)           /* "unfused_ln_bwd": LayerNorm backward as its own launch behind the data-gradient GEMM that produces its dy (default, bf16 / hidden 256: epilogue of that GEMM) */
 #define PMGT_OPT_LOCKSTEP_ATTENTION_BWD (1u << 19)   /* "lockstep_attention_bwd": fused attention backward with both (sequence, head) pairs of a step in the same phase instead of one barrier interval apart -- bit-identical results */
 #define PMGT_OPT_SIDE_STREAM_WGRAD (1u << 20)        /* "side_stream_wgrad": the dense weight-gradient GEMMs of a layer on the engine's side stream, next to the data-gradient chain (same kernels, same reduction order: identical results; opt-in -- the cross-stream hand-offs cost more than the overlap gives at every batch size measured) */
+#define PMGT_OPT_NO_CLS_ONLY_ATTENTION_BWD (1u << 21) /* "no_cls_only_attention_bwd": fused attention backward of the last (shortcut) layer without the skip of query tiles whose d ctx rows are zero -- identical results */
 #define PMGT_OPT_NO_TILE_ATTENTION (1u << 17)        /* "no_tile_attention": S = 64 / head size 64 attention on the cooperative kernels (per-wave fragment loads) instead of the tile forms */
 
 /* ---- which kernel families the calling thread has launched since the last reset (test instrumentation: a parity test at a given

@@ -34,7 +34,7 @@ template <typename T> int attn_bwd(const AttnArgs& a, hipStream_t st);
 // One launch replaces attn_bwd + the Q|K|V|C gemm_tn: dQ|dK|dV|dC still go to HBM once (the data gradient reads them), the
 // weight / bias gradients leave as `parts` = attn_bwd_wgrad_parts(H) partial slabs [parts][4d, d] / [parts][4d] for slab_reduce.
 struct AttnBwdWg {
-    AttnArgs a;                                    // qkvc, dctx, dqkvc, mask, Tseq, S, H, dh, beta, dropout, hm (cls_only_seqs must be 0)
+    AttnArgs a;                                    // qkvc, dctx, dqkvc, mask, Tseq, S, H, dh, beta, dropout, hm, cls_only_seqs (their query rows 16 .. 31 are skipped: d ctx must be zero there)
     const void* x = nullptr; int64_t ldx = 0;      // [Tseq*32, d] the layer input the projection was applied to
     float* slab = nullptr;                         // [parts][4d * d]
     float* bias_slab = nullptr;                    // [parts][4d] or NULL

@@ -1875,6 +1875,7 @@ struct AbwStep {      // (wave-uniform) what a phase needs to know about its ste
     char* gout;
     int t;            // sequence (clamped into the tensor), for the dropout row index
     bool act;         // the sequence exists
+    bool zq1;         // query tile 1 (rows 16 .. 31) of this sequence has no gradient: d ctx is non-zero at row 0 only (t < cls_only_seqs)
 };
 struct AbwCarry {
     f32x4 sc[2], dp[2];      // phase 1 -> 2: raw scores and dP of this wave's query tile against both key tiles
@@ -1905,6 +1906,11 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
     float* madd = rho + 32;
     const int x = 16 * IT + r;
     const char* gin = st.gin;
+    // A query tile without a gradient (last layer of the shortcut path: dO rows 16 .. 31 of a CLS-only sequence are zero) gives dP = 0, hence
+    // dS = 0, dQ = 0 and a zero accumulator half of dC for its rows, exactly: its waves keep what the OTHER tile's waves read from them (the
+    // norms 1 / |c_x| and the mask terms of keys 16 .. 31: cosine wave) and write zero images in phase 2; phase 3 (their KEY tile) is unchanged.
+    const bool zq = IT == 1 && st.zq1;      // (wave-uniform)
+    if (zq && BR == 2) return;
     ABW_MARK2("attn I1.fragments+norms", IT, BR);
     bf16x8 fown, kc[2], fv[2], fo;      // own Q rows (branch 2) | K or C rows of all keys | V rows of all keys | own dO rows
     if (BR == 2) fown = *(const bf16x8*)(gin + abw_g_addr(x, 16 * q));
@@ -1937,6 +1943,7 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
     }
     cy.rho_x = rho_x;
     cy.ss = ss;
+    if (zq) return;
     // scores (transposed: key on (q, e), query on r) do not depend on the other waves: the matrix pipe starts before the barrier
     ABW_MARK2("attn I1.scores_mfma", IT, BR);
 #pragma unroll
@@ -1968,6 +1975,21 @@ __device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd,
     const float rho_x = cy.rho_x;
     f32x4 (&sc)[2] = cy.sc;
     f32x4 (&dp)[2] = cy.dp;
+    if (IT == 1 && st.zq1) {      // (wave-uniform) no gradient reaches this query tile: dS rows, P rows (they meet dO = 0), dQ rows and the dC half are zero
+        const bf16x4 zero4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int ia = abw_img_addr(x, 4 * jt + q);
+            *(bf16x4*)(iS + ia) = zero4;
+            *(bf16x4*)((BR == 1 ? iP1 : iP2) + ia) = zero4;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            if (BR == 2) *(bf16x4*)(st.gout + abw_g_addr(x, (16 * ct + 4 * q) * 2)) = zero4;
+            else cy.dch[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     ABW_MARK2("attn I2.softmax", IT, BR);
     // first half, query tile IT: this branch's softmax and its backward
     f32x4 rj[2];
@@ -2174,6 +2196,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             const int t = seq_of(s);
             st.act = t < a.Tseq;
             st.t = min(t, a.Tseq - 1);
+            st.zq1 = st.act && t < a.cls_only_seqs;
             st.gin = smem + in_tile(s) + ul * (32 * 256);
             st.gout = smem + out_tile(s) + ul * (32 * 256);
             st.oin = smem + C::O0 + (s & 1) * C::OB + ul * (32 * 64);
@@ -2508,7 +2531,7 @@ bool attn_bwd_wgrad_supported(const AttnBwdWg& w) {
     const AttnArgs& a = w.a;
     const int d = a.H * 32;
     if ((int64_t)a.Tseq * 32 * 4 * d * 2 >= (int64_t)1 << 32) return false;      // 32-bit byte offsets inside Q|K|V|C (the saddr addressing form)
-    return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.Tseq >= 2 && a.cls_only_seqs == 0 && w.x != nullptr && w.ldx % 8 == 0 &&
+    return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.Tseq >= 2 && a.cls_only_seqs >= 0 && w.x != nullptr && w.ldx % 8 == 0 &&
            w.slab != nullptr && a.qkvc != nullptr && a.dctx != nullptr && a.dqkvc != nullptr && ((uintptr_t)w.x % 16) == 0 &&
            ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.dctx % 16) == 0 && ((uintptr_t)a.dqkvc % 16) == 0;
 }

@@ -331,6 +331,7 @@ enum PathOpt : uint32_t {
     OPT_NO_TILE_ATTENTION = 1u << 17,   // S = 64 / head size 64 attention: the cooperative kernels (per-wave fragment loads from global memory) instead of the tile forms
     OPT_UNFUSED_LN_BWD = 1u << 18,      // LayerNorm backward as its own launch behind the data-gradient GEMM that produces its dy
     OPT_LOCKSTEP_ATTENTION_BWD = 1u << 19,      // fused attention backward: both pairs of a step in the same phase (round 3's schedule) instead of one interval apart
+    OPT_NO_CLS_ONLY_ATTENTION_BWD = 1u << 21,   // fused attention backward of the shortcut layer: the attention waves of query rows 16 .. 31 run their softmax phases for CLS-only sequences too (d ctx is zero there: identical results)
     OPT_SIDE_STREAM_WGRAD = 1u << 20,   // the dense weight-gradient GEMMs of a layer on the engine's side stream, next to the data-gradient chain (opt-in: measured slower at every batch size, profiles/r04/NOTES.md section 9)
 };
 

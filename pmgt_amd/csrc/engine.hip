@@ -994,10 +994,11 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                 // one [128, d] block per workgroup
                 AttnBwdWg w;
                 w.a = a; w.x = hin; w.ldx = d;
-                // last layer of the fast path: dctx is zero outside the rows the loss read (memset + scatter_rows above), so the GENERAL
-                // fused kernel computes the same sums as the CLS-only pair of kernels (one launch of ~575 us against 380 + 250 us)
-                // (A/B on one box, C2 B = 1 024: attention block of the step 2.31 -> 2.25 ms, identical loss)
-                w.a.cls_only_seqs = 0;
+                // last layer of the fast path: dctx is zero outside the rows the loss read (memset + scatter_rows above), so the fused
+                // kernel computes the same sums as the CLS-only pair of kernels (one launch against 380 + 250 us); the attention waves of
+                // query rows 16 .. 31 skip their softmax phases for the sequences that are read at row 0 only (their dO rows are zero:
+                // exact zeros either way, option no_cls_only_attention_bwd runs them)
+                if (e->opts & OPT_NO_CLS_ONLY_ATTENTION_BWD) w.a.cls_only_seqs = 0;
                 const int parts = attn_bwd_wgrad_parts(H);
                 SideReduce sr(e, st);
                 const int slot = b.wg_idx & 1;
@@ -1593,7 +1594,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;

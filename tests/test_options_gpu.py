@@ -319,3 +319,27 @@ def test_side_stream_weight_gradients_are_bit_identical_to_in_line_ones(dtype):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b)
     assert torch.equal(res["side"][1], res["inline"][1]) and res["side"][2] == res["inline"][2]
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_shortcut_layer_attention_backward_skips_gradient_free_query_tiles_exactly(dropout):
+    """Last layer of the training fast path: target and pair sequences are read at row 0 only, so rows 16 .. 31 of their d ctx are zero and the
+    fused attention backward lets the waves of that query tile skip scores / softmax / softmax backward (they write zero dS / P images, zero
+    dQ rows and a zero dC half: what the full computation produces, as exact zeros).  Must be bit-identical to running them
+    (option no_cls_only_attention_bwd), gradients and loss, with and without dropout."""
+    case = gu.model_case("m3")
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    res = []
+    for off in (0, 1):
+        eng = make_engine(case, dtype="bf16", hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+        eng.set_option("no_cls_only_attention_bwd", off)
+        eng.grads.fill_(float("nan"))
+        eng.profile_begin()
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+        prof = eng.profile_end()
+        assert prof["bwd.attention_wgrad"][0] == case["cfg"]["num_hidden_layers"]       # the fused kernel ran on every layer, the shortcut one included
+        res.append((out["loss"].item(), eng.grads.clone()))
+    assert torch.isfinite(res[0][1]).all()
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
