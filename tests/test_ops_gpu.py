@@ -618,6 +618,14 @@ def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, 
         assert H.pmgt_launch_trace_count(b"gemm_rowln") == (1 if (not force and ln and N == 512 and M >= 4096) else 0)
         outs.append((Cd.float(), aux.float(), None if lno is None else lno.float(), stats))
     ws, tile = outs
+    if ln and N == 512 and M >= 4096:      # the full-row tile combines its row statistics across waves in a fixed order: run to run identical
+        L.use()
+        Cd2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        lno2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        stats2 = torch.zeros(M, 2, device="cuda")
+        _lib.check(L.pmgt_op_linear(1, P(A), K, P(W), K, P(Cd2), N, M, N, K, P(bias), epi, None, N, P(R), N, drop, 33, P(rng), P(lno2), P(stats2),
+                                    P(gam), P(bet), 1e-12, stream()))
+        assert torch.equal(Cd2.float(), ws[0]) and torch.equal(lno2.float(), ws[2]) and torch.equal(stats2, ws[3])
     assert rel_err(ws[0], tile[0]) < 1e-2
     if epi == 1:
         assert rel_err(ws[1], tile[1]) < 1e-2
