@@ -445,6 +445,18 @@ def main():
             except Exception as exc:                      # capture is an optimisation, never a reason to lose the bench line
                 ent["hipgraph_replay"] = {"error": repr(exc)[:200]}
             sweep[str(Bx)] = ent
+        # ... and above the headline's batch: the metric names no batch size, and a 288-GB device takes much larger shards (B = 4 096 is 1.57 M
+        # tokens, ~52 GB of activations) -- the launches' fill / drain and the tile tails shrink with it (one box: 113.4k -> 117.6k -> 121.5k nodes/s)
+        for Bx in (2048, 4096):
+            if Bx <= B or args.workload not in ("c2", "c3"):
+                continue
+            try:
+                st_x = stage(Bx, 3, ctr0=2 * 10 ** 6)
+                ms = time_steps(trainer, st_x, steps=8, warmup=3) * 1e3
+                sweep[str(Bx)] = {"nodes_per_s": round(Bx / ms * 1e3, 1), "ms_per_step": round(ms, 4)}
+                del st_x
+            except Exception as exc:                      # (memory, a 32-bit offset bound of a kernel ...): the headline does not depend on it
+                sweep[str(Bx)] = {"error": repr(exc)[:200]}
         out["batch_sweep"] = sweep
 
     # ---- end to end with the live host sampler (threaded C++ MCNSampling -> pinned slots -> side-stream H2D): the rate a
@@ -485,7 +497,7 @@ def main():
 
 
 # (BASELINE.json's configs 4 / 5 name the graph and the model, not a batch size: B = 256 is the reference's CLI default; the third line is the
-#  same model with the shard a 288-GB GPU is sized for -- 393 216 tokens per step, as the headline -- where the d = 512 kernels' per-launch
+#  same model with a shard sized for a 288-GB GPU -- 786 432 tokens per step -- where the d = 512 kernels' per-launch
 #  fill / drain is a smaller share: +5 % nodes/s on one box)
 EXTRA_WORKLOADS = (("c4_bf16", ["--workload", "c4", "--batch", "256", "--dtype", "bf16"]),
                    ("c5_fp8", ["--workload", "c4", "--batch", "256", "--dtype", "fp8"]),
