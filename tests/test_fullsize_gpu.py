@@ -117,3 +117,53 @@ def test_full_size_step_is_reproducible_and_descends(world):
         losses.append(out["loss"].item())
     assert np.all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
     assert np.isfinite(a.grad_norm().item()) and a.grad_norm().item() < 1e3            # the clip coefficient was not 0
+
+
+def test_a_step_of_4096_targets_equals_its_1024_target_quarter_repeated():
+    """The bench line's batch_sweep goes up to B = 4 096 (1.57 M tokens: byte offsets up to 3.2 GB inside Q|K|V|C, which several kernels
+    address with 32-bit offsets against scalar bases).  Size-independent property: a batch made of FOUR copies of one 1 024-target batch
+    (same ids, same NFR masks, dropout off) has the same loss and -- every loss term being a mean -- the same gradients as that quarter alone;
+    a kernel that mis-addresses the upper rows of the big batch breaks the equality.  bf16: sums in a different order only."""
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
+    from pmgt_amd.engine import Engine
+    from pmgt_amd.graph import synthetic_graph
+    from pmgt_amd.models import reference_init, synthetic_features
+    from oracle import pmgt_oracle as po
+    n, Bq, S = 7252, 1024, 32
+    graph = synthetic_graph(n, 88606, seed=0)
+    vis, txt = synthetic_features(n, seed=0)
+    cfg = PMGTConfig(hidden_size=256, num_hidden_layers=4, num_attention_heads=8, intermediate_size=256,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, beta=0.5)
+    smp = MCNSampler(graph, max_ctx_neigh=S - 1)
+    tgt, pair, num_pairs, labels = smp.batch(np.arange(2, 2 + Bq), MODE_TRAIN, threads=4, base_seed=7, counter=0)
+    g = torch.Generator().manual_seed(11)
+    ids = tgt["node_ids"]
+    r1, r2 = torch.rand(Bq, S - 1, generator=g), torch.rand(Bq, S - 1, generator=g)
+    repl = torch.randint(2, n + 2, (Bq * (S - 1),), generator=g)
+    masked, m2, tidx = po.nfr_masking(ids, n, r1, repl, r2)
+    full = torch.full_like(ids, -1)
+    full[:, 1:][m2] = tidx
+    rep = lambda t, k: torch.cat([t] * k, 0).cuda()
+    res = {}
+    for k in (1, 4):
+        eng = Engine(cfg, dtype="bf16", seed=5)
+        reference_init(eng, seed=0)
+        eng.set_tables(vis, txt)
+        batch = ({kk: rep(v, k) for kk, v in tgt.items()}, {kk: rep(v, k) for kk, v in pair.items()}, rep(num_pairs, k), rep(labels, k))
+        eng.grads.fill_(float("nan"))
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=(rep(masked, k), rep(full, k)), want_hidden=False)
+        torch.cuda.synchronize()
+        res[k] = (out["loss"].item(), out["gsr"].item(), out["nfr"].item(), eng.grads.clone(), out["logits"].float().clone())
+        del eng, batch, out
+        torch.cuda.empty_cache()
+    one, four = res[1], res[4]
+    assert torch.isfinite(four[3]).all()
+    for i in range(3):
+        np.testing.assert_allclose(four[i], one[i], rtol=2e-4)
+    # every copy of a pair sequence gets the same logit (same kernels, same row-local arithmetic): exactly
+    assert torch.equal(four[4].view(4, -1), one[4].view(1, -1).expand(4, -1))
+    cos = torch.nn.functional.cosine_similarity(four[3], one[3], dim=0).item()
+    assert cos > 0.9999, cos
+    rel = ((four[3] - one[3]).norm() / one[3].norm()).item()
+    assert rel < 5e-3, rel
