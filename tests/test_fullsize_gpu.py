@@ -119,10 +119,12 @@ def test_full_size_step_is_reproducible_and_descends(world):
     assert np.isfinite(a.grad_norm().item()) and a.grad_norm().item() < 1e3            # the clip coefficient was not 0
 
 
-def test_a_step_of_4096_targets_equals_its_1024_target_quarter_repeated():
+@pytest.mark.parametrize("copies", [4, 6])
+def test_a_step_of_many_targets_equals_its_1024_target_part_repeated(copies):
     """The bench line's batch_sweep goes up to B = 4 096 (1.57 M tokens: byte offsets up to 3.2 GB inside Q|K|V|C, which several kernels
-    address with 32-bit offsets against scalar bases).  Size-independent property: a batch made of FOUR copies of one 1 024-target batch
-    (same ids, same NFR masks, dropout off) has the same loss and -- every loss term being a mean -- the same gradients as that quarter alone;
+    address with 32-bit offsets against scalar bases); at B = 6 144 those offsets pass 4 GB and the engine must leave the fused attention
+    kernels for the forms with 64-bit addressing.  Size-independent property: a batch made of k copies of one 1 024-target batch
+    (same ids, same NFR masks, dropout off) has the same loss and -- every loss term being a mean -- the same gradients as that part alone;
     a kernel that mis-addresses the upper rows of the big batch breaks the equality.  bf16: sums in a different order only."""
     from pmgt_amd.configuration_pmgt import PMGTConfig
     from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
@@ -146,7 +148,7 @@ def test_a_step_of_4096_targets_equals_its_1024_target_quarter_repeated():
     full[:, 1:][m2] = tidx
     rep = lambda t, k: torch.cat([t] * k, 0).cuda()
     res = {}
-    for k in (1, 4):
+    for k in (1, copies):
         eng = Engine(cfg, dtype="bf16", seed=5)
         reference_init(eng, seed=0)
         eng.set_tables(vis, txt)
@@ -157,12 +159,15 @@ def test_a_step_of_4096_targets_equals_its_1024_target_quarter_repeated():
         res[k] = (out["loss"].item(), out["gsr"].item(), out["nfr"].item(), eng.grads.clone(), out["logits"].float().clone())
         del eng, batch, out
         torch.cuda.empty_cache()
-    one, four = res[1], res[4]
+    one, four = res[1], res[copies]
     assert torch.isfinite(four[3]).all()
     for i in range(3):
         np.testing.assert_allclose(four[i], one[i], rtol=2e-4)
     # every copy of a pair sequence gets the same logit (same kernels, same row-local arithmetic): exactly
-    assert torch.equal(four[4].view(4, -1), one[4].view(1, -1).expand(4, -1))
+    if copies == 4:      # (same kernels in both runs)
+        assert torch.equal(four[4].view(copies, -1), one[4].view(1, -1).expand(copies, -1))
+    else:
+        assert float((four[4].view(copies, -1) - one[4].view(1, -1)).abs().max()) < 3e-2
     cos = torch.nn.functional.cosine_similarity(four[3], one[3], dim=0).item()
     assert cos > 0.9999, cos
     rel = ((four[3] - one[3]).norm() / one[3].norm()).item()
