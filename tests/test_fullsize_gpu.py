@@ -172,3 +172,61 @@ def test_a_step_of_many_targets_equals_its_1024_target_part_repeated(copies):
     assert cos > 0.9999, cos
     rel = ((four[3] - one[3]).norm() / one[3].norm()).item()
     assert rel < 5e-3, rel
+
+
+def test_hidden_512_step_of_1024_targets_equals_its_256_target_quarter_repeated():
+    """The same property at the C4 shapes' kernels (hidden 512, S = 64, token mode: a graph larger than half the token count): B = 1 024 is the
+    third `workloads` line of the bench -- 786 432 tokens, 3.2 GB of Q|K|V|C per layer -- against the B = 256 quarter it is four copies of."""
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.engine import Engine
+    from pmgt_amd.models import reference_init
+    from oracle import pmgt_oracle as po
+    n, Bq, S, Pn = 500_000, 256, 64, 10
+    cfg = PMGTConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, intermediate_size=512,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, beta=0.5)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    tabs = []
+    for f in (1536, 768):
+        a = torch.randn(n + 2, f, generator=gen, device="cuda", dtype=torch.float32)
+        a[:2] = 0
+        tabs.append(a.to(torch.bfloat16))
+        del a
+    g = torch.Generator().manual_seed(3)
+    def seqs(count):
+        ids = torch.randint(2, n + 2, (count, S), generator=g)
+        mask = torch.ones(count, S)
+        ln = torch.randint(S // 2, S + 1, (count,), generator=g)
+        for i in range(0, count, 7):
+            ids[i, ln[i]:] = 0
+            mask[i, ln[i]:] = 0
+        return {"node_ids": ids, "attention_mask": mask}
+    tgt, pair = seqs(Bq), seqs(Bq * Pn)
+    num_pairs = torch.full((Bq,), Pn, dtype=torch.int64)
+    labels = (torch.rand(Bq * Pn, generator=g) < 0.5).float()
+    ids = tgt["node_ids"]
+    r1, r2 = torch.rand(Bq, S - 1, generator=g), torch.rand(Bq, S - 1, generator=g)
+    repl = torch.randint(2, n + 2, (Bq * (S - 1),), generator=g)
+    masked, m2, tidx = po.nfr_masking(ids, n, r1, repl, r2)
+    full = torch.full_like(ids, -1)
+    full[:, 1:][m2] = tidx
+    rep = lambda t, k: torch.cat([t] * k, 0).cuda()
+    res = {}
+    for k in (1, 4):
+        eng = Engine(cfg, dtype="bf16", seed=5)
+        reference_init(eng, seed=0)
+        eng.set_tables(*tabs)
+        batch = ({kk: rep(v, k) for kk, v in tgt.items()}, {kk: rep(v, k) for kk, v in pair.items()}, rep(num_pairs, k), rep(labels, k))
+        eng.grads.fill_(float("nan"))
+        out = eng.pretrain_step(batch, training=True, backward=True, nfr_inject=(rep(masked, k), rep(full, k)), want_hidden=False)
+        torch.cuda.synchronize()
+        res[k] = (out["loss"].item(), out["gsr"].item(), out["nfr"].item(), eng.grads.clone(), out["logits"].float().clone())
+        del eng, batch, out
+        torch.cuda.empty_cache()
+    one, four = res[1], res[4]
+    assert torch.isfinite(four[3]).all()
+    for i in range(3):
+        np.testing.assert_allclose(four[i], one[i], rtol=2e-4)
+    assert float((four[4].view(4, -1) - one[4].view(1, -1)).abs().max()) < 3e-2
+    cos = torch.nn.functional.cosine_similarity(four[3], one[3], dim=0).item()
+    assert cos > 0.9999, cos
+    assert ((four[3] - one[3]).norm() / one[3].norm()).item() < 5e-3
