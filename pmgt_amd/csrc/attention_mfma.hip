@@ -2292,6 +2292,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         for (int j = 0; j < C::KQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // per-lane pieces of the fragment addresses (row part and swizzle key of the "lo" rows; "hi" rows = + 4 rows)
     const int frow = 8 * q + (r >> 2), fkey = abw_f(frow), fsub = (r & 3) >> 1, fhalf = 8 * (r & 1);
+    // (fsub is bit 0 of the chunk index, fkey has bit 0 clear; tile bases are multiples of 16 KB from the start of the dynamic LDS)
+    const uint32_t fla = (uint32_t)(frow * 256 + ((fkey ^ fsub) << 4) + fhalf), flb = (uint32_t)(frow * C::XROW + ((fkey ^ fsub) << 4) + fhalf);
+    static_assert(C::G0 % 512 == 0 && C::GB % 512 == 0 && C::XB % 512 == 0, "tile bases must keep the row / chunk / half bit fields disjoint");
     const int hoff = a.hm ? 4 * h * 32 : h * 32, ms = a.hm ? 32 : D;
     // lane parts of the DMA source addresses (see the DMA block): x rows (lane / LPR = row inside the instruction, lane % LPR = LDS chunk
     // slot) and Q|K|V|C rows (lane >> 4, lane & 15)
@@ -2303,12 +2306,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         // A fragments: dQKVC^T, n tiles 4 gn .. 4 gn + 3 (A[n][k = row]); B fragments: x, this wave's k tiles (B[k = row][n = x column])
         bf16x8 fa[4], fb[4];
         uint32_t aa[4], ab[4];
-        int fr_ = frow, fk_ = fkey ^ fsub;        // (fsub is bit 0 of the chunk index, fkey has bit 0 clear)
-        asm volatile("" : "+v"(fr_), "+v"(fk_));    // opaque: the eight addresses below are recomputed here, not kept in VGPRs across the loop
+        // Eight fragment addresses from TWO loop-invariant lane registers: row part | swizzle key | half are disjoint bit fields of an address
+        // inside a tile that starts on a multiple of its row pitch times 64, so "chunk c ^ key" is the lane register XOR (c << 4) -- one add of
+        // the (uniform) tile base per operand and one XOR per fragment instead of a multiply-add, an XOR and a shift-add each (this role's
+        // integer address arithmetic was two thirds of its vector instructions: profiles/r04/abw_instruction_mix.md).
+        uint32_t ba = fla + gb + (uint32_t)(32 * ks * 256), bb = flb + xb + (uint32_t)(32 * ks * C::XROW);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            aa[u] = gb + (32 * ks + fr_) * 256 + (((2 * (4 * gn + u)) ^ fk_) << 4) + fhalf;
-            ab[u] = xb + (32 * ks + fr_) * C::XROW + (((2 * (C::KQ * gk + (u % C::KQ))) ^ fk_) << 4) + fhalf;
+            aa[u] = ba ^ (uint32_t)((2 * (4 * gn + u)) << 4);
+            ab[u] = bb ^ (uint32_t)((2 * (C::KQ * gk + (u % C::KQ))) << 4);
         }
         // All sixteen transposing reads of the k-step go out back to back (x fragments first), and the MFMAs of dQKVC fragment nt start as
         // soon as ITS two reads have landed (LDS returns in order: lgkmcnt counts down): ONE LDS round trip per k-step instead of two
