@@ -64,6 +64,10 @@ def parse():
                     help="A/B: set a path option of the engine (include/pmgt_ops.h, e.g. no_role_split_ln); repeatable; reported in the line")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="skip the c4 (bf16) / c5 (fp8) lines the default N = 1 run appends under \"workloads\" (child processes)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1: initialise a ONE-rank nccl (= RCCL) process group and run the N > 1 code path unchanged on it -- AVG probe, "
+                         "bucketed async all-reduce from the engine's gradient-ready callback, wait in front of the optimizer, the "
+                         "allreduce measurement, barrier, destroy: RCCL executes the exchange on a one-GPU box")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher check that needs no GPU: the ranks rendezvous over gloo, all-reduce their ranks and rank 0 prints "
                          "a line with n_gpus = world and value = null")
@@ -172,6 +176,26 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def clock_probe(n_blocks=64):
+    """{cycles, wall ticks, XCC} samples of the library's probe kernel on the current stream (device tensor; read it after a sync)."""
+    import ctypes as C
+    from pmgt_amd import _lib
+    out = torch.zeros(n_blocks, 4, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.hip().pmgt_op_clock_probe(C.c_void_p(out.data_ptr()), n_blocks, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def sustained_sclk_mhz(before, after):
+    """Shader clock between two probes: per XCC, (cycle counter difference) / (100 MHz wall counter difference); median over the XCCs."""
+    a, b = before.cpu().numpy(), after.cpu().numpy()
+    per = []
+    for x in sorted(set(a[:, 2].tolist()) & set(b[:, 2].tolist())):
+        ra, rb = a[a[:, 2] == x][0], b[b[:, 2] == x][0]
+        if rb[1] > ra[1]:
+            per.append(float(rb[0] - ra[0]) / (float(rb[1] - ra[1]) / 100.0))
+    return round(float(np.median(per)), 1) if per else None
+
+
 def time_steps(trainer, staged, steps, warmup):
     for i in range(warmup):
         trainer.train_step(staged[i % len(staged)])
@@ -195,9 +219,19 @@ def main():
                  f"for a different GPU count than was asked for")
     if args.rehearse_launch:
         return rehearse_launch(world, rank)
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:          # --force-exchange without a launcher: a one-rank rendezvous of our own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(port))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # rehearsal of the N > 1 control flow on a one-GPU box: PMGT_BENCH_BACKEND=gloo PMGT_BENCH_ONE_DEVICE=1 (every rank
         # on cuda:0, gradients all-reduced through the host); the driver's runs use the defaults (RCCL, one GPU per rank)
         backend = os.environ.get("PMGT_BENCH_BACKEND", "nccl")
@@ -214,7 +248,7 @@ def main():
     from pmgt_amd.datasets import MODE_TRAIN, MCNSampler
     from pmgt_amd.engine import Engine
     from pmgt_amd.graph import synthetic_graph
-    from pmgt_amd.models import executed_flops_per_node, reference_init, synthetic_features, train_flops_per_node
+    from pmgt_amd.models import encoder_flops_per_node, executed_flops_per_node, reference_init, synthetic_features, train_flops_per_node
     from pmgt_amd.trainer import Trainer
 
     nodes, edges, L, H, d, I, S = WORKLOADS[args.workload]
@@ -250,7 +284,8 @@ def main():
     reference_init(eng, seed=0)
     eng.set_tables(vis, txt)
     del vis, txt
-    trainer = Trainer(eng, lr=1e-4, weight_decay=1e-2, max_grad_norm=5.0, world_size=world, buckets=args.buckets)
+    trainer = Trainer(eng, lr=1e-4, weight_decay=1e-2, max_grad_norm=5.0, world_size=world, buckets=args.buckets,
+                      force_exchange=args.force_exchange and world == 1)
     trainer.broadcast_parameters()
 
     # ---- pre-stage node-context batches in HBM (host MCNSampling, C++ worker pool)
@@ -288,7 +323,7 @@ def main():
     del slot
 
     def barrier():
-        if world > 1:
+        if exchange:
             dist.barrier()
 
     setup_s = time.perf_counter() - t_setup
@@ -297,17 +332,19 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    probe0 = clock_probe()
     t0 = time.perf_counter()
     loss_first = None
     for i in range(args.steps):
         l = trainer.train_step(staged[(args.warmup + i) % n_stage])
         if i == 0:
             loss_first = l.clone()  # device scalar of the first timed step (the engine recycles its output buffers); read after the timed region
+    probe1 = clock_probe()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
@@ -328,6 +365,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        # shader clock the timed steps sustained (two probe launches around them: cycle counter vs the 100 MHz wall counter, per XCC)
+        "sustained_sclk_mhz": sustained_sclk_mhz(probe0, probe1),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -348,7 +387,8 @@ def main():
                          "cpu_share": round(share, 1)},
         "allreduce": None,
     }
-    if world > 1:
+    if exchange:
+        out["exchange_backend"] = dist.get_backend()
         # (a side measurement: every rank enters it, and a failure inside it must not cost the line its headline numbers; a collective that
         #  raises does so on every rank at the same call, so the ranks stay in step)
         try:
@@ -359,6 +399,11 @@ def main():
     flops_node = train_flops_per_node(d, I, L, S)
     out["train_gflop_per_node"] = round(flops_node / 1e9, 3)
     out["mfma_util_vs_bf16_dense_peak"] = round(value / world * flops_node / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
+    # north_star's target is quoted "on the PMGT encoder": the same rate priced on the encoder's algorithmic flops alone (SURVEY 8d:
+    # "encoder 4.45" of the 5.38 GFLOP at C2 -- without the per-token feature projection and the NFR head)
+    enc_node = encoder_flops_per_node(d, I, L, S)
+    out["encoder_gflop_per_node"] = round(enc_node / 1e9, 3)
+    out["mfma_util_encoder"] = round(value / world * enc_node / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
     # the same rate priced on the flops the engine EXECUTES: table mode and the last-layer shortcut remove work the algorithmic
     # count above still includes (per-kernel matrix-pipe busy counters are under profiles/)
     exec_node = executed_flops_per_node(d, I, L, S, nodes, B)
@@ -401,6 +446,25 @@ def main():
                                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                                    "avg_launch_ms": round(avg_s * 1e3, 5), "algorithmic_mb_per_launch": round(byts / 1e6, 3)}
 
+        # the three most expensive phases that have an algorithmic model, each against the roof that bounds it (the step has several kernels
+        # within 2x of each other: one line is not the picture)
+        peak_t = MFMA_F32_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
+        top = []
+        for k in phases:
+            wk = phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz)
+            if wk is None or len(top) == 3:
+                continue
+            c_k, ms_k = prof[k]
+            t_k = ms_k / c_k / 1e3
+            fl, by = wk
+            mf = fl > 0 and fl / (peak_t * 1e12) >= by / (HBM_PEAK_GBS * 1e9)
+            ach = fl / t_k / 1e12 if mf else by / t_k / 1e9
+            top.append({"kernel": k, "bound": "mfma" if mf else "hbm", "achieved": round(ach, 2), "unit": "TFLOP/s" if mf else "GB/s",
+                        "frac": round(ach / (peak_t if mf else HBM_PEAK_GBS), 5), "avg_launch_ms": round(t_k * 1e3, 5),
+                        "launches_per_step": c_k // nprof, "traffic": None, "traffic_ratio": None,
+                        "algorithmic_mb_per_launch": round(by / 1e6, 3)})
+        out["roofline_top3"] = top
+
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them
     # in separate passes, tools/gpu_profile.sh); the committed summary of the last such run is quoted when it is for
     # this workload, else traffic stays null.
@@ -415,6 +479,13 @@ def main():
                 if "matrix_pipe_busy" in ph:        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the same profile set
                     out["roofline"]["matrix_pipe_busy"] = ph["matrix_pipe_busy"]
                     out["roofline"]["valu_per_mfma"] = ph.get("valu_per_mfma")
+            wl = args.workload + (f"_i{args.intermediate}" if args.intermediate else "")
+            if fresh and tr.get("workload_key", tr["workload"]) == wl and tr["batch"] == B and args.dtype == "bf16":
+                for ent in out.get("roofline_top3", []):
+                    pk = tr["phases"].get(ent["kernel"])
+                    if pk:
+                        ent["traffic"] = pk["hbm_mb_per_launch"]
+                        ent["traffic_ratio"] = round(pk["hbm_mb_per_launch"] / ent["algorithmic_mb_per_launch"], 3)
         except (OSError, KeyError, ValueError):
             pass
 
@@ -467,7 +538,7 @@ def main():
         # untimed pass first: pinned slots, device slots and the worker pool exist, pages touched, and (N = 1) the step is captured once
         # per slot -- the timed pass replays it with one launch per step (a launch thread that loses its CPU mid-step on a shared
         # host otherwise shows up as GPU idle time inside the step)
-        live_graphs = world == 1
+        live_graphs = world == 1 and not args.force_exchange
         trainer.run_live(sampler, shard, B, steps=6, threads=threads, graphs=live_graphs)
         e2e = trainer.run_live(sampler, shard, B, steps=max(min(args.steps, 40), 10), threads=threads, graphs=live_graphs)
         if world > 1:
@@ -490,7 +561,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if exchange:
         torch.cuda.synchronize()
         dist.barrier()                      # nobody tears the group down while a peer is still inside a collective
         dist.destroy_process_group()
@@ -501,7 +572,10 @@ def main():
 #  fill / drain is a smaller share: +5 % nodes/s on one box)
 EXTRA_WORKLOADS = (("c4_bf16", ["--workload", "c4", "--batch", "256", "--dtype", "bf16"]),
                    ("c5_fp8", ["--workload", "c4", "--batch", "256", "--dtype", "fp8"]),
-                   ("c4_bf16_b1024", ["--workload", "c4", "--batch", "1024", "--dtype", "bf16", "--steps", "5", "--warmup", "2"]))
+                   ("c4_bf16_b1024", ["--workload", "c4", "--batch", "1024", "--dtype", "bf16", "--steps", "5", "--warmup", "2"]),
+                   # SURVEY 8(d)'s I = 4 d rows (the author's own ratio: hidden 32 / intermediate 128, scripts/run_pmgt.sh:18): 9.00 and 100.6 GFLOP per node
+                   ("c2_i1024", ["--workload", "c2", "--batch", "1024", "--dtype", "bf16", "--intermediate", "1024"]),
+                   ("c4_i2048", ["--workload", "c4", "--batch", "256", "--dtype", "bf16", "--intermediate", "2048"]))
 EXTRA_BUDGET_S = 150.0
 
 
@@ -520,8 +594,10 @@ def extra_workloads():
                 continue
             d = json.loads(line[-1])
             res[name] = {"nodes_per_s": d["value"], "ms_per_step": d["ms_per_step"], "batch": int(extra[extra.index("--batch") + 1]), "steps": d["steps"],
-                         "mfma_util_vs_bf16_dense_peak": d.get("mfma_util_vs_bf16_dense_peak"),
-                         "mfma_util_executed": d.get("mfma_util_executed"), "roofline": d.get("roofline"),
+                         "train_gflop_per_node": d.get("train_gflop_per_node"),
+                         "mfma_util_vs_bf16_dense_peak": d.get("mfma_util_vs_bf16_dense_peak"), "mfma_util_encoder": d.get("mfma_util_encoder"),
+                         "mfma_util_executed": d.get("mfma_util_executed"), "roofline": d.get("roofline"), "roofline_top3": d.get("roofline_top3"),
+                         "sustained_sclk_mhz": d.get("sustained_sclk_mhz"),
                          "loss_first": d.get("loss_first"), "loss_last": d.get("loss_last"), "setup_s": d.get("setup_s"),
                          "wall_s": round(time.perf_counter() - t0, 1),
                          "phases_top": dict(list(d.get("phases", {}).items())[:8])}

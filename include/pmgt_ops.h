@@ -46,6 +46,16 @@ void pmgt_launch_trace_reset(void);
 int64_t pmgt_launch_trace_count(const char* family);
 
 /* ---- single-kernel entry points (unit/parity tests of each kernel against the oracle) ------------ */
+/* Token order of the table-mode backward (the gather of pmgt/pmgt/utils.py:43-50 run in reverse: per-node sums of per-token gradients):
+ * the stable sort of the M tokens by node id -- skeys [M] sorted ids, perm [M] token index at each sorted position (ties in index order),
+ * seg_off [n_rows + 1] first sorted position of every id.  ids [M] int64 with values < n_rows; scratch_keys / scratch_vals [M] uint32;
+ * temp: pmgt_op_seg_sort_temp_bytes(M) bytes.  Integer work: bit-exact against any stable sort. */
+/* Measurement plumbing: `blocks` one-wave workgroups each write {shader-cycle counter, 100 MHz wall counter, XCC id, 1} to out [blocks][4]
+ * (uint64).  Two probes on a stream around a timed region -> the shader clock the region sustained (bench.py: sustained_sclk_mhz). */
+int pmgt_op_clock_probe(uint64_t* out, int blocks, void* stream);
+int64_t pmgt_op_seg_sort_temp_bytes(int M);
+int pmgt_op_seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* scratch_keys, uint32_t* scratch_vals, uint32_t* skeys, uint32_t* perm,
+                     int* seg_off, void* temp, int64_t temp_bytes, void* stream);
 /* per-row absmax e4m3 quantisation (weights per output channel, activations per token): scale[r] = max|row| / 448 */
 int pmgt_op_quant_rows_e4m3(int src_dtype, const void* src, int64_t lds, int rows, int cols, void* dst, int64_t ldd,
                             float* scale, void* stream);

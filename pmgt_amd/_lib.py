@@ -64,7 +64,7 @@ OPS_SYMBOLS = [
     "pmgt_op_layernorm_fwd", "pmgt_op_layernorm_bwd", "pmgt_op_linear", "pmgt_op_linear_ln_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd",
     "pmgt_op_qkvc_attention_fwd", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts",
     "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8", "pmgt_op_qkvc_attention_fwd_f8",
-    "pmgt_launch_trace_reset", "pmgt_launch_trace_count",
+    "pmgt_launch_trace_reset", "pmgt_launch_trace_count", "pmgt_op_seg_sort", "pmgt_op_seg_sort_temp_bytes", "pmgt_op_clock_probe",
 ]
 # path options: pmgt_engine_set_option keys -> bit in the `path_opts` argument of the pmgt_op_* entries (include/pmgt_ops.h)
 OPT = {k: 1 << i for i, k in enumerate((
@@ -141,6 +141,10 @@ def hip():
     L.pmgt_launch_trace_count.argtypes = [C.c_char_p]
     L.pmgt_launch_trace_count.restype = C.c_int64
     L.pmgt_launch_trace_reset.restype = None
+    L.pmgt_op_clock_probe.argtypes = [vp, i, vp]
+    L.pmgt_op_seg_sort_temp_bytes.argtypes = [i]
+    L.pmgt_op_seg_sort_temp_bytes.restype = i64
+    L.pmgt_op_seg_sort.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, i64, vp]
     L.pmgt_op_linear_ln_bwd.argtypes = [vp, i64, vp, i64, i, i, i, vp, i64, vp, vp, vp, vp, vp, vp, vp, f, u32, vp, vp, vp, u32, vp]
     L.pmgt_op_attention_fwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]
     L.pmgt_op_attention_bwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]

@@ -36,7 +36,7 @@ void note_launch(int tag) { if (tag >= 0 && tag < LT_COUNT) ++g_launch_count[tag
 static const char* const g_launch_names[LT_COUNT] = {
     "gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_tile",
     "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
-    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln"};
+    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf"};
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -118,11 +118,18 @@ struct pmgt_engine {
     void* grad_cb_user = nullptr;
     bool grad_cb_fine() const { return grad_cb != nullptr && !(overlap() && side != nullptr) && !(opts & OPT_ONE_BUCKET); }
     void grad_ready(int64_t off, int64_t numel) const { if (grad_cb && numel > 0) grad_cb(grad_cb_user, off, numel); }
-    hipEvent_t next_sync() {
-        if (sync_ev.empty()) {
-            sync_ev.resize(256);
-            for (auto& ev : sync_ev) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    // Ring of fork / join events.  An event handed out may still be pending when the ring comes round to it again (side_last of a
+    // side-stream weight gradient is held across several later next_sync() calls), so the ring must be longer than the number of events
+    // one pass consumes: reserve_sync() grows it to the caller's bound before a pass starts.
+    void reserve_sync(size_t n) {
+        while (sync_ev.size() < n) {
+            hipEvent_t ev = nullptr;
+            (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            sync_ev.push_back(ev);
         }
+    }
+    hipEvent_t next_sync() {
+        reserve_sync(256);
         return sync_ev[sync_next++ % sync_ev.size()];
     }
 };
@@ -486,7 +493,9 @@ static const void* zero_page() {
 template <typename T>
 static inline bool ln_from_y_applies(const pmgt_engine* e, int Mt, int K, bool compacted) {
     if (sizeof(T) != 2 || compacted || (e->opts & (OPT_STORE_LN_INPUT | OPT_TILE_GEMM | OPT_UNFUSED_LN))) return false;
-    return e->d == 256 && Mt >= 64 && K >= 64 && K <= 512 && (K & (K - 1)) == 0;
+    if (e->d != 256) return false;
+    if (K > 512) return !e->fp8 && gemm_nt_lnf_shape(Mt, 256, K);      // whole-row 256 x 256 tile with the LayerNorm epilogue (gemm_nt_lnf)
+    return Mt >= 64 && K >= 64 && (K & (K - 1)) == 0;
 }
 
 template <typename T>
@@ -494,6 +503,10 @@ static int linear(const pmgt_engine* e, const char* name, const GemmWS& g, hipSt
     if constexpr (sizeof(T) == 2) {
         if (g.ln_out && gemm_rowln_ok(g)) {      // N = 512: whole rows in one workgroup, LayerNorm in the epilogue (gemm_rowln.hip)
             RUNP(name, gemm_rowln(g, st));
+            return 0;
+        }
+        if (g.ln_out && gemm_nt_lnf_ok(g)) {     // N = 256, K > 512: whole rows in the 256 x 256 tile, LayerNorm behind its main loop (gemm.hip)
+            RUNP(name, gemm_nt_lnf(g, st));
             return 0;
         }
         if (!(g.opts & OPT_TILE_GEMM) && gemm_ws_supported(g)) {
@@ -896,6 +909,9 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
     // costs more than a 10 - 25 us weight gradient overlaps.
     b.side_wgrad = b.defer && e->side != nullptr && (e->opts & OPT_SIDE_STREAM_WGRAD);
     b.side_pending = false;
+    // events one backward pass can take from the ring: per layer <= 3 side-stream weight gradients x (fork + done) + a join per flush
+    // (<= 4) + the fused attention backward's reduce pair; plus the token sort's pair, the embedding pass and the final join
+    const_cast<pmgt_engine*>(e)->reserve_sync((size_t)2 * (12 * (size_t)L + 32));
     const float* P = t->params;
     float* G = t->grads;
     const float pd = e->cfg.hidden_dropout_prob, pa = e->cfg.attention_probs_dropout_prob;
@@ -951,6 +967,17 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                 RUNP("bwd.dgrad_ffn1_lnb", gemm_wsr_lnb(g, st));
                 RUN(queue_reduce<T>(e, b, g.lnb_part, parts, 3 * d, G + o.ln1g, acc, st));                                                                                 // dgamma | dbeta | dbo
                 ln1_fused = true;
+            } else if (ln1_from_y && b.defer && I > 512) {
+                // intermediate sizes above 512: K = I is outside the streaming family; the 256 x 256 tile owns whole rows of du as well
+                // (the form that runs the LN2 backward behind dX = dQKVC W below)
+                GemmNT f = g;
+                if (gemm_nt_lnb_ok(f)) {
+                    const int parts = gemm_nt_lnb_parts(Mt);
+                    RUN(take_partials<T>(e, b, (int64_t)parts * 3 * d, &f.lnb_part, st));
+                    RUNP("bwd.dgrad_ffn1_lnb", gemm_nt_lnb(f, st));
+                    RUN(queue_reduce<T>(e, b, f.lnb_part, parts, 3 * d, G + o.ln1g, acc, st));                                                                             // dgamma | dbeta | dbo
+                    ln1_fused = true;
+                }
             }
         }
         if (!ln1_fused) {
@@ -1545,6 +1572,13 @@ int pmgt_op_gemm_tn_bias(int dtype, const void* P, int64_t ldp, const void* Q, i
     rc = slab_reduce(slab, g.splits, (int64_t)N1 * N2, out, false, (hipStream_t)stream);
     if (rc || !bias_slab) return rc;
     return slab_reduce(bias_slab, g.splits, N1, bias_out, false, (hipStream_t)stream);
+}
+
+int pmgt_op_clock_probe(uint64_t* out, int blocks, void* stream) { return clock_probe(out, blocks, (hipStream_t)stream); }
+int64_t pmgt_op_seg_sort_temp_bytes(int M) { return seg_sort_temp_bytes(M); }
+int pmgt_op_seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* scratch_keys, uint32_t* scratch_vals, uint32_t* skeys, uint32_t* perm,
+                     int* seg_off, void* temp, int64_t temp_bytes, void* stream) {
+    return seg_sort(ids, M, n_rows, scratch_keys, scratch_vals, skeys, perm, seg_off, temp, temp_bytes, (hipStream_t)stream);
 }
 
 int pmgt_op_colsum(int dtype, const void* Y, int64_t ldy, int M, int N, float* slab, float* out, void* stream) {

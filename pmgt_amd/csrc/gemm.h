@@ -36,6 +36,15 @@ struct GemmNT {
     // gemm_nt_lnb only: the residual lives in COMPACT row order -- row m of the output adds row lnb_res_inv[m] of `res`, or nothing
     // where lnb_res_inv[m] < 0 (last-layer shortcut: the residual branch exists on the rows the loss read only)
     const int* lnb_res_inv = nullptr;
+    // LayerNorm-FORWARD epilogue (gemm_nt_lnf: the 256 x 256 tile at N = 256, K > 512 -- BertOutput at intermediate sizes above 512):
+    // C = bf16(dropout(A B^T + bias) + res) as everywhere, lnf_out = LayerNorm(C) with lnf_gamma / lnf_beta / lnf_eps, lnf_stats =
+    // {mean, rstd} per row; lnf_skip_c: C itself is not stored (the backward takes x^ from lnf_out).  Filled by gemm_nt_lnf from GemmWS::ln_*.
+    void* lnf_out = nullptr;
+    float* lnf_stats = nullptr;
+    const float* lnf_gamma = nullptr;
+    const float* lnf_beta = nullptr;
+    float lnf_eps = 1e-12f;
+    bool lnf_skip_c = false;
     uint32_t opts = 0;                 // PathOpt bits of the calling engine (OPT_TILE_GEMM: register-staged 128 x 128 tile only)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
@@ -63,6 +72,13 @@ struct GemmWS : GemmNT {
 bool gemm_ws_supported(const GemmWS& g);
 bool gemm_ws_fuses_ln(const GemmWS& g);     // false: the caller runs LayerNorm as its own launch
 int gemm_ws(const GemmWS& g, hipStream_t st);
+// K > 512, N = 256 (FFN2 forward at intermediate sizes above 512): the 256 x 256 LDS-DMA tile owns whole rows, so the residual + LayerNorm
+// epilogue runs on the tile behind the main loop (gemm.hip) instead of tile GEMM -> C -> standalone LayerNorm launch; linear() dispatches
+// to it.  gemm_nt_lnf_shape: the part of the predicate that depends on the problem shape only (the engine derives "the LayerNorm
+// input is not stored" from it, forward and backward alike).
+bool gemm_nt_lnf_shape(int M, int N, int K);
+bool gemm_nt_lnf_ok(const GemmWS& g);
+int gemm_nt_lnf(const GemmWS& g, hipStream_t st);
 // 16-wave role-split form of the residual + LayerNorm mode at K = N = 256 (gemm_wsr.hip); gemm_ws dispatches to it
 bool gemm_wsr_ok(const GemmWS& g);
 int gemm_wsr(const GemmWS& g, hipStream_t st);

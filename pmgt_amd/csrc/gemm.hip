@@ -232,10 +232,13 @@ __device__ unsigned int g_nt_prof[2][8][6];
 #endif
 // LNB (BN = 256 only): the tile holds whole rows of an N = 256 output that is the gradient dy of a LayerNorm (GemmNT::lnb_*): behind
 // the main loop the workgroup runs that LayerNorm's backward on its 256 rows (see the phase below) instead of storing dy.
-template <int BN, int NW, bool LNB = false>
+// EPL = 2 (BN = 256 only; GemmNT::lnf_*): the rows are the input of a LayerNorm -- x = bf16(dropout(acc + bias) + residual) goes to the same
+// LDS image and the LayerNorm FORWARD runs on it (BertOutput at intermediate sizes above 512: K = I, N = 256).
+template <int BN, int NW, int EPL = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
     typedef bf16 T;
-    static_assert(!LNB || BN == 256, "LayerNorm-backward phase: whole rows in the tile");
+    constexpr bool LNB = EPL == 1, LNF = EPL == 2;
+    static_assert(EPL == 0 || BN == 256, "LayerNorm phases: whole rows in the tile");
     constexpr int BM = 256, ROWB = 64, STAGE = (BM + BN) * ROWB, NST = BN == 256 ? 4 : 3;
     constexpr int WN = BN / 64, AI = 16 / NW, BI = BN / 16 / NW, PER = AI + BI;     // DMA instructions per wave per stage
     static_assert(NW / WN == 2, "two wave rows of 128 output rows each");
@@ -661,6 +664,89 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         }
         return;
     }
+    if constexpr (LNF) {
+        // ---- x = bf16(dropout(acc + bias) + residual): the register layout of the direct epilogue (lane (r, q) owns 8 consecutive columns of
+        // row 16 i + r per block pair), stored as C unless the backward takes x^ from the LayerNorm output, and written to LDS as the bf16
+        // [256][256] image of the LayerNorm-backward form above (chunk c of row R in slot c ^ (R & 31))
+        const int cb = ((q & 1) << 4) | ((q & 2) << 2);
+        const int ncol = wn * 64 + cb;
+        {
+            u32x4 rr[8][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = min(m0 + wm * 128 + 16 * i + r, g.M - 1);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    rr[i][pr] = R ? *(const u32x4*)(R + (int64_t)m * g.ldr + ncol + 32 * pr) : (u32x4){0u, 0u, 0u, 0u};
+            }
+            f32x4 bv[2][2];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                bv[pr][0] = g.bias ? *(const f32x4*)(g.bias + ncol + 32 * pr) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                bv[pr][1] = g.bias ? *(const f32x4*)(g.bias + ncol + 32 * pr + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wm * 128 + 16 * i + r;
+                const int m = m0 + row;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    f32x4 a = acc[i][2 * pr], b = acc[i][2 * pr + 1];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+                                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+                    a += bv[pr][0];
+                    b += bv[pr][1];
+                    if (dk.on) {
+                        float d0[4], d1[4];
+                        drop_mul4(dk, (uint32_t)m, (uint32_t)(ncol + 32 * pr) >> 2, d0);
+                        drop_mul4(dk, (uint32_t)m, ((uint32_t)(ncol + 32 * pr) >> 2) + 1, d1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] *= d0[e]; b[e] *= d1[e]; }
+                    }
+                    const bf16x8 rv8 = __builtin_bit_cast(bf16x8, rr[i][pr]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] += (float)rv8[e]; b[e] += (float)rv8[4 + e]; }
+                    const bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+                    const int ch = (ncol + 32 * pr) >> 3;
+                    *(bf16x8*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)) = o;
+                    if (!g.lnf_skip_c && m < g.M) *(bf16x8*)(Cp + (int64_t)m * g.ldc + ncol + 32 * pr) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LayerNorm of the tile's rows: 32 lanes per row, 8 columns per lane, sixteen passes of 16 rows; statistics exactly as the streaming
+        // kernels compute them (gemm_ws.hip: mean, centred sum of squares, v_rsq_f32) on the bf16-rounded row the backward re-derives
+        const int erow = tid >> 5, ecl = (tid & 31) * 8;
+        float gam[8], bet[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gam[e] = g.lnf_gamma[ecl + e]; bet[e] = g.lnf_beta[ecl + e]; }
+        T* LNO = (T*)g.lnf_out;
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int row = 16 * p + erow;
+            const int m = m0 + row;
+            const bf16x8 xv = *(const bf16x8*)(smem + row * 512 + (((tid & 31) ^ (row & 31)) << 4));
+            float v[8], sacc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] = (float)xv[e]; sacc += v[e]; }
+            const float mean = sum_lanes32(sacc) * (1.f / 256.f);
+            float ss = 0.f, tc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { tc[e] = v[e] - mean; ss = fmaf(tc[e], tc[e], ss); }
+            ss = sum_lanes32(ss);
+            const float rstd = __builtin_amdgcn_rsqf(ss * (1.f / 256.f) + g.lnf_eps);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(tc[e] * rstd * gam[e] + bet[e]);
+            if (m < g.M) {
+                *(bf16x8*)(LNO + (int64_t)m * g.ldc + ecl) = o;
+                if ((tid & 31) == 0) *(float2*)(g.lnf_stats + 2 * (int64_t)m) = make_float2(mean, rstd);
+            }
+        }
+        return;
+    }
     if constexpr (SWAPPED) {
         if (g.epi == EPI_NONE && !dk.on) {
             // ---- direct epilogue (bias / residual only: the data-gradient GEMMs): no LDS staging, no barriers.  Blocks (j, j + 1)
@@ -804,9 +890,33 @@ bool gemm_nt_lnb_ok(const GemmNT& g) {
 int gemm_nt_lnb(const GemmNT& g, hipStream_t st) {
     PMGT_CHECK(gemm_nt_lnb_ok(g) && g.lnb_part != nullptr, -2, "gemm_nt_lnb: unsupported shape / epilogue M=%d N=%d K=%d", g.M, g.N, g.K);
     constexpr int smem = 4 * (256 + 256) * 64;
-    PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8, true>), smem);
+    PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8, 1>), smem);
     note_launch(LT_NT_LNB);
-    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8, true>), dim3(cdiv(cdiv(g.M, 256), 8) * 8), dim3(512), smem, st, g);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8, 1>), dim3(cdiv(cdiv(g.M, 256), 8) * 8), dim3(512), smem, st, g);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
+// ---- C = dropout(A W^T + bias) + res, ln_out = LayerNorm(C) in the same launch (K > 512, N = 256: FFN2 forward at I = 4d)
+bool gemm_nt_lnf_shape(int M, int N, int K) {
+    // (K <= 512 belongs to the weight-stationary streaming kernels; fewer than 96 tiles: see nt_big_ok)
+    return N == 256 && K > 512 && K % 64 == 0 && M >= 4096 && cdiv(M, 256) >= 96 && (int64_t)M * N * 2 < (int64_t)1 << 32;
+}
+bool gemm_nt_lnf_ok(const GemmWS& g) {
+    return gemm_nt_lnf_shape(g.M, g.N, g.K) && nt_big_ok(g) && !(g.opts & OPT_UNFUSED_LN) && g.ln_out != nullptr && g.ln_stats != nullptr &&
+           g.ln_gamma != nullptr && g.ln_beta != nullptr && g.q8 == nullptr && g.a_rows == nullptr && g.epi == EPI_NONE && g.res != nullptr &&
+           g.ldr % 8 == 0 && ((uintptr_t)g.ln_out % 16) == 0 && ((uintptr_t)g.ln_stats % 8) == 0 && ((uintptr_t)g.A % 16) == 0 &&
+           ((uintptr_t)g.B % 16) == 0 && ((uintptr_t)g.ln_gamma % 16) == 0 && ((uintptr_t)g.ln_beta % 16) == 0;
+}
+int gemm_nt_lnf(const GemmWS& gw, hipStream_t st) {
+    PMGT_CHECK(gemm_nt_lnf_ok(gw), -2, "gemm_nt_lnf: unsupported shape / epilogue M=%d N=%d K=%d", gw.M, gw.N, gw.K);
+    GemmNT g = gw;
+    g.lnf_out = gw.ln_out; g.lnf_stats = gw.ln_stats; g.lnf_gamma = gw.ln_gamma; g.lnf_beta = gw.ln_beta; g.lnf_eps = gw.ln_eps;
+    g.lnf_skip_c = gw.skip_c;
+    constexpr int smem = 4 * (256 + 256) * 64;
+    PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8, 2>), smem);
+    note_launch(LT_NT_LNF);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8, 2>), dim3(cdiv(cdiv(g.M, 256), 8) * 8), dim3(512), smem, st, g);
     PMGT_LAUNCH_OK();
     return 0;
 }

@@ -16,6 +16,7 @@ struct AdamArgs {
 };
 int adamw_step(const AdamArgs& a, hipStream_t st);
 int advance_rng(uint64_t* rng, hipStream_t st);
+int clock_probe(uint64_t* out, int blocks, hipStream_t st);      // out: [blocks][4] = {shader cycles, 100 MHz wall ticks, XCC id, 1}
 
 struct MirrorDesc {
     int64_t src;      // offset (floats) of W[rows, cols] in the flat parameter buffer

@@ -171,4 +171,23 @@ template <typename T> int cast_to_f32(const T* src, float* dst, int64_t n, hipSt
 template int cast_to_f32<float>(const float*, float*, int64_t, hipStream_t);
 template int cast_to_f32<bf16>(const bf16*, float*, int64_t, hipStream_t);
 
+// Clock probe (measurement plumbing of bench.py): one wave per workgroup writes {shader-cycle counter, 100 MHz wall counter, XCC id}.
+// Two probes on the stream around a timed region give the shader clock the region sustained, per XCC (the cycle counters of
+// different XCCs need not share an origin: samples are paired by XCC id).
+__global__ void clock_probe_kernel(uint64_t* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const uint64_t cyc = __builtin_readcyclecounter();
+    const uint64_t wall = __builtin_amdgcn_s_memrealtime();
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+    out[blockIdx.x * 4 + 0] = cyc;
+    out[blockIdx.x * 4 + 1] = wall;
+    out[blockIdx.x * 4 + 2] = xcc;
+    out[blockIdx.x * 4 + 3] = 1;
+}
+int clock_probe(uint64_t* out, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, st, out);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+
 }  // namespace pmgt

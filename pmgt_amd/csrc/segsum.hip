@@ -3,12 +3,19 @@
 //     dE_all[n, :] = sum over tokens m with ids[m] == n of dE[m, :]
 //
 // so that dW_m = dE_all^T x table_m is a GEMM over N+2 rows instead of one over all M tokens (54x fewer flops at
-// C2 / B = 1024).  Deterministic: tokens are ordered by a STABLE radix sort of (id, token index) (rocPRIM: index
-// preparation, not arithmetic), every segment is summed in that order -- runs inside a 256-position chunk by one
-// workgroup in registers, segments that span chunks through per-chunk partial rows added in chunk order.
+// C2 / B = 1024).  Deterministic: tokens are ordered by a STABLE sort of (id, token index) (index preparation, not
+// arithmetic), every segment is summed in that order -- runs inside a 64-position chunk by one wave in registers,
+// segments that span chunks through per-chunk partial rows added in chunk order.
+//
+// The sort is a hand-written least-significant-digit radix sort sized for what the keys are: node ids < n_rows <= M / 2
+// (13 bits at the benchmark graph), i.e. ceil(bits / 8) counting passes -- two at C2 -- of
+//     [pass 0 only] per-tile digit histogram -> exclusive scan over [digit][tile] -> stable scatter,
+// where the scatter of pass p also counts the NEXT digit per destination tile (integer atomics: order-free), so later passes
+// need no histogram launch.  Inside a tile (16 rounds x 4 waves x 64 lanes, in index order) the rank of an element among its
+// equals is: equals in earlier (round, wave) slots -- a prefix over 64 LDS counters per digit -- plus equals in lower lanes of
+// its own wave -- eight ballots.  The result is THE stable order, the same permutation any stable sort produces.
+// (Rounds 1 - 4 called rocPRIM here: 21 launches, 0.44 ms of GPU time per step next to the forward pass.)
 #include <string.h>
-
-#include <rocprim/rocprim.hpp>
 
 #include "segsum.h"
 
@@ -16,9 +23,115 @@ namespace pmgt {
 
 static constexpr int SEG_CH = 64;       // sorted positions per WAVE (a chunk); a 256-thread workgroup walks four chunks
 
-__global__ void seg_keys_kernel(const int64_t* __restrict__ ids, int M, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) { keys[m] = (uint32_t)ids[m]; vals[m] = (uint32_t)m; }
+static constexpr int RS_ROUNDS = 16, RS_TILE = 256 * RS_ROUNDS, RS_SLOTS = 4 * RS_ROUNDS, RS_MAXBINS = 256;
+
+// pass 0: digit counts of every tile, hist[digit][tile]
+__global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict__ ids, int M, uint32_t mask, int ntiles, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[RS_MAXBINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        const int idx = base + j * 256 + threadIdx.x;
+        if (idx < M) atomicAdd(&h[(uint32_t)ids[idx] & mask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= mask) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of hist[0 .. n) in place (one workgroup: n = bins x tiles is a few 10^4), and zero-fill of the buffer the
+// next scatter counts into
+__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hist, int n, uint32_t* __restrict__ zero_buf, int nz) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < n; t0 += 4096) {
+        const int i = t0 + tid * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i + k < n ? hist[i + k] : 0u;
+        const uint32_t tot = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = tot;                 // inclusive scan over the wave's lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        uint32_t run = carry_s + woff + inc - tot;
+        __syncthreads();                    // everyone has read carry_s / wsum
+        if (tid == 1023) carry_s = run + tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < n) hist[i + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nz; i += 1024) zero_buf[i] = 0u;
+}
+
+// One counting pass: element (key, val) of tile t goes to base[digit][t] + (equals before it inside the tile).  FROM_IDS: pass 0
+// reads the int64 ids (val = token index).  NEXT: also count the next pass's digit per DESTINATION tile.
+template <bool FROM_IDS, bool NEXT>
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ kin,
+                                                         const uint32_t* __restrict__ vin, int M, int shift, uint32_t mask, int ntiles,
+                                                         const uint32_t* __restrict__ base, uint32_t* __restrict__ kout,
+                                                         uint32_t* __restrict__ vout, int shift2, uint32_t mask2, uint32_t* __restrict__ hist2) {
+    __shared__ uint16_t cnt[RS_MAXBINS][RS_SLOTS + 2];     // 66 entries = 33 dwords per row: the per-digit prefix walks rows conflict-free
+    __shared__ uint32_t tbase[RS_MAXBINS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+    for (int i = tid; i < RS_MAXBINS * (RS_SLOTS + 2) / 2; i += 256) ((uint32_t*)cnt)[i] = 0u;
+    if ((uint32_t)tid <= mask) tbase[tid] = base[(int64_t)tid * ntiles + tile];
+    __syncthreads();
+    uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
+    uint32_t rank[RS_ROUNDS];
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        const int idx = tile * RS_TILE + j * 256 + wave * 64 + lane;
+        const bool valid = idx < M;
+        const int ic = valid ? idx : M - 1;
+        key[j] = FROM_IDS ? (uint32_t)ids[ic] : kin[ic];
+        val[j] = FROM_IDS ? (uint32_t)ic : vin[ic];
+        const uint32_t dg = (key[j] >> shift) & mask;
+        uint64_t m = __builtin_amdgcn_ballot_w64(valid);            // lanes holding the same digit as this one
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit);
+            m &= bit ? bal : ~bal;
+        }
+        rank[j] = (uint32_t)__popcll(m & below);
+        if (valid && rank[j] == 0) cnt[dg][j * 4 + wave] = (uint16_t)__popcll(m);
+        if (!valid) rank[j] = 0xffffffffu;
+    }
+    __syncthreads();
+    if ((uint32_t)tid <= mask) {           // exclusive prefix over the (round, wave) slots of digit `tid`
+        uint32_t run = 0;
+        for (int sidx = 0; sidx < RS_SLOTS; ++sidx) {
+            const uint32_t c = cnt[tid][sidx];
+            cnt[tid][sidx] = (uint16_t)run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        if (rank[j] != 0xffffffffu) {
+            const uint32_t dg = (key[j] >> shift) & mask;
+            const uint32_t pos = tbase[dg] + cnt[dg][j * 4 + wave] + rank[j];
+            kout[pos] = key[j];
+            vout[pos] = val[j];
+            if (NEXT) atomicAdd(&hist2[(int64_t)((key[j] >> shift2) & mask2) * ntiles + pos / RS_TILE], 1u);
+        }
+    }
 }
 
 // seg_off[n] = first sorted position whose key is >= n  (n = 0 .. n_rows)
@@ -133,24 +246,44 @@ __global__ __launch_bounds__(256) void seg_fix_kernel(const int* __restrict__ se
     }
 }
 
-int64_t seg_sort_temp_bytes(int M) {
-    size_t bytes = 0;
-    uint32_t* nul = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)M, 0, 32, (hipStream_t)0);
-    return (int64_t)bytes + 256;
+static inline int rs_tiles(int M) { return cdiv(M, RS_TILE); }
+
+int64_t seg_sort_temp_bytes(int M) {       // two [256][tiles] count tables (the scan of pass p, the counts of pass p + 1)
+    return (int64_t)2 * RS_MAXBINS * rs_tiles(M) * 4 + 256;
 }
 
 int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* vals, uint32_t* skeys, uint32_t* perm, int* seg_off,
              void* temp, int64_t temp_bytes, hipStream_t st) {
     PMGT_CHECK(M > 0 && n_rows > 0, -2, "seg_sort: empty input");
-    hipLaunchKernelGGL(seg_keys_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, ids, M, keys, vals);
-    PMGT_LAUNCH_OK();
+    PMGT_CHECK(temp_bytes >= seg_sort_temp_bytes(M), -4, "seg_sort: temporary storage too small (%lld > %lld)", (long long)seg_sort_temp_bytes(M),
+               (long long)temp_bytes);
     int bits = 1;
     while ((1ll << bits) < (int64_t)n_rows) ++bits;
-    size_t need = 0;
-    PMGT_HIP(rocprim::radix_sort_pairs(nullptr, need, keys, skeys, vals, perm, (size_t)M, 0, bits, st));
-    PMGT_CHECK((int64_t)need <= temp_bytes, -4, "seg_sort: temporary storage too small (%lld > %lld)", (long long)need, (long long)temp_bytes);
-    PMGT_HIP(rocprim::radix_sort_pairs(temp, need, keys, skeys, vals, perm, (size_t)M, 0, bits, st));
+    const int passes = cdiv(bits, 8), w = cdiv(bits, passes);       // digits of equal width (13 bits: 7 + 7)
+    const int ntiles = rs_tiles(M);
+    uint32_t* hist[2] = {(uint32_t*)temp, (uint32_t*)temp + (int64_t)RS_MAXBINS * ntiles};
+    const uint32_t mask = (1u << w) - 1u;
+    const int n = (int)(mask + 1u) * ntiles;
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(ntiles), dim3(256), 0, st, ids, M, mask, ntiles, hist[0]);
+    const uint32_t *kin = nullptr, *vin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const bool last = p == passes - 1;
+        // the last pass lands in (skeys, perm); the buffers alternate backwards from there
+        uint32_t* kout = ((passes - 1 - p) & 1) ? keys : skeys;
+        uint32_t* vout = ((passes - 1 - p) & 1) ? vals : perm;
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, hist[p & 1], n, hist[(p + 1) & 1], last ? 0 : n);
+        const int shift = p * w, shift2 = (p + 1) * w;
+        if (p == 0 && !last)
+            hipLaunchKernelGGL((rs_scatter_kernel<true, true>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout, shift2, mask, hist[1]);
+        else if (p == 0)
+            hipLaunchKernelGGL((rs_scatter_kernel<true, false>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout, 0, 0u, nullptr);
+        else if (!last)
+            hipLaunchKernelGGL((rs_scatter_kernel<false, true>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[p & 1], kout, vout, shift2, mask, hist[(p + 1) & 1]);
+        else
+            hipLaunchKernelGGL((rs_scatter_kernel<false, false>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[p & 1], kout, vout, 0, 0u, nullptr);
+        kin = kout; vin = vout;
+    }
+    PMGT_LAUNCH_OK();
     hipLaunchKernelGGL(seg_bounds_kernel, dim3(cdiv(n_rows + 1, 256)), dim3(256), 0, st, skeys, M, n_rows, seg_off);
     PMGT_LAUNCH_OK();
     return 0;

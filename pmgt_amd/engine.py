@@ -112,22 +112,33 @@ class Engine:
     LN_CARRIER_MAX_RATIO = 8.0
     LN_CARRIER_MIN_GAMMA = 1e-6
 
-    def check_layernorm_carrier(self) -> float:
-        """max over the encoder's LayerNorm channels of |beta| / |gamma|; above LN_CARRIER_MAX_RATIO -- or with a channel whose
-        gamma is (nearly) zero, where x^ cannot be recovered from the output at all -- the engine switches to stored LayerNorm
-        inputs.  Called wherever parameters arrive in bulk (load_params, the modules' load_state_dict), by the Trainer every
-        `check_carrier_every` optimizer steps and before a step is captured into a graph."""
+    def layernorm_carrier_ratio(self) -> float:
+        """max over the encoder's LayerNorm channels of |beta| / |gamma| (inf with a (nearly) zero gamma)."""
         worst = 0.0
         for e in self.entries:
             if e["name"].endswith("LayerNorm.weight") and "encoder.layer" in e["name"]:
                 g = self.view(e["name"]).abs()
                 b = self.view(e["name"][:-len("weight")] + "bias").abs()
-                tiny = g < self.LN_CARRIER_MIN_GAMMA
-                if bool(tiny.any()):
-                    worst = float("inf")
-                    break
+                if bool((g < self.LN_CARRIER_MIN_GAMMA).any()):
+                    return float("inf")
                 worst = max(worst, float((b / g).max()))
+        return worst
+
+    def carrier_needs_stored_inputs(self) -> bool:
+        """True when the parameters no longer allow x^ from the LayerNorm output and the engine still runs that form."""
+        return not self.get_option("store_ln_input") and self.layernorm_carrier_ratio() > self.LN_CARRIER_MAX_RATIO
+
+    def check_layernorm_carrier(self) -> float:
+        """max over the encoder's LayerNorm channels of |beta| / |gamma|; above LN_CARRIER_MAX_RATIO -- or with a channel whose
+        gamma is (nearly) zero, where x^ cannot be recovered from the output at all -- the engine switches to stored LayerNorm
+        inputs.  Called wherever parameters arrive in bulk (load_params, the modules' load_state_dict), by the Trainer every
+        `check_carrier_every` optimizer steps and before a step is captured into a graph."""
+        worst = self.layernorm_carrier_ratio()
         if worst > self.LN_CARRIER_MAX_RATIO and not self.get_option("store_ln_input"):
+            if getattr(self, "_live_graphs", 0) > 0:
+                raise RuntimeError(f"pmgt_amd: LayerNorm |beta / gamma| reaches {worst:.1f}, so the backward must switch to stored "
+                                   "LayerNorm inputs, but captured steps of this engine are alive and keep the old kernels: call "
+                                   "Trainer.drop_captured_steps() (run_live does it by itself) and capture again")
             import warnings
             warnings.warn(f"pmgt_amd: LayerNorm |beta / gamma| reaches {worst:.1f}: x^ from the LayerNorm output would lose "
                           "precision, storing LayerNorm inputs instead (option store_ln_input)")
@@ -348,10 +359,18 @@ class Engine:
         self._raise_hook_error()
 
     # ---- clip + AdamW ----------------------------------------------------------------------------------
-    def optimizer_step(self, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+    def ensure_optimizer_state(self):
+        """Adam moments, allocated and zero-filled OUTSIDE any stream capture: a zero-fill recorded into a captured step would
+        reset both moments on every replay (the device-side step counter keeps counting, so nothing would look wrong)."""
         if self.exp_avg is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("pmgt_amd: the optimizer state must exist before a step is captured "
+                                   "(call Engine.ensure_optimizer_state() first)")
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)
+
+    def optimizer_step(self, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+        self.ensure_optimizer_state()
         ac = _lib.AdamC(self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.decay_mask.data_ptr(), lr, weight_decay,
                         betas[0], betas[1], eps, float(max_grad_norm) if max_grad_norm else 0.0,
                         self.opt_step.data_ptr(), self.opt_scalars.data_ptr(), self.opt_scratch.data_ptr())

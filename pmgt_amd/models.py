@@ -57,6 +57,13 @@ def train_flops_per_node(d, I, L, S, Fv=1536, Ft=768, pairs=10):
     return tok * (3 * enc + 2 * proj) + nfr
 
 
+def encoder_flops_per_node(d, I, L, S, pairs=10):
+    """The encoder's share of train_flops_per_node (SURVEY.md section 8d "encoder 4.45" at C2): 3 x the forward flops of the L layers and
+    the embedding mix over the 12 S tokens of a target -- no feature projection, no NFR head.  The denominator of north_star's
+    ">= 30 % bf16 MFMA utilisation on the PMGT encoder"."""
+    return (pairs + 2) * S * 3 * (L * (10 * d * d + 4 * d * I + 6 * S * d) + 8 * d)
+
+
 def executed_flops_per_node(d, I, L, S, n_nodes, batch, Fv=1536, Ft=768, pairs=10, shortcut=True):
     """FLOPs the engine actually EXECUTES per target node for the same step (same conventions as train_flops_per_node), with its
     two structural savings taken out: table mode (2 (N + 2) <= tokens: the feature projection and its weight gradient run over

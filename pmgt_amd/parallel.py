@@ -40,11 +40,11 @@ def backend_averages(device) -> bool:
     return _AVG_OK
 
 
-def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
-    """In-place average of a flat buffer over all ranks (DDP gradient semantics)."""
+def allreduce_mean_(flat: torch.Tensor, force: bool = False) -> torch.Tensor:
+    """In-place average of a flat buffer over all ranks (DDP gradient semantics).  force: issue the collective on a one-rank group too."""
     import torch.distributed as dist
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_initialized()):
         return flat
     if backend_averages(flat.device):
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
@@ -127,9 +127,9 @@ def gather_predictions(preds: np.ndarray, labels: np.ndarray):
     return np.concatenate([p for p, _ in parts]), np.concatenate([l for _, l in parts])
 
 
-def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
+def broadcast_(flat: torch.Tensor, src: int = 0, force: bool = False) -> torch.Tensor:
     import torch.distributed as dist
-    if world()[1] > 1:
+    if world()[1] > 1 or (force and dist.is_initialized()):
         dist.broadcast(flat, src=src)
     return flat
 

@@ -27,8 +27,11 @@ class Trainer:
     def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
                  random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True,
-                 buckets: str = "layer", check_carrier_every: int = 200):
+                 buckets: str = "layer", check_carrier_every: int = 200, force_exchange: bool = False):
         self.engine = engine
+        # force_exchange: run the data-parallel exchange (bucketed all-reduce from the engine's callback, wait in front of the optimizer)
+        # even with ONE rank -- the N > 1 code path unchanged on a single-rank process group, so that RCCL executes it on a one-GPU box
+        self.force_exchange = bool(force_exchange)
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
         self.world_size = world_size
@@ -50,7 +53,7 @@ class Trainer:
         if buckets not in ("layer", "two", "one"):
             raise ValueError(f"buckets={buckets!r}: expected 'layer', 'two' or 'one'")
         self.buckets = buckets
-        if world_size > 1 and overlap_allreduce:
+        if (world_size > 1 or self.force_exchange) and overlap_allreduce:
             bounds = ()
             if buckets == "two" and engine.config.num_hidden_layers > 0:
                 bounds = (engine.entry("bert.encoder.layer.0.attention.self.query.weight")["offset"],)
@@ -60,14 +63,14 @@ class Trainer:
 
     def broadcast_parameters(self, src: int = 0):
         """DDP constructor semantics: every replica starts from rank `src`'s parameters."""
-        if self.world_size > 1:
-            broadcast_(self.engine.params, src=src)
+        if self.world_size > 1 or self.force_exchange:
+            broadcast_(self.engine.params, src=src, force=self.force_exchange)
 
     def training_step(self, batch, batch_idx: int = 0) -> torch.Tensor:
         """loss = net(*batch)[0] with gradients left in engine.grads (pmgt/pmgt/trainer.py:156-160).  The returned device
         scalar lives in the engine's output ring (valid for the next Engine.OUTPUT_RING - 1 steps; clone it to keep it)."""
         if self._exchange is not None:      # gradients are exchanged once per optimizer step: on the last micro-batch
-            self._exchange.enabled = self.world_size > 1 and self._micro == self.accum - 1
+            self._exchange.enabled = (self.world_size > 1 or self.force_exchange) and self._micro == self.accum - 1
         out = self.engine.pretrain_step(batch, training=True, backward=True, accumulate=self._micro > 0,
                                         random_node_ratio=self.random_node_ratio, mask_node_ratio=self.mask_node_ratio,
                                         want_hidden=False, private_outputs=getattr(self, "_capturing", False))
@@ -77,10 +80,10 @@ class Trainer:
 
     def optimizer_step(self):
         eng = self.engine
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_exchange:
             done = self._exchange.wait() if self._exchange is not None else 0
             if done == 0:
-                allreduce_mean_(eng.grads)
+                allreduce_mean_(eng.grads, force=self.force_exchange)
             elif done != eng.n_params:
                 raise RuntimeError(f"gradient exchange covered {done} of {eng.n_params} elements")
         if self.accum > 1:
@@ -108,11 +111,13 @@ class Trainer:
         are fed by copying into the tensors of `batch` (static input buffers), as with any captured graph.
         `warmup` eager steps run first (one-time kernel attribute calls are not capturable).  Single-GPU step only:
         the gradient all-reduce is not captured."""
-        assert self.world_size == 1 and self.accum == 1, "capture covers the single-GPU, non-accumulating step"
+        assert self.world_size == 1 and self.accum == 1 and not self.force_exchange, "capture covers the single-GPU, non-accumulating step"
         dev = self.engine.device
         # replays never run the Python-side guard: decide "x^ from the LayerNorm output or from stored inputs" once, on the
         # parameters as they are now, before the kernels are frozen into the graph
         self.engine.check_layernorm_carrier()
+        # Adam moments exist before the capture: their zero-fill must not become a node of the graph (it would reset them on every replay)
+        self.engine.ensure_optimizer_state()
         st = torch.cuda.Stream(device=dev)
         st.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(st):
@@ -139,7 +144,24 @@ class Trainer:
         weakref.finalize(graph, lambda: setattr(eng, "_live_graphs", eng._live_graphs - 1))
         replay.graph = graph
         replay.outputs = outputs          # loss / logits / nfr_count the replays write (kept alive with the graph)
+        # everything the captured launches address by raw pointer lives as long as the replay handle: the engine's workspace (a later,
+        # larger call makes the engine allocate a NEW one and drop its reference to this one), the static input tensors, the moments
+        replay.keep = (eng._ws, batch, eng.exp_avg, eng.exp_avg_sq, eng.params, eng.grads)
         return replay
+
+    def _hyper_key(self):
+        """What a captured step froze into kernel arguments: a replay is only valid for the same values."""
+        return (float(self.lr), float(self.weight_decay), tuple(float(b) for b in self.betas), float(self.eps),
+                None if self.max_grad_norm is None else float(self.max_grad_norm), float(self.random_node_ratio), float(self.mask_node_ratio))
+
+    def drop_captured_steps(self):
+        """Forgets every step run_live(graphs=True) captured (call after changing lr / weight decay / clip / ratios / engine options by
+        hand; run_live itself re-captures when the hyper-parameters it was captured with no longer match).  Waits for the GPU first: a
+        graph must not be destroyed while a replay of it is still executing."""
+        reps = self.__dict__.get("_live_replays")
+        if reps:
+            torch.cuda.synchronize(self.engine.device)
+            reps.clear()
 
     # ---- live input pipeline: threaded C++ MCNSampling -> pinned buffers -> side-stream H2D ------------
     def run_live(self, sampler, node_ids: np.ndarray, batch_size: int, steps: int, threads: int = 8, depth: int = 3,
@@ -156,7 +178,7 @@ class Trainer:
         copy_stream = torch.cuda.Stream(device=dev)
         # the slots (pinned host + device buffers) live as long as the trainer: a second pass over the same shapes re-uses them -- and, with
         # graphs=True, the steps captured over them
-        skey = (id(sampler), batch_size, depth)
+        skey = (int(sampler.S), int(sampler.max_pairs(MODE_TRAIN)), batch_size, depth)      # shapes, not id(sampler): an id can be re-used
         cache = self.__dict__.setdefault("_live_slots", {})
         if skey not in cache:
             sl = [sampler.alloc(batch_size, MODE_TRAIN, pinned=True) for _ in range(depth)]
@@ -201,7 +223,11 @@ class Trainer:
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         t_launch = 0.0
-        replays = self.__dict__.setdefault("_live_replays", {})       # (slot buffers, shape) -> captured step, kept across calls
+        replays = self.__dict__.setdefault("_live_replays", {})       # (slot buffers, shape, hyper-parameters) -> captured step, kept across calls
+        hyper = self._hyper_key()
+        if graphs and any(k[-1] != hyper for k in replays):
+            self.drop_captured_steps()       # lr / weight decay / clip / ratios changed since the capture: those are frozen kernel arguments
+        checked_at = -1
         try:
             for i, (slot, (b, ev)) in enumerate(pipe):
                 if t0 is None:
@@ -209,13 +235,24 @@ class Trainer:
                 tl = time.perf_counter()
                 torch.cuda.current_stream().wait_event(ev)
                 ev_a[i].record()
-                key = (b[0]["node_ids"].data_ptr(), tuple(b[0]["node_ids"].shape), tuple(b[1]["node_ids"].shape)) if graphs else None
+                key = (b[0]["node_ids"].data_ptr(), tuple(b[0]["node_ids"].shape), tuple(b[1]["node_ids"].shape), hyper) if graphs else None
+                if graphs and self.check_carrier_every and self._opt_steps % self.check_carrier_every == 0 and self._opt_steps != checked_at:
+                    # replays never run optimizer_step's Python-side guard: look at the LayerNorm parameters here (one small read per
+                    # LayerNorm every N steps); when they no longer allow x^ from the LayerNorm output, the captured steps are dropped,
+                    # the engine switches to stored inputs and the slots are captured again below
+                    checked_at = self._opt_steps
+                    if eng.carrier_needs_stored_inputs():
+                        self.drop_captured_steps()
+                        eng.check_layernorm_carrier()
                 if graphs and key in replays:
                     self.last_loss = replays[key]()
-                elif graphs and self.world_size == 1 and self.accum == 1:
+                    self._opt_steps += 1
+                elif graphs and self.world_size == 1 and self.accum == 1 and not self.force_exchange:
                     # first batch of this slot: record the step (nothing executes during capture), then replay it like every later one.
                     # thread_local: the producer thread keeps issuing its own copies / event waits while this thread captures
-                    replays[key] = self.capture_step(b, warmup=0, capture_error_mode="thread_local")
+                    if replays and eng.carrier_needs_stored_inputs():
+                        self.drop_captured_steps()       # (capture_step switches the option; it must not find live graphs then)
+                    replays[key] = self.capture_step(b, warmup=0, capture_error_mode="thread_local")      # (counts one optimizer step: the recording)
                     self.last_loss = replays[key]()
                 else:
                     self.train_step(b)

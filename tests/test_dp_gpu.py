@@ -187,3 +187,20 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path, launch):
     ar = out["allreduce"]
     assert ar["buckets"] == (6 if launch == "driver" else 2) and ar["ms_per_step"] > 0
     assert abs(ar["mb"] - 4 * 3.06) < 0.5                                                   # the whole flat gradient buffer, once
+
+
+def test_rccl_single_rank_group_runs_the_exchange_unchanged():
+    """RCCL executes the exchange step on the hardware the dev loop has: a ONE-rank `nccl` process group (librccl load, communicator
+    init, the ReduceOp.AVG probe, asynchronous all_reduce on the process group's stream issued from the engine's C callback, the
+    stream-ordered wait in front of the optimizer, barrier, destroy) under Trainer(force_exchange=True) for all three bucket policies and
+    the blocking form.  A one-rank average is the identity, so gradients / moments / parameters must equal the no-exchange run bit for
+    bit over three optimizer steps.  Own process: the rendezvous environment and the communicator do not leak into the test session."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank.py")], env=env, capture_output=True, text=True,
+                       timeout=420)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["backend"] == "nccl"
+    assert line["policies"]["layer"]["collectives_per_step"] == 3 + 2          # NFR head, three layers, embeddings
+    assert line["policies"]["two"]["collectives_per_step"] == 2 and line["policies"]["one"]["collectives_per_step"] == 1

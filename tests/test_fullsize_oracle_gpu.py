@@ -196,6 +196,66 @@ def test_c2_step_at_the_bench_batch_matches_the_oracle(dtype):
     compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tables])[0])
 
 
+C2_I4D = dict(C2, intermediate_size=1024)
+
+
+@pytest.mark.parametrize("B,dtype", [(192, "bf16"), (192, "fp32"), pytest.param(1024, "bf16", marks=pytest.mark.slow),
+                                     pytest.param(1024, "fp32", marks=pytest.mark.slow)])
+def test_c2_with_intermediate_4d_matches_the_oracle(B, dtype):
+    """SURVEY 8(d)'s second C2 row: d = 256 with I = 4 d = 1 024 (the shape of the author's own run: hidden 32 / intermediate 128,
+    scripts/run_pmgt.sh:18, train.py:253-258; BertIntermediate / BertOutput, pmgt/pmgt/modeling_pmgt.py:293-294,322-325), full size against
+    the oracle at B = 192 and at the bench's B = 1 024.  FFN2 (K = 1 024) is outside the weight-stationary streaming family: the launch
+    trace asserts that it runs the 256 x 256 tile with the residual + LayerNorm epilogue (nt_lnf, no stored LayerNorm input) and that both
+    LayerNorm backwards of a full layer run behind the data-gradient tiles that produce their dy (nt_lnb: dX = dFF W1 with K = 1 024 and
+    dX = dQKVC W), next to the fused attention kernels -- not the round-1 tile GEMM + standalone LayerNorm launches."""
+    from pmgt_amd import _lib
+    case = make_case(7252, 88606, C2_I4D, S=32, B=B, seed=61)
+    tables = po.synth_tables(7252, case["cfg"]["feat_hidden_sizes"], 9)
+    L = _lib.hip()
+    L.pmgt_launch_trace_reset()
+    eng, out = run_engine(case, dtype, [t.numpy() for t in tables])
+    ran = launch_counts(("nt_lnf", "nt_lnb", "gemm_wsr", "gemm_wsr_lnb", "gemm_ws", "qkvc_attn_fwd", "attn_bwd_wgrad", "nt_big", "tn_big", "tn_dma"))
+    if dtype == "bf16":
+        # three full layers + the last one on the compacted rows: FFN2 forward x 3 on nt_lnf; LN1 backward x 3 and LN2 backward x 3 on nt_lnb;
+        # attn-out (K = 256) stays on the role-split streaming kernel; FFN1 / dgrad_FFN2 (N = 1 024: four weight slabs) on gemm_ws
+        assert ran["nt_lnf"] == 3 and ran["nt_lnb"] == 6 and ran["gemm_wsr"] >= 3 and ran["gemm_wsr_lnb"] == 0, ran
+        assert ran["qkvc_attn_fwd"] == 4 and ran["attn_bwd_wgrad"] == 4 and ran["gemm_ws"] >= 8, ran
+    if B <= 192:
+        p, ref = run_oracle(case, tables)
+    else:
+        p, ref = run_oracle_chunked(case, tables, chunk=128)
+    compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tables])[0])
+
+
+@pytest.mark.slow
+def test_hidden_512_intermediate_2048_at_benchmark_token_counts_matches_the_oracle():
+    """SURVEY 8(d)'s second C4 row: d = 512 with I = 4 d = 2 048, L = 2, S = 64, B = 96 targets (73 728 tokens), table mode, fp32 and bf16
+    engines against the oracle in 32-target chunks; the launch trace names the kernels behind the `c4_i2048` bench line: FFN1 / dgrad_FFN2
+    (N = 2 048) on the role-split K = 512 streaming kernel, FFN2 + LayerNorm (K = 2 048) on the full-row tile, dX = dFF W1 (K = 2 048) on the
+    256 x 256 tile, weight gradients on the 256 x 256 TN tile."""
+    from pmgt_amd import _lib
+    n, e, S, B = 20_000, 240_000, 64, 96
+    case = make_case(n, e, dict(hidden_size=512, num_attention_heads=8, num_hidden_layers=2, intermediate_size=2048), S, B, seed=43)
+    g = torch.Generator().manual_seed(12)
+    tabs = []
+    for f in case["cfg"]["feat_hidden_sizes"]:
+        t = torch.randn(n + 2, f, generator=g).to(torch.bfloat16).float()
+        t[:2] = 0
+        tabs.append(t)
+    p, ref = run_oracle_chunked(case, tabs, chunk=32)
+    L = _lib.hip()
+    for dtype in ("fp32", "bf16"):
+        L.pmgt_launch_trace_reset()
+        eng, out = run_engine(case, dtype, [t.numpy() for t in tabs])
+        ran = launch_counts(("gemm_wsr512", "gemm_rowln", "nt_big", "tn_big", "attn_tiles_fwd", "attn_tiles_bwd"))
+        if dtype == "bf16":
+            assert ran["gemm_wsr512"] >= 4 and ran["gemm_rowln"] >= 2 and ran["nt_big"] >= 2 and ran["tn_big"] >= 4, ran
+            assert ran["attn_tiles_fwd"] >= 1 and ran["attn_tiles_bwd"] >= 1, ran
+        compare(eng, out, p, ref, dtype, fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tabs])[0])
+        del eng, out
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_million_node_tables_l6_d512_s64_match_the_oracle(dtype):
     """C4 / C5 shapes at their real node count: the engine gathers rows of [10^6 + 2, 1536] / [.., 768] tables (row offsets

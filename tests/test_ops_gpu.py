@@ -589,6 +589,9 @@ def test_role_split_k512_gemm_is_bit_identical_to_the_lockstep_kernel(M, N, epi,
     (4096, 2048, 512, 0, False, 0.0, False),   # ... eight column slabs
     (3001, 256, 512, 0, True, 0.1, True),      # FFN2 with I = 2 d: K = 512 form WITH the fused LayerNorm (N = 256), ragged M
     (2048, 256, 512, 0, True, 0.0, False),     # ... residual only
+    (24577, 256, 1024, 0, True, 0.1, True),    # FFN2 with I = 4 d at d = 256 (K = 1024): the 256 x 256 tile with the residual + LayerNorm epilogue (nt_lnf), one row in the last tile
+    (24576, 256, 1024, 0, True, 0.0, True),    # ... no dropout: also against fp64
+    (24000, 256, 1024, 0, True, 0.0, True),    # ... below 96 tiles: tile GEMM + LayerNorm launch
 ])
 def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, drop, ln):
     """bf16 weight-stationary streaming GEMM (gemm_ws.hip) == tiled kernel (same dropout masks) == torch."""
@@ -616,6 +619,7 @@ def test_linear_streaming_kernel_matches_tiled_and_reference(M, N, K, epi, res, 
                                     1e-12, stream()))
         # the full-row form runs exactly where the docstring of gemm_rowln.hip says (N = 512 with a LayerNorm behind it, M >= 4096)
         assert H.pmgt_launch_trace_count(b"gemm_rowln") == (1 if (not force and ln and N == 512 and M >= 4096) else 0)
+        assert H.pmgt_launch_trace_count(b"nt_lnf") == (1 if (not force and ln and N == 256 and K > 512 and M >= 96 * 256 - 255) else 0)
         outs.append((Cd.float(), aux.float(), None if lno is None else lno.float(), stats))
     ws, tile = outs
     if ln and N == 512 and M >= 4096:      # the full-row tile combines its row statistics across waves in a fixed order: run to run identical
@@ -866,3 +870,37 @@ def test_attention_tile_forms_match_the_oracle_restatement(opts):
     assert rel_err(probs, w_ref.detach()) < 2e-2
     for m in range(4):          # dQ, dK, dV, dC blocks separately (their scales differ)
         assert rel_err(dx[..., m * d:(m + 1) * d], xr.grad[..., m * d:(m + 1) * d]) < 3e-2, m
+
+
+# ------------------------------------------------------------------------------------------- token order of the table-mode backward
+@pytest.mark.parametrize("M,n_rows,skew", [(393216, 7254, True), (393216, 7254, False), (1000, 40, False), (4096, 2048, False), (4097, 3, True),
+                                           (73728, 20002, True), (300001, 150000, False), (1572864, 70000, True), (65, 130, False)])
+def test_token_sort_by_node_id_is_the_stable_sort(M, n_rows, skew):
+    """seg_sort (segsum.hip): the hand-written LSD radix sort that orders a step's tokens by node id for the per-node gradient sums (the
+    gather of pmgt/pmgt/utils.py:43-50 in reverse).  Integer work, so bit-exact: sorted keys, permutation and segment offsets equal numpy's
+    STABLE argsort / searchsorted -- one, two and three counting passes (n_rows <= 2^8, 2^16, > 2^16), ragged last tiles, heavy
+    duplicates (padded tokens carry id 0: the pad segment alone can be a third of the batch), run to run identical."""
+    _lib, L = _setup()
+    H = _lib.hip()
+    rs = np.random.RandomState(M % 1000 + n_rows)
+    ids = rs.randint(0, n_rows, size=M).astype(np.int64)
+    if skew:
+        ids[rs.rand(M) < 0.3] = 0
+        ids[rs.rand(M) < 0.05] = 1
+    d_ids = torch.from_numpy(ids).cuda()
+    mk = lambda n, dt: torch.full((n,), -1, dtype=dt, device="cuda")
+    nb = int(H.pmgt_op_seg_sort_temp_bytes(M))
+    outs = []
+    for rep in range(2):
+        k1, v1, sk, pm = mk(M, torch.int32), mk(M, torch.int32), mk(M, torch.int32), mk(M, torch.int32)
+        off = mk(n_rows + 1, torch.int32)
+        tmp = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        _lib.check(H.pmgt_op_seg_sort(P(d_ids), M, n_rows, P(k1), P(v1), P(sk), P(pm), P(off), P(tmp), nb, stream()))
+        torch.cuda.synchronize()
+        outs.append((sk.cpu().numpy(), pm.cpu().numpy(), off.cpu().numpy()))
+    order = np.argsort(ids, kind="stable")
+    assert np.array_equal(outs[0][1].astype(np.int64), order)
+    assert np.array_equal(outs[0][0].astype(np.int64), ids[order])
+    assert np.array_equal(outs[0][2].astype(np.int64), np.searchsorted(ids[order], np.arange(n_rows + 1), side="left"))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)

@@ -158,6 +158,107 @@ def test_trainer_eval_export_and_live_pipeline():
     assert emb.shape == (n, 64) and emb.dtype == np.float32 and np.isfinite(emb).all()
 
 
+def _live_world(seed=0):
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.datasets import MCNSampler
+    from pmgt_amd.engine import Engine
+    from pmgt_amd.graph import synthetic_graph
+    from pmgt_amd.models import reference_init, synthetic_features
+    n, S = 500, 16
+    graph = synthetic_graph(n, 4000, seed=1)
+    eng = Engine(PMGTConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64), dtype="bf16", seed=seed)
+    reference_init(eng, 0)
+    eng.set_tables(*synthetic_features(n, seed=1))
+    return eng, MCNSampler(graph, S - 1), np.arange(2, n + 2)
+
+
+def test_live_graph_replay_on_a_fresh_trainer_equals_eager_steps():
+    """Round-4 advisor finding (high): run_live(graphs=True) on a trainer that had never stepped captured the lazy zero-fill of the Adam
+    moments into slot 0's graph, so every replay of that slot reset both moments.  The moments now exist before any capture; N replayed
+    steps on a fresh trainer leave the parameters N eager steps leave (same batches: the threaded sampler draws per-target counter
+    streams; same dropout: device-side counters), and the moments keep growing."""
+    from pmgt_amd.trainer import Trainer
+    steps, res = 8, {}
+    for graphs in (False, True):
+        eng, smp, ids = _live_world()
+        assert eng.exp_avg is None
+        tr = Trainer(eng, lr=1e-3, max_grad_norm=5.0)
+        tr.run_live(smp, ids, batch_size=32, steps=steps, threads=3, depth=3, graphs=graphs)
+        torch.cuda.synchronize()
+        assert int(eng.opt_step.item()) == steps
+        res[graphs] = (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone())
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    assert float(res[True][2].abs().sum()) > 0
+
+
+def test_live_graph_cache_follows_hyperparameters_and_keeps_its_workspace():
+    """Round-4 advisor findings (medium): captured steps freeze lr / weight decay / clip as kernel arguments and address the workspace by
+    raw pointer.  A changed learning rate must re-capture (lr = 0 leaves the parameters untouched); a later, larger eager call makes the
+    engine allocate a new workspace while the replays keep the old one alive; drop_captured_steps() frees the option lock."""
+    from pmgt_amd.trainer import Trainer
+    eng, smp, ids = _live_world()
+    tr = Trainer(eng, lr=1e-3, max_grad_norm=5.0)
+    tr.run_live(smp, ids, batch_size=32, steps=4, threads=3, depth=2, graphs=True)
+    assert len(tr._live_replays) == 2
+    old_ws = eng._ws
+    assert all(r.keep[0] is old_ws for r in tr._live_replays.values())
+    tr.train_step(_eager_batch(smp, ids[:96]))                 # three times the rows: a larger workspace
+    assert eng._ws is not old_ws and all(r.keep[0] is old_ws for r in tr._live_replays.values())
+    tr.run_live(smp, ids, batch_size=32, steps=4, threads=3, depth=2, graphs=True)                      # replays over the old workspace: still valid
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.params).all()
+    before = eng.params.clone()
+    tr.lr = 0.0
+    tr.weight_decay = 0.0
+    tr.run_live(smp, ids, batch_size=32, steps=3, threads=3, depth=2, graphs=True)
+    torch.cuda.synchronize()
+    assert torch.equal(before, eng.params)                     # the lr = 1e-3 graphs were not replayed
+    with pytest.raises(RuntimeError, match="captured step"):
+        eng.set_option("store_ln_input", 1)
+    tr.drop_captured_steps()
+    import gc
+    gc.collect()
+    eng.set_option("store_ln_input", 1)
+
+
+def _eager_batch(smp, targets):
+    from pmgt_amd.datasets import MODE_TRAIN
+    tgt, pair, num_pairs, labels = smp.batch(np.asarray(targets), MODE_TRAIN, threads=2, base_seed=3, counter=0)
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}
+    return cu(tgt), cu(pair), num_pairs.cuda(), labels.cuda()
+
+
+def test_live_graph_replays_run_the_layernorm_carrier_guard():
+    """Round-4 advisor finding (medium): replays never ran the guard that switches the backward to stored LayerNorm inputs when
+    |beta / gamma| drifts past the bound.  run_live now looks every `check_carrier_every` replays, drops the captured steps, switches and
+    re-captures."""
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.datasets import MCNSampler
+    from pmgt_amd.engine import Engine
+    from pmgt_amd.graph import synthetic_graph
+    from pmgt_amd.models import reference_init, synthetic_features
+    from pmgt_amd.trainer import Trainer
+    n, S = 300, 32
+    graph = synthetic_graph(n, 3000, seed=2)
+    eng = Engine(PMGTConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=8, intermediate_size=256), dtype="bf16")
+    reference_init(eng, 0)
+    eng.set_tables(*synthetic_features(n, seed=2))
+    smp = MCNSampler(graph, S - 1)
+    tr = Trainer(eng, lr=1e-4, max_grad_norm=5.0, check_carrier_every=2)
+    ids = np.arange(2, n + 2)
+    tr.run_live(smp, ids, batch_size=16, steps=4, threads=3, depth=2, graphs=True)
+    assert not eng.get_option("store_ln_input") and len(tr._live_replays) == 2
+    eng.view("bert.encoder.layer.0.output.LayerNorm.bias").fill_(20.0)        # |beta / gamma| = 20 > 8 (set behind the engine's back)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr.run_live(smp, ids, batch_size=16, steps=6, threads=3, depth=2, graphs=True)
+    torch.cuda.synchronize()
+    assert eng.get_option("store_ln_input") and len(tr._live_replays) == 2
+    assert torch.isfinite(eng.params).all() and np.isfinite(tr.last_loss.item())
+
+
 @pytest.mark.parametrize("name", list(gu.NCF_CASES))
 def test_ncf_second_caller_on_hip_encoder(name):
     """PMGT_NCF with the item tower on the HIP engine (pmgt_encode_train / pmgt_encode_backward through autograd):
