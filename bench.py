@@ -57,7 +57,9 @@ def parse():
     ap.add_argument("--end-to-end", action="store_true", help="N = 1: on by default; N > 1: also time steps fed by the live host sampler on every rank")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the live-sampler pass")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the B=32 / B=256 extra measurements (N=1 only)")
-    ap.add_argument("--buckets", default="layer", choices=["layer", "two", "one"],
+    # default "two": one-rank RCCL runs (profiles/r05/rccl_single_rank_exchange.txt) put six per-bucket collectives at +2.5 % of the step, two at
+    # +1.8 %; the first of the two (9.8 MB: NFR head + layers) travels under the embedding backward, only the 2.5 MB embedding bucket is exposed
+    ap.add_argument("--buckets", default="two", choices=["layer", "two", "one"],
                     help="N > 1: gradient all-reduce per engine bucket (NFR head, each layer, embeddings), as two collectives "
                          "(head + encoder layers | embeddings), or as one after the backward pass")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY",

@@ -41,7 +41,7 @@ extern "C" {
 /* ---- which kernel families the calling thread has launched since the last reset (test instrumentation: a parity test at a given
  * size only covers a kernel if the dispatcher actually picked it).  Families: gemm_wsr, gemm_wsr_lnb, gemm_wsr512, gemm_ws, nt_big,
  * nt_big_gather, nt_big_128, nt_lnb, nt_tile, tn_big, tn_big_gather, tn_dma, tn_dma_gather, tn_tile, attn_tiles_fwd, attn_tiles_bwd,
- * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile, f8_wsr512.  Unknown name: -1. */
+ * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile, f8_wsr512, gemm_rowln, nt_lnf, embed_tok8.  Unknown name: -1. */
 void pmgt_launch_trace_reset(void);
 int64_t pmgt_launch_trace_count(const char* family);
 

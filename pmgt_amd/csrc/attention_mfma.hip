@@ -2392,7 +2392,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     auto dma_attn = [&](int i, bool early) __attribute__((always_inline)) {
         const int m0 = 64 * (xs + i * gx);
         if (i < nsteps) {
+#ifdef PMGT_ABW_NO_QKVC_IN
+            // (ablation build, profiles/r05: the Q|K|V|C rows are not fetched -- what a backward that RECOMPUTES them from the x tile would
+            //  save on the DMA side, before paying for the recompute; results are garbage)
+            if (false) {
+#else
             if ((g < 4) == early) {
+#endif
                 char* gt = smem + in_tile(i);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -2413,7 +2419,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         }
     };
     // vector-memory operations of this wave per iteration, in issue order: [E: early pieces] [L: x rows, late pieces] [2 copy-out stores]
+#ifdef PMGT_ABW_NO_QKVC_IN
+    const int attnE = (g < 2 ? 1 : 0), attnL = ((g == 2 || g == 3) ? 1 : 0);
+#else
     const int attnE = (g < 4 ? 2 : 0) + (g < 2 ? 1 : 0), attnL = (g >= 4 ? 2 : 0) + ((g == 2 || g == 3) ? 1 : 0);      // (uniform)
+#endif
     auto wait_vm = [](int n) __attribute__((always_inline)) {      // s_waitcnt vmcnt(n) as an immediate; n <= 9 here
         switch (n) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;

@@ -65,7 +65,7 @@ void set_error(const char* fmt, ...);
 enum LaunchTag {
     LT_GEMM_WSR = 0, LT_GEMM_WSR_LNB, LT_GEMM_WSR512, LT_GEMM_WS, LT_NT_BIG, LT_NT_BIG_GATHER, LT_NT_BIG_128, LT_NT_LNB, LT_NT_TILE,
     LT_TN_BIG, LT_TN_BIG_GATHER, LT_TN_DMA, LT_TN_DMA_GATHER, LT_TN_TILE, LT_ATTN_TILES_FWD, LT_ATTN_TILES_BWD, LT_QKVC_ATTN_FWD,
-    LT_ATTN_BWD_WGRAD, LT_F8_BIG, LT_F8_TILE, LT_F8_WSR512, LT_GEMM_ROWLN, LT_NT_LNF, LT_COUNT
+    LT_ATTN_BWD_WGRAD, LT_F8_BIG, LT_F8_TILE, LT_F8_WSR512, LT_GEMM_ROWLN, LT_NT_LNF, LT_EMBED_TOK8, LT_COUNT
 };
 void note_launch(int tag);
 

@@ -606,6 +606,7 @@ template <typename T> int embed_mix_fwd(const EmbedMix& e, hipStream_t st) {
         if (e.phase == 2 && e.d == 256 && e.e_rows != nullptr) {
             PMGT_CHECK(e.S > 0 && e.M % e.S == 0, -2, "embed_mix_fwd: %d tokens are not whole sequences of %d", e.M, e.S);
             const int tasks = tok_tasks(e.M, e.S);
+            note_launch(LT_EMBED_TOK8);
             hipLaunchKernelGGL((embed_tok8_fwd_kernel<T>), dim3(cdiv(tasks, 4)), dim3(256), 0, st, e);
             PMGT_LAUNCH_OK();
             return 0;
@@ -816,6 +817,7 @@ template <typename T> int embed_mix_bwd(const EmbedMix& e, hipStream_t st) {
         if constexpr (sizeof(T) == 2) {
             PMGT_CHECK(e.d == 256 && e.e_rows != nullptr && e.E != nullptr && e.pos != nullptr && e.role != nullptr && e.S > 0 && e.M % e.S == 0, -2,
                        "embed_mix_bwd: recomputed pre-LayerNorm sum needs the table-mode token phase at hidden size 256 (d=%d)", e.d);
+            note_launch(LT_EMBED_TOK8);
             hipLaunchKernelGGL((embed_tok8_bwd_kernel<T>), grid, block, lds, st, e);
             PMGT_LAUNCH_OK();
             return 0;
