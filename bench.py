@@ -50,6 +50,9 @@ def parse():
                     help="bf16 = BASELINE.json's metric; fp8 = bf16 engine with e4m3 feature tables / fp8-MFMA feature + Q|K|V|C projections (config 5)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--intermediate", type=int, default=0, help="override intermediate size")
+    ap.add_argument("--beta", type=float, default=0.5,
+                    help="PMGTConfig.beta (default 0.5 = the config default, configuration_pmgt.py:21); 1.0 = the author's script (scripts/run_pmgt.sh:24): "
+                         "the dot-product branch is dead and the fused kernels skip Q / K altogether")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-profile", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="partial-sum reductions on the engine's side stream (A/B; measured neutral)")
@@ -106,7 +109,7 @@ def rehearse_launch(world, rank):
     dist.destroy_process_group()
 
 
-def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
+def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz, vc=False):
     """Algorithmic (flops, bytes) of ONE launch group of a phase, for the roofline object.
     M = tokens in the step, esz = bytes per activation element."""
     F = Fv + Ft
@@ -141,6 +144,11 @@ def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz):
         "fwd.embed_mix": (0.0, M * 4 * d * esz),
         "bwd.embed_mix": (0.0, M * 7 * d * esz),
     }
+    if vc:      # beta == 1 with the dead branch skipped: V | C only (2 d columns instead of 4 d), the cosine branch alone
+        table["fwd.qkvc_attention"] = (g(M, 2 * d, d) + 3.0 * M * S * d, M * 4 * d * esz)                      # x in, V | C + ctx out
+        table["bwd.attention_wgrad"] = (8.0 * M * S * d + g(M, 2 * d, d), M * 6 * d * esz)                     # V | C, d ctx, x in; dV | dC out
+        table["bwd.dgrad_qkvc"] = (g(M, d, 2 * d), M * 4 * d * esz)
+        table["bwd.dgrad_qkvc_lnb"] = (g(M, d, 2 * d), M * 6 * d * esz)
     return table.get(name)
 
 
@@ -258,7 +266,7 @@ def main():
         I = args.intermediate
     B = args.batch
     cfg = PMGTConfig(hidden_size=d, num_hidden_layers=L, num_attention_heads=H, intermediate_size=I,
-                     hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout, beta=0.5)
+                     hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout, beta=args.beta)
     t_setup = time.perf_counter()
     big = nodes >= 500_000
     if big:
@@ -377,7 +385,7 @@ def main():
                  if big else "synthetic (seeded G(n,m)+ring item graph, N(0,1) visual/textual features, random-init weights)"),
         "config": {"workload": f"{args.workload}: {nodes} nodes / {edges} edges, L={L} H={H} d={d} I={I} S={S} "
                                f"(context=S tokens incl. target), B={B} targets/GPU/step, 12 sequences/target, "
-                               f"dropout {args.dropout}, clip 5.0, AdamW lr 1e-4 wd 1e-2",
+                               f"dropout {args.dropout}, beta {args.beta:g}, clip 5.0, AdamW lr 1e-4 wd 1e-2",
                    "parallelism": f"dp{world}", "global_batch": world * B, "seq_len": S},
         "loss_first": round(loss_first.item(), 5),
         "loss_last": round(loss_last, 5),
@@ -428,8 +436,9 @@ def main():
         out["phases"] = phases
         esz = 4 if args.dtype == "fp32" else 2
         M = 12 * B * S
-        dom = next((k for k in phases if phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz) is not None), next(iter(phases)))
-        w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz)
+        vc = args.beta == 1.0 and args.dtype == "bf16" and S == 32 and d // H == 32 and H % 4 == 0 and "no_beta_skip" not in args.engine_option
+        dom = next((k for k in phases if phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc) is not None), next(iter(phases)))
+        w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc)
         cnt, ms = prof[dom]
         avg_s = ms / cnt / 1e3
         if w is not None:
@@ -453,7 +462,7 @@ def main():
         peak_t = MFMA_F32_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
         top = []
         for k in phases:
-            wk = phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz)
+            wk = phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc)
             if wk is None or len(top) == 3:
                 continue
             c_k, ms_k = prof[k]
@@ -475,14 +484,14 @@ def main():
             tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
             ph = tr["phases"].get(out["roofline"]["kernel"])
             fresh = tr.get("kernel_sources_sha") == kernel_sources_sha()       # measured on THESE kernels, else it is stale: null
-            if ph and fresh and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16":
+            if ph and fresh and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16" and args.beta == 0.5:
                 out["roofline"]["traffic"] = ph["hbm_mb_per_launch"]
                 out["roofline"]["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
                 if "matrix_pipe_busy" in ph:        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the same profile set
                     out["roofline"]["matrix_pipe_busy"] = ph["matrix_pipe_busy"]
                     out["roofline"]["valu_per_mfma"] = ph.get("valu_per_mfma")
             wl = args.workload + (f"_i{args.intermediate}" if args.intermediate else "")
-            if fresh and tr.get("workload_key", tr["workload"]) == wl and tr["batch"] == B and args.dtype == "bf16":
+            if fresh and tr.get("workload_key", tr["workload"]) == wl and tr["batch"] == B and args.dtype == "bf16" and args.beta == 0.5:
                 for ent in out.get("roofline_top3", []):
                     pk = tr["phases"].get(ent["kernel"])
                     if pk:
@@ -577,7 +586,10 @@ EXTRA_WORKLOADS = (("c4_bf16", ["--workload", "c4", "--batch", "256", "--dtype",
                    ("c4_bf16_b1024", ["--workload", "c4", "--batch", "1024", "--dtype", "bf16", "--steps", "5", "--warmup", "2"]),
                    # SURVEY 8(d)'s I = 4 d rows (the author's own ratio: hidden 32 / intermediate 128, scripts/run_pmgt.sh:18): 9.00 and 100.6 GFLOP per node
                    ("c2_i1024", ["--workload", "c2", "--batch", "1024", "--dtype", "bf16", "--intermediate", "1024"]),
-                   ("c4_i2048", ["--workload", "c4", "--batch", "256", "--dtype", "bf16", "--intermediate", "2048"]))
+                   ("c4_i2048", ["--workload", "c4", "--batch", "256", "--dtype", "bf16", "--intermediate", "2048"]),
+                   # the author's own attention mix (scripts/run_pmgt.sh:24: --beta 1.0): the dot-product branch is dead, the fused kernels project, store
+                   # and differentiate V | C only; the flop count of the line stays the algorithmic one of the full model
+                   ("c2_beta1", ["--workload", "c2", "--batch", "1024", "--dtype", "bf16", "--beta", "1.0"]))
 EXTRA_BUDGET_S = 150.0
 
 

@@ -36,12 +36,13 @@ extern "C" {
 #define PMGT_OPT_LOCKSTEP_ATTENTION_BWD (1u << 19)   /* "lockstep_attention_bwd": fused attention backward with both (sequence, head) pairs of a step in the same phase instead of one barrier interval apart -- bit-identical results */
 #define PMGT_OPT_SIDE_STREAM_WGRAD (1u << 20)        /* "side_stream_wgrad": the dense weight-gradient GEMMs of a layer on the engine's side stream, next to the data-gradient chain (same kernels, same reduction order: identical results; opt-in -- the cross-stream hand-offs cost more than the overlap gives at every batch size measured) */
 #define PMGT_OPT_NO_CLS_ONLY_ATTENTION_BWD (1u << 21) /* "no_cls_only_attention_bwd": fused attention backward of the last (shortcut) layer without the skip of query tiles whose d ctx rows are zero -- identical results */
+#define PMGT_OPT_NO_BETA_SKIP (1u << 22)            /* "no_beta_skip": beta == 1 (scripts/run_pmgt.sh:24) on the general fused kernels: Q / K projected, dot-product branch run and differentiated although it contributes exactly nothing (pmgt/pmgt/modeling_pmgt.py:519-521); default: skipped */
 #define PMGT_OPT_NO_TILE_ATTENTION (1u << 17)        /* "no_tile_attention": S = 64 / head size 64 attention on the cooperative kernels (per-wave fragment loads) instead of the tile forms */
 
 /* ---- which kernel families the calling thread has launched since the last reset (test instrumentation: a parity test at a given
  * size only covers a kernel if the dispatcher actually picked it).  Families: gemm_wsr, gemm_wsr_lnb, gemm_wsr512, gemm_ws, nt_big,
  * nt_big_gather, nt_big_128, nt_lnb, nt_tile, tn_big, tn_big_gather, tn_dma, tn_dma_gather, tn_tile, attn_tiles_fwd, attn_tiles_bwd,
- * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile, f8_wsr512, gemm_rowln, nt_lnf, embed_tok8.  Unknown name: -1. */
+ * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile, f8_wsr512, gemm_rowln, nt_lnf, embed_tok8, qkvc_attn_fwd_vc, attn_bwd_wgrad_vc, nt_vc (the last three: the beta == 1 forms, counted in addition to their general family).  Unknown name: -1. */
 void pmgt_launch_trace_reset(void);
 int64_t pmgt_launch_trace_count(const char* family);
 
@@ -110,6 +111,11 @@ int pmgt_op_linear_ln_bwd(const void* A, int64_t lda, const void* B, int64_t ldb
 int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,
                                int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
                                const uint64_t* rng, void* stream);
+/* the same with layout / mode flags: bit 0 = qkvc written head-major ((head, matrix, w) columns), bit 1 = vc_only (beta == 1, H % 4 == 0: V and C
+ * projected and stored only, cosine branch alone; the Q / K columns of qkvc are left untouched) */
+int pmgt_op_qkvc_attention_fwd_ex(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx,
+                                  int n_seq, int S, int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
+                                  const uint64_t* rng, int flags, void* stream);
 int pmgt_op_attention_fwd(int dtype, const void* qkvc, const float* mask, void* ctx, float* probs, int n_seq, int S,
                           int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2,
                           const uint64_t* rng, uint32_t path_opts, void* stream);
@@ -120,7 +126,8 @@ int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const 
  * 256; replaces pmgt_op_attention_bwd + the [M, 4d]^T [M, d] weight-gradient GEMM, i.e. autograd through
  * pmgt/pmgt/modeling_pmgt.py:429-433 and :435-526).  x = the layer input [n_seq * 32, d]; dqkvc as pmgt_op_attention_bwd;
  * slab [parts][4d * d] / bias_slab [parts][4d] (parts = pmgt_op_attention_bwd_wgrad_parts(H)) receive per-workgroup partial
- * sums in q | k | v | c row order, to be added up by the caller.  head_major = the column layout of qkvc / dqkvc. */
+ * sums in q | k | v | c row order, to be added up by the caller.  head_major: bit 0 = the column layout of qkvc / dqkvc, bit 1 = vc_only
+ * (beta == 1: Q / K columns of qkvc are not read, dQ / dK columns of dqkvc not written, query / key rows of the partial sums are zeros). */
 int pmgt_op_attention_bwd_wgrad_parts(int H);
 int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void* dctx, const void* x, void* dqkvc, float* slab,
                                 float* bias_slab, int n_seq, int H, float beta, float drop_p, uint32_t site1, uint32_t site2,

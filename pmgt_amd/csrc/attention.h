@@ -19,6 +19,10 @@ struct AttnArgs {
     // m * d + h * dh + w, i.e. 4 * dh contiguous elements per (row, head).  Written by the fused forward, understood by
     // the one-wave MFMA backward (the only pair used together).
     bool hm = false;
+    // beta == 1 with the dead branch skipped (pmgt/pmgt/modeling_pmgt.py:519-521: the dot-product softmax then contributes exactly nothing):
+    // Q and K are NEITHER READ NOR WRITTEN by the fused kernels -- the forward that set it left their columns of qkvc unwritten, the fused
+    // backward leaves the dQ / dK columns of dqkvc unwritten and reports zero weight / bias gradients for query / key (what autograd gives)
+    bool vc_only = false;
     const void* dctx = nullptr;   // backward: [Tseq*S, d]
     void* dqkvc = nullptr;        // backward: [Tseq*S, 4d]
     uint32_t opts = 0;            // PathOpt bits: OPT_VALU_ATTENTION, OPT_WAVE_ATTENTION_BWD
@@ -56,6 +60,9 @@ struct QkvcAttn {
     DropCfg drop1 = {nullptr, 0.f, 0}, drop2 = {nullptr, 0.f, 0};
     int cls_only_seqs = 0;                        // see AttnArgs
     bool hm = false;                              // write Q|K|V|C head-major (see AttnArgs)
+    // beta == 1 only (the author's own setting, scripts/run_pmgt.sh:24): project V and C only -- a column slab is {V, C} x FOUR heads instead of
+    // {Q, K, V, C} x two -- and run the cosine branch alone; the Q / K columns of qkvc are not written (see AttnArgs::vc_only)
+    bool vc_only = false;
     // fp8 mode (hidden 256 only): the projection runs on the block-scaled fp8 MFMA (unit scales) -- W8 = e4m3 copy of W quantised per
     // output channel (value = byte * wscale[n]), x quantised per row inside the kernel (fp8.h contract); the outputs and the
     // attention stay bf16

@@ -1899,9 +1899,12 @@ __device__ __forceinline__ void abw_draw_mval(const AttnArgs& a, const DropKey& 
     }
 }
 
-template <int IT, int BR>
+// VC (beta == 1, AttnArgs::vc_only): the dot-product branch is dead -- its wave (BR 2) keeps only its 16 columns of dV (third phase, from the
+// cosine branch's image alone); no Q / K fragments, scores, softmax, dS2 / P2 images, dQ or dK
+template <int IT, int BR, bool VC = false>
 __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, float mraw, int h, char* scr, int r, int q, int lane) {
     constexpr float L2E = 1.4426950408889634f;
+    if (VC && BR == 2) return;
     float* rho = (float*)(scr + 8192);
     float* madd = rho + 32;
     const int x = 16 * IT + r;
@@ -1962,10 +1965,11 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
     if (BR == 2) abw_draw_mval<BR>(a, kd, st.t, h, x, q, cy.mval);
 }
 
-template <int IT, int BR>
+template <int IT, int BR, bool VC = false>
 __device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, int h, char* scr, int r, int q) {
     constexpr float L2E = 1.4426950408889634f;
     constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
+    if (VC && BR == 2) return;
     char* iS = scr + (BR == 1 ? 0 : 2048);               // dS1 (rows scaled by 1 / |c_i|) | dS2
     char* iP1 = scr + 4096;
     char* iP2 = scr + 6144;
@@ -2064,7 +2068,7 @@ __device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd,
     }
 }
 
-template <int IT, int BR>
+template <int IT, int BR, bool VC = false>
 __device__ __forceinline__ void abw_phase3(const AbwStep& st, AbwCarry& cy, char* scr, int r, int q) {
     constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
     const char* iS = scr + (BR == 1 ? 0 : 2048);
@@ -2079,15 +2083,16 @@ __device__ __forceinline__ void abw_phase3(const AbwStep& st, AbwCarry& cy, char
     // dC, the dot-product wave dK.
     {
         constexpr int CV = BR == 1 ? 0 : 1;
-        const bf16x8 bp1 = abw_tr_img(iP1, 16 * IT, r, q), bp2 = abw_tr_img(iP2, 16 * IT, r, q);
+        const bf16x8 bp1 = abw_tr_img(iP1, 16 * IT, r, q);
         const bf16x8 ao = abw_tr_o(st.oin, 16 * CV, r, q);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp1, z, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp2, dv, 0, 0, 0);                      // P = P1 + P2 meets in the accumulator
+        if (!VC) dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, abw_tr_img(iP2, 16 * IT, r, q), dv, 0, 0, 0);      // P = P1 + P2 meets in the accumulator
         *(bf16x4*)(gout + abw_g_addr(x, 128 + (16 * CV + 4 * q) * 2)) = pack4(dv);              // dV block
     }
     ABW_MARK2("attn I3.dk_or_dc", IT, BR);
-    if (BR == 2) {
+    if (BR == 2 && VC) {
+    } else if (BR == 2) {
         const bf16x8 bs = abw_tr_img(iS, 16 * IT, r, q);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -2146,7 +2151,11 @@ __device__ __forceinline__ void abw_read128x2(uint32_t a0, uint32_t a1, u32x4 (&
         : "memory");
 }
 
-template <int KT>
+// VC (beta == 1, AttnArgs::vc_only): the Q / K halves of every tile are dead.  Attention role: see the phases.  GEMM role: the Q / K rows
+// are not fetched (the DMA lanes of their chunks are masked off), dQ / dK are not copied out, and the weight gradient is dW_{v,c}[64, d] only --
+// all eight waves share ITS n tiles (4 .. 7) and split the k tiles eight ways (half the MFMAs and accumulators per wave); the workgroup's
+// partial carries zeros in the query / key rows, which is what autograd reports for them (pmgt/pmgt/modeling_pmgt.py:519-521).
+template <int KT, bool VC = false>
 __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     using C = AbwCfg<KT>;
     constexpr int D = C::D;
@@ -2174,7 +2183,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     // A SIMD holds waves {k, k + 4, k + 8, k + 12}; issue arbitration is oldest-first, and the per-wave stamps showed the younger wave
     // of each role (4-7, 12-15) taking 40 % longer per interval than its older twin -- at every barrier the workgroup waited for it.
     // Static priority for the younger half evens the two out (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
-    if (wave & 4) __builtin_amdgcn_s_setprio(1);
+    if (VC ? (wave < 4 || wave >= 12) : (wave & 4) != 0) __builtin_amdgcn_s_setprio(1);      // (VC: the four cosine waves instead of the idle half of the attention role)
     // tile ring: step s reads its inputs from ring slot (2 s) & 3 and writes its results to slot (2 s + 1) & 3
     auto in_tile = [](int s) { return C::G0 + ((2 * s) & 3) * C::GB; };
     auto out_tile = [](int s) { return C::G0 + ((2 * s + 1) & 3) * C::GB; };
@@ -2182,7 +2191,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     if (wave < 8) {
         // ================================ attention role ================================
         // waves w and w + 4 share a SIMD: same (tile, branch), the two pairs of the step
-        const int ul = wave >> 2, it = (wave >> 1) & 1, br = wave & 1;         // br = 0: cosine branch (BR 1), 1: dot-product branch (BR 2)
+        // br = 0: cosine branch (BR 1), 1: dot-product branch (BR 2).  VC: the dot-product waves only keep their dV columns, so the four
+        // cosine waves -- the whole attention role then -- are spread one per SIMD (waves 0 .. 3) instead of two on SIMDs 0 and 2
+        const int ul = VC ? (wave & 3) >> 1 : wave >> 2, it = VC ? wave & 1 : (wave >> 1) & 1, br = VC ? wave >> 2 : wave & 1;
         char* scr = smem + C::S0 + ul * C::SCR;
         const DropKey kd = make_drop_key(br == 0 ? a.drop1 : a.drop2);
         auto seq_of = [&](int s) { return 2 * (xs + s * gx) + ul; };
@@ -2234,12 +2245,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     if (on_) {
                         const float mraw = mnext;
                         mnext = mask_of(s + 1);
-                        abw_phase1<IT, BR>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                        abw_phase1<IT, BR, VC>(a, kd, st, cy, mraw, h, scr, r, q, lane);
                     }
                     bar(0);
-                    if (on_) abw_phase2<IT, BR>(a, kd, st, cy, h, scr, r, q);
+                    if (on_) abw_phase2<IT, BR, VC>(a, kd, st, cy, h, scr, r, q);
                     bar(2);
-                    if (on_) abw_phase3<IT, BR>(st, cy, scr, r, q);
+                    if (on_) abw_phase3<IT, BR, VC>(st, cy, scr, r, q);
                     bar(4);
                 }
             } else {
@@ -2251,7 +2262,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     if (s3 >= 0 && s3 < nsteps) {
 #endif
                         const AbwStep st3 = step_of(s3);
-                        abw_phase3<IT, BR>(st3, cy, scr, r, q);
+                        abw_phase3<IT, BR, VC>(st3, cy, scr, r, q);
                     }
                     bar(0);
 #ifdef PMGT_ABW_NO_ATTN
@@ -2263,10 +2274,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     if (on) {
                         const float mraw = mnext;
                         mnext = mask_of(s1 + 1);
-                        abw_phase1<IT, BR>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                        abw_phase1<IT, BR, VC>(a, kd, st, cy, mraw, h, scr, r, q, lane);
                     }
                     bar(2);
-                    if (on) abw_phase2<IT, BR>(a, kd, st, cy, h, scr, r, q);
+                    if (on) abw_phase2<IT, BR, VC>(a, kd, st, cy, h, scr, r, q);
                     bar(4);
                 }
             }
@@ -2282,14 +2293,17 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     }
     // ==================================== GEMM role ====================================
     const int g = wave - 8, gn = g & 1, gk = g >> 1;                 // n tiles 4 gn .. 4 gn + 3, k tiles KQ gk .. KQ gk + KQ - 1
+    constexpr int KQM = VC ? C::KQ / 2 : C::KQ;                      // (VC: n tiles 4 .. 7 for every wave, k tiles KQM g .. KQM g + KQM - 1)
+    static_assert(KQM >= 1, "k tiles per GEMM wave");
+    const int nbase = VC ? 4 : 4 * gn, kbase = VC ? KQM * g : C::KQ * gk, bsel = VC ? (g & 3) : (gk & 3);
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef __attribute__((address_space(1))) const void gbl_void_t;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    f32x4 acc[4][C::KQ], accb = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][KQM], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < C::KQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KQM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // per-lane pieces of the fragment addresses (row part and swizzle key of the "lo" rows; "hi" rows = + 4 rows)
     const int frow = 8 * q + (r >> 2), fkey = abw_f(frow), fsub = (r & 3) >> 1, fhalf = 8 * (r & 1);
     // (fsub is bit 0 of the chunk index, fkey has bit 0 clear; tile bases are multiples of 16 KB from the start of the dynamic LDS)
@@ -2313,8 +2327,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
         uint32_t ba = fla + gb + (uint32_t)(32 * ks * 256), bb = flb + xb + (uint32_t)(32 * ks * C::XROW);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            aa[u] = ba ^ (uint32_t)((2 * (4 * gn + u)) << 4);
-            ab[u] = bb ^ (uint32_t)((2 * (C::KQ * gk + (u % C::KQ))) << 4);
+            aa[u] = ba ^ (uint32_t)((2 * (nbase + u)) << 4);
+            ab[u] = bb ^ (uint32_t)((2 * (kbase + (u % KQM))) << 4);
         }
         // All sixteen transposing reads of the k-step go out back to back (x fragments first), and the MFMAs of dQKVC fragment nt start as
         // soon as ITS two reads have landed (LDS returns in order: lgkmcnt counts down): ONE LDS round trip per k-step instead of two
@@ -2354,11 +2368,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             if (nt == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[6]), "+v"(ta[7]));
             fa[nt] = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * nt][0], ta[2 * nt][1], ta[2 * nt + 1][0], ta[2 * nt + 1][1]});
 #pragma unroll
-            for (int u = 0; u < C::KQ; ++u) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
+            for (int u = 0; u < KQM; ++u) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
         }
-        // bias gradient = column sums of the tile: one more product against all-ones; this wave sums n tile 4 gn + (gk & 3)
+        // bias gradient = column sums of the tile: one more product against all-ones; this wave sums n tile nbase + bsel
         const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-        const bf16x8 fsel = (gk & 3) == 0 ? fa[0] : ((gk & 3) == 1 ? fa[1] : ((gk & 3) == 2 ? fa[2] : fa[3]));
+        const bf16x8 fsel = bsel == 0 ? fa[0] : (bsel == 1 ? fa[1] : (bsel == 2 ? fa[2] : fa[3]));
         accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fsel, ones, accb, 0, 0, 0);
     };
     // LDS-DMA: 52 (d = 256) one-KB instructions per iteration, fixed shares per GEMM wave, straight-line code.  Per-lane address = two
@@ -2407,7 +2421,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);          // source chunk of the head's 256 bytes
                     const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
                     const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
-                    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
+                    // (VC: chunks 0 .. 7 of a row are its Q | K halves -- those lanes sit the instruction out)
+                    if (!VC || c >= 8u)
+                        __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
                 }
             }
             if (g < 4 && (g < 2) == early) {
@@ -2495,7 +2511,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
             for (int p = 0; p < 2; ++p) {
                 const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
                 const int m = 64 * (xs + sg * gx) + row;
-                if (m < M) *(u32x4*)((char*)a.dqkvc + (size_t)(((uint32_t)m * 4u * D + (uint32_t)(hoff + (c >> 2) * ms + (c & 3) * 8)) * 2u)) = v[p];
+                if (m < M && (!VC || c >= 8)) *(u32x4*)((char*)a.dqkvc + (size_t)(((uint32_t)m * 4u * D + (uint32_t)(hoff + (c >> 2) * ms + (c & 3) * 8)) * 2u)) = v[p];
             }
         }
         bar(2);
@@ -2526,18 +2542,25 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     float* slab = w.slab + (int64_t)xs * 4 * D * D;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int n = 4 * gn + nt;                              // 16-row block of the head's 128 rows: matrix n >> 1, half n & 1
+        const int n = nbase + nt;                               // 16-row block of the head's 128 rows: matrix n >> 1, half n & 1
         const int wrow = (n >> 1) * D + h * 32 + 16 * (n & 1) + 4 * q;
 #pragma unroll
-        for (int j = 0; j < C::KQ; ++j)
+        for (int j = 0; j < KQM; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) slab[(int64_t)(wrow + e) * D + 16 * (C::KQ * gk + j) + r] = acc[nt][j][e];
+            for (int e = 0; e < 4; ++e) slab[(int64_t)(wrow + e) * D + 16 * (kbase + j) + r] = acc[nt][j][e];
     }
-    if (r == 0 && w.bias_slab) {
-        const int n = 4 * gn + (gk & 3);
+    if (r == 0 && w.bias_slab && (!VC || g < 4)) {
+        const int n = nbase + bsel;
         const int wrow = (n >> 1) * D + h * 32 + 16 * (n & 1) + 4 * q;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w.bias_slab[(int64_t)xs * 4 * D + wrow + e] = accb[e];
+    }
+    if constexpr (VC) {      // the query / key rows of the head: exact zeros (wave g: rows 8 g .. 8 g + 7 of the 64)
+        for (int i = 0; i < 8; ++i) {
+            const int rr = 8 * g + i, wrow = (rr >> 5) * D + h * 32 + (rr & 31);
+            for (int cc = lane * 4; cc < D; cc += 256) *(f32x4*)(slab + (int64_t)wrow * D + cc) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g == 0 && w.bias_slab) w.bias_slab[(int64_t)xs * 4 * D + (lane >> 5) * D + h * 32 + (lane & 31)] = 0.f;
     }
 }
 
@@ -2552,12 +2575,13 @@ bool attn_bwd_wgrad_supported(const AttnBwdWg& w) {
            ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.dctx % 16) == 0 && ((uintptr_t)a.dqkvc % 16) == 0;
 }
 
-template <int KT> static int launch_abw(const AttnBwdWg& w, hipStream_t st) {
+template <int KT, bool VC = false> static int launch_abw(const AttnBwdWg& w, hipStream_t st) {
     using C = AbwCfg<KT>;
-    auto kern = attn_bwd_wgrad_kernel<KT>;
+    auto kern = attn_bwd_wgrad_kernel<KT, VC>;
     PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
     const int gx = attn_bwd_wgrad_parts(w.a.H);
     note_launch(LT_ATTN_BWD_WGRAD);
+    if (VC) note_launch(LT_ATTN_BWD_WGRAD_VC);
     hipLaunchKernelGGL(kern, dim3(gx * w.a.H), dim3(1024), C::SMEM, st, w);
     PMGT_LAUNCH_OK();
     return 0;
@@ -2565,6 +2589,10 @@ template <int KT> static int launch_abw(const AttnBwdWg& w, hipStream_t st) {
 
 int attn_bwd_wgrad(const AttnBwdWg& w, hipStream_t st) {
     PMGT_CHECK(attn_bwd_wgrad_supported(w), -2, "attn_bwd_wgrad: unsupported shape S=%d dh=%d H=%d", w.a.S, w.a.dh, w.a.H);
+    if (w.a.vc_only) {
+        PMGT_CHECK(w.a.beta == 1.f, -2, "attn_bwd_wgrad: vc_only is the beta == 1 form (beta = %g)", (double)w.a.beta);
+        return w.a.H * 32 == 256 ? launch_abw<16, true>(w, st) : launch_abw<8, true>(w, st);
+    }
     return w.a.H * 32 == 256 ? launch_abw<16>(w, st) : launch_abw<8>(w, st);
 }
 

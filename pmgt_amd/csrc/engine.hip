@@ -36,7 +36,7 @@ void note_launch(int tag) { if (tag >= 0 && tag < LT_COUNT) ++g_launch_count[tag
 static const char* const g_launch_names[LT_COUNT] = {
     "gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_tile",
     "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
-    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf", "embed_tok8"};
+    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc"};
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -284,6 +284,7 @@ template <typename T> struct Bufs {
     bool side_wgrad = false, side_pending = false;
     hipEvent_t side_last = nullptr;
     bool qkvc_hm = false;   // Q|K|V|C (and its gradient) are stored head-major (fused forward + one-wave MFMA backward)
+    bool qkvc_vc = false;   // beta == 1: only the V | C columns of Q|K|V|C (and of its gradient) exist (vc_only_applies)
     bool e_by_id = false;   // E holds the projection of the whole table (rows = node ids) instead of one row per token
     float *a, *emb_stats;
     std::vector<LayerBufs<T>> layer;
@@ -549,6 +550,17 @@ static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool 
     return S == 32 && e->dh == 32 && (e->d == 256 || e->d == 128) && e->H % 2 == 0 && Tseq >= 2;
 }
 
+// beta == 1 (the author's own setting, scripts/run_pmgt.sh:24): the dot-product softmax is multiplied by exactly 0 (pmgt/pmgt/modeling_pmgt.py:519-521),
+// so Q and K, their softmax and its backward are dead.  The fused forward / backward pair then projects, stores and differentiates V | C only
+// (AttnArgs::vc_only); the query / key weight and bias gradients are exact zeros, as autograd reports them.  A pure function of configuration,
+// shape and options: the forward and a separate backward call take the same decision.  (The generic kernels still READ Q and K, so the pair
+// is all-or-nothing: no fused backward, no skip.)
+template <typename T>
+static inline bool vc_only_applies(const pmgt_engine* e, int Tseq, int S, bool want_probs) {
+    if (e->cfg.beta != 1.f || e->fp8 || e->H % 4 != 0 || (e->opts & (OPT_NO_BETA_SKIP | OPT_NO_FUSED_ATTENTION_BWD))) return false;
+    return fused_qa_applies<T>(e, Tseq, S, want_probs);
+}
+
 static inline bool use_table_projection(const pmgt_engine* e, const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {
     // (the per-node buffers of the table mode live inside per-token buffers: [N+2, (NF+1) d] in E [M, max(NF, 2) d],
     //  dE [N+2, NF d] in a [M, d] temporary)
@@ -637,12 +649,16 @@ static int encoder_forward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>&
             f.drop2 = dropcfg(t, train, pa, l, SITE_A2);
             f.cls_only_seqs = (shortcut && l == L - 1) ? n_cls_only : 0;
             f.hm = train && !(e->opts & OPT_NO_HEAD_MAJOR);        // the backward that reads it understands the layout; inference keeps q | k | v | c
+            f.vc_only = vc_only_applies<T>(e, Tseq, S, attn_probs != nullptr);
             if (e->fp8) { f.W8 = b.mirror8 + o.m8Wqkvc; f.wscale = b.mscale + o.s8Wqkvc; }
             if (e->fp8 && x8_ok) { f.X8 = b.x8; f.xscale = b.xscale; f.ldx = d; }
             if (fused_qa_applies<T>(e, Tseq, S, attn_probs != nullptr) && qkvc_attn_supported(f)) {
                 RUNP("fwd.qkvc_attention", qkvc_attn_fwd(f, st));
                 fused = true;
                 b.qkvc_hm = f.hm;
+                b.qkvc_vc = f.vc_only;
+            } else {
+                PMGT_CHECK(!f.vc_only, -2, "beta == 1 skip: the fused projection + attention kernel refused a shape vc_only_applies() accepted");
             }
         }
         if (!fused && e->fp8) {   // per-row e4m3 of the layer input, then the fp8 GEMM
@@ -1007,6 +1023,16 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
         }
         RUN(wait_event(st, w1_done));                // the attention backward writes dQ|dK|dV|dC into the buffer d ff_pre lived in
         bool fused_bw = false;
+        // (beta == 1 skip) whether dX = dQKVC W can walk the V | C blocks only: decided here, in front of the launch that writes dQKVC
+        bool vc_dgrad_kmap = false;
+        if constexpr (sizeof(T) == 2) {
+            if (b.qkvc_vc && b.qkvc_hm) {
+                GemmNT gp; gp.opts = e->opts;
+                gp.A = b.big; gp.lda = 4 * d; gp.B = b.mirror + o.mWqkvcT_hm; gp.ldb = 4 * d; gp.C = b.bA; gp.ldc = d; gp.M = M; gp.N = d; gp.K = 2 * d;
+                gp.res = sc ? nullptr : b.bB; gp.ldr = d; gp.kmap_vc = 1;
+                vc_dgrad_kmap = gemm_nt_big_applies(gp);
+            }
+        }
         {
             AttnArgs a; a.opts = e->opts;
             a.qkvc = lb.qkvc; a.mask = b.mask; a.Tseq = Tseq; a.S = S; a.H = H; a.dh = e->dh; a.beta = e->cfg.beta;
@@ -1015,6 +1041,7 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             a.dctx = b.bD; a.dqkvc = b.big;
             a.cls_only_seqs = sc ? n_cls_only : 0;       // their dctx is non-zero at row 0 only (scatter_rows above)
             a.hm = b.qkvc_hm;
+            a.vc_only = b.qkvc_vc;
             if constexpr (sizeof(T) == 2) {
                 // headline shape: attention backward and the Q|K|V|C weight gradient in ONE launch (attention waves + GEMM waves per
                 // CU): dQ|dK|dV|dC are not re-read for the weight gradient, and its partial sums shrink from one slab per M-split to
@@ -1033,6 +1060,10 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                 w.bias_slab = b.part_side + (int64_t)slot * b.part_side_elems;
                 const bool abw_ok = !(e->opts & (OPT_NO_FUSED_ATTENTION_BWD | OPT_TILE_GEMM | OPT_VALU_ATTENTION)) && (int64_t)parts * 4 * d * d <= b.slab_elems &&
                                     (int64_t)parts * 4 * d <= b.part_side_elems && attn_bwd_wgrad_supported(w);
+                PMGT_CHECK(abw_ok || !b.qkvc_vc, -2, "beta == 1 skip: the forward left Q / K unwritten but the fused attention backward does not apply here");
+                // dX = dV W_v + dC W_c below skips the dQ / dK blocks of a head-major gradient by k-step on the 256 x 256 tile; where that tile
+                // does not run (small M) the full product runs over dQ = dK = 0
+                if (b.qkvc_vc && b.qkvc_hm && !vc_dgrad_kmap) PMGT_HIP(hipMemsetAsync(b.big, 0, (size_t)M * 4 * d * sizeof(T), st));
                 if (abw_ok && b.defer) {
                     RUN(take_partials2<T>(e, b, (int64_t)parts * 4 * d * d, &w.slab, (int64_t)parts * 4 * d, &w.bias_slab, st));
                     RUNP("bwd.attention_wgrad", attn_bwd_wgrad(w, st));
@@ -1063,6 +1094,8 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
             GemmNT g; g.opts = e->opts;
             g.A = b.big; g.lda = 4 * d; g.B = b.mirror + (b.qkvc_hm ? o.mWqkvcT_hm : o.mWqkvcT); g.ldb = 4 * d; g.C = b.bA; g.ldc = d;
             g.M = M; g.N = d; g.K = 4 * d; g.res = sc ? nullptr : b.bB; g.ldr = d;
+            if (b.qkvc_vc && vc_dgrad_kmap) { g.kmap_vc = 1; g.K = 2 * d; }                       // head-major: the V | C block of every head
+            else if (b.qkvc_vc && !b.qkvc_hm) { g.A = b.big + 2 * d; g.B = b.mirror + o.mWqkvcT + 2 * d; g.K = 2 * d; }      // q | k | v | c: the upper half
             bool with_ln = false;
             if constexpr (sizeof(T) == 2) {
                 // d hin is the gradient of layer l - 1's output LayerNorm (BertOutput): its backward runs on the tile's rows behind the
@@ -1322,6 +1355,7 @@ static int encode_backward(pmgt_engine* e, const pmgt_tensors* t, const void* co
     tt.rng_state = (uint64_t*)b.rng_snap;          // the forward's (seed, step)
     b.e_by_id = use_table_projection(e, t, (int64_t)Tseq * S, feats == nullptr);      // same decisions as the forward took
     b.qkvc_hm = train && !(e->opts & OPT_NO_HEAD_MAJOR) && fused_qa_applies<T>(e, Tseq, S, false);
+    b.qkvc_vc = vc_only_applies<T>(e, Tseq, S, false);
     PMGT_HIP(hipMemcpyAsync(b.bA, d_last, (size_t)Tseq * S * e->d * sizeof(T), hipMemcpyDeviceToDevice, st));
     RUN(encoder_backward<T>(e, &tt, b, Tseq, S, acc, st, false, train, feats));
     return 0;
@@ -1628,7 +1662,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}, {"no_beta_skip", OPT_NO_BETA_SKIP}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;
@@ -1720,6 +1754,19 @@ int pmgt_op_qkvc_attention_fwd(const void* x, const void* w, const float* bias, 
     PMGT_CHECK(qkvc_attn_supported(f), -3, "pmgt_op_qkvc_attention_fwd: unsupported shape (needs bf16, S = 32, dh = 32, d in {128, 256})");
     return qkvc_attn_fwd(f, (hipStream_t)stream);
 }
+int pmgt_op_qkvc_attention_fwd_ex(const void* x, const void* w, const float* bias, const float* mask, void* qkvc, void* ctx, int n_seq, int S,
+                                  int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng, int flags, void* stream) {
+    QkvcAttn f;
+    const int d = H * dh;
+    f.X = x; f.ldx = d; f.W = w; f.ldw = d; f.bias = bias; f.qkvc = qkvc; f.ldq = 4 * d; f.ctx = ctx; f.ldc = d; f.mask = mask;
+    f.Tseq = n_seq; f.S = S; f.H = H; f.dh = dh; f.beta = beta;
+    f.drop1 = DropCfg{rng, drop_p, site1};
+    f.drop2 = DropCfg{rng, drop_p, site2};
+    f.hm = (flags & 1) != 0; f.vc_only = (flags & 2) != 0;
+    PMGT_CHECK(x && w && qkvc && ctx, -2, "pmgt_op_qkvc_attention_fwd_ex: NULL argument");
+    PMGT_CHECK(qkvc_attn_supported(f), -3, "pmgt_op_qkvc_attention_fwd_ex: unsupported shape / flags (bf16, S = 32, dh = 32, d in {128, 256}; vc_only: beta == 1, H %% 4 == 0)");
+    return qkvc_attn_fwd(f, (hipStream_t)stream);
+}
 
 int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const void* dctx, void* dqkvc, int n_seq, int S,
                           int H, int dh, float beta, float drop_p, uint32_t site1, uint32_t site2, const uint64_t* rng,
@@ -1736,7 +1783,7 @@ int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void*
                                 const uint64_t* rng, int head_major, void* stream) {
     AttnBwdWg w;
     w.a = mk_attn(qkvc, mask, n_seq, 32, H, 32, beta, drop_p, site1, site2, rng);
-    w.a.dctx = dctx; w.a.dqkvc = dqkvc; w.a.hm = head_major != 0;
+    w.a.dctx = dctx; w.a.dqkvc = dqkvc; w.a.hm = (head_major & 1) != 0; w.a.vc_only = (head_major & 2) != 0;
     w.x = x; w.ldx = (int64_t)H * 32; w.slab = slab; w.bias_slab = bias_slab;
     PMGT_CHECK(attn_bwd_wgrad_supported(w), -3, "pmgt_op_attention_bwd_wgrad: unsupported shape (needs bf16, S = 32, dh = 32, d in {128, 256}, n_seq >= 2)");
     return attn_bwd_wgrad(w, (hipStream_t)stream);

@@ -45,9 +45,14 @@ struct GemmNT {
     const float* lnf_beta = nullptr;
     float lnf_eps = 1e-12f;
     bool lnf_skip_c = false;
+    // 256 x 256 LDS-DMA tile only (dX = dQKVC W at beta == 1, where dQ = dK = 0 and their columns of A were never written): A and B are
+    // head-major Q|K|V|C-shaped along k ([head][q, k, v, c][32]); K counts the V | C elements (2 d) and logical k-step kt reads block
+    // 2 + (kt & 1) of head kt >> 1.  Every other kernel refuses it.
+    int kmap_vc = 0;
     uint32_t opts = 0;                 // PathOpt bits of the calling engine (OPT_TILE_GEMM: register-staged 128 x 128 tile only)
 };
 template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st);
+bool gemm_nt_big_applies(const GemmNT& g);      // bf16: whether gemm_nt takes the 256-row LDS-DMA tiles for this problem (kmap_vc: the 256-wide one)
 // the 256 x 256 LDS-DMA tile with the LayerNorm-backward phase behind its main loop (lnb_* fields; bf16, N = 256, K % 64 == 0);
 // partials: [gemm_nt_lnb_parts(M)][3][256]
 bool gemm_nt_lnb_ok(const GemmNT& g);

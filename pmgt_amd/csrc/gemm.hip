@@ -272,15 +272,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         const int ch = (lane & 3) ^ nt_swz(row);
         bsrc[j] = (const char*)g.B + (int64_t)(n0 + row) * g.ldb * 2 + ch * 16;
     }
+    // (uniform) byte offset of logical k-step kt inside a row of A / B.  kmap_vc: the operands are head-major Q|K|V|C-shaped ([.., head, {q, k, v, c},
+    // 32]) and only the V | C blocks take part (beta == 1: dQ = dK = 0 exactly) -- logical step kt is block 2 + (kt & 1) of head kt >> 1
+    const bool kvc = g.kmap_vc != 0;
+    auto koff = [&](int kt) { return (int64_t)(kvc ? ((kt >> 1) << 2) + 2 + (kt & 1) : kt) * ROWB; };
     auto issue = [&](int kt) {
         char* st = smem + (kt % NST) * STAGE;
+        const int64_t ko = koff(kt);
 #pragma unroll
         for (int j = 0; j < AI; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + (int64_t)kt * ROWB),
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + ko),
                                              (lds_void_t*)(st + 16 * (AI * wave + j) * ROWB), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < BI; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + (int64_t)kt * ROWB),
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + ko),
                                              (lds_void_t*)(st + BM * ROWB + 16 * (BI * wave + j) * ROWB), 16, 0, 0);
     };
     // one DMA instruction of a stage (piece 0 .. AI - 1: A rows, AI .. PER - 1: B rows)
@@ -293,10 +298,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
         if (piece >= AI && g.M > 0) return;
 #endif
         if (piece < AI)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[piece] + (int64_t)kt * ROWB),
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[piece] + koff(kt)),
                                              (lds_void_t*)(st + 16 * (AI * wave + piece) * ROWB), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[piece - AI] + (int64_t)kt * ROWB),
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[piece - AI] + koff(kt)),
                                              (lds_void_t*)(st + BM * ROWB + 16 * (BI * wave + piece - AI) * ROWB), 16, 0, 0);
     };
     f32x4 acc[8][4];
@@ -869,6 +874,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_big_kernel(GemmNT g) {
 }
 
 static bool nt_big_ok(const GemmNT& g) {
+    if (g.kmap_vc && !(g.N == 256 && g.K % 64 == 0 && g.lda >= 2 * g.K && g.ldb >= 2 * g.K)) return false;      // V | C-only k-steps: the 256-wide tile only
     // fewer than ~96 tiles of 256 rows leave most of the 256 CUs idle: the 128 x 128 tile then wins (dX = dQKVC W at B = 32 targets,
     // M = 12 288, K = 1 024, N = 256: 48 big tiles 32.5 us, 192 small ones 22.6 us; equal at M = 24 576)
     if ((int64_t)cdiv(g.M, 256) * cdiv(g.N, 256) < 96) return false;
@@ -877,6 +883,8 @@ static bool nt_big_ok(const GemmNT& g) {
            (g.aux == nullptr || g.ldaux % 8 == 0) && ((uintptr_t)g.C % 16) == 0 && (g.res == nullptr || ((uintptr_t)g.res % 16) == 0) &&
            (g.aux == nullptr || ((uintptr_t)g.aux % 16) == 0) && (g.bias == nullptr || ((uintptr_t)g.bias % 16) == 0);
 }
+
+bool gemm_nt_big_applies(const GemmNT& g) { return nt_big_ok(g) && (!g.kmap_vc || (g.N % 256 == 0 && g.K % 64 == 0)); }
 
 // ---- dy = A W^T + res (K > 512: dX = dQKVC W) followed by the LayerNorm backward of dy in the same launch
 int gemm_nt_lnb_parts(int M) { return cdiv(M, 256); }
@@ -892,6 +900,7 @@ int gemm_nt_lnb(const GemmNT& g, hipStream_t st) {
     constexpr int smem = 4 * (256 + 256) * 64;
     PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8, 1>), smem);
     note_launch(LT_NT_LNB);
+    if (g.kmap_vc) note_launch(LT_NT_VC);
     hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8, 1>), dim3(cdiv(cdiv(g.M, 256), 8) * 8), dim3(512), smem, st, g);
     PMGT_LAUNCH_OK();
     return 0;
@@ -932,6 +941,7 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
     PMGT_CHECK(g.epi == EPI_NONE || g.aux != nullptr, -2, "gemm_nt: epilogue %d needs aux", g.epi);
     PMGT_CHECK(g.N % 4 == 0 && g.ldc % 4 == 0 && (g.res == nullptr || g.ldr % 4 == 0) && (g.aux == nullptr || g.ldaux % 4 == 0),
                -2, "gemm_nt: N and the output leading dimensions must be multiples of 4 (N=%d ldc=%lld)", g.N, (long long)g.ldc);
+    PMGT_CHECK(!g.kmap_vc || (sizeof(T) == 2 && gemm_nt_big_applies(g)), -2, "gemm_nt: the V | C-only k-step map needs the 256 x 256 tile (M=%d N=%d K=%d)", g.M, g.N, g.K);
     constexpr int BM = 128, BN = 128;
     const int num_m = cdiv(g.M, BM), num_n = cdiv(g.N, BN);
     const int grid = cdiv(num_m, 8) * 8 * num_n;
@@ -942,6 +952,7 @@ template <typename T> int gemm_nt(const GemmNT& g, hipStream_t st) {
                 constexpr int smem = 4 * (256 + 256) * 64;
                 PMGT_SMEM_ATTR(((const void*)gemm_nt_big_kernel<256, 8>), smem);
                 note_launch(g.a_rows ? LT_NT_BIG_GATHER : LT_NT_BIG);
+                if (g.kmap_vc) note_launch(LT_NT_VC);
                 hipLaunchKernelGGL((gemm_nt_big_kernel<256, 8>), dim3(cdiv(nm, 8) * 8 * (g.N / 256)), dim3(512), smem, st, g);
             } else {
                 constexpr int smem = 3 * (256 + 128) * 64;

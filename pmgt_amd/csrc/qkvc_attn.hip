@@ -130,19 +130,21 @@ struct QaAttnConst {
 // `mv` = additive mask term of key (lane & 31), (1 - mask) * -10000 (0 for an inactive tile), loaded by the caller -- the role-split kernel
 // fetches it one problem ahead; `mid()` runs between the softmax and the P V half (that kernel's workgroup barrier; empty otherwise).
 // IT >= 0: the query half as a compile-time constant (the diagonal term and the operand selects below fold away)
-template <int IT = -1, typename Mid>
+// MODE 1 (beta == 1): the tile holds V | C of FOUR heads (chunks 4 uh + q | 16 + 4 uh + q) and only the cosine branch runs -- no Q / K fragments,
+// no dot-product scores, row maximum, exponentials or dropout draws of that branch (about half of this VALU-bound phase)
+template <int IT = -1, int MODE = 0, typename Mid>
 __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* qt, int R0, int uh, int it_rt, int t, int h, int H,
                                             bool has_mask, float mv, float* rho, float* madd, bf16* ctx_row, bool act, int r, int q,
                                             int lane, Mid&& mid) {
     const int it = IT >= 0 ? IT : it_rt;
     constexpr float L2E = 1.4426950408889634f;
-    auto blk = [&](int mtx) { return 4 * (2 * mtx + uh) + q; };
+    auto blk = [&](int mtx) { return MODE == 1 ? 4 * ((mtx == 3 ? 4 : 0) + uh) + q : 4 * (2 * mtx + uh) + q; };
     bf16x8 fq, fk[2], fc[2];
     float ss[2], rho_own[2];
-    fq = *(const bf16x8*)(qt + qt_addr(R0 + 16 * it + r, blk(0)));
+    if (MODE == 0) fq = *(const bf16x8*)(qt + qt_addr(R0 + 16 * it + r, blk(0)));
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-        fk[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(1)));
+        if (MODE == 0) fk[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(1)));
         fc[jt] = *(const bf16x8*)(qt + qt_addr(R0 + 16 * jt + r, blk(3)));
         float s = 0.f;
 #pragma unroll
@@ -168,7 +170,7 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
         for (int e = 0; e < 4; ++e) z1[e] = (kc.dg[e] && it == jt) ? -ss[jt] : 0.f;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         a1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[jt], it == 0 ? fc[0] : fc[1], z1, 0, 0, 0);
-        a2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq, z, 0, 0, 0);
+        if (MODE == 0) a2[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq, z, 0, 0, 0);
     }
     const float rl = (it == 0 ? rho_own[0] : rho_own[1]) * L2E;
     constexpr float isql = 0.17677669529663687f * L2E;      // log2(e) / sqrt(32)
@@ -181,24 +183,28 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             a1[jt][e] = fmaf(-a1[jt][e], rl * rj[e], mj[e]);
-            a2[jt][e] = fmaf(a2[jt][e], isql, mj[e]);
-            m2 = raw_max(m2, a2[jt][e]);
+            if (MODE == 0) {
+                a2[jt][e] = fmaf(a2[jt][e], isql, mj[e]);
+                m2 = raw_max(m2, a2[jt][e]);
+            }
         }
     }
-    m2 = qred(m2, true);
+    if (MODE == 0) m2 = qred(m2, true);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             a1[jt][e] = __builtin_amdgcn_exp2f(a1[jt][e]);
-            a2[jt][e] = __builtin_amdgcn_exp2f(a2[jt][e] - m2);
             s1 += a1[jt][e];
-            s2 += a2[jt][e];
+            if (MODE == 0) {
+                a2[jt][e] = __builtin_amdgcn_exp2f(a2[jt][e] - m2);
+                s2 += a2[jt][e];
+            }
         }
     s1 = qred(s1, false);
-    s2 = qred(s2, false);
-    const float c1 = kc.c_beta * __builtin_amdgcn_rcpf(s1), c2 = kc.c_omb * __builtin_amdgcn_rcpf(s2);
+    if (MODE == 0) s2 = qred(s2, false);
+    const float c1 = kc.c_beta * __builtin_amdgcn_rcpf(s1), c2 = MODE == 0 ? kc.c_omb * __builtin_amdgcn_rcpf(s2) : 0.f;
     mid();
     // mix + dropout -> P^T, packed as the B operand (k slot e of lane (r, q): key 16 (e >> 2) + 4 q + (e & 3))
     bf16x8 pb;
@@ -210,10 +216,11 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
             bool kp1[4] = {true, true, true, true}, kp2[4] = {true, true, true, true};
             if (kc.k1.on) {
                 drop_keep4(kc.k1, hrow, (uint32_t)(4 * jt + q), kp1);
-                drop_keep4(kc.k2, hrow, (uint32_t)(4 * jt + q), kp2);
+                if (MODE == 0) drop_keep4(kc.k2, hrow, (uint32_t)(4 * jt + q), kp2);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pb[4 * jt + e] = (bf16)fmaf(c1, kp1[e] ? a1[jt][e] : 0.f, kp2[e] ? c2 * a2[jt][e] : 0.f);
+            for (int e = 0; e < 4; ++e)
+                pb[4 * jt + e] = MODE == 0 ? (bf16)fmaf(c1, kp1[e] ? a1[jt][e] : 0.f, kp2[e] ? c2 * a2[jt][e] : 0.f) : (bf16)(kp1[e] ? c1 * a1[jt][e] : 0.f);
         }
     }
     // O^T[c][i] = sum_j V[j][c] P[i][j]: A operand = transposed read of the V block (rows = keys)
@@ -221,7 +228,7 @@ __device__ __forceinline__ void qa_attention(const QaAttnConst& kc, const char* 
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int row_lo = R0 + 4 * q + (r >> 2), row_hi = row_lo + 16;
-        const int cb = (2 * 2 + uh) * 64 + (16 * ct + 4 * (r & 3)) * 2;      // byte column inside the row: V block of this head
+        const int cb = (MODE == 1 ? uh : 2 * 2 + uh) * 64 + (16 * ct + 4 * (r & 3)) * 2;      // byte column inside the row: V block of this head
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_lo, cb >> 4) + (cb & 15)));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qt + qt_addr(row_hi, cb >> 4) + (cb & 15)));
         const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -493,20 +500,27 @@ template <int KS> struct QaCfg3 {
 typedef __attribute__((address_space(3))) void qa_lds_void_t;
 typedef __attribute__((address_space(1))) const void qa_gbl_void_t;
 
-template <int KS>
+// VC (beta == 1, QkvcAttn::vc_only): a column slab is {V, C} x {heads 4 y .. 4 y + 3} -- GEMM wave g = (matrix 2 + (g >> 2), head 4 y + (g & 3)) --
+// so a step covers FOUR heads of its sequence with the same projection work per wave, and the eight attention waves (head uh = aw >> 1,
+// query half aw & 1) each run the cosine branch of one problem per step instead of both branches of one problem per two steps: half the
+// iterations per launch, and Q / K are neither projected nor written.
+template <int KS, bool VC = false>
 __global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
     using C = QaCfg3<KS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int d = a.H * 32, ny = a.H / 2;
+    const int d = a.H * 32, ny = VC ? a.H / 4 : a.H / 2;
     const int b = blockIdx.x;
     const int y = (b >> 3) % ny, x = (b & 7) + 8 * (b / (8 * ny));
     const int gx = gridDim.x / ny;
     const int nsteps = x < a.Tseq ? (a.Tseq - x + gx - 1) / gx : 0;       // sequences x, x + gx, ... (uniform over the workgroup)
     const int NI = nsteps + 2;
-    auto gcol = [&](int c) { return (c >> 6) * d + (2 * y + ((c >> 5) & 1)) * 32 + (c & 31); };
-    auto ocol = [&](int c) { return a.hm ? ((2 * y + ((c >> 5) & 1)) * 4 + (c >> 6)) * 32 + (c & 31) : gcol(c); };
+    // tile column c -> (matrix, head): {q, k, v, c} x two heads, or (VC) {v, c} x four heads
+    auto cmat = [&](int c) { return VC ? 2 + (c >> 7) : (c >> 6); };
+    auto chead = [&](int c) { return VC ? 4 * y + ((c >> 5) & 3) : 2 * y + ((c >> 5) & 1); };
+    auto gcol = [&](int c) { return cmat(c) * d + chead(c) * 32 + (c & 31); };
+    auto ocol = [&](int c) { return a.hm ? (chead(c) * 4 + cmat(c)) * 32 + (c & 31) : gcol(c); };
     QA3_PROF_DECL
     // LDS operations of this wave done, then the workgroup barrier (no vmcnt wait: the DMA ring stays in flight across it)
     auto bar = [&]() __attribute__((always_inline)) {
@@ -519,8 +533,8 @@ __global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
 
     if (wave >= 8) {
         // ================================ attention role ================================
-        const int aw = wave - 8, grp = aw >> 2, uh = (aw >> 1) & 1, it = aw & 1;
-        const int h = 2 * y + uh;
+        const int aw = wave - 8, grp = aw >> 2, uh = VC ? aw >> 1 : (aw >> 1) & 1, it = aw & 1;
+        const int h = (VC ? 4 : 2) * y + uh;
         const QaAttnConst kc = qa_attn_const(a, r, q);
         float* rho = (float*)(smem + C::WL0) + aw * 64;
         float* madd = rho + 32;
@@ -530,6 +544,26 @@ __global__ __launch_bounds__(1024) void qkvc_attn_fwd3_kernel(QkvcAttn a) {
         // ever makes them wait on vmcnt -- a global load of the mask value, even one problem ahead, put an s_waitcnt vmcnt(0) at the top of
         // every problem, which waited for the previous problem's context STORE to be acknowledged (65 us of a 390 us launch).
         __builtin_amdgcn_s_barrier();                     // the GEMM role's "x(0) has landed" barrier
+        if constexpr (VC) {
+            // every wave, every step: the problem of step s (tile written in iteration s) runs inside iteration s + 1
+            bar();
+            auto nomid = []() {};
+            for (int s = 0; s < nsteps; ++s) {
+                const int t = x + s * gx;
+                const float mv = has_mask ? (1.f - *(const float*)(smem + C::MK0 + (s & 7) * 128 + (lane & 31) * 4)) * -10000.f : 0.f;
+                const char* qt = smem + C::Q0 + (s & 3) * C::QTB;
+                if (!(it == 1 && t < a.cls_only_seqs)) {
+                    bf16* crow = CTX + ((int64_t)t * 32 + 16 * it + r) * a.ldc + h * 32;
+                    if (it == 0) qa_attention<0, 1>(kc, qt, 0, uh, 0, t, h, a.H, has_mask, mv, rho, madd, crow, true, r, q, lane, nomid);
+                    else qa_attention<1, 1>(kc, qt, 0, uh, 1, t, h, a.H, has_mask, mv, rho, madd, crow, true, r, q, lane, nomid);
+                }
+                QA3_STAMP(2);
+                bar();
+            }
+            bar();
+            QA3_PROF_FLUSH;
+            return;
+        }
         int nb = 0;
         for (; nb < 1 + grp; ++nb) bar();                 // the iterations before this group's first tile exists
         for (int s = grp; s < nsteps; s += 2, nb += 2) {
@@ -727,6 +761,7 @@ bool qkvc_attn_supported(const QkvcAttn& a) {
     if (!a.W8 && !qa3_ok(a)) return false;      // bf16: the role-split form only
     if (a.W8 && !(d == 256 && a.wscale && ((uintptr_t)a.W8 % 8) == 0)) return false;
     if (a.X8 && !(a.W8 && a.xscale && ((uintptr_t)a.X8 % 8) == 0)) return false;
+    if (a.vc_only && !(a.beta == 1.f && a.H % 4 == 0 && !a.W8)) return false;      // V | C of four heads per slab, cosine branch alone
     return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.H % 2 == 0 && a.Tseq >= 2 && a.ldx % 8 == 0 && a.ldw % 8 == 0 &&
            a.ldq % 8 == 0 && a.ldc % 4 == 0 && (a.X8 != nullptr || (a.X != nullptr && ((uintptr_t)a.X % 16) == 0)) && ((uintptr_t)a.W % 16) == 0 &&
            ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.ctx % 8) == 0 && (a.bias == nullptr || ((uintptr_t)a.bias % 16) == 0) &&
@@ -746,13 +781,14 @@ template <int KS, int F8> static int launch_qa2(const QkvcAttn& a, hipStream_t s
     return 0;
 }
 
-template <int KS> static int launch_qa3(const QkvcAttn& a, hipStream_t st) {
+template <int KS, bool VC = false> static int launch_qa3(const QkvcAttn& a, hipStream_t st) {
     using C = QaCfg3<KS>;
-    auto kern = qkvc_attn_fwd3_kernel<KS>;
+    auto kern = qkvc_attn_fwd3_kernel<KS, VC>;
     PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
-    const int ny = a.H / 2;
+    const int ny = VC ? a.H / 4 : a.H / 2;
     const int gx = std::max(8, std::min(256 / ny, a.Tseq) / 8 * 8);       // one 16-wave workgroup per CU
     note_launch(LT_QKVC_ATTN_FWD);
+    if (VC) note_launch(LT_QKVC_ATTN_FWD_VC);
     hipLaunchKernelGGL(kern, dim3(gx * ny), dim3(1024), C::SMEM, st, a);
     PMGT_LAUNCH_OK();
     return 0;
@@ -765,6 +801,7 @@ int qkvc_attn_fwd(const QkvcAttn& a, hipStream_t st) {
     PMGT_CHECK(qkvc_attn_supported(a), -2, "qkvc_attn_fwd: unsupported shape S=%d dh=%d H=%d", a.S, a.dh, a.H);
     if (a.W8 && a.X8) return launch_qa2<8, 2>(a, st);
     if (a.W8) return launch_qa2<8, 1>(a, st);
+    if (a.vc_only) return a.H * 32 == 256 ? launch_qa3<8, true>(a, st) : launch_qa3<4, true>(a, st);
     return a.H * 32 == 256 ? launch_qa3<8>(a, st) : launch_qa3<4>(a, st);
 }
 

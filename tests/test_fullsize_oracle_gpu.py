@@ -112,6 +112,9 @@ def compare(eng, out, p, ref, dtype, fp32_engine=None):
         if ".key.bias" in name:          # the softmax over keys is invariant to the key bias: exactly 0 in exact arithmetic
             assert float(a.abs().max()) < 1e-4 * gscale and float(b.abs().max()) < 1e-4 * gscale, name
             continue
+        if float(b.abs().max()) == 0.0:  # a gradient the reference reports as exactly zero (query / key at beta = 1): nothing to take a cosine of
+            assert float(a.abs().max()) <= 1e-6 * gscale, name
+            continue
         err = float((a - b).abs().max())
         if dtype == "fp32":
             if err > 2e-3 * float(b.abs().max()) + 1e-9:
@@ -295,6 +298,49 @@ def test_hidden_512_step_at_the_headline_shard_matches_the_oracle():
     assert ran["nt_big_gather"] == 2 and ran["tn_big_gather"] == 2 and ran["gemm_wsr512"] >= 4 and ran["attn_tiles_bwd"] >= 1, ran
     p, ref = run_oracle_chunked(case, tabs, chunk=32)
     compare(eng, out, p, ref, "bf16", fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tabs])[0])
+
+
+@pytest.mark.parametrize("B", [192, 7])
+def test_c2_at_beta_one_skips_the_dead_branch_and_matches_the_oracle(B):
+    """beta = 1.0 is what the author trains with (scripts/run_pmgt.sh:24): the dot-product softmax is multiplied by exactly 0
+    (pmgt/pmgt/modeling_pmgt.py:519-521).  C2 at beta = 1 against the oracle (pinned at beta = 1 by the m1_beta1 and e_script fixtures): the launch
+    trace shows the vc_only forward / backward and, at full size, the V | C-only k-steps of dX = dQKVC W; query / key weight and bias
+    gradients are EXACT zeros (what autograd reports); the general kernels (`no_beta_skip`) give the same step.  B = 7: the small-M path
+    (the 128 x 128 tiles run dX over zero-filled dQ | dK)."""
+    from pmgt_amd import _lib
+    from pmgt_amd.configuration_pmgt import PMGTConfig
+    from pmgt_amd.engine import Engine
+    case = make_case(7252, 88606, C2, S=32, B=B, seed=71, beta=1.0)
+    tables = po.synth_tables(7252, case["cfg"]["feat_hidden_sizes"], 9)
+    L = _lib.hip()
+    L.pmgt_launch_trace_reset()
+    eng, out = run_engine(case, "bf16", [t.numpy() for t in tables])
+    ran = launch_counts(("qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc", "qkvc_attn_fwd", "attn_bwd_wgrad"))
+    assert ran["qkvc_attn_fwd_vc"] == 4 and ran["attn_bwd_wgrad_vc"] == 4 and ran["qkvc_attn_fwd"] == 4 and ran["attn_bwd_wgrad"] == 4, ran
+    assert ran["nt_vc"] == (4 if B >= 192 else 0), ran
+    for l in range(4):
+        for nm in ("query", "key"):
+            for wb in ("weight", "bias"):
+                g = eng.view(f"bert.encoder.layer.{l}.attention.self.{nm}.{wb}", grad=True)
+                assert float(g.abs().max()) == 0.0, (l, nm, wb)
+    p, ref = run_oracle(case, tables)
+    for l in range(4):
+        for nm in ("query", "key"):
+            assert float(p[f"bert.encoder.layer.{l}.attention.self.{nm}.weight"].grad.abs().max()) == 0.0      # the reference: exact zeros too
+    compare(eng, out, p, ref, "bf16", fp32_engine=lambda: run_engine(case, "fp32", [t.numpy() for t in tables])[0])
+    # the general kernels on the same step
+    kw = {k: v for k, v in case["cfg"].items() if k != "fp8"}
+    gen = Engine(PMGTConfig(**kw), dtype="bf16", seed=0)
+    gen.set_option("no_beta_skip", 1)
+    gen.load_params(case["params"])
+    gen.set_tables(*[t.numpy() for t in tables])
+    L.pmgt_launch_trace_reset()
+    og = gen.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=case["inj"], want_hidden=False)
+    torch.cuda.synchronize()
+    assert launch_counts(("qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc")) == {"qkvc_attn_fwd_vc": 0, "attn_bwd_wgrad_vc": 0, "nt_vc": 0}
+    np.testing.assert_allclose(out["loss"].item(), og["loss"].item(), rtol=2e-3)
+    cos = torch.nn.functional.cosine_similarity(eng.grads, gen.grads, dim=0).item()
+    assert cos > 0.9995, cos
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])

@@ -904,3 +904,74 @@ def test_token_sort_by_node_id_is_the_stable_sort(M, n_rows, skew):
     assert np.array_equal(outs[0][2].astype(np.int64), np.searchsorted(ids[order], np.arange(n_rows + 1), side="left"))
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------- beta == 1: the dead dot-product branch skipped
+@pytest.mark.parametrize("T,H,hm,p", [(7, 8, 1, 0.0), (64, 8, 0, 0.0), (9, 4, 1, 0.0), (700, 8, 1, 0.1), (2, 4, 0, 0.2), (33, 8, 1, 0.1)])
+def test_fused_kernels_at_beta_one_skip_the_dead_branch(T, H, hm, p):
+    """beta = 1 (scripts/run_pmgt.sh:24): attention_probs = 1 * A1 + 0 * A2 (pmgt/pmgt/modeling_pmgt.py:519-521) -- Q, K, the dot-product
+    softmax and their backward contribute exactly nothing.  The vc_only forms of the two fused kernels (forward: {V, C} x four heads per
+    slab, cosine branch alone; backward: Q / K neither fetched nor differentiated, dW_{v,c} only) against
+      * the fp64 autograd restatement of modeling_pmgt.py:435-526 at beta = 1 (p = 0),
+      * the GENERAL fused kernels at beta = 1 on the same inputs and dropout keys: same context, same dV | dC, same V / C weight-gradient
+        partial sums; dQ = dK = 0 there, untouched (NaN-filled) columns here; query / key weight and bias partials exactly 0 in both."""
+    _lib, L = _setup()
+    S, dh, beta = 32, 32, 1.0
+    d = H * dh
+    g = torch.Generator().manual_seed(T * 10 + H + 5)
+    x = torch.randn(T, S, d, generator=g)
+    W = torch.randn(4 * d, d, generator=g) / math.sqrt(d)
+    bias = torch.randn(4 * d, generator=g) * 0.1
+    dctx = torch.randn(T, S, d, generator=g)
+    mask = torch.ones(T, S)
+    for t in range(T):
+        mask[t, 1 + (t * 7) % S:] = 0
+    mask[0] = 1
+    xd, Wd, bd, md, dod = to_dev(x, torch.bfloat16), to_dev(W, torch.bfloat16), bias.cuda(), mask.cuda(), to_dev(dctx, torch.bfloat16)
+    rng = torch.tensor([77, 4], dtype=torch.int64, device="cuda")
+    nan = float("nan")
+    res = {}
+    for vc in (0, 1):
+        qk = torch.full((T, S, 4 * d), nan, device="cuda", dtype=torch.bfloat16)
+        cx = torch.full((T, S, d), nan, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.pmgt_op_qkvc_attention_fwd_ex(P(xd), P(Wd), P(bd), P(md), P(qk), P(cx), T, S, H, dh, beta, p, 17, 18, P(rng), hm | (2 * vc),
+                                                   stream()))
+        parts = L.pmgt_op_attention_bwd_wgrad_parts(H)
+        dx = torch.full((T, S, 4 * d), nan, device="cuda", dtype=torch.bfloat16)
+        slab = torch.full((parts, 4 * d, d), nan, device="cuda")
+        bslab = torch.full((parts, 4 * d), nan, device="cuda")
+        _lib.check(L.pmgt_op_attention_bwd_wgrad(P(qk), P(md), P(dod), P(xd), P(dx), P(slab), P(bslab), T, H, beta, p, 17, 18, P(rng),
+                                                 hm | (2 * vc), stream()))
+        torch.cuda.synchronize()
+        q_std = _from_head_major(qk, H, dh) if hm else qk
+        dx_std = _from_head_major(dx, H, dh) if hm else dx
+        res[vc] = (q_std.float(), cx.float(), dx_std.float(), slab.sum(0), bslab.sum(0))
+    gen, vcr = res[0], res[1]
+    assert torch.isfinite(gen[0]).all() and torch.isfinite(gen[2]).all()
+    # forward: V | C and the context agree; Q | K of the vc form were never written
+    assert torch.isnan(vcr[0][..., :2 * d]).all() and torch.isnan(vcr[2][..., :2 * d]).all()
+    assert torch.equal(vcr[0][..., 2 * d:], gen[0][..., 2 * d:])
+    assert torch.isfinite(vcr[1]).all() and rel_err(vcr[1], gen[1]) < 3e-3
+    # backward: dQ = dK = 0 in the general form; dV | dC agree
+    assert float(gen[2][..., :2 * d].abs().max()) == 0.0
+    assert torch.isfinite(vcr[2][..., 2 * d:]).all() and rel_err(vcr[2][..., 2 * d:], gen[2][..., 2 * d:]) < 1e-2
+    # weight / bias partial sums: query / key rows exactly zero, value / ctx_attention rows = (dV | dC)^T x of what the kernel stored
+    assert float(vcr[3][:2 * d].abs().max()) == 0.0 and float(vcr[4][:2 * d].abs().max()) == 0.0
+    assert float(gen[3][:2 * d].abs().max()) == 0.0
+    G = vcr[2][..., 2 * d:].double().reshape(T * S, 2 * d).cpu()
+    X = xd.double().reshape(T * S, d).cpu()
+    assert rel_err(vcr[3][2 * d:].double().cpu(), G.T @ X) < 1e-4
+    assert float((vcr[4][2 * d:].double().cpu() - G.sum(0)).abs().max()) < 1e-4 * float(G.abs().sum(0).max())
+    if p == 0.0:
+        qr = rounded(x, torch.bfloat16).reshape(T * S, d) @ rounded(W, torch.bfloat16).T + bias.double()
+        qin = torch.zeros(T, S, 4 * d, dtype=torch.float64)
+        qin[..., 2 * d:] = vcr[0][..., 2 * d:].double().cpu()          # the bf16 V | C the kernel stored; Q | K do not matter at beta = 1
+        assert rel_err(vcr[0][..., 2 * d:].reshape(T * S, 2 * d), qr[:, 2 * d:]) < 4e-3
+        qin.requires_grad_(True)
+        ref, _ = _attn_ref(qin, mask.double(), H, 1.0)
+        assert rel_err(vcr[1], ref.detach()) < tol("bf16")
+        ref.backward(rounded(dctx, torch.bfloat16))
+        assert rel_err(vcr[2][..., 2 * d:], qin.grad[..., 2 * d:]) < 2e-2
+        assert float(qin.grad[..., :2 * d].abs().max()) == 0.0            # autograd: exact zeros for Q and K
+    # the vc form refuses anything but beta == 1
+    assert L.pmgt_op_qkvc_attention_fwd_ex(P(xd), P(Wd), P(bd), P(md), P(qk), P(cx), T, S, H, dh, 0.5, p, 17, 18, P(rng), hm | 2, stream()) == -3
