@@ -975,3 +975,37 @@ def test_fused_kernels_at_beta_one_skip_the_dead_branch(T, H, hm, p):
         assert float(qin.grad[..., :2 * d].abs().max()) == 0.0            # autograd: exact zeros for Q and K
     # the vc form refuses anything but beta == 1
     assert L.pmgt_op_qkvc_attention_fwd_ex(P(xd), P(Wd), P(bd), P(md), P(qk), P(cx), T, S, H, dh, 0.5, p, 17, 18, P(rng), hm | 2, stream()) == -3
+
+
+@pytest.mark.parametrize("M,N1,N2", [(393216, 256, 256), (70001, 256, 256), (66000, 256, 264), (98304, 1024, 256), (40000, 256, 1536), (33000, 512, 64)])
+def test_weight_gradient_macro_tile_matches_the_128_tile_and_fp64(M, N1, N2):
+    """gemm_tn_dma2_kernel (256 x 128 tile: every column of P in one workgroup, 768 instead of 1 024 operand column-reads per reduction row at
+    dW [256, 256]; opt-in `tn_macro_tile`: measured neutral) against the default 128 x 128 LDS-DMA tile and fp64, with the bias sums riding along; the launch trace shows
+    which one ran.  Ragged row tails, a partial N2 tile, several N1 tiles."""
+    _lib, L = _setup()
+    H = _lib.hip()
+    g = torch.Generator().manual_seed(M % 977 + N2)
+    Pm = torch.randn(M, N1, generator=g).bfloat16()
+    Q = torch.randn(M, N2, generator=g).bfloat16()
+    Pd, Qd = Pm.cuda(), Q.cuda()
+    outs = []
+    for off in (0, 1):
+        L.use(*([] if off else ["tn_macro_tile"]))
+        slab = torch.empty(L.pmgt_op_gemm_tn_slab_elems(1, M, N1, N2), device="cuda")
+        bslab = torch.empty(512 * N1, device="cuda")
+        out = torch.full((N1, N2), float("nan"), device="cuda")
+        bout = torch.full((N1,), float("nan"), device="cuda")
+        H.pmgt_launch_trace_reset()
+        _lib.check(L.pmgt_op_gemm_tn_bias(1, P(Pd), N1, P(Qd), N2, M, N1, N2, P(slab), P(out), P(bslab), P(bout), 0, 0, stream()))
+        torch.cuda.synchronize()
+        big = M >= 65536 and N1 % 256 == 0 and N2 % 256 == 0 and N1 * N2 >= 4 * 65536
+        tiles = (N1 // 256) * -(-N2 // 128)
+        long_enough = M >= 16 * 32 * max(8, (256 // tiles) // 8 * 8)
+        assert H.pmgt_launch_trace_count(b"tn_dma2") == (0 if (off or big or not long_enough) else 1)
+        outs.append((out.clone(), bout.clone()))
+    L.use()
+    ref = Pm.double().T @ Q.double()
+    for out, bout in outs:
+        assert rel_err(out, ref) < 2e-3
+        assert float((bout.double().cpu() - Pm.double().sum(0)).abs().max()) < 2e-3 * float(Pm.double().abs().sum(0).max())
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5
