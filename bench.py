@@ -481,22 +481,23 @@ def main():
     # this workload, else traffic stays null.
     if "roofline" in out:
         try:
-            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
-            ph = tr["phases"].get(out["roofline"]["kernel"])
-            fresh = tr.get("kernel_sources_sha") == kernel_sources_sha()       # measured on THESE kernels, else it is stale: null
-            if ph and fresh and tr["workload"] == args.workload and tr["batch"] == B and not args.intermediate and args.dtype == "bf16" and args.beta == 0.5:
-                out["roofline"]["traffic"] = ph["hbm_mb_per_launch"]
-                out["roofline"]["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
-                if "matrix_pipe_busy" in ph:        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the same profile set
-                    out["roofline"]["matrix_pipe_busy"] = ph["matrix_pipe_busy"]
-                    out["roofline"]["valu_per_mfma"] = ph.get("valu_per_mfma")
             wl = args.workload + (f"_i{args.intermediate}" if args.intermediate else "")
+            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json" if wl == "c2" else f"traffic_{wl}.json")))
+            fresh = tr.get("kernel_sources_sha") == kernel_sources_sha()       # measured on THESE kernels, else it is stale: null
             if fresh and tr.get("workload_key", tr["workload"]) == wl and tr["batch"] == B and args.dtype == "bf16" and args.beta == 0.5:
-                for ent in out.get("roofline_top3", []):
-                    pk = tr["phases"].get(ent["kernel"])
-                    if pk:
-                        ent["traffic"] = pk["hbm_mb_per_launch"]
-                        ent["traffic_ratio"] = round(pk["hbm_mb_per_launch"] / ent["algorithmic_mb_per_launch"], 3)
+                src = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
+                for ent in [out["roofline"]] + out.get("roofline_top3", []):
+                    ph = tr["phases"].get(ent["kernel"])
+                    if not ph:
+                        continue
+                    ent["traffic"] = ph["hbm_mb_per_launch"]
+                    ent["traffic_unit"] = src
+                    if "algorithmic_mb_per_launch" in ent:
+                        ent["traffic_ratio"] = round(ph["hbm_mb_per_launch"] / ent["algorithmic_mb_per_launch"], 3)
+                    if "matrix_pipe_busy" in ph:        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the same profile set
+                        ent["matrix_pipe_busy"] = ph["matrix_pipe_busy"]
+                        ent["valu_per_mfma"] = ph.get("valu_per_mfma")
+                out["step_hbm_gb"] = tr.get("step_hbm_gb")
         except (OSError, KeyError, ValueError):
             pass
 

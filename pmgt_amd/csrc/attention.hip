@@ -137,36 +137,50 @@ __global__ void attn_fwd_kernel(AttnArgs a, int group_bytes) {
 
     const float sq = sqrtf((float)DH);
     float mx1 = -INFINITY, mx2 = -INFINITY;
+    // beta in {0, 1}: one branch is multiplied by exactly 0 (pmgt/pmgt/modeling_pmgt.py:519-521) -- its scores, softmax and dropout draws are
+    // skipped (uniform branches); `no_beta_skip` (OPT_NO_BETA_SKIP) keeps the general arithmetic, which gives the same zeros the long way
+    const bool dead1 = a.beta == 0.f && !(a.opts & OPT_NO_BETA_SKIP), dead2 = a.beta == 1.f && !(a.opts & OPT_NO_BETA_SKIP);
     if (ract) {
         for (int j = 0; j < S; ++j) {
-            const float d1 = dot_row<T, DH>(cc, sC + j * RS);
-            const float d2 = dot_row<T, DH>(q, sK + j * RS);
-            const float s1 = 1.f - d1 / (rho_i * rho[j]) + (j == li ? 1.f : 0.f) + madd[j];
-            const float s2 = d2 / sq + madd[j];
-            sc1[j * ST + li] = s1;
-            sc2[j * ST + li] = s2;
-            mx1 = fmaxf(mx1, s1);
-            mx2 = fmaxf(mx2, s2);
+            if (!dead1) {
+                const float d1 = dot_row<T, DH>(cc, sC + j * RS);
+                const float s1 = 1.f - d1 / (rho_i * rho[j]) + (j == li ? 1.f : 0.f) + madd[j];
+                sc1[j * ST + li] = s1;
+                mx1 = fmaxf(mx1, s1);
+            }
+            if (!dead2) {
+                const float d2 = dot_row<T, DH>(q, sK + j * RS);
+                const float s2 = d2 / sq + madd[j];
+                sc2[j * ST + li] = s2;
+                mx2 = fmaxf(mx2, s2);
+            }
         }
         float sum1 = 0.f, sum2 = 0.f;
         for (int j = 0; j < S; ++j) {
-            const float e1 = expf(sc1[j * ST + li] - mx1);
-            const float e2 = expf(sc2[j * ST + li] - mx2);
-            sc1[j * ST + li] = e1;
-            sc2[j * ST + li] = e2;
-            sum1 += e1;
-            sum2 += e2;
+            if (!dead1) {
+                const float e1 = expf(sc1[j * ST + li] - mx1);
+                sc1[j * ST + li] = e1;
+                sum1 += e1;
+            }
+            if (!dead2) {
+                const float e2 = expf(sc2[j * ST + li] - mx2);
+                sc2[j * ST + li] = e2;
+                sum2 += e2;
+            }
         }
         const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
-        const float w1 = a.beta / sum1, w2 = (1.f - a.beta) / sum2;
+        const float w1 = dead1 ? 0.f : a.beta / sum1, w2 = dead2 ? 0.f : (1.f - a.beta) / sum2;
         float o[DH];
 #pragma unroll
         for (int e = 0; e < DH; ++e) o[e] = 0.f;
         const uint64_t pbase = (((uint64_t)t * H + h) * S + li) * S;
         const uint32_t prow = (uint32_t)(((uint64_t)t * H + h) * S + li);
         for (int j = 0; j < S; ++j) {
-            float p1 = sc1[j * ST + li] * w1, p2 = sc2[j * ST + li] * w2;
-            if (k1.on) { p1 *= drop_mul1(k1, prow, (uint32_t)j); p2 *= drop_mul1(k2, prow, (uint32_t)j); }
+            float p1 = dead1 ? 0.f : sc1[j * ST + li] * w1, p2 = dead2 ? 0.f : sc2[j * ST + li] * w2;
+            if (k1.on) {
+                if (!dead1) p1 *= drop_mul1(k1, prow, (uint32_t)j);
+                if (!dead2) p2 *= drop_mul1(k2, prow, (uint32_t)j);
+            }
             const float p = p1 + p2;
             if (a.probs) a.probs[pbase + j] = p;
             axpy_row<T, DH>(o, p, sV + j * RS);
@@ -217,6 +231,9 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
     const float sq = sqrtf((float)DH);
     const DropKey k1 = make_drop_key(a.drop1), k2 = make_drop_key(a.drop2);
     const float beta = a.beta, omb = 1.f - a.beta;
+    // beta in {0, 1}: the dead branch (see the forward) -- its probabilities are never formed, dS = 0, and dQ = dK = 0 (beta = 1) or dC = 0 (beta = 0)
+    // are stored as the exact zeros autograd reports
+    const bool dead1 = a.beta == 0.f && !(a.opts & OPT_NO_BETA_SKIP), dead2 = a.beta == 1.f && !(a.opts & OPT_NO_BETA_SKIP);
     float rho_i = 0.f;
     {
         float cc[DH];
@@ -238,25 +255,30 @@ __global__ void attn_bwd_kernel(AttnArgs a, int group_bytes) {
             load_row<T, DH>(X + (int64_t)li * 4 * d, q);
             float mx1 = -INFINITY, mx2 = -INFINITY;
             for (int j = 0; j < S; ++j) {
-                const float d1 = dot_row<T, DH>(cc, sC + j * RS);
-                const float d2 = dot_row<T, DH>(q, sK + j * RS);
-                const float s1 = 1.f - d1 / (rho_i * rho[j]) + (j == li ? 1.f : 0.f) + madd[j];
-                const float s2 = d2 / sq + madd[j];
+                float s1 = 0.f, s2 = 0.f;
+                if (!dead1) {
+                    const float d1 = dot_row<T, DH>(cc, sC + j * RS);
+                    s1 = 1.f - d1 / (rho_i * rho[j]) + (j == li ? 1.f : 0.f) + madd[j];
+                    mx1 = fmaxf(mx1, s1);
+                }
+                if (!dead2) {
+                    const float d2 = dot_row<T, DH>(q, sK + j * RS);
+                    s2 = d2 / sq + madd[j];
+                    mx2 = fmaxf(mx2, s2);
+                }
                 A1[j * ST + li] = s1;
                 A2[j * ST + li] = s2;
-                mx1 = fmaxf(mx1, s1);
-                mx2 = fmaxf(mx2, s2);
             }
             float sum1 = 0.f, sum2 = 0.f;
             for (int j = 0; j < S; ++j) {
-                const float e1 = expf(A1[j * ST + li] - mx1);
-                const float e2 = expf(A2[j * ST + li] - mx2);
+                const float e1 = dead1 ? 0.f : expf(A1[j * ST + li] - mx1);
+                const float e2 = dead2 ? 0.f : expf(A2[j * ST + li] - mx2);
                 A1[j * ST + li] = e1;
                 A2[j * ST + li] = e2;
                 sum1 += e1;
                 sum2 += e2;
             }
-            const float i1 = 1.f / sum1, i2 = 1.f / sum2;
+            const float i1 = dead1 ? 0.f : 1.f / sum1, i2 = dead2 ? 0.f : 1.f / sum2;      // a dead branch: all-zero probabilities, hence dS = 0 below
             for (int j = 0; j < S; ++j) {
                 A1[j * ST + li] *= i1;
                 A2[j * ST + li] *= i2;

@@ -175,7 +175,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path, launch):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + tail
     else:
-        cmd = [sys.executable] + tail + ["--buckets", "two"]
+        cmd = [sys.executable] + tail + ["--buckets", "layer"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -185,7 +185,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path, launch):
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["loss_last"])
     assert "phases" in out and "cpu_baseline" not in out and "end_to_end" not in out       # the live pipeline is an N = 1 (or opt-in) pass
     ar = out["allreduce"]
-    assert ar["buckets"] == (6 if launch == "driver" else 2) and ar["ms_per_step"] > 0
+    assert ar["buckets"] == (2 if launch == "driver" else 6) and ar["ms_per_step"] > 0      # default policy "two" (profiles/r05: one-rank RCCL runs); per-bucket on request
     assert abs(ar["mb"] - 4 * 3.06) < 0.5                                                   # the whole flat gradient buffer, once
 
 

@@ -88,6 +88,33 @@ def test_train_loss_and_grads_match_reference(name):
     torch.testing.assert_close(eng.grads, 2 * g1, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["m1_beta1", "m1_beta0", "e_script"])
+def test_dead_attention_branch_is_skipped_and_its_gradients_are_exact_zeros(name):
+    """beta in {0, 1} (the author's script trains with --beta 1.0, scripts/run_pmgt.sh:24): one softmax branch is multiplied by exactly 0
+    (pmgt/pmgt/modeling_pmgt.py:519-521).  The default path skips it (test_train_loss_and_grads_match_reference above checks that path against
+    the reference's loss, logits and gradients); here it is compared with the general arithmetic (`no_beta_skip`): same loss and live
+    gradients up to fp32 round-off, and the dead projections' gradients EXACTLY zero in both -- what autograd reports."""
+    case = gu.model_case(name)
+    inj, _ = inject_for(case)
+    res = []
+    for off in (0, 1):
+        eng = make_engine(case)
+        eng.set_option("no_beta_skip", off)
+        out = eng.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=inj)
+        torch.cuda.synchronize()
+        res.append((out["loss"].item(), eng.grads.clone(), eng))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-8)
+    dead = ("query", "key") if case["cfg"]["beta"] == 1.0 else ("ctx_attention",)
+    for _, _, eng in res:
+        for l in range(case["cfg"]["num_hidden_layers"]):
+            for nm in dead:
+                for wb in ("weight", "bias"):
+                    assert float(eng.view(f"bert.encoder.layer.{l}.attention.self.{nm}.{wb}", grad=True).abs().max()) == 0.0, (l, nm, wb)
+            live = eng.view(f"bert.encoder.layer.{l}.attention.self.value.weight", grad=True)
+            assert float(live.abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("name", ["m1", "m1_pad", "m4"])
 def test_clip_adamw_curve_matches_reference(name):
     case = gu.model_case(name)

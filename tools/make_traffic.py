@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the committed PMC summaries of one profile set.
 
-Usage: tools/make_traffic.py profiles/rNN/<tag> [kernel_sources_sha]   (reads <tag>_pmc_fetch_size.txt and <tag>_pmc_write_size.txt;
-the fingerprint defaults to the current sources: run it on the tree the counters were measured on)
+Usage: tools/make_traffic.py profiles/rNN/<tag> [kernel_sources_sha] [workload_key batch]   (reads <tag>_pmc_fetch_size.txt and
+<tag>_pmc_write_size.txt; the fingerprint defaults to the current sources: run it on the tree the counters were measured on).  With a
+workload key other than "c2" (c2_i1024, c4 ...) the result goes to profiles/traffic_<key>.json, which bench.py reads for that workload.
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (counters in KiB; gfx950 tallies 128-B read requests at 64 B,
 /opt/skills/guides/MI355X_MICROARCH.md).  bench.py quotes the entry of its dominant phase as `roofline.traffic`."""
@@ -12,12 +13,18 @@ import re
 import sys
 
 PHASE_KERNELS = {           # bench.py phase name -> substring of the kernel that dominates it
-    "bwd.dgrad_qkvc_lnb": "gemm_nt_big_kernel<256, 8, true>",
+    "bwd.dgrad_qkvc_lnb": "gemm_nt_big_kernel<256, 8, 1>",
+    "fwd.gemm_ffn2": "gemm_nt_big_kernel<256, 8, 2>",          # (I = 4 d: the 256 x 256 tile with the LayerNorm epilogue)
+    "fwd.gemm_ffn1": "gemm_ws2_kernel<8, 1>",
+    "bwd.dgrad_ffn2": "gemm_ws2_kernel<8, 2>",
+    "bwd.wgrad_ffn1": "gemm_tn_big_kernel<false>",
+    "fwd.gemm_qkvc": "gemm_wsr512_kernel<0>",
+    "fwd.attention": "attn_fwd_tiles_kernel",
     "bwd.dgrad_ffn1_lnb": "gemm_wsr_kernel<true>",
     "fwd.qkvc_attention": "qkvc_attn_fwd",
-    "bwd.attention": "attn_bwd_mfma_kernel",
+    "bwd.attention": "attn_bwd_tiles_kernel",
     "bwd.attention_wgrad": "attn_bwd_wgrad_kernel",
-    "bwd.dgrad_qkvc": "gemm_nt_big_kernel<256, 8, false>",
+    "bwd.dgrad_qkvc": "gemm_nt_big_kernel<256, 8, 0>",
     "bwd.wgrad_qkvc": "gemm_tn_big_kernel",
     "bwd.layernorm": "ln_bwd_kernel",
 }
@@ -78,10 +85,12 @@ def main():
             pass
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_sources_sha
+    wkey = sys.argv[3] if len(sys.argv) > 3 else "c2"
+    wbatch = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     out = {
-        "workload": "c2", "batch": 1024,
+        "workload": wkey.split("_")[0], "workload_key": wkey, "batch": wbatch,
         # fingerprint of pmgt_amd/csrc at measurement time: bench.py nulls `traffic` when the kernels have changed since
-        "kernel_sources_sha": sys.argv[2] if len(sys.argv) > 2 else kernel_sources_sha(),
+        "kernel_sources_sha": sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else kernel_sources_sha(),
         "source": f"{prefix}_pmc_fetch_size.txt + {os.path.basename(prefix)}_pmc_write_size.txt "
                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
         "correction": "HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE; counters in KiB",
@@ -89,7 +98,7 @@ def main():
         "step_hbm_gb_method": step_how,
         "phases": phases,
     }
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json" if wkey == "c2" else f"traffic_{wkey}.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(phases, indent=1))
     print("HBM traffic per training step: %.2f GB" % out["step_hbm_gb"])
