@@ -9,9 +9,8 @@
 //
 // The sort is a hand-written least-significant-digit radix sort sized for what the keys are: node ids < n_rows <= M / 2
 // (13 bits at the benchmark graph), i.e. ceil(bits / 8) counting passes -- two at C2 -- of
-//     [pass 0 only] per-tile digit histogram -> exclusive scan over [digit][tile] -> stable scatter,
-// where the scatter of pass p also counts the NEXT digit per destination tile (integer atomics: order-free), so later passes
-// need no histogram launch.  Inside a tile (16 rounds x 4 waves x 64 lanes, in index order) the rank of an element among its
+//     per-tile digit histogram -> exclusive scan over [digit][tile] -> stable scatter.
+// Inside a tile (16 rounds x 4 waves x 64 lanes, in index order) the rank of an element among its
 // equals is: equals in earlier (round, wave) slots -- a prefix over 64 LDS counters per digit -- plus equals in lower lanes of
 // its own wave -- eight ballots.  The result is THE stable order, the same permutation any stable sort produces.
 // (Rounds 1 - 4 called rocPRIM here: 21 launches, 0.44 ms of GPU time per step next to the forward pass.)
@@ -25,8 +24,10 @@ static constexpr int SEG_CH = 64;       // sorted positions per WAVE (a chunk); 
 
 static constexpr int RS_ROUNDS = 16, RS_TILE = 256 * RS_ROUNDS, RS_SLOTS = 4 * RS_ROUNDS, RS_MAXBINS = 256;
 
-// pass 0: digit counts of every tile, hist[digit][tile]
-__global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict__ ids, int M, uint32_t mask, int ntiles, uint32_t* __restrict__ hist) {
+// digit counts of every tile of the current order, hist[digit][tile] (pass 0 reads the int64 ids, later passes the keys of the previous scatter)
+template <bool FROM_IDS>
+__global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ kin, int M, int shift, uint32_t mask,
+                                                      int ntiles, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[RS_MAXBINS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -34,15 +35,14 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict_
 #pragma unroll 4
     for (int j = 0; j < RS_ROUNDS; ++j) {
         const int idx = base + j * 256 + threadIdx.x;
-        if (idx < M) atomicAdd(&h[(uint32_t)ids[idx] & mask], 1u);
+        if (idx < M) atomicAdd(&h[((FROM_IDS ? (uint32_t)ids[idx] : kin[idx]) >> shift) & mask], 1u);
     }
     __syncthreads();
     if (threadIdx.x <= mask) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of hist[0 .. n) in place (one workgroup: n = bins x tiles is a few 10^4), and zero-fill of the buffer the
-// next scatter counts into
-__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hist, int n, uint32_t* __restrict__ zero_buf, int nz) {
+// exclusive scan of hist[0 .. n) in place (one workgroup: n = bins x tiles is a few 10^4)
+__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hist, int n) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,16 +74,16 @@ __global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hi
         }
         __syncthreads();
     }
-    for (int i = tid; i < nz; i += 1024) zero_buf[i] = 0u;
 }
 
 // One counting pass: element (key, val) of tile t goes to base[digit][t] + (equals before it inside the tile).  FROM_IDS: pass 0
-// reads the int64 ids (val = token index).  NEXT: also count the next pass's digit per DESTINATION tile.
-template <bool FROM_IDS, bool NEXT>
+// reads the int64 ids (val = token index).  (A first form also counted the NEXT pass's digit per destination tile with global atomics, to
+// save the later histogram launches: 393 216 device-scope atomics made that scatter 81 us; a histogram launch is 8.)
+template <bool FROM_IDS>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ kin,
                                                          const uint32_t* __restrict__ vin, int M, int shift, uint32_t mask, int ntiles,
                                                          const uint32_t* __restrict__ base, uint32_t* __restrict__ kout,
-                                                         uint32_t* __restrict__ vout, int shift2, uint32_t mask2, uint32_t* __restrict__ hist2) {
+                                                         uint32_t* __restrict__ vout) {
     __shared__ uint16_t cnt[RS_MAXBINS][RS_SLOTS + 2];     // 66 entries = 33 dwords per row: the per-digit prefix walks rows conflict-free
     __shared__ uint32_t tbase[RS_MAXBINS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
@@ -129,21 +129,20 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restri
             const uint32_t pos = tbase[dg] + cnt[dg][j * 4 + wave] + rank[j];
             kout[pos] = key[j];
             vout[pos] = val[j];
-            if (NEXT) atomicAdd(&hist2[(int64_t)((key[j] >> shift2) & mask2) * ntiles + pos / RS_TILE], 1u);
         }
     }
 }
 
-// seg_off[n] = first sorted position whose key is >= n  (n = 0 .. n_rows)
+// seg_off[n] = first sorted position whose key is >= n  (n = 0 .. n_rows): one pass over the sorted keys -- position p writes the entries of
+// the ids in (skeys[p - 1], skeys[p]] (more than one where ids in between do not occur), the last position also the tail up to n_rows
 __global__ void seg_bounds_kernel(const uint32_t* __restrict__ skeys, int M, int n_rows, int* __restrict__ seg_off) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n > n_rows) return;
-    int lo = 0, hi = M;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (skeys[mid] < (uint32_t)n) lo = mid + 1; else hi = mid;
-    }
-    seg_off[n] = lo;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    const int k = (int)skeys[p];
+    const int lo = p == 0 ? 0 : (int)skeys[p - 1] + 1;
+    for (int n = lo; n <= min(k, n_rows); ++n) seg_off[n] = p;
+    if (p == M - 1)
+        for (int n = k + 1; n <= n_rows; ++n) seg_off[n] = M;
 }
 
 // One WAVE per chunk of SEG_CH sorted positions; lane l owns columns 4l .. 4l+3 (+ 256 g): a row is read with 8-byte
@@ -248,8 +247,8 @@ __global__ __launch_bounds__(256) void seg_fix_kernel(const int* __restrict__ se
 
 static inline int rs_tiles(int M) { return cdiv(M, RS_TILE); }
 
-int64_t seg_sort_temp_bytes(int M) {       // two [256][tiles] count tables (the scan of pass p, the counts of pass p + 1)
-    return (int64_t)2 * RS_MAXBINS * rs_tiles(M) * 4 + 256;
+int64_t seg_sort_temp_bytes(int M) {       // one [256][tiles] count table
+    return (int64_t)RS_MAXBINS * rs_tiles(M) * 4 + 256;
 }
 
 int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* vals, uint32_t* skeys, uint32_t* perm, int* seg_off,
@@ -261,30 +260,24 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
     while ((1ll << bits) < (int64_t)n_rows) ++bits;
     const int passes = cdiv(bits, 8), w = cdiv(bits, passes);       // digits of equal width (13 bits: 7 + 7)
     const int ntiles = rs_tiles(M);
-    uint32_t* hist[2] = {(uint32_t*)temp, (uint32_t*)temp + (int64_t)RS_MAXBINS * ntiles};
+    uint32_t* hist[1] = {(uint32_t*)temp};
     const uint32_t mask = (1u << w) - 1u;
     const int n = (int)(mask + 1u) * ntiles;
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(ntiles), dim3(256), 0, st, ids, M, mask, ntiles, hist[0]);
     const uint32_t *kin = nullptr, *vin = nullptr;
     for (int p = 0; p < passes; ++p) {
-        const bool last = p == passes - 1;
         // the last pass lands in (skeys, perm); the buffers alternate backwards from there
         uint32_t* kout = ((passes - 1 - p) & 1) ? keys : skeys;
         uint32_t* vout = ((passes - 1 - p) & 1) ? vals : perm;
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, hist[p & 1], n, hist[(p + 1) & 1], last ? 0 : n);
-        const int shift = p * w, shift2 = (p + 1) * w;
-        if (p == 0 && !last)
-            hipLaunchKernelGGL((rs_scatter_kernel<true, true>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout, shift2, mask, hist[1]);
-        else if (p == 0)
-            hipLaunchKernelGGL((rs_scatter_kernel<true, false>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout, 0, 0u, nullptr);
-        else if (!last)
-            hipLaunchKernelGGL((rs_scatter_kernel<false, true>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[p & 1], kout, vout, shift2, mask, hist[(p + 1) & 1]);
-        else
-            hipLaunchKernelGGL((rs_scatter_kernel<false, false>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[p & 1], kout, vout, 0, 0u, nullptr);
+        const int shift = p * w;
+        if (p == 0) hipLaunchKernelGGL(rs_hist_kernel<true>, dim3(ntiles), dim3(256), 0, st, ids, kin, M, shift, mask, ntiles, hist[0]);
+        else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(ntiles), dim3(256), 0, st, ids, kin, M, shift, mask, ntiles, hist[0]);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, hist[0], n);
+        if (p == 0) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout);
+        else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout);
         kin = kout; vin = vout;
     }
     PMGT_LAUNCH_OK();
-    hipLaunchKernelGGL(seg_bounds_kernel, dim3(cdiv(n_rows + 1, 256)), dim3(256), 0, st, skeys, M, n_rows, seg_off);
+    hipLaunchKernelGGL(seg_bounds_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, skeys, M, n_rows, seg_off);
     PMGT_LAUNCH_OK();
     return 0;
 }
