@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""profiles/rNN/README.md (per-kernel table) from a committed profile set, followed by the hand-written profiles/rNN/NOTES.md when there
-is one.  Usage: tools/make_profile_readme.py profiles/r04/a"""
+"""profiles/rNN/README.md (per-kernel tables) from a committed profile set, followed by the hand-written profiles/rNN/NOTES.md when there
+is one.  Usage: tools/make_profile_readme.py profiles/r05/a
+
+A set is what tools/gpu_collect.sh leaves: <pre>_kernel_stats.txt + <pre>_pmc_*.txt for the headline workload, and the same files behind a
+second prefix for every other workload that was profiled (<pre>_c2_i1024_*, <pre>_c2_beta1_*, <pre>_c4_*)."""
 import json
 import os
 import re
 import sys
 
+STEPS = 13          # tools/gpu_profile.sh: --steps 10 --warmup 3
+PMC_STEPS = 3       # counter passes: --steps 2 --warmup 1
+
 
 def parse(path):
     rows = {}
+    if not os.path.exists(path):
+        return rows
     for line in open(path).read().splitlines()[1:]:
         m = re.match(r"^(.*?)\s+(\d+)\s+([0-9.]+)\s*$", line)
         if m:
@@ -16,78 +24,78 @@ def parse(path):
     return rows
 
 
-def main():
-    pre = sys.argv[1]
+def stats(path):
     ks = {}
-    steps = 13          # tools/gpu_profile.sh: --steps 10 --warmup 3
-    for line in open(pre + "_kernel_stats.txt").read().splitlines()[1:]:
+    for line in open(path).read().splitlines()[1:]:
         m = re.match(r"^(.*?)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
         if m:
             ks[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
-    f, w = parse(pre + "_pmc_fetch_size.txt"), parse(pre + "_pmc_write_size.txt")
-    busy, cu = parse(pre + "_pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt"), parse(pre + "_pmc_SQ_BUSY_CU_CYCLES.txt")
-    valu, mf = parse(pre + "_pmc_SQ_INSTS_VALU.txt"), parse(pre + "_pmc_SQ_INSTS_MFMA.txt")
-    tr = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(pre))), "traffic.json")))
-    out = [
-        "# %s -- one MI355X, C2 (7 252 nodes, L4 H8 d256 S32), bf16, B = 1 024, dropout 0.1\n" % os.path.dirname(pre),
-        "Files: `a_kernel_stats.txt` (`rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3`: 13 steps), `a_pmc_*.txt` (separate "
-        "`--pmc` passes of 3 steps, and of 6 steps for `*_6steps.txt`: FETCH_SIZE / WRITE_SIZE in KiB per launch; SQ counters), `a_bench_*.json` (bench lines: default C2, C3 "
-        "graph, C4 / C5 shapes, C2 in fp8 mode, a 4-rank gloo rehearsal on one GPU), `a_kernel_stats_B32.txt` / `_B256.txt` (the "
-        "reference's own batch sizes). Collected by `tools/gpu_collect.sh` -> `tools/gpu_profile.sh`; `profiles/traffic.json` comes from this set "
-        "(`tools/make_traffic.py`), the tables of this file from `tools/make_profile_readme.py`, the notes behind them from `NOTES.md`.\n",
-        "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md). Matrix pipe busy = "
-        "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES).\n",
-        "| kernel | launches / step | avg us | ms / step | HBM MB / launch | TB/s | matrix pipe busy | VALU per MFMA |", "|---|---|---|---|---|---|---|---|"]
-    for k, (calls, tms, avg) in sorted(ks.items(), key=lambda kv: -kv[1][1])[:24]:
+    return ks
+
+
+def table(pre, title, traffic_file, rows=22, lds=False):
+    """One workload's table; pre = file prefix including the trailing underscore."""
+    if not os.path.exists(pre + "kernel_stats.txt"):
+        return []
+    ks = stats(pre + "kernel_stats.txt")
+    f, w = parse(pre + "pmc_fetch_size.txt"), parse(pre + "pmc_write_size.txt")
+    busy, cu = parse(pre + "pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt"), parse(pre + "pmc_SQ_BUSY_CU_CYCLES.txt")
+    valu, mf = parse(pre + "pmc_SQ_INSTS_VALU.txt"), parse(pre + "pmc_SQ_INSTS_MFMA.txt")
+    lc, la = parse(pre + "pmc_SQ_LDS_BANK_CONFLICT.txt"), parse(pre + "pmc_SQ_LDS_IDX_ACTIVE.txt")
+    base = os.path.basename(pre)
+    out = [f"## {title}\n", f"`{base}kernel_stats.txt`, `{base}pmc_*.txt`.\n",
+           "| kernel | launches / step | avg us | ms / step | HBM MB / launch | TB/s | matrix pipe busy | VALU per MFMA |" + (" LDS busy | conflict share |" if lds else ""),
+           "|---|---|---|---|---|---|---|---|" + ("---|---|" if lds else "")]
+    n = 0
+    for k, (calls, tms, avg) in sorted(ks.items(), key=lambda kv: -kv[1][1]):
         if "pmgt" not in k:
             continue
+        n += 1
+        if n > rows:
+            break
         mb = (2 * f[k][1] + w.get(k, (0, 0))[1]) * 1024 / 1e6 if k in f else None
         b, c = busy.get(k, (0, 0))[1], cu.get(k, (0, 0))[1]
         name = re.sub(r"^_ZN4pmgt\d+", "", re.sub(r"\(.*", "", k).replace("pmgt::", ""))
-        out.append(f"| `{name[:48]}` | {calls / steps:.1f} | {avg:.1f} | {tms / steps:.3f} | {'%.0f' % mb if mb else '-'} | "
-                   f"{'%.2f' % (mb / avg) if mb else '-'} | {'%.2f' % (b / (4 * c)) if c else '-'} | "
-                   f"{'%.1f' % (valu[k][1] / mf[k][1]) if k in mf and mf[k][1] > 0 else '-'} |")
-    how = tr.get("step_hbm_gb_method", "every kernel's dispatches x its average, per step")
-    out.append(f"\nWhole step: {sum(v[1] for v in ks.values()) / steps:.2f} ms of kernel time under the profiler, **{tr['step_hbm_gb']} GB of HBM "
-               f"traffic per step** by the counters ({how}).\n")
-    # ---- C4 shapes (10^6 nodes, L6 d512 S64, B = 256): same passes with BENCH_EXTRA="--workload c4 --batch 256"
-    c4 = pre + "_kernel_stats_c4shapes_B256.txt"
-    if os.path.exists(c4):
-        ks4 = {}
-        for line in open(c4).read().splitlines()[1:]:
-            m = re.match(r"^(.*?)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
-            if m:
-                ks4[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
-        q = pre + "_c4shapes_pmc_"
-        f4, w4 = parse(q + "fetch.txt"), parse(q + "write.txt")
-        b4, c4u = parse(q + "SQ_VALU_MFMA_BUSY_CYCLES.txt"), parse(q + "SQ_BUSY_CU_CYCLES.txt")
-        v4, m4 = parse(q + "SQ_INSTS_VALU.txt"), parse(q + "SQ_INSTS_MFMA.txt")
-        lc, la = parse(q + "SQ_LDS_BANK_CONFLICT.txt"), parse(q + "SQ_LDS_IDX_ACTIVE.txt")
-        out += ["## C4 shapes (10^6 nodes, L6 H8 d512 I512 S64), bf16, B = 256\n",
-                "`a_kernel_stats_c4shapes_B256.txt`, `a_c4shapes_pmc_*.txt` (same passes, `BENCH_EXTRA=\"--workload c4 --batch 256\"`). LDS busy = "
-                "SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES; conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.\n",
-                "| kernel | launches / step | avg us | ms / step | HBM MB / launch | TB/s | matrix pipe busy | VALU per MFMA | LDS busy | conflict share |",
-                "|---|---|---|---|---|---|---|---|---|---|"]
-        tot_gb = 0.0
-        for k, (calls, tms, avg) in sorted(ks4.items(), key=lambda kv: -kv[1][1]):
-            if k in f4:
-                tot_gb += (2 * f4[k][1] + w4.get(k, (0, 0))[1]) * 1024 / 1e9 * f4[k][0] / 3.0       # counter passes: 3 steps
-        for k, (calls, tms, avg) in sorted(ks4.items(), key=lambda kv: -kv[1][1])[:16]:
-            if "pmgt" not in k:
-                continue
-            mb = (2 * f4[k][1] + w4.get(k, (0, 0))[1]) * 1024 / 1e6 if k in f4 else None
-            b, c = b4.get(k, (0, 0))[1], c4u.get(k, (0, 0))[1]
-            name = re.sub(r"^_ZN4pmgt\d+", "", re.sub(r"\(.*", "", k).replace("pmgt::", ""))
-            out.append(f"| `{name[:48]}` | {calls / steps:.1f} | {avg:.1f} | {tms / steps:.3f} | {'%.0f' % mb if mb else '-'} | "
-                       f"{'%.2f' % (mb / avg) if mb else '-'} | {'%.2f' % (b / (4 * c)) if c else '-'} | "
-                       f"{'%.1f' % (v4[k][1] / m4[k][1]) if k in m4 and m4[k][1] > 0 else '-'} | "
-                       f"{'%.2f' % (la[k][1] / c) if k in la and c else '-'} | {'%.2f' % (lc[k][1] / la[k][1]) if k in la and la[k][1] > 0 else '-'} |")
-        out.append(f"\nWhole step: {sum(v[1] for v in ks4.values()) / steps:.2f} ms of kernel time under the profiler, {tot_gb:.1f} GB of HBM traffic per step.\n")
-    notes = os.path.join(os.path.dirname(pre), "NOTES.md")
+        line = (f"| `{name[:48]}` | {calls / STEPS:.1f} | {avg:.1f} | {tms / STEPS:.3f} | {'%.0f' % mb if mb else '-'} | "
+                f"{'%.2f' % (mb / avg) if mb else '-'} | {'%.2f' % (b / (4 * c)) if c else '-'} | "
+                f"{'%.1f' % (valu[k][1] / mf[k][1]) if k in mf and mf[k][1] > 0 else '-'} |")
+        if lds:
+            line += (f" {'%.2f' % (la[k][1] / c) if k in la and c else '-'} | "
+                     f"{'%.2f' % (lc[k][1] / la[k][1]) if k in la and la[k][1] > 0 else '-'} |")
+        out.append(line)
+    tail = f"\nWhole step: {sum(v[1] for v in ks.values()) / STEPS:.2f} ms of kernel time under the profiler"
+    if traffic_file and os.path.exists(traffic_file):
+        tr = json.load(open(traffic_file))
+        tail += f", **{tr['step_hbm_gb']} GB of HBM traffic per step** by the counters ({tr.get('step_hbm_gb_method', '')}; `{os.path.relpath(traffic_file, os.path.dirname(os.path.dirname(pre)))}`)"
+    out.append(tail + ".\n")
+    return out
+
+
+def main():
+    pre = sys.argv[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(pre)))
+    d = os.path.dirname(pre)
+    out = [
+        "# %s -- one MI355X, bf16, dropout 0.1\n" % d,
+        "Files: `a_kernel_stats.txt` (`rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3`: 13 steps), `a_pmc_*.txt` (separate "
+        "`--pmc` passes of 3 steps, and of 6 steps for `*_6steps.txt`: FETCH_SIZE / WRITE_SIZE in KiB per launch; SQ counters), the same behind "
+        "`a_c2_i1024_` (C2 with I = 4d), `a_c2_beta1_` (C2 at beta = 1) and `a_c4_` (C4 shapes, B = 256), `a_bench_*.json` (bench lines: the default "
+        "line with its `workloads`, C3 graph, C2 in fp8 mode, the one-rank RCCL runs, a 4-rank gloo rehearsal on one GPU), `a_kernel_stats_B32.txt` / "
+        "`_B256.txt` (the reference's own batch sizes). Collected by `tools/gpu_collect.sh <tag> lines | c2 | i4d | c4 | small` -> `tools/gpu_profile.sh`; "
+        "`profiles/traffic*.json` come from these sets (`tools/make_traffic.py`), the tables of this file from `tools/make_profile_readme.py`, the "
+        "notes behind them from `NOTES.md`; `trace_*.txt` and the A/B files are named in the notes.\n",
+        "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md). Matrix pipe busy = "
+        "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES). Per-launch HBM bytes are what the counters saw DURING the launch: the 256-MB Infinity "
+        "Cache moves write-backs of one launch into the next, so a writer can show fewer bytes than it produced.\n"]
+    out += table(pre + "_", "C2 (7 252 nodes, L4 H8 d256 I256 S32), B = 1 024 -- the headline", os.path.join(root, "traffic.json"))
+    out += table(pre + "_c2_i1024_", "C2 with I = 4d = 1 024, B = 1 024 (bench `c2_i1024`)", os.path.join(root, "traffic_c2_i1024.json"), rows=14)
+    out += table(pre + "_c2_beta1_", "C2 at beta = 1 (bench `c2_beta1`: the vc_only kernels)", None, rows=8)
+    out += table(pre + "_c4_", "C4 shapes (10^6 nodes, L6 H8 d512 I512 S64), B = 256", os.path.join(root, "traffic_c4.json"), rows=16, lds=True)
+    notes = os.path.join(d, "NOTES.md")
     if os.path.exists(notes):
         out.append(open(notes).read())
-    open(os.path.join(os.path.dirname(pre), "README.md"), "w").write("\n".join(out))
-    print("\n".join(out[4:16]))
+    open(os.path.join(d, "README.md"), "w").write("\n".join(out))
+    print("\n".join(out[4:20]))
 
 
 if __name__ == "__main__":
