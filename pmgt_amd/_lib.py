@@ -64,13 +64,13 @@ OPS_SYMBOLS = [
     "pmgt_op_layernorm_fwd", "pmgt_op_layernorm_bwd", "pmgt_op_linear", "pmgt_op_linear_ln_bwd", "pmgt_op_attention_fwd", "pmgt_op_attention_bwd",
     "pmgt_op_qkvc_attention_fwd", "pmgt_op_attention_bwd_wgrad", "pmgt_op_attention_bwd_wgrad_parts",
     "pmgt_op_quant_rows_e4m3", "pmgt_op_gemm_nt_f8", "pmgt_op_gemm_tn_f8", "pmgt_op_qkvc_attention_fwd_f8",
-    "pmgt_launch_trace_reset", "pmgt_launch_trace_count", "pmgt_op_seg_sort", "pmgt_op_seg_sort_temp_bytes", "pmgt_op_clock_probe", "pmgt_op_qkvc_attention_fwd_ex",
+    "pmgt_launch_trace_reset", "pmgt_launch_trace_count", "pmgt_op_seg_sort", "pmgt_op_seg_sort_temp_bytes", "pmgt_op_clock_probe", "pmgt_op_qkvc_attention_fwd_ex", "pmgt_op_attention_bwd_wgrad_vc2_parts",
 ]
 # path options: pmgt_engine_set_option keys -> bit in the `path_opts` argument of the pmgt_op_* entries (include/pmgt_ops.h)
 OPT = {k: 1 << i for i, k in enumerate((
     "tile_gemm", "valu_attention", "wave_attention_bwd", "no_shortcut", "no_fused_qkvc_attention", "no_head_major",
     "no_table_projection", "no_segment_sum", "consumer_quant", "no_fused_attention_bwd", "store_ln_input", "eager_reduce",
-    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena", "no_role_split_ln", "no_tile_attention", "unfused_ln_bwd", "lockstep_attention_bwd", "side_stream_wgrad", "no_cls_only_attention_bwd", "no_beta_skip", "tn_macro_tile"))}
+    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena", "no_role_split_ln", "no_tile_attention", "unfused_ln_bwd", "lockstep_attention_bwd", "side_stream_wgrad", "no_cls_only_attention_bwd", "no_beta_skip", "tn_macro_tile", "no_vc2_attention_bwd"))}
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
     "pmgt_sampler_context", "pmgt_sampler_batch", "pmgt_sampler_batch_mt", "pmgt_sampler_max_pairs",
@@ -151,6 +151,7 @@ def hip():
     L.pmgt_op_attention_bwd.argtypes = [i, vp, vp, vp, vp, i, i, i, i, f, f, u32, u32, vp, u32, vp]
     L.pmgt_op_attention_bwd_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, f, f, u32, u32, vp, i, vp]
     L.pmgt_op_attention_bwd_wgrad_parts.argtypes = [i]
+    L.pmgt_op_attention_bwd_wgrad_vc2_parts.argtypes = [i]
     L.pmgt_op_gemm_tn_bias.argtypes = [i, vp, i64, vp, i64, i, i, i, vp, vp, vp, vp, i, i, u32, vp]
     L.pmgt_quantize_e4m3.argtypes = [vp, vp, i64, f, vp]
     L.pmgt_dequantize_e4m3.argtypes = [vp, vp, i64, f, vp]

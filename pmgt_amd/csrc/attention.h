@@ -46,6 +46,11 @@ struct AttnBwdWg {
 int attn_bwd_wgrad_parts(int H);
 bool attn_bwd_wgrad_supported(const AttnBwdWg& w);
 int attn_bwd_wgrad(const AttnBwdWg& w, hipStream_t st);
+// beta == 1 (vc_only), two heads per step: `slab` is [attn_bwd_wgrad_vc2_parts(H)][2 d * d] and `bias_slab` [..][2 d] -- the value | ctx_attention rows
+// only (row = matrix * d + head * 32 + w); the query / key gradients are zeros the CALLER writes
+int attn_bwd_wgrad_vc2_parts(int H);
+bool attn_bwd_wgrad_vc2_supported(const AttnBwdWg& w);
+int attn_bwd_wgrad_vc2(const AttnBwdWg& w, hipStream_t st);
 
 // Fused Q|K|V|C projection + attention forward (qkvc_attn.hip): bf16, S = 32, head size 32, hidden 256 or 128.
 struct QkvcAttn {

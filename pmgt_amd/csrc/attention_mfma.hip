@@ -1876,6 +1876,7 @@ struct AbwStep {      // (wave-uniform) what a phase needs to know about its ste
     int t;            // sequence (clamped into the tensor), for the dropout row index
     bool act;         // the sequence exists
     bool zq1;         // query tile 1 (rows 16 .. 31) of this sequence has no gradient: d ctx is non-zero at row 0 only (t < cls_only_seqs)
+    int vcol = 128, ccol = 192;      // byte columns of this wave's V and C blocks inside a tile row ([Q K V C] of one head; VC 2: [V0 C0 V1 C1])
 };
 struct AbwCarry {
     f32x4 sc[2], dp[2];      // phase 1 -> 2: raw scores and dP of this wave's query tile against both key tiles
@@ -1899,13 +1900,16 @@ __device__ __forceinline__ void abw_draw_mval(const AttnArgs& a, const DropKey& 
     }
 }
 
-// VC (beta == 1, AttnArgs::vc_only): the dot-product branch is dead -- its wave (BR 2) keeps only its 16 columns of dV (third phase, from the
-// cosine branch's image alone); no Q / K fragments, scores, softmax, dS2 / P2 images, dQ or dK
-template <int IT, int BR, bool VC = false>
+// VC 1 (beta == 1, AttnArgs::vc_only): the dot-product branch is dead -- its wave (BR 2) keeps only its 16 columns of dV (third phase, from the
+// cosine branch's image alone); no Q / K fragments, scores, softmax, dS2 / P2 images, dQ or dK.  VC 2 (the two-heads-per-step form of the same
+// mode): every attention wave is a cosine wave (BR 1) of one (pair, head, tile); it also has all 32 columns of its dV, and the pair's scratch
+// holds dS1 | P1 | norms only.
+template <int VC> struct AbwScr { static constexpr int P1 = VC == 2 ? 2048 : 4096, P2 = 6144, RHO = VC == 2 ? 4096 : 8192; };
+template <int IT, int BR, int VC = 0>
 __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, float mraw, int h, char* scr, int r, int q, int lane) {
     constexpr float L2E = 1.4426950408889634f;
-    if (VC && BR == 2) return;
-    float* rho = (float*)(scr + 8192);
+    if (VC == 1 && BR == 2) return;
+    float* rho = (float*)(scr + AbwScr<VC>::RHO);
     float* madd = rho + 32;
     const int x = 16 * IT + r;
     const char* gin = st.gin;
@@ -1920,8 +1924,8 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
     fo = *(const bf16x8*)(st.oin + abw_o_addr(x, 16 * q));
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-        kc[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, (BR == 1 ? 192 : 64) + 16 * q));
-        fv[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, 128 + 16 * q));
+        kc[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, (BR == 1 ? st.ccol : 64) + 16 * q));
+        fv[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, st.vcol + 16 * q));
     }
     float ss = 0.f, rho_x = 0.f;
     if (BR == 1) {
@@ -1965,15 +1969,15 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
     if (BR == 2) abw_draw_mval<BR>(a, kd, st.t, h, x, q, cy.mval);
 }
 
-template <int IT, int BR, bool VC = false>
+template <int IT, int BR, int VC = 0>
 __device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, int h, char* scr, int r, int q) {
     constexpr float L2E = 1.4426950408889634f;
     constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
-    if (VC && BR == 2) return;
+    if (VC == 1 && BR == 2) return;
     char* iS = scr + (BR == 1 ? 0 : 2048);               // dS1 (rows scaled by 1 / |c_i|) | dS2
-    char* iP1 = scr + 4096;
-    char* iP2 = scr + 6144;
-    const float* rho = (const float*)(scr + 8192);
+    char* iP1 = scr + AbwScr<VC>::P1;
+    char* iP2 = scr + AbwScr<VC>::P2;
+    const float* rho = (const float*)(scr + AbwScr<VC>::RHO);
     const float* madd = rho + 32;
     const int x = 16 * IT + r;
     const float rho_x = cy.rho_x;
@@ -2062,18 +2066,18 @@ __device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd,
                 const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(st.gin, 64, 16 * ct, r, q), bs, z, 0, 0, 0);     // K block
                 *(bf16x4*)(st.gout + abw_g_addr(x, (16 * ct + 4 * q) * 2)) = pack4(dq * ISQ);      // dQ block: columns 0..31
             } else {
-                cy.dch[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(st.gin, 192, 16 * ct, r, q), bs, z, 0, 0, 0);        // C block
+                cy.dch[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<true>(st.gin, st.ccol, 16 * ct, r, q), bs, z, 0, 0, 0);        // C block
             }
         }
     }
 }
 
-template <int IT, int BR, bool VC = false>
+template <int IT, int BR, int VC = 0>
 __device__ __forceinline__ void abw_phase3(const AbwStep& st, AbwCarry& cy, char* scr, int r, int q) {
     constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
     const char* iS = scr + (BR == 1 ? 0 : 2048);
-    const char* iP1 = scr + 4096;
-    const char* iP2 = scr + 6144;
+    const char* iP1 = scr + AbwScr<VC>::P1;
+    const char* iP2 = scr + AbwScr<VC>::P2;
     const int x = 16 * IT + r;           // the KEY index now
     const char* gin = st.gin;
     char* gout = st.gout;
@@ -2082,16 +2086,18 @@ __device__ __forceinline__ void abw_phase3(const AbwStep& st, AbwCarry& cy, char
     // second half, key tile IT.  dV^T = dO^T (P1 + P2) is split between the two branch waves (16 columns each): the cosine wave also has
     // dC, the dot-product wave dK.
     {
-        constexpr int CV = BR == 1 ? 0 : 1;
         const bf16x8 bp1 = abw_tr_img(iP1, 16 * IT, r, q);
-        const bf16x8 ao = abw_tr_o(st.oin, 16 * CV, r, q);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp1, z, 0, 0, 0);
-        if (!VC) dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, abw_tr_img(iP2, 16 * IT, r, q), dv, 0, 0, 0);      // P = P1 + P2 meets in the accumulator
-        *(bf16x4*)(gout + abw_g_addr(x, 128 + (16 * CV + 4 * q) * 2)) = pack4(dv);              // dV block
+#pragma unroll
+        for (int CV = (VC == 2 ? 0 : (BR == 1 ? 0 : 1)); CV <= (VC == 2 ? 1 : (BR == 1 ? 0 : 1)); ++CV) {
+            const bf16x8 ao = abw_tr_o(st.oin, 16 * CV, r, q);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp1, z, 0, 0, 0);
+            if (VC == 0) dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, abw_tr_img(iP2, 16 * IT, r, q), dv, 0, 0, 0);      // P = P1 + P2 meets in the accumulator
+            *(bf16x4*)(gout + abw_g_addr(x, st.vcol + (16 * CV + 4 * q) * 2)) = pack4(dv);              // dV block
+        }
     }
     ABW_MARK2("attn I3.dk_or_dc", IT, BR);
-    if (BR == 2 && VC) {
+    if (BR == 2 && VC != 0) {
     } else if (BR == 2) {
         const bf16x8 bs = abw_tr_img(iS, 16 * IT, r, q);
 #pragma unroll
@@ -2106,16 +2112,16 @@ __device__ __forceinline__ void abw_phase3(const AbwStep& st, AbwCarry& cy, char
         f32x4 chv[2], dch[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x4 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<false>(gin, 192, 16 * ct, r, q), bt, cy.dch[ct], 0, 0, 0);
+            const f32x4 dc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abw_tr_g<false>(gin, st.ccol, 16 * ct, r, q), bt, cy.dch[ct], 0, 0, 0);
             const int gc = (16 * ct + 4 * q) * 2;
             dch[ct] = -dc;           // dN = -dS1
-            chv[ct] = load4<bf16>((const bf16*)(gin + abw_g_addr(x, 192 + gc))) * rho_x;        // C^_x
+            chv[ct] = load4<bf16>((const bf16*)(gin + abw_g_addr(x, st.ccol + gc))) * rho_x;        // C^_x
             dt += (dch[ct][0] * chv[ct][0] + dch[ct][1] * chv[ct][1]) + (dch[ct][2] * chv[ct][2] + dch[ct][3] * chv[ct][3]);
         }
         dt = red_q<2>(dt, false);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-            *(bf16x4*)(gout + abw_g_addr(x, 192 + (16 * ct + 4 * q) * 2)) = pack4((dch[ct] - chv[ct] * dt) * rho_x);    // dC block
+            *(bf16x4*)(gout + abw_g_addr(x, st.ccol + (16 * ct + 4 * q) * 2)) = pack4((dch[ct] - chv[ct] * dt) * rho_x);    // dC block
     }
     ABW_MARK2("attn end", IT, BR);
 }
@@ -2245,12 +2251,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     if (on_) {
                         const float mraw = mnext;
                         mnext = mask_of(s + 1);
-                        abw_phase1<IT, BR, VC>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                        abw_phase1<IT, BR, (VC ? 1 : 0)>(a, kd, st, cy, mraw, h, scr, r, q, lane);
                     }
                     bar(0);
-                    if (on_) abw_phase2<IT, BR, VC>(a, kd, st, cy, h, scr, r, q);
+                    if (on_) abw_phase2<IT, BR, (VC ? 1 : 0)>(a, kd, st, cy, h, scr, r, q);
                     bar(2);
-                    if (on_) abw_phase3<IT, BR, VC>(st, cy, scr, r, q);
+                    if (on_) abw_phase3<IT, BR, (VC ? 1 : 0)>(st, cy, scr, r, q);
                     bar(4);
                 }
             } else {
@@ -2262,7 +2268,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     if (s3 >= 0 && s3 < nsteps) {
 #endif
                         const AbwStep st3 = step_of(s3);
-                        abw_phase3<IT, BR, VC>(st3, cy, scr, r, q);
+                        abw_phase3<IT, BR, (VC ? 1 : 0)>(st3, cy, scr, r, q);
                     }
                     bar(0);
 #ifdef PMGT_ABW_NO_ATTN
@@ -2274,10 +2280,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
                     if (on) {
                         const float mraw = mnext;
                         mnext = mask_of(s1 + 1);
-                        abw_phase1<IT, BR, VC>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                        abw_phase1<IT, BR, (VC ? 1 : 0)>(a, kd, st, cy, mraw, h, scr, r, q, lane);
                     }
                     bar(2);
-                    if (on) abw_phase2<IT, BR, VC>(a, kd, st, cy, h, scr, r, q);
+                    if (on) abw_phase2<IT, BR, (VC ? 1 : 0)>(a, kd, st, cy, h, scr, r, q);
                     bar(4);
                 }
             }
@@ -2564,7 +2570,331 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_kernel(AttnBwdWg w) {
     }
 }
 
+// =================================================================================================
+// beta == 1, TWO HEADS PER STEP (round 5).  The one-head vc_only form above does half the work per step and still takes 2.2 us per step:
+// three barrier intervals of latency are the floor of a step, whatever is in it.  Here a workgroup owns a head PAIR: the tile row of a
+// step is [V0 C0 V1 C1] -- the general kernel's 256 bytes per row, so its GEMM role runs unchanged (n tiles 0 .. 7, KQ k tiles per wave:
+// dW_{v,c} of two heads = the general accumulator footprint) -- and the eight attention waves are eight cosine waves, one per (pair,
+// head, tile), each with all 32 columns of its dV.  Half the steps per launch.  LDS: the x tile is SINGLE-buffered -- its two row halves are
+// consumed by k-step 0 (first interval) and k-step 1 (third interval) of the following iteration, so rows 0 .. 31 of the next tile are requested
+// behind the first barrier (as before) and rows 32 .. 63 at the top of the next iteration, behind the last reader of their predecessors:
+// x 32 KB | tile ring 4 x 16 KB | dO 4 x 4 KB (two heads, two steps) | scratch 4 x 4.25 KB = 129 KB.
+// The weight-gradient partial of a workgroup is [2 d, d] (value | ctx_attention rows of its two heads); the caller zero-fills query / key.
+// =================================================================================================
+template <int KT> struct AbwCfg2 {
+    static constexpr int D = 16 * KT, XROW = D * 2, XB = 64 * XROW, GB = 64 * 256, OB = 64 * 64;
+    static constexpr int SCR = 2 * 2048 + 256;        // per (pair, head): dS1, P1 images | rho, madd
+    static constexpr int G0 = XB, O0 = G0 + 4 * GB, S0 = O0 + 4 * OB, SMEM = S0 + 4 * SCR;
+    static constexpr int KQ = KT / 4;
+};
+
+template <int KT>
+__global__ __launch_bounds__(1024) void attn_bwd_wgrad_vc2_kernel(AttnBwdWg w) {
+    using C = AbwCfg2<KT>;
+    constexpr int D = C::D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AttnArgs& a = w.a;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int H = a.H, HP = H / 2;
+    const int b = blockIdx.x;
+    const int hp = (b >> 3) % HP, xs = (b & 7) + 8 * (b / (8 * HP));      // head pair; row slot (workgroups of one slot share an XCD)
+    const int gx = gridDim.x / HP;
+    const int npair = (a.Tseq + 1) / 2;
+    const int nsteps = xs < npair ? (npair - xs + gx - 1) / gx : 0;
+    const int M = a.Tseq * 32;
+    auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+    if (wave & 4) __builtin_amdgcn_s_setprio(1);
+    auto in_tile = [](int s) { return C::G0 + ((2 * s) & 3) * C::GB; };
+    auto out_tile = [](int s) { return C::G0 + ((2 * s + 1) & 3) * C::GB; };
+
+    if (wave < 8) {
+        // ================================ attention role: eight cosine waves ================================
+        const int ul = wave >> 2, uh = (wave >> 1) & 1, it = wave & 1;         // waves w and w + 4 share a SIMD: same (head, tile), the two pairs
+        const int h = 2 * hp + uh;
+        char* scr = smem + C::S0 + (2 * ul + uh) * C::SCR;
+        const DropKey kd = make_drop_key(a.drop1);
+        auto seq_of = [&](int s) { return 2 * (xs + s * gx) + ul; };
+        auto mask_of = [&](int s) {
+            const int t = min(seq_of(s), a.Tseq - 1);
+            return a.mask ? a.mask[(int64_t)t * 32 + (lane & 31)] : 1.f;
+        };
+        auto step_of = [&](int s) {
+            AbwStep st;
+            const int t = seq_of(s);
+            st.act = t < a.Tseq;
+            st.t = min(t, a.Tseq - 1);
+            st.zq1 = st.act && t < a.cls_only_seqs;
+            st.gin = smem + in_tile(s) + ul * (32 * 256);
+            st.gout = smem + out_tile(s) + ul * (32 * 256);
+            st.oin = smem + C::O0 + (2 * (s & 1) + uh) * C::OB + ul * (32 * 64);
+            st.vcol = uh * 128; st.ccol = uh * 128 + 64;
+            return st;
+        };
+        auto run = [&](auto ITc) __attribute__((always_inline)) {
+            constexpr int IT = decltype(ITc)::value;
+            AbwCarry cy;
+            cy.rho_x = 0.f; cy.ss = 0.f;
+#pragma unroll
+            for (int k_ = 0; k_ < 2; ++k_) cy.sc[k_] = cy.dp[k_] = cy.dch[k_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float mnext = mask_of(0);
+            if (ul == 0) {
+                for (int i = 0; i <= nsteps + 1; ++i) {
+                    const int s = i - 1;
+                    const bool on = s >= 0 && s < nsteps;
+                    AbwStep st = step_of(on ? s : 0);
+                    if (on) {
+                        const float mraw = mnext;
+                        mnext = mask_of(s + 1);
+                        abw_phase1<IT, 1, 2>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                    }
+                    bar();
+                    if (on) abw_phase2<IT, 1, 2>(a, kd, st, cy, h, scr, r, q);
+                    bar();
+                    if (on) abw_phase3<IT, 1, 2>(st, cy, scr, r, q);
+                    bar();
+                }
+            } else {          // pair 1: one interval late (see the one-head kernel)
+                for (int i = 0; i <= nsteps + 1; ++i) {
+                    const int s3 = i - 2, s1 = i - 1;
+                    if (s3 >= 0 && s3 < nsteps) {
+                        const AbwStep st3 = step_of(s3);
+                        abw_phase3<IT, 1, 2>(st3, cy, scr, r, q);
+                    }
+                    bar();
+                    const bool on = s1 >= 0 && s1 < nsteps;
+                    AbwStep st = step_of(on ? s1 : 0);
+                    if (on) {
+                        const float mraw = mnext;
+                        mnext = mask_of(s1 + 1);
+                        abw_phase1<IT, 1, 2>(a, kd, st, cy, mraw, h, scr, r, q, lane);
+                    }
+                    bar();
+                    if (on) abw_phase2<IT, 1, 2>(a, kd, st, cy, h, scr, r, q);
+                    bar();
+                }
+            }
+        };
+        if (it == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+        return;
+    }
+    // ==================================== GEMM role (the general kernel's, on the [V0 C0 V1 C1] tile) ====================================
+    const int g = wave - 8, gn = g & 1, gk = g >> 1;                 // n tiles 4 gn .. 4 gn + 3 (= head gn), k tiles KQ gk .. KQ gk + KQ - 1
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void gbl_void_t;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+    f32x4 acc[4][C::KQ], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < C::KQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = 8 * q + (r >> 2), fkey = abw_f(frow), fsub = (r & 3) >> 1, fhalf = 8 * (r & 1);
+    const uint32_t fla = (uint32_t)(frow * 256 + ((fkey ^ fsub) << 4) + fhalf), flb = (uint32_t)(frow * C::XROW + ((fkey ^ fsub) << 4) + fhalf);
+    static_assert(C::G0 % 512 == 0 && C::GB % 512 == 0 && C::XB % 512 == 0, "tile bases must keep the row / chunk / half bit fields disjoint");
+    constexpr int LPRX = 64 / (1024 / C::XROW);
+    const uint32_t dx_chunk = (uint32_t)((lane % LPRX) ^ abw_f(lane / LPRX)), dx_row = (uint32_t)(lane / LPRX) * (uint32_t)w.ldx * 2u;
+    const uint32_t dq_chunk = (uint32_t)((lane & 15) ^ abw_f(lane >> 4)), dq_row = (uint32_t)(lane >> 4) * 4u * (uint32_t)D * 2u;
+    // tile chunk c (16 bytes, 0 .. 15) of a row = (head 2 hp + (c >> 3), matrix v | c = 2 + ((c >> 2) & 1), elements 8 (c & 3) ..): its element column
+    // inside a Q|K|V|C row
+    auto gcol = [&](uint32_t c) {
+        const uint32_t hd = 2u * (uint32_t)hp + (c >> 3), mt = 2u + ((c >> 2) & 1u);
+        return a.hm ? (hd * 4u + mt) * 32u + (c & 3u) * 8u : mt * (uint32_t)D + hd * 32u + (c & 3u) * 8u;
+    };
+    auto kstep = [&](int s, int ks) {
+        const uint32_t gb = lds0 + out_tile(s), xb = lds0;
+        bf16x8 fa[4], fb[4];
+        uint32_t aa[4], ab[4];
+        uint32_t ba = fla + gb + (uint32_t)(32 * ks * 256), bb = flb + xb + (uint32_t)(32 * ks * C::XROW);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            aa[u] = ba ^ (uint32_t)((2 * (4 * gn + u)) << 4);
+            ab[u] = bb ^ (uint32_t)((2 * (C::KQ * gk + (u % C::KQ))) << 4);
+        }
+        u32x2 tb[8], ta[8];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\t"
+            "ds_read_b64_tr_b16 %1, %16 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\t"
+            "ds_read_b64_tr_b16 %3, %17 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\t"
+            "ds_read_b64_tr_b16 %5, %18 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\t"
+            "ds_read_b64_tr_b16 %7, %19 offset:%24\n\t"
+            "ds_read_b64_tr_b16 %8, %20\n\t"
+            "ds_read_b64_tr_b16 %9, %20 offset:%25\n\t"
+            "ds_read_b64_tr_b16 %10, %21\n\t"
+            "ds_read_b64_tr_b16 %11, %21 offset:%25\n\t"
+            "ds_read_b64_tr_b16 %12, %22\n\t"
+            "ds_read_b64_tr_b16 %13, %22 offset:%25\n\t"
+            "ds_read_b64_tr_b16 %14, %23\n\t"
+            "ds_read_b64_tr_b16 %15, %23 offset:%25"
+            : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7]),
+              "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]), "=&v"(ta[7])
+            : "v"(ab[0]), "v"(ab[1]), "v"(ab[2]), "v"(ab[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "n"(4 * C::XROW), "n"(4 * 256)
+            : "memory");
+        asm volatile("s_waitcnt lgkmcnt(6)"
+                     : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(tb[4]), "+v"(tb[5]), "+v"(tb[6]), "+v"(tb[7]), "+v"(ta[0]), "+v"(ta[1]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fb[u] = __builtin_bit_cast(bf16x8, (u32x4){tb[2 * u][0], tb[2 * u][1], tb[2 * u + 1][0], tb[2 * u + 1][1]});
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ta[2]), "+v"(ta[3]));
+            if (nt == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ta[4]), "+v"(ta[5]));
+            if (nt == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[6]), "+v"(ta[7]));
+            fa[nt] = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * nt][0], ta[2 * nt][1], ta[2 * nt + 1][0], ta[2 * nt + 1][1]});
+#pragma unroll
+            for (int u = 0; u < C::KQ; ++u) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
+        }
+        const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+        const bf16x8 fsel = (gk & 3) == 0 ? fa[0] : ((gk & 3) == 1 ? fa[1] : ((gk & 3) == 2 ? fa[2] : fa[3]));
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fsel, ones, accb, 0, 0, 0);
+    };
+    // x rows of step sx into the (single) x tile: wave g owns rows 8 g .. 8 g + 7, i.e. waves 0 - 3 the half k-step 0 reads, waves 4 - 7 the half
+    // k-step 1 reads
+    constexpr int RPI = 1024 / C::XROW, NX = 8 / RPI;                 // rows per instruction, instructions per wave
+    auto dma_x = [&](int sx) __attribute__((always_inline)) {
+        const int m0x = 64 * (xs + sx * gx);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int row0 = 8 * g + RPI * j;
+            const int mrow = min(m0x + row0, M - RPI);
+            const uint32_t off = (uint32_t)mrow * (uint32_t)w.ldx * 2u + dx_row + ((dx_chunk ^ (uint32_t)abw_f(row0)) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)w.x + (size_t)off), (lds_void_t*)(smem + row0 * C::XROW), 16, 0, 0);
+        }
+    };
+    // V | C rows of the two heads for step i (4 rows per instruction: wave g takes rows 8 g .. 8 g + 7) and dO rows (16 per instruction: wave g
+    // takes head g >> 2, rows 16 (g & 3) ..).  Rows 0 .. 31 (pair 0) are EARLY pieces, rows 32 .. 63 (pair 1, an interval late) LATE ones.
+    auto dma_attn = [&](int i, bool early) __attribute__((always_inline)) {
+        const int m0 = 64 * (xs + i * gx);
+        if ((g < 4) == early) {
+            char* gt = smem + in_tile(i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row0 = 8 * g + 4 * j;
+                const int mrow = min(m0 + row0, M - 4);
+                const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);
+                const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + gcol(c)) * 2u + dq_row;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
+            }
+        }
+        if (((g & 3) < 2) == early) {
+            const int uh = g >> 2, row0 = 16 * (g & 3), row = row0 + (lane >> 2), c = (lane & 3) ^ abw_kt(row);
+            const uint32_t m = (uint32_t)min(m0 + row, M - 1);
+            const char* src = (const char*)a.dctx + (size_t)((m * (uint32_t)D + (uint32_t)((2 * hp + uh) * 32 + c * 8)) * 2u);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + C::O0 + (2 * (i & 1) + uh) * C::OB + row0 * 64), 16, 0, 0);
+        }
+    };
+    const int attnE = (g < 4 ? 2 : 0) + ((g & 3) < 2 ? 1 : 0), attnL = (g >= 4 ? 2 : 0) + ((g & 3) >= 2 ? 1 : 0);      // (uniform)
+    auto wait_vm = [](int n) __attribute__((always_inline)) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        }
+    };
+    // Vector-memory operations of this wave per iteration, in issue order:
+    //   [top]  Xhi (waves 4 - 7: NX instructions, rows 32 .. 63 of x(i - 2))   E (early pieces of step i)
+    //   [behind barrier 0]  Xlo (waves 0 - 3: NX instructions, rows 0 .. 31 of x(i - 1))   L (late pieces of step i)   2 copy-out stores
+    // vmcnt retires in issue order, so "everything up to X has landed" = at most (operations issued behind X) outstanding; a smaller count
+    // only waits longer.  Deadlines: L of iteration i - 1 by barrier 0 of iteration i; Xhi by barrier 1 (k-step 1 reads it in the third interval);
+    // E and Xlo by barrier 2 (pair 0's first phase / k-step 0 of the next iteration).
+    int prev_tail = 0;       // operations issued BEHIND the late pieces in the previous iteration (its full tile's 2 stores), -1 = do not count on any
+    for (int i = 0; i <= nsteps + 1; ++i) {
+        const int sg = i - 2;                     // the step whose results are consumed in this iteration
+        const bool xhi = g >= 4 && sg >= 0 && sg < nsteps, xlo = g < 4 && i >= 1 && i - 1 < nsteps, at = i < nsteps;      // (uniform)
+        if (xhi) dma_x(sg);
+        if (at) dma_attn(i, true);
+        const int nXhi = xhi ? NX : 0, nE = at ? attnE : 0, nXlo = xlo ? NX : 0, nL = at ? attnL : 0;
+        if (sg >= 0) kstep(sg, 0);
+        wait_vm(prev_tail >= 0 ? min(prev_tail + nXhi + nE, 9) : 0);      // the previous iteration's late pieces have landed (its stores may stay in flight)
+        bar();
+        u32x4 v[2];
+        const bool copy = sg >= 0;
+        int lc = lane;
+        asm volatile("" : "+v"(lc));
+        if (copy) {
+            const uint32_t gb = lds0 + out_tile(sg);
+            uint32_t ad[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
+                ad[p] = gb + row * 256 + ((c ^ abw_f(row)) << 4);
+            }
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
+        }
+        if (xlo) dma_x(i - 1);
+        if (at) dma_attn(i, false);
+        const bool full = copy && 64 * (xs + sg * gx) + 64 <= M;      // (uniform) no store instruction skipped by an all-false row predicate
+        if (copy) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]) :: "memory");
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
+                const int m = 64 * (xs + sg * gx) + row;
+                if (m < M) *(u32x4*)((char*)a.dqkvc + (size_t)(((uint32_t)m * 4u * D + gcol((uint32_t)c)) * 2u)) = v[p];
+            }
+        }
+        // Xhi of this iteration has landed (k-step 1 below reads it): behind it in issue order E, Xlo, L and the stores
+        if (full) wait_vm(min(nE + nXlo + nL + 2, 9));
+        else if (!copy) wait_vm(min(nE + nXlo + nL, 9));
+        else wait_vm(0);
+        bar();
+        if (sg >= 0) kstep(sg, 1);
+        // E and Xlo have landed: behind them L and the stores
+        if (full) wait_vm(nL + 2);
+        else if (!copy) wait_vm(nL);
+        else wait_vm(0);
+        prev_tail = full ? 2 : (!copy ? 0 : -1);
+        bar();
+    }
+    // ---- the workgroup's partial of dW_{v,c} (and the bias sums) of its two heads: rows = matrix (0 = value, 1 = ctx_attention) * d + head * 32 + w
+    float* slab = w.slab + (int64_t)xs * 2 * D * D;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = 4 * gn + nt;                              // 16-row block of the tile's 128 columns: head n >> 2, matrix (n >> 1) & 1, half n & 1
+        const int wrow = ((n >> 1) & 1) * D + (2 * hp + (n >> 2)) * 32 + 16 * (n & 1) + 4 * q;
+#pragma unroll
+        for (int j = 0; j < C::KQ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab[(int64_t)(wrow + e) * D + 16 * (C::KQ * gk + j) + r] = acc[nt][j][e];
+    }
+    if (r == 0 && w.bias_slab) {
+        const int n = 4 * gn + (gk & 3);
+        const int wrow = ((n >> 1) & 1) * D + (2 * hp + (n >> 2)) * 32 + 16 * (n & 1) + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w.bias_slab[(int64_t)xs * 2 * D + wrow + e] = accb[e];
+    }
+}
+
 int attn_bwd_wgrad_parts(int H) { return std::max(8, (256 / std::max(H, 1)) / 8 * 8); }
+// two-heads-per-step form of the beta == 1 mode: row slots = partial slabs of [2 d, d] (value | ctx_attention rows; twice as many, half as large)
+int attn_bwd_wgrad_vc2_parts(int H) { return std::max(8, (256 / std::max(H / 2, 1)) / 8 * 8); }
+bool attn_bwd_wgrad_vc2_supported(const AttnBwdWg& w) {
+    return w.a.vc_only && w.a.beta == 1.f && w.a.H % 2 == 0 && !(w.a.opts & OPT_NO_VC2_ATTENTION_BWD) && attn_bwd_wgrad_supported(w);
+}
+template <int KT> static int launch_abw_vc2(const AttnBwdWg& w, hipStream_t st) {
+    using C = AbwCfg2<KT>;
+    auto kern = attn_bwd_wgrad_vc2_kernel<KT>;
+    PMGT_SMEM_ATTR((const void*)kern, C::SMEM);
+    const int gx = attn_bwd_wgrad_vc2_parts(w.a.H);
+    note_launch(LT_ATTN_BWD_WGRAD);
+    note_launch(LT_ATTN_BWD_WGRAD_VC);
+    note_launch(LT_ATTN_BWD_WGRAD_VC2);
+    hipLaunchKernelGGL(kern, dim3(gx * (w.a.H / 2)), dim3(1024), C::SMEM, st, w);
+    PMGT_LAUNCH_OK();
+    return 0;
+}
+int attn_bwd_wgrad_vc2(const AttnBwdWg& w, hipStream_t st) {
+    PMGT_CHECK(attn_bwd_wgrad_vc2_supported(w), -2, "attn_bwd_wgrad_vc2: unsupported shape / mode S=%d dh=%d H=%d beta=%g", w.a.S, w.a.dh, w.a.H, (double)w.a.beta);
+    return w.a.H * 32 == 256 ? launch_abw_vc2<16>(w, st) : launch_abw_vc2<8>(w, st);
+}
 
 bool attn_bwd_wgrad_supported(const AttnBwdWg& w) {
     const AttnArgs& a = w.a;

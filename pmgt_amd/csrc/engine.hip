@@ -36,7 +36,7 @@ void note_launch(int tag) { if (tag >= 0 && tag < LT_COUNT) ++g_launch_count[tag
 static const char* const g_launch_names[LT_COUNT] = {
     "gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_tile",
     "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
-    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc", "tn_dma2"};
+    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc", "tn_dma2", "attn_bwd_wgrad_vc2"};
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -1064,7 +1064,20 @@ static int encoder_backward(const pmgt_engine* e, const pmgt_tensors* t, Bufs<T>
                 // dX = dV W_v + dC W_c below skips the dQ / dK blocks of a head-major gradient by k-step on the 256 x 256 tile; where that tile
                 // does not run (small M) the full product runs over dQ = dK = 0
                 if (b.qkvc_vc && b.qkvc_hm && !vc_dgrad_kmap) PMGT_HIP(hipMemsetAsync(b.big, 0, (size_t)M * 4 * d * sizeof(T), st));
-                if (abw_ok && b.defer) {
+                if (abw_ok && b.defer && attn_bwd_wgrad_vc2_supported(w)) {
+                    // beta == 1, two heads per step: partial sums of the value | ctx_attention rows only ([parts2][2 d, d]); query / key are exact zeros
+                    const int parts2 = attn_bwd_wgrad_vc2_parts(H);
+                    PMGT_CHECK((int64_t)parts2 * 2 * d * d <= b.arena_elems, -4, "partial-sum arena too small for the two-heads-per-step attention backward");
+                    RUN(take_partials2<T>(e, b, (int64_t)parts2 * 2 * d * d, &w.slab, (int64_t)parts2 * 2 * d, &w.bias_slab, st));
+                    RUNP("bwd.attention_wgrad", attn_bwd_wgrad_vc2(w, st));
+                    RUN(queue_reduce<T>(e, b, w.slab, parts2, (int64_t)2 * d * d, G + o.Wqkvc + (int64_t)2 * d * d, acc, st));
+                    RUN(queue_reduce<T>(e, b, w.bias_slab, parts2, 2 * d, G + o.bqkvc + 2 * d, acc, st));
+                    if (!acc) {
+                        PMGT_HIP(hipMemsetAsync(G + o.Wqkvc, 0, (size_t)2 * d * d * sizeof(float), st));
+                        PMGT_HIP(hipMemsetAsync(G + o.bqkvc, 0, (size_t)2 * d * sizeof(float), st));
+                    }
+                    fused_bw = true;
+                } else if (abw_ok && b.defer) {
                     RUN(take_partials2<T>(e, b, (int64_t)parts * 4 * d * d, &w.slab, (int64_t)parts * 4 * d, &w.bias_slab, st));
                     RUNP("bwd.attention_wgrad", attn_bwd_wgrad(w, st));
                     RUN(queue_reduce<T>(e, b, w.slab, parts, (int64_t)4 * d * d, G + o.Wqkvc, acc, st));
@@ -1662,7 +1675,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}, {"no_beta_skip", OPT_NO_BETA_SKIP}, {"tn_macro_tile", OPT_TN_MACRO_TILE}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}, {"no_beta_skip", OPT_NO_BETA_SKIP}, {"tn_macro_tile", OPT_TN_MACRO_TILE}, {"no_vc2_attention_bwd", OPT_NO_VC2_ATTENTION_BWD}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;
@@ -1778,6 +1791,7 @@ int pmgt_op_attention_bwd(int dtype, const void* qkvc, const float* mask, const 
 }
 
 int pmgt_op_attention_bwd_wgrad_parts(int H) { return attn_bwd_wgrad_parts(H); }
+int pmgt_op_attention_bwd_wgrad_vc2_parts(int H) { return attn_bwd_wgrad_vc2_parts(H); }
 int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void* dctx, const void* x, void* dqkvc, float* slab,
                                 float* bias_slab, int n_seq, int H, float beta, float drop_p, uint32_t site1, uint32_t site2,
                                 const uint64_t* rng, int head_major, void* stream) {
@@ -1786,6 +1800,10 @@ int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void*
     w.a.dctx = dctx; w.a.dqkvc = dqkvc; w.a.hm = (head_major & 1) != 0; w.a.vc_only = (head_major & 2) != 0;
     w.x = x; w.ldx = (int64_t)H * 32; w.slab = slab; w.bias_slab = bias_slab;
     PMGT_CHECK(attn_bwd_wgrad_supported(w), -3, "pmgt_op_attention_bwd_wgrad: unsupported shape (needs bf16, S = 32, dh = 32, d in {128, 256}, n_seq >= 2)");
+    if (head_major & 4) {      // two-heads-per-step form of the beta == 1 mode: partial sums [vc2_parts][2 d, d] (value | ctx_attention rows)
+        PMGT_CHECK(attn_bwd_wgrad_vc2_supported(w), -3, "pmgt_op_attention_bwd_wgrad: the two-heads-per-step form needs vc_only (bit 1) and beta == 1");
+        return attn_bwd_wgrad_vc2(w, (hipStream_t)stream);
+    }
     return attn_bwd_wgrad(w, (hipStream_t)stream);
 }
 

@@ -318,8 +318,9 @@ def test_c2_at_beta_one_skips_the_dead_branch_and_matches_the_oracle(B):
     L = _lib.hip()
     L.pmgt_launch_trace_reset()
     eng, out = run_engine(case, "bf16", [t.numpy() for t in tables])
-    ran = launch_counts(("qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc", "qkvc_attn_fwd", "attn_bwd_wgrad"))
+    ran = launch_counts(("qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "attn_bwd_wgrad_vc2", "nt_vc", "qkvc_attn_fwd", "attn_bwd_wgrad"))
     assert ran["qkvc_attn_fwd_vc"] == 4 and ran["attn_bwd_wgrad_vc"] == 4 and ran["qkvc_attn_fwd"] == 4 and ran["attn_bwd_wgrad"] == 4, ran
+    assert ran["attn_bwd_wgrad_vc2"] == 4, ran           # the two-heads-per-step form is the default
     assert ran["nt_vc"] == (4 if B >= 192 else 0), ran
     for l in range(4):
         for nm in ("query", "key"):
@@ -344,6 +345,18 @@ def test_c2_at_beta_one_skips_the_dead_branch_and_matches_the_oracle(B):
     np.testing.assert_allclose(out["loss"].item(), og["loss"].item(), rtol=2e-3)
     cos = torch.nn.functional.cosine_similarity(eng.grads, gen.grads, dim=0).item()
     assert cos > 0.9995, cos
+    # ... and the one-head-per-step vc_only backward (`no_vc2_attention_bwd`): the same data gradients element for element, weight-gradient sums in another order
+    one = Engine(PMGTConfig(**kw), dtype="bf16", seed=0)
+    one.set_option("no_vc2_attention_bwd", 1)
+    one.load_params(case["params"])
+    one.set_tables(*[t.numpy() for t in tables])
+    L.pmgt_launch_trace_reset()
+    o1 = one.pretrain_step(dev_batch(case["batch"]), training=True, backward=True, nfr_inject=case["inj"], want_hidden=False)
+    torch.cuda.synchronize()
+    r1 = launch_counts(("attn_bwd_wgrad_vc", "attn_bwd_wgrad_vc2"))
+    assert r1["attn_bwd_wgrad_vc"] == 4 and r1["attn_bwd_wgrad_vc2"] == 0, r1
+    assert out["loss"].item() == o1["loss"].item()
+    assert torch.nn.functional.cosine_similarity(eng.grads, one.grads, dim=0).item() > 0.999999
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])

@@ -973,6 +973,25 @@ def test_fused_kernels_at_beta_one_skip_the_dead_branch(T, H, hm, p):
         ref.backward(rounded(dctx, torch.bfloat16))
         assert rel_err(vcr[2][..., 2 * d:], qin.grad[..., 2 * d:]) < 2e-2
         assert float(qin.grad[..., :2 * d].abs().max()) == 0.0            # autograd: exact zeros for Q and K
+    # ---- the two-heads-per-step backward (flag bit 2): the same V | C gradients BIT FOR BIT (same per-element arithmetic, other step structure),
+    # partial sums [vc2_parts][2 d, d] of the value | ctx_attention rows only
+    H_ = _lib.hip()
+    parts2 = H_.pmgt_op_attention_bwd_wgrad_vc2_parts(H)
+    qk = torch.full((T, S, 4 * d), nan, device="cuda", dtype=torch.bfloat16)
+    cx = torch.full((T, S, d), nan, device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.pmgt_op_qkvc_attention_fwd_ex(P(xd), P(Wd), P(bd), P(md), P(qk), P(cx), T, S, H, dh, beta, p, 17, 18, P(rng), hm | 2, stream()))
+    dx2 = torch.full((T, S, 4 * d), nan, device="cuda", dtype=torch.bfloat16)
+    slab2 = torch.full((parts2, 2 * d, d), nan, device="cuda")
+    bslab2 = torch.full((parts2, 2 * d), nan, device="cuda")
+    H_.pmgt_launch_trace_reset()
+    _lib.check(L.pmgt_op_attention_bwd_wgrad(P(qk), P(md), P(dod), P(xd), P(dx2), P(slab2), P(bslab2), T, H, beta, p, 17, 18, P(rng), hm | 2 | 4, stream()))
+    torch.cuda.synchronize()
+    assert H_.pmgt_launch_trace_count(b"attn_bwd_wgrad_vc2") == 1
+    dx2_std = (_from_head_major(dx2, H, dh) if hm else dx2).float()
+    assert torch.isnan(dx2_std[..., :2 * d]).all() and torch.equal(dx2_std[..., 2 * d:], vcr[2][..., 2 * d:])
+    assert torch.isfinite(slab2).all() and torch.isfinite(bslab2).all()
+    assert rel_err(slab2.double().sum(0).cpu(), G.T @ X) < 1e-4
+    assert float((bslab2.double().sum(0).cpu() - G.sum(0)).abs().max()) < 1e-4 * float(G.abs().sum(0).max())
     # the vc form refuses anything but beta == 1
     assert L.pmgt_op_qkvc_attention_fwd_ex(P(xd), P(Wd), P(bd), P(md), P(qk), P(cx), T, S, H, dh, 0.5, p, 17, 18, P(rng), hm | 2, stream()) == -3
 
