@@ -334,9 +334,20 @@ def test_attention_backward_fused_with_qkvc_weight_gradient(T, H, hm, p):
     dx = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
     slab = torch.full((parts, 4 * d, d), float("nan"), device="cuda")
     bslab = torch.full((parts, 4 * d), float("nan"), device="cuda")
+    _lib.hip().pmgt_launch_trace_reset()
     _lib.check(L.pmgt_op_attention_bwd_wgrad(P(q_in), P(md), P(dod), P(xd), P(dx), P(slab), P(bslab), T, H, beta, p, 11, 12, P(rng), hm,
                                              stream()))
     torch.cuda.synchronize()
+    assert _lib.hip().pmgt_launch_trace_count(b"attn_bwd_wgrad_2b") == 0
+    # the two-barriers-per-step kernel (flag bit 3; opt-in): the same arithmetic per element and the same accumulation order -> bit-identical
+    dx3 = torch.full((T, S, 4 * d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    slab3 = torch.full((parts, 4 * d, d), float("nan"), device="cuda")
+    bslab3 = torch.full((parts, 4 * d), float("nan"), device="cuda")
+    _lib.check(L.pmgt_op_attention_bwd_wgrad(P(q_in), P(md), P(dod), P(xd), P(dx3), P(slab3), P(bslab3), T, H, beta, p, 11, 12, P(rng), hm | 8,
+                                             stream()))
+    torch.cuda.synchronize()
+    assert _lib.hip().pmgt_launch_trace_count(b"attn_bwd_wgrad_2b") == 1
+    assert torch.equal(dx3, dx) and torch.equal(slab3, slab) and torch.equal(bslab3, bslab)
     got = _from_head_major(dx, H, dh) if hm else dx
     assert torch.isfinite(got.float()).all() and torch.isfinite(slab).all() and torch.isfinite(bslab).all()
     if p == 0.0:
