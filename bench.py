@@ -230,7 +230,13 @@ def main():
     if args.rehearse_launch:
         return rehearse_launch(world, rank)
     exchange = world > 1 or args.force_exchange
+    line_out = sys.stdout
     if exchange:
+        # RCCL prints a version banner to the C-level stdout when its first communicator comes up ("RCCL version : ..."): everything any library
+        # writes to file descriptor 1 goes to stderr from here on, the ONE JSON line goes to the real stdout through a duplicate kept aside
+        sys.stdout.flush()
+        line_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:          # --force-exchange without a launcher: a one-rank rendezvous of our own
@@ -572,7 +578,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, graph, S, args.dropout)
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out)
+        line_out.flush()
     if exchange:
         torch.cuda.synchronize()
         dist.barrier()                      # nobody tears the group down while a peer is still inside a collective
