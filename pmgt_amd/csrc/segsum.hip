@@ -9,7 +9,7 @@
 //
 // The sort is a hand-written least-significant-digit radix sort sized for what the keys are: node ids < n_rows <= M / 2
 // (13 bits at the benchmark graph), i.e. ceil(bits / 8) counting passes -- two at C2 -- of
-//     per-tile digit histogram -> exclusive scan over [digit][tile] -> stable scatter.
+//     per-tile digit histogram ([tile][digit] count table) -> stable scatter (each tile derives its own output bases from the table).
 // Inside a tile (16 rounds x 4 waves x 64 lanes, in index order) the rank of an element among its
 // equals is: equals in earlier (round, wave) slots -- a prefix over 64 LDS counters per digit -- plus equals in lower lanes of
 // its own wave -- eight ballots.  The result is THE stable order, the same permutation any stable sort produces.
@@ -22,9 +22,9 @@ namespace pmgt {
 
 static constexpr int SEG_CH = 64;       // sorted positions per WAVE (a chunk); a 256-thread workgroup walks four chunks
 
-static constexpr int RS_ROUNDS = 16, RS_TILE = 256 * RS_ROUNDS, RS_SLOTS = 4 * RS_ROUNDS, RS_MAXBINS = 256;
+static constexpr int RS_ROUNDS = 8, RS_TILE = 256 * RS_ROUNDS, RS_SLOTS = 4 * RS_ROUNDS, RS_MAXBINS = 256;
 
-// digit counts of every tile of the current order, hist[digit][tile] (pass 0 reads the int64 ids, later passes the keys of the previous scatter)
+// digit counts of every tile of the current order, hist[tile][digit] (pass 0 reads the int64 ids, later passes the keys of the previous scatter)
 template <bool FROM_IDS>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ kin, int M, int shift, uint32_t mask,
                                                       int ntiles, uint32_t* __restrict__ hist) {
@@ -38,42 +38,7 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict_
         if (idx < M) atomicAdd(&h[((FROM_IDS ? (uint32_t)ids[idx] : kin[idx]) >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x <= mask) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
-}
-
-// exclusive scan of hist[0 .. n) in place (one workgroup: n = bins x tiles is a few 10^4)
-__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hist, int n) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int t0 = 0; t0 < n; t0 += 4096) {
-        const int i = t0 + tid * 4;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = i + k < n ? hist[i + k] : 0u;
-        const uint32_t tot = v[0] + v[1] + v[2] + v[3];
-        uint32_t inc = tot;                 // inclusive scan over the wave's lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += up;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        uint32_t run = carry_s + woff + inc - tot;
-        __syncthreads();                    // everyone has read carry_s / wsum
-        if (tid == 1023) carry_s = run + tot;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i + k < n) hist[i + k] = run;
-            run += v[k];
-        }
-        __syncthreads();
-    }
+    if (threadIdx.x <= mask) hist[(int64_t)blockIdx.x * (mask + 1u) + threadIdx.x] = h[threadIdx.x];      // [tile][digit]
 }
 
 // One counting pass: element (key, val) of tile t goes to base[digit][t] + (equals before it inside the tile).  FROM_IDS: pass 0
@@ -82,13 +47,47 @@ __global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t* __restrict__ hi
 template <bool FROM_IDS>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ kin,
                                                          const uint32_t* __restrict__ vin, int M, int shift, uint32_t mask, int ntiles,
-                                                         const uint32_t* __restrict__ base, uint32_t* __restrict__ kout,
+                                                         const uint32_t* __restrict__ base /* [tile][digit] counts */, uint32_t* __restrict__ kout,
                                                          uint32_t* __restrict__ vout) {
-    __shared__ uint16_t cnt[RS_MAXBINS][RS_SLOTS + 2];     // 66 entries = 33 dwords per row: the per-digit prefix walks rows conflict-free
+    __shared__ uint16_t cnt[RS_MAXBINS][RS_SLOTS + 2];     // RS_SLOTS + 2 entries = an odd number of dwords per row: the per-digit prefix walks rows conflict-free
     __shared__ uint32_t tbase[RS_MAXBINS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
     for (int i = tid; i < RS_MAXBINS * (RS_SLOTS + 2) / 2; i += 256) ((uint32_t*)cnt)[i] = 0u;
-    if ((uint32_t)tid <= mask) tbase[tid] = base[(int64_t)tid * ntiles + tile];
+    {   // first output position of (digit, this tile) = keys with a smaller digit anywhere + keys with this digit in earlier tiles: digit `tid` walks its
+        // column of the [tile][digit] count table (coalesced across digits: the whole table is a few hundred KB in L2), then one exclusive scan
+        // of the column totals over the digits.  (A first form ran that scan as a launch of its own, one workgroup: two launches of pure latency.)
+        __shared__ uint32_t wtot[4];
+        const uint32_t nb = mask + 1u;
+        uint32_t tot = 0, pre = 0;
+        if ((uint32_t)tid < nb) {
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            int t = 0;
+            for (; t + 4 <= tile; t += 4) {
+                t0 += base[(int64_t)t * nb + tid]; t1 += base[(int64_t)(t + 1) * nb + tid];
+                t2 += base[(int64_t)(t + 2) * nb + tid]; t3 += base[(int64_t)(t + 3) * nb + tid];
+            }
+            for (; t < tile; ++t) t0 += base[(int64_t)t * nb + tid];
+            pre = t0 + t1 + t2 + t3;
+            t0 = t1 = t2 = t3 = 0;
+            for (; t + 4 <= ntiles; t += 4) {
+                t0 += base[(int64_t)t * nb + tid]; t1 += base[(int64_t)(t + 1) * nb + tid];
+                t2 += base[(int64_t)(t + 2) * nb + tid]; t3 += base[(int64_t)(t + 3) * nb + tid];
+            }
+            for (; t < ntiles; ++t) t0 += base[(int64_t)t * nb + tid];
+            tot = pre + t0 + t1 + t2 + t3;
+        }
+        uint32_t inc = tot;                 // inclusive scan over the wave's lanes, then over the four waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w_ = 0; w_ < wave; ++w_) woff += wtot[w_];
+        if ((uint32_t)tid < nb) tbase[tid] = woff + inc - tot + pre;
+    }
     __syncthreads();
     uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
     uint32_t rank[RS_ROUNDS];
@@ -262,7 +261,6 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
     const int ntiles = rs_tiles(M);
     uint32_t* hist[1] = {(uint32_t*)temp};
     const uint32_t mask = (1u << w) - 1u;
-    const int n = (int)(mask + 1u) * ntiles;
     const uint32_t *kin = nullptr, *vin = nullptr;
     for (int p = 0; p < passes; ++p) {
         // the last pass lands in (skeys, perm); the buffers alternate backwards from there
@@ -271,7 +269,6 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
         const int shift = p * w;
         if (p == 0) hipLaunchKernelGGL(rs_hist_kernel<true>, dim3(ntiles), dim3(256), 0, st, ids, kin, M, shift, mask, ntiles, hist[0]);
         else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(ntiles), dim3(256), 0, st, ids, kin, M, shift, mask, ntiles, hist[0]);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, hist[0], n);
         if (p == 0) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout);
         else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout);
         kin = kout; vin = vout;
