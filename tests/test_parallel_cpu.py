@@ -163,3 +163,23 @@ def test_bucket_policy_coalesces_descending_ranges_at_the_boundaries():
     for off, n in [(70, 20), (30, 20), (0, 30)]:
         ex.bucket_ready(off, n)
     assert sent == [(70, 20), (30, 20), (0, 30)]
+
+
+def test_bench_line_helpers():
+    """Pure-host pieces of the bench line: the sustained shader clock from two probe samples (cycle counter against the 100 MHz wall counter, paired
+    per XCC: the counters of different XCCs need not share an origin), the encoder-only flop count SURVEY 8(d) quotes, and the algorithmic bytes
+    of the fused attention kernels in the beta = 1 form."""
+    import torch
+    import bench
+    from pmgt_amd.models import encoder_flops_per_node, train_flops_per_node
+    before = torch.tensor([[1_000, 50, 0, 1], [9_000_000, 50, 1, 1], [77, 60, 0, 1]], dtype=torch.int64)
+    after = torch.tensor([[9_000_000 + 2_100_000, 1_050, 1, 1], [1_000 + 2_100_000, 1_050, 0, 1]], dtype=torch.int64)
+    # 2.1e6 cycles over 1 000 ticks of the 100 MHz counter (10 us): cycles / (ticks / 100) us = MHz (a deliberately unphysical number)
+    assert bench.sustained_sclk_mhz(before, after) == round(2_100_000 / (1_000 / 100.0), 1)
+    assert bench.sustained_sclk_mhz(before, before) is None                       # no elapsed wall time: no number
+    assert abs(encoder_flops_per_node(256, 256, 4, 32) / 1e9 - 4.457) < 1e-3 and abs(train_flops_per_node(256, 256, 4, 32) / 1e9 - 5.380) < 1e-3
+    assert abs(train_flops_per_node(256, 1024, 4, 32) / 1e9 - 9.004) < 1e-3 and abs(train_flops_per_node(512, 2048, 6, 64) / 1e9 - 100.64) < 1e-2
+    M, d = 393216, 256
+    gen = bench.phase_work("bwd.attention_wgrad", M, d, 256, 32, 8, 1536, 768, 1024 * 31, 2)
+    vc = bench.phase_work("bwd.attention_wgrad", M, d, 256, 32, 8, 1536, 768, 1024 * 31, 2, vc=True)
+    assert gen[1] == M * 10 * d * 2 and vc[1] == M * 6 * d * 2 and vc[0] < gen[0]
