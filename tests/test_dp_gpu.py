@@ -204,3 +204,21 @@ def test_rccl_single_rank_group_runs_the_exchange_unchanged():
     assert line["backend"] == "nccl"
     assert line["policies"]["layer"]["collectives_per_step"] == 3 + 2          # NFR head, three layers, embeddings
     assert line["policies"]["two"]["collectives_per_step"] == 2 and line["policies"]["one"]["collectives_per_step"] == 1
+
+
+def test_bench_force_exchange_prints_exactly_one_json_line():
+    """`bench.py --force-exchange`: the N > 1 control flow of the bench on a one-rank RCCL group (init, broadcast, bucketed exchange, MAX over ranks,
+    the all-reduce measurement, barrier -> destroy).  RCCL prints a version banner to the C-level stdout when its first communicator comes up; the
+    bench keeps file descriptor 1 for its ONE JSON line (the driver parses stdout)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-exchange", "--steps", "3", "--warmup", "1", "--batch", "64", "--sampler-threads", "2",
+           "--no-cpu-baseline", "--no-end-to-end", "--no-batch-sweep", "--no-extra-workloads"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["exchange_backend"] == "nccl" and out["allreduce"]["buckets"] == 2 and out["allreduce"]["ms_per_step"] > 0
+    assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["loss_last"])
