@@ -975,6 +975,13 @@ template int gemm_nt<bf16>(const GemmNT&, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // TN (weight gradients)
 // ------------------------------------------------------------------------------------------------
+// A device-side row count (the compacted last layer, the masked NFR rows): the host sizes the row chunks of the splits for the CAPACITY of the
+// buffer, which leaves all live rows to the first few splits (wgrad_nfr at c2: 5 000 live of 31 744 rows -> two of seven splits busy, 75 us).
+// Re-derived here from the live count, every split works; the partial slabs are summed in split order either way.
+__device__ __forceinline__ int tn_live_chunk(const GemmTN& g, int Mlim, int chunk_rows, int gran) {
+    return g.m_dev ? ((Mlim + g.splits - 1) / g.splits + gran - 1) / gran * gran : chunk_rows;
+}
+
 __device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 template <typename T> int gemm_tn_bkm() { return sizeof(T) == 2 ? 64 : 32; }
@@ -1005,6 +1012,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g, int chunk_rows) 
     if (split >= g.splits) return;
     const int n1_0 = (tile / tn2) * 128, n2_0 = (tile % tn2) * 128;
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    chunk_rows = tn_live_chunk(g, Mlim, chunk_rows, 64);
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1221,6 +1229,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_dma_kernel(GemmTN g, int chun
     if (split >= g.splits) return;
     const int n1_0 = (tile / tn2) * 128, n2_0 = (tile % tn2) * 128;
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    chunk_rows = tn_live_chunk(g, Mlim, chunk_rows, 64);
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -1456,6 +1465,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma2_kernel(GemmTN g, int chunk_r
     if (split >= g.splits) return;
     const int n1_0 = (tile / tn2) * 256, n2_0 = (tile % tn2) * 128;
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    chunk_rows = tn_live_chunk(g, Mlim, chunk_rows, 64);
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -1619,6 +1629,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
     if (split >= g.splits) return;
     const int n1_0 = (tile / tn2) * 256, n2_0 = (tile % tn2) * 256;
     const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    chunk_rows = tn_live_chunk(g, Mlim, chunk_rows, 64);
     const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
     // The wave index must be KNOWN to be wave-uniform (readfirstlane): the bias MFMAs below sit under `(i >> 1) == wn`, and
     // a condition derived from threadIdx.x is divergent to the compiler, which then guards the block with an EXEC mask
