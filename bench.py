@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--end-to-end", action="store_true", help="N = 1: on by default; N > 1: also time steps fed by the live host sampler on every rank")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the live-sampler pass")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the B=32 / B=256 extra measurements (N=1 only)")
-    # default "two": one-rank RCCL runs (profiles/r05/rccl_single_rank_exchange.txt) put six per-bucket collectives at +2.5 % of the step, two at
+    # default "two" (= Trainer's default; provisional until a multi-GPU A/B exists -- at N = 8 try "one" next: 12.2 MB is a bandwidth-sized
+    # message over seven xGMI links, and "layer" for the most overlap): one-rank RCCL runs (profiles/r05/rccl_single_rank_exchange.txt) put six per-bucket collectives at +2.5 % of the step, two at
     # +1.8 %; the first of the two (9.8 MB: NFR head + layers) travels under the embedding backward, only the 2.5 MB embedding bucket is exposed
     ap.add_argument("--buckets", default="two", choices=["layer", "two", "one"],
                     help="N > 1: gradient all-reduce per engine bucket (NFR head, each layer, embeddings), as two collectives "
@@ -73,6 +74,9 @@ def parse():
                     help="N = 1: initialise a ONE-rank nccl (= RCCL) process group and run the N > 1 code path unchanged on it -- AVG probe, "
                          "bucketed async all-reduce from the engine's gradient-ready callback, wait in front of the optimizer, the "
                          "allreduce measurement, barrier, destroy: RCCL executes the exchange on a one-GPU box")
+    ap.add_argument("--detail-out", default="", metavar="PATH",
+                    help="where the full record goes (phases, top-3 rooflines, sweeps, per-child detail); default bench_detail.json next to this "
+                         "script (+ a copy under gpurun_out/ when that directory exists).  stdout carries ONE compact line of at most 4 KB")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher check that needs no GPU: the ranks rendezvous over gloo, all-reduce their ranks and rank 0 prints "
                          "a line with n_gpus = world and value = null")
@@ -150,6 +154,17 @@ def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz, vc=False):
         table["bwd.dgrad_qkvc"] = (g(M, d, 2 * d), M * 4 * d * esz)
         table["bwd.dgrad_qkvc_lnb"] = (g(M, d, 2 * d), M * 6 * d * esz)
     return table.get(name)
+
+
+def traffic_key(workload, intermediate, beta):
+    """Name of the committed PMC summary (profiles/traffic[_<key>].json) that belongs to a bench configuration."""
+    return workload + (f"_i{intermediate}" if intermediate else "") + ("_beta1" if beta == 1.0 else "")
+
+
+def dead_branch_skipped(args, d, H, S):
+    """beta == 1 and the shapes the V | C-only kernels take (engine.hip vc_only_applies)."""
+    return (args.beta == 1.0 and args.dtype == "bf16" and S == 32 and d // H == 32 and H % 4 == 0
+            and "no_beta_skip" not in args.engine_option)
 
 
 def host_cpu_share():
@@ -239,25 +254,23 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world == 1:          # --force-exchange without a launcher: a one-rank rendezvous of our own
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(port))
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
+        own_store = None
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            # --force-exchange without a launcher: a one-rank rendezvous of our own through a file (no port to find, so no window in which
+            # another process of a shared host can take it)
+            import tempfile
+            own_store = dist.FileStore(os.path.join(tempfile.mkdtemp(prefix="pmgt_bench_store_"), "store"), 1)
         # rehearsal of the N > 1 control flow on a one-GPU box: PMGT_BENCH_BACKEND=gloo PMGT_BENCH_ONE_DEVICE=1 (every rank
         # on cuda:0, gradients all-reduced through the host); the driver's runs use the defaults (RCCL, one GPU per rank)
         backend = os.environ.get("PMGT_BENCH_BACKEND", "nccl")
         if os.environ.get("PMGT_BENCH_ONE_DEVICE") == "1":
             local = 0
         torch.cuda.set_device(local)
+        kw = {"store": own_store, "rank": 0, "world_size": 1} if own_store is not None else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     dev = f"cuda:{local}"
 
     from pmgt_amd.configuration_pmgt import PMGTConfig
@@ -399,8 +412,11 @@ def main():
         "setup_s": round(setup_s, 1),
         "side_stream_reductions": bool(args.overlap),
         "engine_options": list(args.engine_option),
+        # (per rank; vs_gpu_consumption < 1 means a run fed by the live sampler -- --end-to-end -- is bound by the host on this CPU share, not
+        #  by the GPU: `value` is the pre-staged rate and does not depend on it)
         "host_sampler": {"nodes_per_s": round(sampler_nodes_per_s, 1), "threads": threads, "cpus": os.cpu_count(),
-                         "cpu_share": round(share, 1)},
+                         "cpu_share": round(share, 1), "ranks_on_host": local_world,
+                         "vs_gpu_consumption": round(sampler_nodes_per_s / max(value / world, 1e-9), 3)},
         "allreduce": None,
     }
     if exchange:
@@ -422,9 +438,21 @@ def main():
     out["mfma_util_encoder"] = round(value / world * enc_node / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
     # the same rate priced on the flops the engine EXECUTES: table mode and the last-layer shortcut remove work the algorithmic
     # count above still includes (per-kernel matrix-pipe busy counters are under profiles/)
-    exec_node = executed_flops_per_node(d, I, L, S, nodes, B)
+    dead = dead_branch_skipped(args, d, H, S)
+    exec_node = executed_flops_per_node(d, I, L, S, nodes, B, dead_dot_branch=dead)
     out["executed_gflop_per_node"] = round(exec_node / 1e9, 3)
     out["mfma_util_executed"] = round(value / world * exec_node / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
+    if dead:
+        # beta == 1: the engine skips the dead dot-product branch, so the full model's flop count prices work that is not done: the
+        # utilisation keys carry the EXECUTED figure, the full-model ones stay under names that say so
+        out["mfma_util_full_model_flops"] = out["mfma_util_vs_bf16_dense_peak"]
+        out["mfma_util_encoder_full_model_flops"] = out["mfma_util_encoder"]
+        out["mfma_util_vs_bf16_dense_peak"] = out["mfma_util_executed"]
+        enc_exec = enc_node - 12 * S * 3 * L * (4 * d * d + 2 * S * d)
+        out["mfma_util_encoder"] = round(value / world * enc_exec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)
+    if out["sustained_sclk_mhz"]:
+        # the 2.5 PFLOP/s peak is quoted at 2.4 GHz; the timed steps ran at the clock above: the same utilisation against the peak at THAT clock
+        out["mfma_util_encoder_at_sustained_clock"] = round(out["mfma_util_encoder"] * 2400.0 / out["sustained_sclk_mhz"], 5)
 
     # ---- per-phase HIP-event timers (separate pass, not part of `value`).  EVERY rank runs it, collectives included: the
     # control flow of all ranks is identical from init to destroy (only rank 0 prints), so no rank can be left alone in a
@@ -442,7 +470,7 @@ def main():
         out["phases"] = phases
         esz = 4 if args.dtype == "fp32" else 2
         M = 12 * B * S
-        vc = args.beta == 1.0 and args.dtype == "bf16" and S == 32 and d // H == 32 and H % 4 == 0 and "no_beta_skip" not in args.engine_option
+        vc = dead_branch_skipped(args, d, H, S)
         dom = next((k for k in phases if phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc) is not None), next(iter(phases)))
         w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc)
         cnt, ms = prof[dom]
@@ -487,17 +515,18 @@ def main():
     # this workload, else traffic stays null.
     if "roofline" in out:
         try:
-            wl = args.workload + (f"_i{args.intermediate}" if args.intermediate else "")
-            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json" if wl == "c2" else f"traffic_{wl}.json")))
+            wl = traffic_key(args.workload, args.intermediate, args.beta)
+            tname = "traffic.json" if wl == "c2" else f"traffic_{wl}.json"
+            tr = json.load(open(os.path.join(ROOT, "profiles", tname)))
             fresh = tr.get("kernel_sources_sha") == kernel_sources_sha()       # measured on THESE kernels, else it is stale: null
-            if fresh and tr.get("workload_key", tr["workload"]) == wl and tr["batch"] == B and args.dtype == "bf16" and args.beta == 0.5:
-                src = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
+            if fresh and tr.get("workload_key", tr["workload"]) == wl and tr["batch"] == B and args.dtype == "bf16":
                 for ent in [out["roofline"]] + out.get("roofline_top3", []):
                     ph = tr["phases"].get(ent["kernel"])
                     if not ph:
                         continue
                     ent["traffic"] = ph["hbm_mb_per_launch"]
-                    ent["traffic_unit"] = src
+                    ent["traffic_src"] = "profiles/" + tname            # (MB per launch: 2 x FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections)
+                    ent["traffic_unit"] = "MB per launch (2 x FETCH_SIZE + WRITE_SIZE, " + tr["source"] + ")"
                     if "algorithmic_mb_per_launch" in ent:
                         ent["traffic_ratio"] = round(ph["hbm_mb_per_launch"] / ent["algorithmic_mb_per_launch"], 3)
                     if "matrix_pipe_busy" in ph:        # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the same profile set
@@ -578,7 +607,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, graph, S, args.dropout)
 
     if rank == 0:
-        print(json.dumps(out), file=line_out)
+        detail_path = write_detail(out, args.detail_out)
+        print("bench detail: " + json.dumps(out), file=sys.stderr)
+        print(compact_line(out, detail_path), file=line_out)
         line_out.flush()
     if exchange:
         torch.cuda.synchronize()
@@ -603,18 +634,22 @@ EXTRA_BUDGET_S = 150.0
 
 def extra_workloads():
     import subprocess
+    import tempfile
     res = {}
     for name, extra in EXTRA_WORKLOADS:
+        # (the child's stdout is its own compact line; the parent reads the child's full record from a file of its own)
+        tmp = tempfile.NamedTemporaryFile(prefix=f"pmgt_bench_{name}_", suffix=".json", delete=False)
+        tmp.close()
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-end-to-end",
-               "--no-batch-sweep", "--no-extra-workloads"] + extra
+               "--no-batch-sweep", "--no-extra-workloads", "--detail-out", tmp.name] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=EXTRA_BUDGET_S)
             line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not line:
+            if r.returncode != 0 or not line or os.path.getsize(tmp.name) == 0:
                 res[name] = {"skipped": f"child exited with {r.returncode}: {r.stderr.strip()[-300:]}"}
                 continue
-            d = json.loads(line[-1])
+            d = json.load(open(tmp.name))
             res[name] = {"nodes_per_s": d["value"], "ms_per_step": d["ms_per_step"], "batch": int(extra[extra.index("--batch") + 1]), "steps": d["steps"],
                          "train_gflop_per_node": d.get("train_gflop_per_node"),
                          "mfma_util_vs_bf16_dense_peak": d.get("mfma_util_vs_bf16_dense_peak"), "mfma_util_encoder": d.get("mfma_util_encoder"),
@@ -627,7 +662,96 @@ def extra_workloads():
             res[name] = {"skipped": f"graph build + staging + 13 steps did not finish within {EXTRA_BUDGET_S:.0f} s"}
         except Exception as exc:                      # an extra line is never a reason to lose the headline
             res[name] = {"skipped": repr(exc)[:300]}
+        finally:
+            try:
+                os.unlink(tmp.name)
+            except OSError:
+                pass
     return res
+
+
+# ---- the stdout line.  The driver keeps a bounded tail of stdout and parses the JSON line out of it: round 5's line had grown to 20 KB
+# (six child workloads x (roofline + top-3 + phases) + the full phase map) and its head -- the headline keys -- was the part that got
+# lost.  stdout now carries ONE line of at most LINE_BUDGET bytes; everything else goes to bench_detail.json (and stderr).
+LINE_BUDGET = 4096
+HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+             "config")
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "traffic_src", "avg_launch_ms",
+             "algorithmic_mb_per_launch", "algorithmic_gflop_per_launch", "matrix_pipe_busy")
+SCALAR_KEYS = ("mfma_util_encoder", "mfma_util_vs_bf16_dense_peak", "mfma_util_executed", "mfma_util_encoder_at_sustained_clock",
+               "sustained_sclk_mhz", "step_hbm_gb", "loss_first", "loss_last", "grad_norm_last", "exchange_backend")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _compact_child(w):
+    if not isinstance(w, dict) or "skipped" in w:
+        return {"skipped": str((w or {}).get("skipped", "no record"))[:100]}
+    c = _pick(w, ("nodes_per_s", "ms_per_step", "batch", "mfma_util_encoder", "mfma_util_executed"))
+    r = w.get("roofline") or {}
+    c.update({"roofline_kernel": r.get("kernel"), "roofline_frac": r.get("frac"), "traffic": r.get("traffic")})
+    return c
+
+
+def compact_line(out, detail_path=None, budget=LINE_BUDGET):
+    """The ONE stdout line: the contract's keys first, then `roofline` and `cpu_baseline`, then short summaries of the side measurements, cut
+    back (least important first) until the line is under `budget` bytes.  `out` is the full record that goes to the detail file."""
+    c = _pick(out, HEAD_KEYS)
+    if out.get("roofline"):
+        c["roofline"] = _pick(out["roofline"], ROOF_KEYS)
+    if out.get("cpu_baseline"):
+        c["cpu_baseline"] = dict(out["cpu_baseline"])
+        c["cpu_baseline"]["sample"] = str(c["cpu_baseline"].get("sample", ""))[:200]
+    c.update(_pick(out, SCALAR_KEYS))
+    optional = []       # (key, value) in the order they are given up when the line is too long: last entries go first
+    if out.get("allreduce"):
+        optional.append(("allreduce", _pick(out["allreduce"], ("buckets", "mb", "ms_per_step", "policy", "overlapped_with_backward", "error"))))
+    if out.get("end_to_end"):
+        optional.append(("end_to_end", _pick(out["end_to_end"], ("nodes_per_s", "ms_per_step", "vs_prestaged", "gpu_idle_ms_per_step"))))
+    if out.get("workloads"):
+        optional.append(("workloads", {k: _compact_child(v) for k, v in out["workloads"].items()}))
+    if out.get("host_sampler"):
+        optional.append(("host_sampler", _pick(out["host_sampler"], ("nodes_per_s", "threads", "cpu_share", "vs_gpu_consumption"))))
+    if out.get("batch_sweep"):
+        optional.append(("batch_sweep", {k: (_pick(v, ("nodes_per_s", "ms_per_step")) or {"error": str(v.get("error", ""))[:60]})
+                                         for k, v in out["batch_sweep"].items()}))
+    if out.get("roofline_top3"):
+        optional.append(("roofline_top3", [_pick(t, ("kernel", "bound", "frac", "avg_launch_ms", "traffic_ratio")) for t in out["roofline_top3"]]))
+    if out.get("engine_options"):
+        optional.append(("engine_options", out["engine_options"]))
+    if detail_path:
+        c["detail"] = os.path.basename(detail_path)
+    for k, v in optional:
+        c[k] = v
+    line = json.dumps(c, separators=(",", ":"))
+    while len(line.encode()) >= budget and optional:
+        k, _ = optional.pop()
+        c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line.encode()) >= budget:          # (cannot happen with the keys above; never print a line the driver cannot keep)
+        c["config"] = {"workload": str(c.get("config", {}).get("workload", ""))[:120]}
+        c.pop("cpu_baseline", None)
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def write_detail(out, path=""):
+    """Full record -> bench_detail.json next to this script (or `path`), plus a copy under gpurun_out/ when that directory exists (it is what
+    travels back from a GPU box).  A read-only tree is not a reason to lose the line: returns the path written, or None."""
+    written = None
+    targets = [path] if path else [os.path.join(ROOT, "bench_detail.json")]
+    if not path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or t
+        except OSError:
+            pass
+    return written
 
 
 def measure_allreduce(trainer, eng, dev):

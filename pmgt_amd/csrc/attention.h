@@ -45,6 +45,7 @@ struct AttnBwdWg {
 };
 int attn_bwd_wgrad_parts(int H);
 bool attn_bwd_wgrad_supported(const AttnBwdWg& w);
+bool attn_bwd_wgrad_shape_ok(int Tseq, int S, int dh, int H);
 int attn_bwd_wgrad(const AttnBwdWg& w, hipStream_t st);
 // beta == 1 (vc_only), two heads per step: `slab` is [attn_bwd_wgrad_vc2_parts(H)][2 d * d] and `bias_slab` [..][2 d] -- the value | ctx_attention rows
 // only (row = matrix * d + head * 32 + w); the query / key gradients are zeros the CALLER writes

@@ -3203,11 +3203,17 @@ int attn_bwd_wgrad_vc2(const AttnBwdWg& w, hipStream_t st) {
     return w.a.H * 32 == 256 ? launch_abw_vc2<16>(w, st) : launch_abw_vc2<8>(w, st);
 }
 
+// the part of attn_bwd_wgrad_supported() that is a function of the shape alone: the forward's beta == 1 decision (engine.hip vc_only_applies) asks it
+// BEFORE leaving Q / K unwritten, so that forward and backward cannot disagree (a shape past the offset bound takes the general kernels in both)
+bool attn_bwd_wgrad_shape_ok(int Tseq, int S, int dh, int H) {
+    const int d = H * 32;
+    if ((int64_t)Tseq * 32 * 4 * d * 2 >= (int64_t)1 << 32) return false;      // 32-bit byte offsets inside Q|K|V|C (the saddr addressing form)
+    return S == 32 && dh == 32 && (d == 256 || d == 128) && Tseq >= 2;
+}
+
 bool attn_bwd_wgrad_supported(const AttnBwdWg& w) {
     const AttnArgs& a = w.a;
-    const int d = a.H * 32;
-    if ((int64_t)a.Tseq * 32 * 4 * d * 2 >= (int64_t)1 << 32) return false;      // 32-bit byte offsets inside Q|K|V|C (the saddr addressing form)
-    return a.S == 32 && a.dh == 32 && (d == 256 || d == 128) && a.Tseq >= 2 && a.cls_only_seqs >= 0 && w.x != nullptr && w.ldx % 8 == 0 &&
+    return attn_bwd_wgrad_shape_ok(a.Tseq, a.S, a.dh, a.H) && a.cls_only_seqs >= 0 && w.x != nullptr && w.ldx % 8 == 0 &&
            w.slab != nullptr && a.qkvc != nullptr && a.dctx != nullptr && a.dqkvc != nullptr && ((uintptr_t)w.x % 16) == 0 &&
            ((uintptr_t)a.qkvc % 16) == 0 && ((uintptr_t)a.dctx % 16) == 0 && ((uintptr_t)a.dqkvc % 16) == 0;
 }

@@ -558,7 +558,9 @@ static inline bool fused_qa_applies(const pmgt_engine* e, int Tseq, int S, bool 
 template <typename T>
 static inline bool vc_only_applies(const pmgt_engine* e, int Tseq, int S, bool want_probs) {
     if (e->cfg.beta != 1.f || e->fp8 || e->H % 4 != 0 || (e->opts & (OPT_NO_BETA_SKIP | OPT_NO_FUSED_ATTENTION_BWD))) return false;
-    return fused_qa_applies<T>(e, Tseq, S, want_probs);
+    // (the backward's own conditions: its shape test -- the 32-bit offset bound on Tseq included -- here; its slab capacity is carve()'s, its operands
+    //  are workspace buffers with ldx = d)
+    return fused_qa_applies<T>(e, Tseq, S, want_probs) && attn_bwd_wgrad_shape_ok(Tseq, S, e->dh, e->H);
 }
 
 static inline bool use_table_projection(const pmgt_engine* e, const pmgt_tensors* t, int64_t n_tokens, bool by_ids) {

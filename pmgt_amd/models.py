@@ -64,16 +64,19 @@ def encoder_flops_per_node(d, I, L, S, pairs=10):
     return (pairs + 2) * S * 3 * (L * (10 * d * d + 4 * d * I + 6 * S * d) + 8 * d)
 
 
-def executed_flops_per_node(d, I, L, S, n_nodes, batch, Fv=1536, Ft=768, pairs=10, shortcut=True):
+def executed_flops_per_node(d, I, L, S, n_nodes, batch, Fv=1536, Ft=768, pairs=10, shortcut=True, dead_dot_branch=False):
     """FLOPs the engine actually EXECUTES per target node for the same step (same conventions as train_flops_per_node), with its
     two structural savings taken out: table mode (2 (N + 2) <= tokens: the feature projection and its weight gradient run over
     N + 2 table rows per step instead of one row per token) and the last-layer shortcut (the last layer's attention-output and
-    FFN blocks, forward and backward, run on the B target-CLS + pairs * B pair-CLS + masked rows only)."""
+    FFN blocks, forward and backward, run on the B target-CLS + pairs * B pair-CLS + masked rows only).  `dead_dot_branch`: beta == 1
+    with the dead dot-product branch skipped (V | C projected only, one softmax branch)."""
     F = Fv + Ft
     seqs = pairs + 2
     tok = seqs * S
     masked = 0.16 * (S - 1)
     per_tok_attn = 8 * d * d + 6 * S * d                     # Q|K|V|C projection + the two score / context products
+    if dead_dot_branch:
+        per_tok_attn = 4 * d * d + 4 * S * d                 # V | C projection; C C^T scores + P V (the dot-product scores are never formed)
     per_tok_dense = 2 * d * d + 4 * d * I                    # attention output + FFN
     full_layers = L - 1 if shortcut else L
     enc = tok * (full_layers * (per_tok_attn + per_tok_dense) + 8 * d)

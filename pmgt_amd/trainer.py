@@ -27,7 +27,7 @@ class Trainer:
     def __init__(self, engine, lr: float = 1e-3, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: Optional[float] = None, world_size: int = 1, accumulate_grad_batches: int = 1,
                  random_node_ratio: float = 0.02, mask_node_ratio: float = 0.16, overlap_allreduce: bool = True,
-                 buckets: str = "layer", check_carrier_every: int = 200, force_exchange: bool = False):
+                 buckets: str = "two", check_carrier_every: int = 200, force_exchange: bool = False):
         self.engine = engine
         # force_exchange: run the data-parallel exchange (bucketed all-reduce from the engine's callback, wait in front of the optimizer)
         # even with ONE rank -- the N > 1 code path unchanged on a single-rank process group, so that RCCL executes it on a one-GPU box
@@ -49,7 +49,8 @@ class Trainer:
         self._exchange = None
         # buckets: "layer" = one collective per engine bucket (NFR head, every layer, embeddings); "two" = NFR head + encoder
         # layers as one collective (issued when layer 0's gradients are final), embeddings as the second; "one" = the whole buffer
-        # after the backward pass (engine option one_bucket)
+        # after the backward pass (engine option one_bucket).  Default "two" = bench.py's default (one policy for the library and the measurement);
+        # PROVISIONAL: chosen on one-rank RCCL runs (profiles/r05/rccl_single_rank_exchange.txt), where transport is free -- no multi-GPU A/B exists
         if buckets not in ("layer", "two", "one"):
             raise ValueError(f"buckets={buckets!r}: expected 'layer', 'two' or 'one'")
         self.buckets = buckets

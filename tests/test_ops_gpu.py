@@ -162,6 +162,48 @@ def test_gemm_tn(dt, M, N1, N2):
     assert rel_err(out, ref3) < (1e-5 if dt == "fp32" else 2e-3)
 
 
+@pytest.mark.parametrize("dt,M,N1,N2,gather,kern", [("bf16", 31744, 256, 256, False, b"tn_dma"), ("bf16", 31744, 256, 1536, True, b"tn_dma_gather"),
+                                                    ("bf16", 70016, 1024, 256, False, b"tn_big"), ("bf16", 66000, 512, 512, True, b"tn_big_gather"),
+                                                    ("fp32", 31744, 256, 256, False, b"tn_tile"), ("fp32", 3000, 256, 64, True, b"tn_tile")])
+def test_gemm_tn_row_chunks_follow_the_live_row_count(dt, M, N1, N2, gather, kern):
+    """Weight gradients whose row count is a device-side number (masked NFR rows, the compacted last layer): every TN kernel re-derives its
+    split's row chunk from *m_dev (tn_live_chunk), so the cases that matter are a live count FAR below the capacity (5 000 of 31 744 rows),
+    below splits * 64 (some splits own no rows and must still write a zero slab) and 0 (the output is overwritten with zeros, not left
+    alone).  Each kernel by launch trace; overwrite and accumulate forms against fp64."""
+    _lib, L = _setup()
+    H = _lib.hip()
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M + N2)
+    Pm = torch.randn(M, N1, generator=g)
+    R = 4096
+    Q = torch.randn(R if gather else M, N2, generator=g)
+    rows = torch.randint(0, R, (M,), generator=g) if gather else None
+    Pd, Qd = to_dev(Pm, tdt), to_dev(Q, tdt)
+    rowd = rows.cuda() if gather else None
+    slab = torch.empty(L.pmgt_op_gemm_tn_slab_elems(code, M, N1, N2), device="cuda")
+    Pr, Qr = rounded(Pm, tdt), rounded(Q, tdt)
+    tolr = 1e-5 if dt == "fp32" else 2e-3
+    for live in (0, 1, 63, 5000, M // 7, M - 37, M):
+        if live > M:
+            continue
+        cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+        out = torch.full((N1, N2), float("nan"), device="cuda")
+        H.pmgt_launch_trace_reset()
+        _lib.check(L.pmgt_op_gemm_tn(code, P(Pd), N1, P(Qd), N2, P(rowd), M, N1, N2, P(slab), P(out), 0, P(cnt), stream()))
+        torch.cuda.synchronize()
+        assert H.pmgt_launch_trace_count(kern) == 1, (kern, live)
+        q = Qr[rows[:live]] if gather else Qr[:live]
+        ref = Pr[:live].T @ q
+        if live == 0:
+            assert bool((out == 0).all()), "live == 0: every split writes a zero slab and the reduction overwrites the output"
+        else:
+            assert rel_err(out, ref) < tolr, live
+        # accumulate on top of a known value
+        out.fill_(1.5)
+        _lib.check(L.pmgt_op_gemm_tn(code, P(Pd), N1, P(Qd), N2, P(rowd), M, N1, N2, P(slab), P(out), 1, P(cnt), stream()))
+        assert float((out.double().cpu() - (ref + 1.5)).abs().max()) <= tolr * max(float(ref.abs().max()), 1.0) + 1e-6, live
+
+
 @pytest.mark.parametrize("dt,M,N1,N2,hm", [("fp32", 700, 256, 64, False), ("bf16", 3000, 1024, 256, False), ("bf16", 3000, 1024, 256, True),
                                            ("bf16", 70016, 1024, 256, False), ("bf16", 70016, 1024, 256, True),      # 256 x 256 tile
                                            ("bf16", 66000, 512, 512, False), ("bf16", 40000, 256, 1536, False),
