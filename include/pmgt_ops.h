@@ -37,15 +37,13 @@ extern "C" {
 #define PMGT_OPT_SIDE_STREAM_WGRAD (1u << 20)        /* "side_stream_wgrad": the dense weight-gradient GEMMs of a layer on the engine's side stream, next to the data-gradient chain (same kernels, same reduction order: identical results; opt-in -- the cross-stream hand-offs cost more than the overlap gives at every batch size measured) */
 #define PMGT_OPT_NO_CLS_ONLY_ATTENTION_BWD (1u << 21) /* "no_cls_only_attention_bwd": fused attention backward of the last (shortcut) layer without the skip of query tiles whose d ctx rows are zero -- identical results */
 #define PMGT_OPT_NO_BETA_SKIP (1u << 22)            /* "no_beta_skip": beta == 1 (scripts/run_pmgt.sh:24) on the general fused kernels: Q / K projected, dot-product branch run and differentiated although it contributes exactly nothing (pmgt/pmgt/modeling_pmgt.py:519-521); default: skipped */
-#define PMGT_OPT_TN_MACRO_TILE (1u << 23)           /* "tn_macro_tile": (opt-in) weight gradients dW [N1, N2] with N1 % 256 == 0 on the 256 x 128 LDS-DMA tile instead of the 128 x 128 one -- same products, other split count; measured neutral */
-#define PMGT_OPT_NO_VC2_ATTENTION_BWD (1u << 24)    /* "no_vc2_attention_bwd": beta == 1 on the one-head-per-step vc_only backward instead of the two-heads-per-step form */
-#define PMGT_OPT_TWO_BARRIER_ATTENTION_BWD (1u << 25) /* "two_barrier_attention_bwd": (opt-in) fused attention backward with two barriers per step instead of three (every wave computes the pair's inverse norms / mask terms for itself, phases one and two back to back) -- bit-identical results, measured neutral to 4 % slower */
+#define PMGT_OPT_NO_VC2_ATTENTION_BWD (1u << 23)    /* "no_vc2_attention_bwd": beta == 1 on the one-head-per-step vc_only backward instead of the two-heads-per-step form */
 #define PMGT_OPT_NO_TILE_ATTENTION (1u << 17)        /* "no_tile_attention": S = 64 / head size 64 attention on the cooperative kernels (per-wave fragment loads) instead of the tile forms */
 
 /* ---- which kernel families the calling thread has launched since the last reset (test instrumentation: a parity test at a given
  * size only covers a kernel if the dispatcher actually picked it).  Families: gemm_wsr, gemm_wsr_lnb, gemm_wsr512, gemm_ws, nt_big,
  * nt_big_gather, nt_big_128, nt_lnb, nt_tile, tn_big, tn_big_gather, tn_dma, tn_dma_gather, tn_tile, attn_tiles_fwd, attn_tiles_bwd,
- * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile, f8_wsr512, gemm_rowln, nt_lnf, embed_tok8, qkvc_attn_fwd_vc, attn_bwd_wgrad_vc, nt_vc, tn_dma2, attn_bwd_wgrad_vc2, attn_bwd_wgrad_2b (the vc families: the beta == 1 forms, counted in addition to their general family).  Unknown name: -1. */
+ * qkvc_attn_fwd, attn_bwd_wgrad, f8_big, f8_tile, f8_wsr512, gemm_rowln, nt_lnf, embed_tok8, qkvc_attn_fwd_vc, attn_bwd_wgrad_vc, nt_vc, attn_bwd_wgrad_vc2 (the vc families: the beta == 1 forms, counted in addition to their general family).  Unknown name: -1. */
 void pmgt_launch_trace_reset(void);
 int64_t pmgt_launch_trace_count(const char* family);
 

@@ -70,7 +70,7 @@ OPS_SYMBOLS = [
 OPT = {k: 1 << i for i, k in enumerate((
     "tile_gemm", "valu_attention", "wave_attention_bwd", "no_shortcut", "no_fused_qkvc_attention", "no_head_major",
     "no_table_projection", "no_segment_sum", "consumer_quant", "no_fused_attention_bwd", "store_ln_input", "eager_reduce",
-    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena", "no_role_split_ln", "no_tile_attention", "unfused_ln_bwd", "lockstep_attention_bwd", "side_stream_wgrad", "no_cls_only_attention_bwd", "no_beta_skip", "tn_macro_tile", "no_vc2_attention_bwd", "two_barrier_attention_bwd"))}
+    "side_stream_reduce", "unfused_ln", "one_bucket", "small_arena", "no_role_split_ln", "no_tile_attention", "unfused_ln_bwd", "lockstep_attention_bwd", "side_stream_wgrad", "no_cls_only_attention_bwd", "no_beta_skip", "no_vc2_attention_bwd"))}
 SAMPLER_SYMBOLS = [
     "pmgt_sampler_create", "pmgt_sampler_destroy", "pmgt_sampler_last_error", "pmgt_sampler_seed",
     "pmgt_sampler_context", "pmgt_sampler_batch", "pmgt_sampler_batch_mt", "pmgt_sampler_max_pairs",

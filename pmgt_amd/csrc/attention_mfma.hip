@@ -1905,14 +1905,11 @@ __device__ __forceinline__ void abw_draw_mval(const AttnArgs& a, const DropKey& 
 // mode): every attention wave is a cosine wave (BR 1) of one (pair, head, tile); it also has all 32 columns of its dV, and the pair's scratch
 // holds dS1 | P1 | norms only.
 template <int VC> struct AbwScr { static constexpr int P1 = VC == 2 ? 2048 : 4096, P2 = 6144, RHO = VC == 2 ? 4096 : 8192; };
-// PRIV (the two-barrier kernel): the norms 1 / |c_j| of ALL 32 keys and the mask terms are computed by every wave for itself into a wave-private
-// [rho 32 | madd 32] array (LDS operations of one wave execute in order: no barrier), so the second phase can follow the first without one
-template <int IT, int BR, int VC = 0, bool PRIV = false>
-__device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, float mraw, int h, char* scr, int r, int q, int lane,
-                                           float* priv = nullptr) {
+template <int IT, int BR, int VC = 0>
+__device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, float mraw, int h, char* scr, int r, int q, int lane) {
     constexpr float L2E = 1.4426950408889634f;
     if (VC == 1 && BR == 2) return;
-    float* rho = PRIV ? priv : (float*)(scr + AbwScr<VC>::RHO);
+    float* rho = (float*)(scr + AbwScr<VC>::RHO);
     float* madd = rho + 32;
     const int x = 16 * IT + r;
     const char* gin = st.gin;
@@ -1931,21 +1928,7 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
         fv[jt] = *(const bf16x8*)(gin + abw_g_addr(16 * jt + r, st.vcol + 16 * q));
     }
     float ss = 0.f, rho_x = 0.f;
-    if (BR == 1 && PRIV) {
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            float sj = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bf16x2_t c2 = {kc[jt][2 * e], kc[jt][2 * e + 1]};
-                sj = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, sj, false);
-            }
-            sj = red_q<2>(sj, false);
-            const float rj = st.act ? __builtin_amdgcn_rsqf(sj) : 0.f;
-            if (q == 0) rho[16 * jt + r] = rj;
-            if (jt == IT) { ss = sj; rho_x = rj; }
-        }
-    } else if (BR == 1) {
+    if (BR == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bf16x2_t c2 = {kc[IT][2 * e], kc[IT][2 * e + 1]};
@@ -1955,9 +1938,9 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
         rho_x = st.act ? __builtin_amdgcn_rsqf(ss) : 0.f;
         if (q == 0) rho[x] = rho_x;
     }
-    if (BR == 1 || PRIV) {
+    if (BR == 1) {
         // the mask term sits with the cosine wave: the dot-product wave reads one fragment more, and the in-kernel stamps showed its
-        // first interval at 1 340 cycles against 770 here with the mask term over there (PRIV: every wave computes its own)
+        // first interval at 1 340 cycles against 770 here with the mask term over there
         const float mv = (1.f - mraw) * -10000.f;
         float mm = mv;
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x121, 0xf, 0xf, false)));
@@ -1965,7 +1948,7 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x124, 0xf, 0xf, false)));
         mm = raw_max(mm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mm), 0x128, 0xf, 0xf, false)));
         mm = red_q<2>(mm, true);
-        if (PRIV ? lane < 32 : (lane >> 4) == IT) madd[lane & 31] = (mv - mm) * L2E;      // (shared form: each tile's cosine wave writes 16 of the 32 entries)
+        if ((lane >> 4) == IT) madd[lane & 31] = (mv - mm) * L2E;      // (each tile's cosine wave writes 16 of the 32 entries)
     }
     cy.rho_x = rho_x;
     cy.ss = ss;
@@ -1988,16 +1971,15 @@ __device__ __forceinline__ void abw_phase1(const AttnArgs& a, const DropKey& kd,
     if (BR == 2) abw_draw_mval<BR>(a, kd, st.t, h, x, q, cy.mval);
 }
 
-template <int IT, int BR, int VC = 0, bool PRIV = false>
-__device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, int h, char* scr, int r, int q,
-                                           const float* priv = nullptr) {
+template <int IT, int BR, int VC = 0>
+__device__ __forceinline__ void abw_phase2(const AttnArgs& a, const DropKey& kd, const AbwStep& st, AbwCarry& cy, int h, char* scr, int r, int q) {
     constexpr float L2E = 1.4426950408889634f;
     constexpr float ISQ = 0.17677669529663687f;          // 1 / sqrt(32)
     if (VC == 1 && BR == 2) return;
     char* iS = scr + (BR == 1 ? 0 : 2048);               // dS1 (rows scaled by 1 / |c_i|) | dS2
     char* iP1 = scr + AbwScr<VC>::P1;
     char* iP2 = scr + AbwScr<VC>::P2;
-    const float* rho = PRIV ? priv : (const float*)(scr + AbwScr<VC>::RHO);
+    const float* rho = (const float*)(scr + AbwScr<VC>::RHO);
     const float* madd = rho + 32;
     const int x = 16 * IT + r;
     const float rho_x = cy.rho_x;
@@ -2893,292 +2875,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_wgrad_vc2_kernel(AttnBwdWg w) {
     }
 }
 
-// =================================================================================================
-// The general (any beta) kernel with TWO barriers per step (round 5; OPT-IN: `two_barrier_attention_bwd`).  Built on the reading that the
-// three-barrier form above spends ~1.3 of its 2.7 us per step on the latency of its barrier intervals (the beta == 1 forms: half the work per
-// step took 2.2 us, twice the work 3.1).  MEASURED: bit-identical and NOT faster -- 530 vs 522 us and 569 vs 545 us per launch on two boxes (both pairs
-// in the same phase: 601) -- so the per-step floor is not the number of barriers; a wave's first and second phase back to back is as long as the two
-// intervals were (profiles/r05/NOTES.md).  Kept with its parity test as the record of that experiment.  The first
-// barrier only publishes 32 inverse norms and 32 mask terms of the pair; here every wave computes those for itself (PRIV forms of the phases:
-// eight more dot products and a wave maximum), so phases one and two run back to back:
-//     pair 0:  [phase 1 + 2 of step i - 1]  |  [phase 3 of step i - 1]  |
-//     pair 1:  [phase 3 of step i - 2]      |  [phase 1 + 2 of step i - 1]  |          (still one interval late: heavy against light per SIMD)
-//     GEMM:    [x hi half, early pieces, k-step 0 of step i - 2]  |  [copy-out of step i - 2, x lo half, late pieces, k-step 1]  |
-// Same rings: every tile is overwritten behind the barrier that follows its last reader, every DMA piece has at least a whole iteration to land
-// (x tile double-buffered as before, its row halves requested where their predecessors' last reader has passed: rows 0 .. 31 of x(i) in the second
-// interval of iteration i, rows 32 .. 63 in the first interval of iteration i + 1).
-// =================================================================================================
-template <int KT>
-__global__ __launch_bounds__(1024) void attn_bwd_wgrad_2b_kernel(AttnBwdWg w) {
-    using C = AbwCfg<KT>;
-    constexpr int D = C::D;
-    constexpr int PRV0 = C::SMEM;                     // wave-private [rho 32 | madd 32] of the eight attention waves behind the kernel's LDS
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const AttnArgs& a = w.a;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const int H = a.H;
-    const int b = blockIdx.x;
-    const int h = (b >> 3) % H, xs = (b & 7) + 8 * (b / (8 * H));
-    const int gx = gridDim.x / H;
-    const int npair = (a.Tseq + 1) / 2;
-    const int nsteps = xs < npair ? (npair - xs + gx - 1) / gx : 0;
-    const int M = a.Tseq * 32;
-    auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
-    if (wave & 4) __builtin_amdgcn_s_setprio(1);
-    auto in_tile = [](int s) { return C::G0 + ((2 * s) & 3) * C::GB; };
-    auto out_tile = [](int s) { return C::G0 + ((2 * s + 1) & 3) * C::GB; };
-
-    if (wave < 8) {
-        // ================================ attention role ================================
-        const int ul = wave >> 2, it = (wave >> 1) & 1, br = wave & 1;         // br = 0: cosine branch (BR 1), 1: dot-product branch (BR 2)
-        char* scr = smem + C::S0 + ul * C::SCR;
-        float* priv = (float*)(smem + PRV0 + wave * 256);
-        const DropKey kd = make_drop_key(br == 0 ? a.drop1 : a.drop2);
-        auto seq_of = [&](int s) { return 2 * (xs + s * gx) + ul; };
-        const int role = 2 * it + br;
-        auto mask_of = [&](int s) {
-            const int t = min(seq_of(s), a.Tseq - 1);
-            return a.mask ? a.mask[(int64_t)t * 32 + (lane & 31)] : 1.f;
-        };
-        auto step_of = [&](int s) {
-            AbwStep st;
-            const int t = seq_of(s);
-            st.act = t < a.Tseq;
-            st.t = min(t, a.Tseq - 1);
-            st.zq1 = st.act && t < a.cls_only_seqs;
-            st.gin = smem + in_tile(s) + ul * (32 * 256);
-            st.gout = smem + out_tile(s) + ul * (32 * 256);
-            st.oin = smem + C::O0 + (s & 1) * C::OB + ul * (32 * 64);
-            return st;
-        };
-        auto run = [&](auto ITc, auto BRc) __attribute__((always_inline)) {
-            constexpr int IT = decltype(ITc)::value, BR = decltype(BRc)::value;
-            AbwCarry cy;
-            cy.rho_x = 0.f; cy.ss = 0.f;
-#pragma unroll
-            for (int k_ = 0; k_ < 2; ++k_) cy.sc[k_] = cy.dp[k_] = cy.dch[k_] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            float mnext = mask_of(0);
-            auto phase12 = [&](const AbwStep& st, int s) __attribute__((always_inline)) {
-                const float mraw = mnext;
-                mnext = mask_of(s + 1);
-                abw_phase1<IT, BR, 0, true>(a, kd, st, cy, mraw, h, scr, r, q, lane, priv);
-                __builtin_amdgcn_wave_barrier();      // (this wave's own norms / mask terms: LDS operations of one wave execute in order)
-                abw_phase2<IT, BR, 0, true>(a, kd, st, cy, h, scr, r, q, priv);
-            };
-            if (ul == 0 || (a.opts & OPT_LOCKSTEP_ATTENTION_BWD)) {
-                for (int i = 0; i <= nsteps + 1; ++i) {
-                    const int s = i - 1;
-                    const bool on = s >= 0 && s < nsteps;
-                    AbwStep st = step_of(on ? s : 0);
-                    if (on) phase12(st, s);
-                    bar();
-                    if (on) abw_phase3<IT, BR, 0>(st, cy, scr, r, q);
-                    bar();
-                }
-            } else {
-                for (int i = 0; i <= nsteps + 1; ++i) {
-                    const int s3 = i - 2, s1 = i - 1;
-                    if (s3 >= 0 && s3 < nsteps) {
-                        const AbwStep st3 = step_of(s3);
-                        abw_phase3<IT, BR, 0>(st3, cy, scr, r, q);
-                    }
-                    bar();
-                    const bool on = s1 >= 0 && s1 < nsteps;
-                    AbwStep st = step_of(on ? s1 : 0);
-                    if (on) phase12(st, s1);
-                    bar();
-                }
-            }
-        };
-        if (role == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        else if (role == 1) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        else if (role == 2) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-        else run(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
-        return;
-    }
-    // ==================================== GEMM role ====================================
-    const int g = wave - 8, gn = g & 1, gk = g >> 1;                 // n tiles 4 gn .. 4 gn + 3, k tiles KQ gk .. KQ gk + KQ - 1
-    typedef __attribute__((address_space(3))) void lds_void_t;
-    typedef __attribute__((address_space(1))) const void gbl_void_t;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    f32x4 acc[4][C::KQ], accb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < C::KQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int frow = 8 * q + (r >> 2), fkey = abw_f(frow), fsub = (r & 3) >> 1, fhalf = 8 * (r & 1);
-    const uint32_t fla = (uint32_t)(frow * 256 + ((fkey ^ fsub) << 4) + fhalf), flb = (uint32_t)(frow * C::XROW + ((fkey ^ fsub) << 4) + fhalf);
-    static_assert(C::G0 % 512 == 0 && C::GB % 512 == 0 && C::XB % 512 == 0, "tile bases must keep the row / chunk / half bit fields disjoint");
-    const int hoff = a.hm ? 4 * h * 32 : h * 32, ms = a.hm ? 32 : D;
-    constexpr int LPRX = 64 / (1024 / C::XROW);
-    const uint32_t dx_chunk = (uint32_t)((lane % LPRX) ^ abw_f(lane / LPRX)), dx_row = (uint32_t)(lane / LPRX) * (uint32_t)w.ldx * 2u;
-    const uint32_t dq_chunk = (uint32_t)((lane & 15) ^ abw_f(lane >> 4)), dq_row = (uint32_t)(lane >> 4) * 4u * (uint32_t)D * 2u;
-    auto kstep = [&](int s, int ks) {
-        const uint32_t gb = lds0 + out_tile(s), xb = lds0 + (s & 1) * C::XB;
-        bf16x8 fa[4], fb[4];
-        uint32_t aa[4], ab[4];
-        uint32_t ba = fla + gb + (uint32_t)(32 * ks * 256), bb = flb + xb + (uint32_t)(32 * ks * C::XROW);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            aa[u] = ba ^ (uint32_t)((2 * (4 * gn + u)) << 4);
-            ab[u] = bb ^ (uint32_t)((2 * (C::KQ * gk + (u % C::KQ))) << 4);
-        }
-        u32x2 tb[8], ta[8];
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %16\n\t"
-            "ds_read_b64_tr_b16 %1, %16 offset:%24\n\t"
-            "ds_read_b64_tr_b16 %2, %17\n\t"
-            "ds_read_b64_tr_b16 %3, %17 offset:%24\n\t"
-            "ds_read_b64_tr_b16 %4, %18\n\t"
-            "ds_read_b64_tr_b16 %5, %18 offset:%24\n\t"
-            "ds_read_b64_tr_b16 %6, %19\n\t"
-            "ds_read_b64_tr_b16 %7, %19 offset:%24\n\t"
-            "ds_read_b64_tr_b16 %8, %20\n\t"
-            "ds_read_b64_tr_b16 %9, %20 offset:%25\n\t"
-            "ds_read_b64_tr_b16 %10, %21\n\t"
-            "ds_read_b64_tr_b16 %11, %21 offset:%25\n\t"
-            "ds_read_b64_tr_b16 %12, %22\n\t"
-            "ds_read_b64_tr_b16 %13, %22 offset:%25\n\t"
-            "ds_read_b64_tr_b16 %14, %23\n\t"
-            "ds_read_b64_tr_b16 %15, %23 offset:%25"
-            : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]), "=&v"(tb[4]), "=&v"(tb[5]), "=&v"(tb[6]), "=&v"(tb[7]),
-              "=&v"(ta[0]), "=&v"(ta[1]), "=&v"(ta[2]), "=&v"(ta[3]), "=&v"(ta[4]), "=&v"(ta[5]), "=&v"(ta[6]), "=&v"(ta[7])
-            : "v"(ab[0]), "v"(ab[1]), "v"(ab[2]), "v"(ab[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "n"(4 * C::XROW), "n"(4 * 256)
-            : "memory");
-        asm volatile("s_waitcnt lgkmcnt(6)"
-                     : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(tb[4]), "+v"(tb[5]), "+v"(tb[6]), "+v"(tb[7]), "+v"(ta[0]), "+v"(ta[1]));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) fb[u] = __builtin_bit_cast(bf16x8, (u32x4){tb[2 * u][0], tb[2 * u][1], tb[2 * u + 1][0], tb[2 * u + 1][1]});
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (nt == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ta[2]), "+v"(ta[3]));
-            if (nt == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ta[4]), "+v"(ta[5]));
-            if (nt == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[6]), "+v"(ta[7]));
-            fa[nt] = __builtin_bit_cast(bf16x8, (u32x4){ta[2 * nt][0], ta[2 * nt][1], ta[2 * nt + 1][0], ta[2 * nt + 1][1]});
-#pragma unroll
-            for (int u = 0; u < C::KQ; ++u) acc[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nt], fb[u], acc[nt][u], 0, 0, 0);
-        }
-        const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-        const bf16x8 fsel = (gk & 3) == 0 ? fa[0] : ((gk & 3) == 1 ? fa[1] : ((gk & 3) == 2 ? fa[2] : fa[3]));
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fsel, ones, accb, 0, 0, 0);
-    };
-    // x rows of step sx into x slot sx & 1: wave g owns rows 8 g .. 8 g + 7 (waves 0 - 3: the half k-step 0 reads, waves 4 - 7: the half k-step 1 reads)
-    constexpr int RPI = 1024 / C::XROW, NX = 8 / RPI;
-    auto dma_x = [&](int sx) __attribute__((always_inline)) {
-        const int m0x = 64 * (xs + sx * gx);
-        char* xb = smem + (sx & 1) * C::XB;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const int row0 = 8 * g + RPI * j;
-            const int mrow = min(m0x + row0, M - RPI);
-            const uint32_t off = (uint32_t)mrow * (uint32_t)w.ldx * 2u + dx_row + ((dx_chunk ^ (uint32_t)abw_f(row0)) << 4);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)w.x + (size_t)off), (lds_void_t*)(xb + row0 * C::XROW), 16, 0, 0);
-        }
-    };
-    auto dma_attn = [&](int i, bool early) __attribute__((always_inline)) {
-        const int m0 = 64 * (xs + i * gx);
-        if ((g < 4) == early) {
-            char* gt = smem + in_tile(i);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row0 = 8 * g + 4 * j;
-                const int mrow = min(m0 + row0, M - 4);
-                const uint32_t c = dq_chunk ^ (uint32_t)abw_f(row0);
-                const uint32_t col = a.hm ? c * 8u : (c >> 2) * (uint32_t)D + (c & 3u) * 8u;
-                const uint32_t off = ((uint32_t)mrow * 4u * (uint32_t)D + (uint32_t)hoff + col) * 2u + dq_row;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)a.qkvc + (size_t)off), (lds_void_t*)(gt + row0 * 256), 16, 0, 0);
-            }
-        }
-        if (g < 4 && (g < 2) == early) {
-            const int row0 = 16 * g, row = row0 + (lane >> 2), c = (lane & 3) ^ abw_kt(row);
-            const uint32_t m = (uint32_t)min(m0 + row, M - 1);
-            const char* src = (const char*)a.dctx + (size_t)((m * (uint32_t)D + (uint32_t)(h * 32 + c * 8)) * 2u);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + C::O0 + (i & 1) * C::OB + row0 * 64), 16, 0, 0);
-        }
-    };
-    const int attnE = (g < 4 ? 2 : 0) + (g < 2 ? 1 : 0), attnL = (g >= 4 ? 2 : 0) + ((g == 2 || g == 3) ? 1 : 0);      // (uniform)
-    auto wait_vm = [](int n) __attribute__((always_inline)) {
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        }
-    };
-    // Vector-memory operations of this wave per iteration i, in issue order:
-    //   first interval:   Xhi = rows 32 .. 63 of x(i - 1) (waves 4 - 7)    E = early pieces of step i (pair 0's rows)
-    //   second interval:  Xlo = rows 0 .. 31 of x(i) (waves 0 - 3)         L = late pieces of step i (pair 1's rows)     2 copy-out stores
-    // Deadlines (vmcnt retires in issue order: "X has landed" = at most the operations issued behind X outstanding):
-    //   before barrier 1 of iteration i:  L of iteration i - 1 (pair 1 reads it in this iteration's second interval) -- and with it, older, Xhi of
-    //                                     iteration i - 1 (k-step 1 of this iteration) and Xlo of iteration i - 1 (k-step 0 of the next);
-    //   before barrier 2 of iteration i:  E of iteration i (pair 0 reads it in the next iteration's first interval).
-    int prev_tail = 0;
-    for (int i = 0; i <= nsteps + 1; ++i) {
-        const int sg = i - 2;
-        const bool xhi = g >= 4 && i >= 1 && i - 1 < nsteps, xlo = g < 4 && i < nsteps, at = i < nsteps;      // (uniform)
-        if (xhi) dma_x(i - 1);
-        if (at) dma_attn(i, true);
-        const int nXhi = xhi ? NX : 0, nE = at ? attnE : 0, nXlo = xlo ? NX : 0, nL = at ? attnL : 0;
-        if (sg >= 0) kstep(sg, 0);
-        wait_vm(prev_tail >= 0 ? min(prev_tail + nXhi + nE, 9) : 0);
-        bar();
-        u32x4 v[2];
-        const bool copy = sg >= 0;
-        int lc = lane;
-        asm volatile("" : "+v"(lc));
-        if (copy) {
-            const uint32_t gb = lds0 + out_tile(sg);
-            uint32_t ad[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
-                ad[p] = gb + row * 256 + ((c ^ abw_f(row)) << 4);
-            }
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
-        }
-        if (xlo) dma_x(i);
-        if (at) dma_attn(i, false);
-        const bool full = copy && 64 * (xs + sg * gx) + 64 <= M;
-        if (copy) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]) :: "memory");
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int idx = 64 * (8 * p + g) + lc, row = idx >> 4, c = idx & 15;
-                const int m = 64 * (xs + sg * gx) + row;
-                if (m < M) *(u32x4*)((char*)a.dqkvc + (size_t)(((uint32_t)m * 4u * D + (uint32_t)(hoff + (c >> 2) * ms + (c & 3) * 8)) * 2u)) = v[p];
-            }
-        }
-        if (sg >= 0) kstep(sg, 1);
-        const bool lock2 = (a.opts & OPT_LOCKSTEP_ATTENTION_BWD) != 0;      // (uniform) both pairs in the same phase: every piece is due at the END of its iteration
-        if (full) wait_vm(lock2 ? 2 : min(nXlo + nL + 2, 9));
-        else if (!copy) wait_vm(lock2 ? 0 : min(nXlo + nL, 9));
-        else wait_vm(0);
-        prev_tail = full ? 2 : (!copy ? 0 : -1);
-        bar();
-    }
-    float* slab = w.slab + (int64_t)xs * 4 * D * D;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = 4 * gn + nt;
-        const int wrow = (n >> 1) * D + h * 32 + 16 * (n & 1) + 4 * q;
-#pragma unroll
-        for (int j = 0; j < C::KQ; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) slab[(int64_t)(wrow + e) * D + 16 * (C::KQ * gk + j) + r] = acc[nt][j][e];
-    }
-    if (r == 0 && w.bias_slab) {
-        const int n = 4 * gn + (gk & 3);
-        const int wrow = (n >> 1) * D + h * 32 + 16 * (n & 1) + 4 * q;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w.bias_slab[(int64_t)xs * 4 * D + wrow + e] = accb[e];
-    }
-}
 
 int attn_bwd_wgrad_parts(int H) { return std::max(8, (256 / std::max(H, 1)) / 8 * 8); }
 // two-heads-per-step form of the beta == 1 mode: row slots = partial slabs of [2 d, d] (value | ctx_attention rows; twice as many, half as large)
@@ -3230,23 +2926,8 @@ template <int KT, bool VC = false> static int launch_abw(const AttnBwdWg& w, hip
     return 0;
 }
 
-template <int KT> static int launch_abw_2b(const AttnBwdWg& w, hipStream_t st) {
-    using C = AbwCfg<KT>;
-    auto kern = attn_bwd_wgrad_2b_kernel<KT>;
-    constexpr int smem = C::SMEM + 8 * 256;
-    PMGT_SMEM_ATTR((const void*)kern, smem);
-    const int gx = attn_bwd_wgrad_parts(w.a.H);
-    note_launch(LT_ATTN_BWD_WGRAD);
-    note_launch(LT_ATTN_BWD_WGRAD_2B);
-    hipLaunchKernelGGL(kern, dim3(gx * w.a.H), dim3(1024), smem, st, w);
-    PMGT_LAUNCH_OK();
-    return 0;
-}
-
 int attn_bwd_wgrad(const AttnBwdWg& w, hipStream_t st) {
     PMGT_CHECK(attn_bwd_wgrad_supported(w), -2, "attn_bwd_wgrad: unsupported shape S=%d dh=%d H=%d", w.a.S, w.a.dh, w.a.H);
-    if (!w.a.vc_only && (w.a.opts & OPT_TWO_BARRIER_ATTENTION_BWD))
-        return w.a.H * 32 == 256 ? launch_abw_2b<16>(w, st) : launch_abw_2b<8>(w, st);
     if (w.a.vc_only) {
         PMGT_CHECK(w.a.beta == 1.f, -2, "attn_bwd_wgrad: vc_only is the beta == 1 form (beta = %g)", (double)w.a.beta);
         return w.a.H * 32 == 256 ? launch_abw<16, true>(w, st) : launch_abw<8, true>(w, st);

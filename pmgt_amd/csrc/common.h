@@ -65,7 +65,7 @@ void set_error(const char* fmt, ...);
 enum LaunchTag {
     LT_GEMM_WSR = 0, LT_GEMM_WSR_LNB, LT_GEMM_WSR512, LT_GEMM_WS, LT_NT_BIG, LT_NT_BIG_GATHER, LT_NT_BIG_128, LT_NT_LNB, LT_NT_TILE,
     LT_TN_BIG, LT_TN_BIG_GATHER, LT_TN_DMA, LT_TN_DMA_GATHER, LT_TN_TILE, LT_ATTN_TILES_FWD, LT_ATTN_TILES_BWD, LT_QKVC_ATTN_FWD,
-    LT_ATTN_BWD_WGRAD, LT_F8_BIG, LT_F8_TILE, LT_F8_WSR512, LT_GEMM_ROWLN, LT_NT_LNF, LT_EMBED_TOK8, LT_QKVC_ATTN_FWD_VC, LT_ATTN_BWD_WGRAD_VC, LT_NT_VC, LT_TN_DMA2, LT_ATTN_BWD_WGRAD_VC2, LT_ATTN_BWD_WGRAD_2B, LT_COUNT
+    LT_ATTN_BWD_WGRAD, LT_F8_BIG, LT_F8_TILE, LT_F8_WSR512, LT_GEMM_ROWLN, LT_NT_LNF, LT_EMBED_TOK8, LT_QKVC_ATTN_FWD_VC, LT_ATTN_BWD_WGRAD_VC, LT_NT_VC, LT_ATTN_BWD_WGRAD_VC2, LT_COUNT
 };
 void note_launch(int tag);
 
@@ -333,9 +333,7 @@ enum PathOpt : uint32_t {
     OPT_LOCKSTEP_ATTENTION_BWD = 1u << 19,      // fused attention backward: both pairs of a step in the same phase (round 3's schedule) instead of one interval apart
     OPT_NO_CLS_ONLY_ATTENTION_BWD = 1u << 21,   // fused attention backward of the shortcut layer: the attention waves of query rows 16 .. 31 run their softmax phases for CLS-only sequences too (d ctx is zero there: identical results)
     OPT_NO_BETA_SKIP = 1u << 22,                // beta == 1: the fused kernels keep projecting / differentiating Q and K and run the (dead) dot-product branch
-    OPT_TN_MACRO_TILE = 1u << 23,               // (opt-in) weight gradients with N1 % 256 == 0 on the 256 x 128 LDS-DMA tile of gemm_tn_dma2_kernel instead of the 128 x 128 one: built against the "operands travel L2 -> LDS twice" reading of round 4, measured neutral (profiles/r05)
-    OPT_NO_VC2_ATTENTION_BWD = 1u << 24,        // beta == 1: the one-head-per-step vc_only backward instead of the two-heads-per-step form (A/B)
-    OPT_TWO_BARRIER_ATTENTION_BWD = 1u << 25,   // (opt-in) fused attention backward on the two-barriers-per-step kernel (every wave computes the pair's norms / mask terms itself): bit-identical, measured neutral to 4 % slower (profiles/r05)
+    OPT_NO_VC2_ATTENTION_BWD = 1u << 23,        // beta == 1: the one-head-per-step vc_only backward instead of the two-heads-per-step form (A/B)
     OPT_SIDE_STREAM_WGRAD = 1u << 20,   // the dense weight-gradient GEMMs of a layer on the engine's side stream, next to the data-gradient chain (opt-in: measured slower at every batch size, profiles/r04/NOTES.md section 9)
 };
 

@@ -36,7 +36,7 @@ void note_launch(int tag) { if (tag >= 0 && tag < LT_COUNT) ++g_launch_count[tag
 static const char* const g_launch_names[LT_COUNT] = {
     "gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_tile",
     "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
-    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc", "tn_dma2", "attn_bwd_wgrad_vc2", "attn_bwd_wgrad_2b"};
+    "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "nt_lnf", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "nt_vc", "attn_bwd_wgrad_vc2"};
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -1677,7 +1677,7 @@ static uint32_t option_bit(const char* key) {
         {"no_shortcut", OPT_NO_SHORTCUT}, {"no_fused_qkvc_attention", OPT_NO_FUSED_QKVC_ATTENTION}, {"no_head_major", OPT_NO_HEAD_MAJOR},
         {"no_table_projection", OPT_NO_TABLE_PROJECTION}, {"no_segment_sum", OPT_NO_SEGMENT_SUM}, {"consumer_quant", OPT_CONSUMER_QUANT},
         {"no_fused_attention_bwd", OPT_NO_FUSED_ATTENTION_BWD}, {"store_ln_input", OPT_STORE_LN_INPUT}, {"eager_reduce", OPT_EAGER_REDUCE},
-        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}, {"no_beta_skip", OPT_NO_BETA_SKIP}, {"tn_macro_tile", OPT_TN_MACRO_TILE}, {"no_vc2_attention_bwd", OPT_NO_VC2_ATTENTION_BWD}, {"two_barrier_attention_bwd", OPT_TWO_BARRIER_ATTENTION_BWD}};
+        {"side_stream_reduce", OPT_SIDE_STREAM_REDUCE}, {"unfused_ln", OPT_UNFUSED_LN}, {"one_bucket", OPT_ONE_BUCKET}, {"small_arena", OPT_SMALL_ARENA}, {"no_role_split_ln", OPT_NO_ROLE_SPLIT_LN}, {"no_tile_attention", OPT_NO_TILE_ATTENTION}, {"unfused_ln_bwd", OPT_UNFUSED_LN_BWD}, {"lockstep_attention_bwd", OPT_LOCKSTEP_ATTENTION_BWD}, {"side_stream_wgrad", OPT_SIDE_STREAM_WGRAD}, {"no_cls_only_attention_bwd", OPT_NO_CLS_ONLY_ATTENTION_BWD}, {"no_beta_skip", OPT_NO_BETA_SKIP}, {"no_vc2_attention_bwd", OPT_NO_VC2_ATTENTION_BWD}};
     for (const auto& t : tab)
         if (key && strcmp(key, t.name) == 0) return t.bit;
     return 0;
@@ -1710,6 +1710,9 @@ int pmgt_op_linear(int dtype, const void* A, int64_t lda, const void* B, int64_t
                    const float* bias, int epilogue, void* aux, int64_t ldaux, const void* residual, int64_t ldr, float drop_p,
                    uint32_t drop_site, const uint64_t* rng, void* ln_out, float* ln_stats, const float* ln_gamma,
                    const float* ln_beta, float ln_eps, uint32_t path_opts, void* stream) {
+    // (a NULL output is a GPU fault, not an error code: skip_c -- "do not store the LayerNorm input" -- is an engine-internal form)
+    PMGT_CHECK(A && B && C, -2, "pmgt_op_linear: NULL operand (A, B and C are required)");
+    PMGT_CHECK(epilogue == 0 || aux, -2, "pmgt_op_linear: epilogue %d needs aux", epilogue);
     GemmWS g; g.opts = path_opts;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux; g.res = residual; g.ldr = ldr;
@@ -1800,7 +1803,6 @@ int pmgt_op_attention_bwd_wgrad(const void* qkvc, const float* mask, const void*
     AttnBwdWg w;
     w.a = mk_attn(qkvc, mask, n_seq, 32, H, 32, beta, drop_p, site1, site2, rng);
     w.a.dctx = dctx; w.a.dqkvc = dqkvc; w.a.hm = (head_major & 1) != 0; w.a.vc_only = (head_major & 2) != 0;
-    if (head_major & 8) w.a.opts |= OPT_TWO_BARRIER_ATTENTION_BWD;
     w.x = x; w.ldx = (int64_t)H * 32; w.slab = slab; w.bias_slab = bias_slab;
     PMGT_CHECK(attn_bwd_wgrad_supported(w), -3, "pmgt_op_attention_bwd_wgrad: unsupported shape (needs bf16, S = 32, dh = 32, d in {128, 256}, n_seq >= 2)");
     if (head_major & 4) {      // two-heads-per-step form of the beta == 1 mode: partial sums [vc2_parts][2 d, d] (value | ctx_attention rows)

@@ -1446,161 +1446,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_dma_kernel(GemmTN g, int chun
 }
 
 // ------------------------------------------------------------------------------------------------
-// TN, bf16, LDS-DMA pipeline, 256 (N1) x 128 (N2) tile on eight waves (round 5).  The 128 x 128 kernel above moves every operand
-// column through L2 -> LDS once per output tile it touches: at dW [256, 256] that is 4 tiles x 256 columns = 1 024 column-reads per
-// row of the reduction, twice the algorithmic 512, and the launch is bound by exactly that path (41 GB/s per CU: 77 us at c2).  Here a
-// workgroup keeps ALL 256 columns of P against a 128-column half of Q: 2 tiles x 384 = 768 column-reads per row, one workgroup per CU
-// at 128 row splits.  MEASURED NEUTRAL (c2, B = 1 024: 77 - 91 us per launch against 80 - 88 on the 128 x 128 tile; profiles/r05/NOTES.md): the second
-// reader of an operand column is served by L2 / Infinity Cache and both kernels sit at the ~5 TB/s these launches take from HBM -- the
-// re-read was not the bound.  Opt-in (`tn_macro_tile`), kept with its test as the record of that experiment.  Same ring discipline (four 32-row stages, three in flight, counted vmcnt + one raw barrier per stage), same
-// swizzle (source chunk = slot ^ 2 tn_f(row)); a stage is P [32][256] (512-byte rows: two rows per 1-KB DMA instruction) followed
-// by Q [32][128]; wave (wm, wn) of the 4 x 2 grid owns 64 x 64 outputs: 8 + 8 transposing reads and 16 MFMAs per stage.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_tn_dma2_kernel(GemmTN g, int chunk_rows) {
-    constexpr int BKM = 32, PROW = 512, QROW = 256, QOFF = BKM * PROW, STAGE = QOFF + BKM * QROW, NST = 4;      // 24 KiB per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tn1 = (g.N1 + 255) / 256, tn2 = (g.N2 + 127) / 128, tiles = tn1 * tn2;
-    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
-    const int tile = bidx % tiles, split = xcd + 8 * (bidx / tiles);
-    if (split >= g.splits) return;
-    const int n1_0 = (tile / tn2) * 256, n2_0 = (tile % tn2) * 128;
-    const int Mlim = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    chunk_rows = tn_live_chunk(g, Mlim, chunk_rows, 64);
-    const int mbeg = split * chunk_rows, mend = min(Mlim, mbeg + chunk_rows);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 15, q = lane >> 4;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = g.bias_slab != nullptr && n2_0 == 0 && wn == 0;
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // this wave's three DMA instructions of a stage: P rows 4 w + {0, 1} and 4 w + {2, 3} (lane >> 5 = row inside the instruction, lane & 31
-    // = chunk slot), Q rows 4 w .. 4 w + 3 (lane >> 4, lane & 15)
-    const char* zero = (const char*)g.zeros;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-    auto issue = [&](int kt) {
-        const int mb = mbeg + kt * BKM;
-        char* st = smem + (kt & (NST - 1)) * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 4 * wave + 2 * j + (lane >> 5);
-            const int ch = (lane & 31) ^ (tn_f(row) << 1);
-            const int m = mb + row, cp = n1_0 + ch * 8;
-            const char* sp = (m < mend && cp < g.N1) ? (const char*)g.P + ((int64_t)m * g.ldp + cp) * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)sp, (lds_void_t*)(st + (4 * wave + 2 * j) * PROW), 16, 0, 0);
-        }
-        {
-            const int row = 4 * wave + (lane >> 4);
-            const int ch = (lane & 15) ^ (tn_f(row) << 1);
-            const int m = mb + row, cq = n2_0 + ch * 8;
-            const char* sq = (m < mend && cq < g.N2) ? (const char*)g.Q + ((int64_t)m * g.ldq + cq) * 2 : zero;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)sq, (lds_void_t*)(st + QOFF + 4 * wave * QROW), 16, 0, 0);
-        }
-    };
-    const int nk = mend > mbeg ? (mend - mbeg + BKM - 1) / BKM : 0;
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    // per-lane byte offsets of the 4 + 4 fragment reads inside a stage (row = 8 q + (r >> 2); + 4 rows = + 2048 B in P, + 1024 B in Q)
-    uint32_t offa[4], offb[4];
-    {
-        const int row = 8 * q + (r >> 2);
-        const int sw = tn_f(row) << 1;                 // same for row and row + 4
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ca = wm * 64 + i * 16 + 4 * (r & 3), cb = wn * 64 + i * 16 + 4 * (r & 3);
-            offa[i] = (uint32_t)(row * PROW + (((ca >> 3) ^ sw) << 4) + ((ca & 7) << 1));
-            offb[i] = (uint32_t)(QOFF + row * QROW + (((cb >> 3) ^ sw) << 4) + ((cb & 7) << 1));
-        }
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        const int younger = min(2, nk - 1 - kt);       // three DMA instructions per wave and stage
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3);
-        // (inline asm: the compiler would drain the DMA ring in front of any LDS read it can see -- see gemm_tn_dma_kernel)
-        const uint32_t sbase = lds_base + (uint32_t)((kt & (NST - 1)) * STAGE);
-        u32x2 t[16];
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %16\n\t"
-            "ds_read_b64_tr_b16 %1, %16 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %2, %17\n\t"
-            "ds_read_b64_tr_b16 %3, %17 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %4, %18\n\t"
-            "ds_read_b64_tr_b16 %5, %18 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %6, %19\n\t"
-            "ds_read_b64_tr_b16 %7, %19 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %8, %20\n\t"
-            "ds_read_b64_tr_b16 %9, %20 offset:1024\n\t"
-            "ds_read_b64_tr_b16 %10, %21\n\t"
-            "ds_read_b64_tr_b16 %11, %21 offset:1024\n\t"
-            "ds_read_b64_tr_b16 %12, %22\n\t"
-            "ds_read_b64_tr_b16 %13, %22 offset:1024\n\t"
-            "ds_read_b64_tr_b16 %14, %23\n\t"
-            "ds_read_b64_tr_b16 %15, %23 offset:1024\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
-              "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15])
-            : "v"(sbase + offa[0]), "v"(sbase + offa[1]), "v"(sbase + offa[2]), "v"(sbase + offa[3]),
-              "v"(sbase + offb[0]), "v"(sbase + offb[1]), "v"(sbase + offb[2]), "v"(sbase + offb[3])
-            : "memory");
-        bf16x8 fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i] = __builtin_bit_cast(bf16x8, (u32x4){t[2 * i][0], t[2 * i][1], t[2 * i + 1][0], t[2 * i + 1][1]});
-            fb[i] = __builtin_bit_cast(bf16x8, (u32x4){t[8 + 2 * i][0], t[8 + 2 * i][1], t[9 + 2 * i][0], t[9 + 2 * i][1]});
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (do_bias) {
-            const bf16 one = (bf16)1.f;
-            const bf16x8 ones = {one, one, one, one, one, one, one, one};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
-        }
-    }
-    auto rowmap = [&](int n1) {       // head-major column of P -> row of dW in q | k | v | c order
-        if (g.perm_dh <= 0) return n1;
-        const int w = n1 % g.perm_dh, hm = n1 / g.perm_dh;
-        return (hm & 3) * g.perm_d + (hm >> 2) * g.perm_dh + w;
-    };
-    if (do_bias && r == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
-                if (n1 < g.N1) g.bias_slab[(int64_t)split * g.N1 + rowmap(n1)] = accb[i][e];
-            }
-    }
-    float* out = g.slab + (int64_t)split * g.N1 * g.N2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n2 = n2_0 + wn * 64 + j * 16 + r;
-            if (n2 >= g.N2) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n1 = n1_0 + wm * 64 + i * 16 + 4 * q + e;
-                if (n1 < g.N1) out[(int64_t)rowmap(n1) * g.N2 + n2] = acc[i][j][e];
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
 // TN, bf16, 256 x 256 output tile, 512 threads (8 waves as 2 x 4, 128 x 64 outputs each), same 4-stage LDS-DMA ring
 // (32 rows of P and of Q per stage, 512-byte rows).  The 128 x 128 kernel re-reads P once per 128 columns of Q and Q
 // once per 128 columns of P through L2 (dW_qkvc at M = 393k: 3.2 GB of L2 -> CU traffic for 1 GB of HBM bytes, i.e.
@@ -1878,13 +1723,6 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmTN g, int chunk_ro
         }
 }
 
-// the 256 x 128 tile of gemm_tn_dma2_kernel: bf16, no row gather, N1 a multiple of 256 (every column of P lives in one workgroup), enough
-// rows that each of its splits walks at least 16 stages
-static bool tn_dma2_shape(int M, int N1, int N2, int bkm, uint32_t opts) {
-    if (bkm != 64 || (opts & OPT_TILE_GEMM) || !(opts & OPT_TN_MACRO_TILE) || N1 % 256 != 0 || N2 % 8 != 0) return false;
-    const int tiles = (N1 / 256) * cdiv(N2, 128);
-    return tiles <= 256 && M >= 16 * 32 * std::max(8, (256 / tiles) / 8 * 8);
-}
 // the 256 x 256 tile pays off when the 128 x 128 kernel would re-read its operands through L2 four times or more
 static bool tn_big_shape(int M, int N1, int N2, int bkm, uint32_t opts) {
     return bkm == 64 && !(opts & OPT_TILE_GEMM) && M >= 65536 && N1 % 256 == 0 && N2 % 256 == 0 && N1 * N2 >= 4 * 256 * 256;
@@ -1896,10 +1734,6 @@ int gemm_tn_pick_splits(int M, int N1, int N2, int bkm, uint32_t opts) {
         int splits = cdiv(256, tiles);                   // one 8-wave workgroup per CU
         splits = std::max(8, splits / 8 * 8);
         return splits;
-    }
-    if (tn_dma2_shape(M, N1, N2, bkm, opts)) {
-        const int tiles = (N1 / 256) * cdiv(N2, 128);
-        return std::max(8, (256 / tiles) / 8 * 8);       // one 8-wave workgroup per CU, whole XCD groups
     }
     const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
     // one workgroup per CU: the LDS-DMA ring hides the latency by itself, and the slab traffic (splits * N1 * N2 * 4 B
@@ -1943,17 +1777,6 @@ template <typename T> int gemm_tn(const GemmTN& g, hipStream_t st) {
             note_launch(g.q_rows ? LT_TN_BIG_GATHER : LT_TN_BIG);
             if (g.q_rows) hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
             else hipLaunchKernelGGL(gemm_tn_big_kernel<false>, dim3(8 * tiles256 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk256);
-            PMGT_LAUNCH_OK();
-            return 0;
-        }
-        if (g.zeros != nullptr && g.q_rows == nullptr && tn_dma2_shape(g.M, g.N1, g.N2, bkm, g.opts) &&
-            g.splits == gemm_tn_pick_splits(g.M, g.N1, g.N2, bkm, g.opts)) {
-            constexpr int smem = 4 * (32 * 512 + 32 * 256);
-            PMGT_SMEM_ATTR((const void*)gemm_tn_dma2_kernel, smem);
-            const int tiles2 = (g.N1 / 256) * cdiv(g.N2, 128);
-            const int chunk2 = cdiv(cdiv(std::max(g.M, 1), g.splits), 32) * 32;
-            note_launch(LT_TN_DMA2);
-            hipLaunchKernelGGL(gemm_tn_dma2_kernel, dim3(8 * tiles2 * cdiv(g.splits, 8)), dim3(512), smem, st, g, chunk2);
             PMGT_LAUNCH_OK();
             return 0;
         }

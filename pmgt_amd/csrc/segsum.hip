@@ -9,7 +9,8 @@
 //
 // The sort is a hand-written least-significant-digit radix sort sized for what the keys are: node ids < n_rows <= M / 2
 // (13 bits at the benchmark graph), i.e. ceil(bits / 8) counting passes -- two at C2 -- of
-//     per-tile digit histogram ([tile][digit] count table) -> stable scatter (each tile derives its own output bases from the table).
+//     per-tile digit histogram ([tile][digit] count table) -> stable scatter (each tile derives its own output bases from the table; above
+//     256 tiles a column-scan launch in between turns the table into prefixes once instead of once per tile).
 // Inside a tile (16 rounds x 4 waves x 64 lanes, in index order) the rank of an element among its
 // equals is: equals in earlier (round, wave) slots -- a prefix over 64 LDS counters per digit -- plus equals in lower lanes of
 // its own wave -- eight ballots.  The result is THE stable order, the same permutation any stable sort produces.
@@ -41,14 +42,42 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict_
     if (threadIdx.x <= mask) hist[(int64_t)blockIdx.x * (mask + 1u) + threadIdx.x] = h[threadIdx.x];      // [tile][digit]
 }
 
+// Large token counts (more than RS_FOLD_TILES tiles): the folded form below has EVERY tile walk the whole [tile][digit] table for its bases --
+// O(tiles^2 x digits) reads behind a tiles-deep dependent loop per workgroup (768 tiles at B = 4 096: 0.3 GB of L2 reads per pass).  Here the
+// column prefixes are computed ONCE per pass, in place: wave = one digit, lane l = a strip of ceil(tiles / 64) consecutive tiles (strip sums ->
+// wave scan -> exclusive prefixes written over the counts); tot[digit] = the column total.  The scatter then reads one table row.
+__global__ __launch_bounds__(256) void rs_colscan_kernel(uint32_t* __restrict__ hist, int ntiles, uint32_t nb, uint32_t* __restrict__ tot) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t dg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (dg >= nb) return;                 // (wave-uniform)
+    const int per = (ntiles + 63) / 64, t0 = lane * per, t1 = min(ntiles, t0 + per);
+    uint32_t s = 0;
+    for (int t = t0; t < t1; ++t) s += hist[(int64_t)t * nb + dg];
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    uint32_t run = inc - s;
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t c = hist[(int64_t)t * nb + dg];
+        hist[(int64_t)t * nb + dg] = run;
+        run += c;
+    }
+    if (lane == 63) tot[dg] = inc;
+}
+static constexpr int RS_FOLD_TILES = 256;
+
 // One counting pass: element (key, val) of tile t goes to base[digit][t] + (equals before it inside the tile).  FROM_IDS: pass 0
 // reads the int64 ids (val = token index).  (A first form also counted the NEXT pass's digit per destination tile with global atomics, to
 // save the later histogram launches: 393 216 device-scope atomics made that scatter 81 us; a histogram launch is 8.)
-template <bool FROM_IDS>
+template <bool FROM_IDS, bool SCANNED = false>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ kin,
                                                          const uint32_t* __restrict__ vin, int M, int shift, uint32_t mask, int ntiles,
-                                                         const uint32_t* __restrict__ base /* [tile][digit] counts */, uint32_t* __restrict__ kout,
-                                                         uint32_t* __restrict__ vout) {
+                                                         const uint32_t* __restrict__ base /* [tile][digit] counts (SCANNED: column prefixes) */,
+                                                         const uint32_t* __restrict__ coltot /* SCANNED: [digit] column totals */,
+                                                         uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
     __shared__ uint16_t cnt[RS_MAXBINS][RS_SLOTS + 2];     // RS_SLOTS + 2 entries = an odd number of dwords per row: the per-digit prefix walks rows conflict-free
     __shared__ uint32_t tbase[RS_MAXBINS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
@@ -59,7 +88,9 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restri
         __shared__ uint32_t wtot[4];
         const uint32_t nb = mask + 1u;
         uint32_t tot = 0, pre = 0;
-        if ((uint32_t)tid < nb) {
+        if (SCANNED) {
+            if ((uint32_t)tid < nb) { pre = base[(int64_t)tile * nb + tid]; tot = coltot[tid]; }
+        } else if ((uint32_t)tid < nb) {
             uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
             int t = 0;
             for (; t + 4 <= tile; t += 4) {
@@ -246,8 +277,8 @@ __global__ __launch_bounds__(256) void seg_fix_kernel(const int* __restrict__ se
 
 static inline int rs_tiles(int M) { return cdiv(M, RS_TILE); }
 
-int64_t seg_sort_temp_bytes(int M) {       // one [256][tiles] count table
-    return (int64_t)RS_MAXBINS * rs_tiles(M) * 4 + 256;
+int64_t seg_sort_temp_bytes(int M) {       // one [tiles][256] count table + [256] column totals (the scanned form of large token counts)
+    return (int64_t)RS_MAXBINS * rs_tiles(M) * 4 + 256 + RS_MAXBINS * 4;
 }
 
 int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* vals, uint32_t* skeys, uint32_t* perm, int* seg_off,
@@ -260,6 +291,7 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
     const int passes = cdiv(bits, 8), w = cdiv(bits, passes);       // digits of equal width (13 bits: 7 + 7)
     const int ntiles = rs_tiles(M);
     uint32_t* hist[1] = {(uint32_t*)temp};
+    uint32_t* coltot = (uint32_t*)((char*)temp + (int64_t)RS_MAXBINS * ntiles * 4 + 256);
     const uint32_t mask = (1u << w) - 1u;
     const uint32_t *kin = nullptr, *vin = nullptr;
     for (int p = 0; p < passes; ++p) {
@@ -269,8 +301,14 @@ int seg_sort(const int64_t* ids, int M, int n_rows, uint32_t* keys, uint32_t* va
         const int shift = p * w;
         if (p == 0) hipLaunchKernelGGL(rs_hist_kernel<true>, dim3(ntiles), dim3(256), 0, st, ids, kin, M, shift, mask, ntiles, hist[0]);
         else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(ntiles), dim3(256), 0, st, ids, kin, M, shift, mask, ntiles, hist[0]);
-        if (p == 0) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout);
-        else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], kout, vout);
+        if (ntiles > RS_FOLD_TILES) {
+            hipLaunchKernelGGL(rs_colscan_kernel, dim3(cdiv((int)mask + 1, 4)), dim3(256), 0, st, hist[0], ntiles, mask + 1u, coltot);
+            if (p == 0) hipLaunchKernelGGL((rs_scatter_kernel<true, true>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], coltot, kout, vout);
+            else hipLaunchKernelGGL((rs_scatter_kernel<false, true>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], coltot, kout, vout);
+        } else {
+            if (p == 0) hipLaunchKernelGGL((rs_scatter_kernel<true, false>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], coltot, kout, vout);
+            else hipLaunchKernelGGL((rs_scatter_kernel<false, false>), dim3(ntiles), dim3(256), 0, st, ids, kin, vin, M, shift, mask, ntiles, hist[0], coltot, kout, vout);
+        }
         kin = kout; vin = vout;
     }
     PMGT_LAUNCH_OK();

@@ -93,7 +93,21 @@ class Trainer:
                            max_grad_norm=self.max_grad_norm)
         self._opt_steps += 1
         if self.check_carrier_every and self._opt_steps % self.check_carrier_every == 0 and not getattr(self, "_capturing", False):
-            eng.check_layernorm_carrier()
+            self._check_carrier()
+
+    def _check_carrier(self):
+        """The periodic LayerNorm-carrier guard of an EAGER step.  When the guard has to switch the engine to stored LayerNorm inputs while
+        captured steps are alive, the ones this trainer owns (run_live(graphs=True)) are dropped first -- run_live re-captures them on its next
+        call, exactly as its own periodic check does -- so a user who mixes run_live(graphs=True) with later eager train_step calls does not
+        meet an error at the flip.  Replay handles the CALLER holds (capture_step) cannot be dropped from here: that case keeps the engine's
+        error, which names the remedy."""
+        eng = self.engine
+        flips = eng.layernorm_carrier_ratio() > eng.LN_CARRIER_MAX_RATIO and not eng.get_option("store_ln_input")
+        if flips and getattr(eng, "_live_graphs", 0) > 0 and self.__dict__.get("_live_replays"):
+            import gc
+            self.drop_captured_steps()
+            gc.collect()
+        eng.check_layernorm_carrier()
 
     def train_step(self, batch) -> torch.Tensor:
         """One micro-batch; steps the optimizer every `accumulate_grad_batches` calls."""

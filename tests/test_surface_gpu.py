@@ -222,6 +222,81 @@ def test_live_graph_cache_follows_hyperparameters_and_keeps_its_workspace():
     eng.set_option("store_ln_input", 1)
 
 
+def test_replays_interleaved_with_a_larger_eager_step_equal_the_all_eager_run():
+    """Round-5 advisor finding: a captured step keeps replaying on the workspace it was captured over, while a later, larger eager call
+    makes the engine carve a NEW workspace -- capture_step's public API allows both to alternate.  What a step needs from earlier steps
+    (parameters, moments, the RNG / AdamW counters) lives in the engine, and each forward rebuilds its weight mirrors in its own workspace
+    from the parameters: replay, replay, larger eager step, replay leaves exactly the parameters and moments the same four steps leave
+    when all of them run eagerly."""
+    from pmgt_amd.trainer import Trainer
+    res = {}
+    for graphs in (False, True):
+        eng, smp, ids = _live_world()
+        tr = Trainer(eng, lr=1e-3, max_grad_norm=5.0)
+        small = [_eager_batch(smp, ids[32 * i: 32 * (i + 1)]) for i in range(3)]
+        big = _eager_batch(smp, ids[100:196])
+        static = tuple({k: v.clone() for k, v in x.items()} if isinstance(x, dict) else x.clone() for x in small[0])
+
+        def feed(b):
+            for dst, src in zip(static, b):
+                if isinstance(dst, dict):
+                    for k in dst:
+                        dst[k].copy_(src[k])
+                else:
+                    dst.copy_(src)
+        if graphs:
+            replay = tr.capture_step(static, warmup=2)        # two eager steps on batch 0, then the capture (not executed)
+            ws0 = eng._ws
+            step_small = lambda b: (feed(b), replay())
+        else:
+            tr.train_step(small[0])
+            tr.train_step(small[0])
+            step_small = lambda b: tr.train_step(b)
+        step_small(small[0])
+        step_small(small[1])
+        tr.train_step(big)                                    # three times the rows: the engine re-allocates its workspace
+        if graphs:
+            assert eng._ws is not ws0 and replay.keep[0] is ws0
+        step_small(small[2])
+        tr.train_step(big)
+        torch.cuda.synchronize()
+        assert int(eng.opt_step.item()) == 7
+        res[graphs] = (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone())
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+
+
+def test_eager_steps_after_run_live_graphs_survive_a_layernorm_carrier_flip():
+    """Round-5 advisor finding: the periodic carrier guard of an EAGER optimizer step raised whenever captured steps were alive -- a user
+    mixing run_live(graphs=True) with later eager train_step calls met a RuntimeError at the flip.  The trainer now drops the captured steps
+    it owns, switches, and run_live re-captures on its next call; a replay handle the CALLER holds still gets the engine's error."""
+    from pmgt_amd.trainer import Trainer
+    eng, smp, ids = _live_world()
+    tr = Trainer(eng, lr=1e-4, max_grad_norm=5.0, check_carrier_every=2)
+    tr.run_live(smp, ids, batch_size=32, steps=4, threads=3, depth=2, graphs=True)
+    assert len(tr._live_replays) == 2 and not eng.get_option("store_ln_input")
+    eng.view("bert.encoder.layer.0.output.LayerNorm.bias").fill_(20.0)        # |beta / gamma| = 20 > 8, behind the engine's back
+    b = _eager_batch(smp, ids[:32])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr.train_step(b)
+        tr.train_step(b)                                      # optimizer step 6: the guard runs, drops the trainer's replays, switches
+    assert eng.get_option("store_ln_input") and len(tr._live_replays) == 0
+    tr.run_live(smp, ids, batch_size=32, steps=3, threads=3, depth=2, graphs=True)      # re-captured under the new option
+    torch.cuda.synchronize()
+    assert len(tr._live_replays) == 2 and torch.isfinite(eng.params).all()
+    # a handle the caller holds cannot be dropped by the trainer: the error names the remedy
+    eng2, smp2, ids2 = _live_world()
+    tr2 = Trainer(eng2, lr=1e-4, max_grad_norm=5.0, check_carrier_every=1)
+    b2 = _eager_batch(smp2, ids2[:32])
+    replay = tr2.capture_step(b2, warmup=1)
+    eng2.view("bert.encoder.layer.0.output.LayerNorm.bias").fill_(20.0)
+    with pytest.raises(RuntimeError, match="captured steps of this engine are alive"):
+        tr2.train_step(b2)
+    del replay
+
+
 def _eager_batch(smp, targets):
     from pmgt_amd.datasets import MODE_TRAIN
     tgt, pair, num_pairs, labels = smp.batch(np.asarray(targets), MODE_TRAIN, threads=2, base_seed=3, counter=0)

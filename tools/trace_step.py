@@ -14,8 +14,7 @@ sys.path.insert(0, ROOT)
 
 FAMILIES = ["gemm_wsr", "gemm_wsr_lnb", "gemm_wsr512", "gemm_ws", "nt_big", "nt_big_gather", "nt_big_128", "nt_lnb", "nt_lnf", "nt_tile",
             "tn_big", "tn_big_gather", "tn_dma", "tn_dma_gather", "tn_tile", "attn_tiles_fwd", "attn_tiles_bwd", "qkvc_attn_fwd",
-            "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "attn_bwd_wgrad_vc2", "nt_vc",
-            "tn_dma2"]
+            "attn_bwd_wgrad", "f8_big", "f8_tile", "f8_wsr512", "gemm_rowln", "embed_tok8", "qkvc_attn_fwd_vc", "attn_bwd_wgrad_vc", "attn_bwd_wgrad_vc2", "nt_vc"]
 
 
 def main():
