@@ -658,6 +658,8 @@ def extra_workloads():
                          "loss_first": d.get("loss_first"), "loss_last": d.get("loss_last"), "setup_s": d.get("setup_s"),
                          "wall_s": round(time.perf_counter() - t0, 1),
                          "phases_top": dict(list(d.get("phases", {}).items())[:8])}
+            if "fp8" in extra:
+                res[name]["parity_mode_only"] = True
         except subprocess.TimeoutExpired:
             res[name] = {"skipped": f"graph build + staging + 13 steps did not finish within {EXTRA_BUDGET_S:.0f} s"}
         except Exception as exc:                      # an extra line is never a reason to lose the headline
@@ -711,7 +713,9 @@ def compact_line(out, detail_path=None, budget=LINE_BUDGET):
     if out.get("end_to_end"):
         optional.append(("end_to_end", _pick(out["end_to_end"], ("nodes_per_s", "ms_per_step", "vs_prestaged", "gpu_idle_ms_per_step"))))
     if out.get("workloads"):
-        optional.append(("workloads", {k: _compact_child(v) for k, v in out["workloads"].items()}))
+        # (a child marked parity_mode_only -- the fp8 mode, measured at 0.98 - 0.99 of bf16: DESIGN section 3 -- stays in the detail file only)
+        optional.append(("workloads", {k: _compact_child(v) for k, v in out["workloads"].items()
+                                       if not (isinstance(v, dict) and v.get("parity_mode_only"))}))
     if out.get("host_sampler"):
         optional.append(("host_sampler", _pick(out["host_sampler"], ("nodes_per_s", "threads", "cpu_share", "vs_gpu_consumption"))))
     if out.get("batch_sweep"):
