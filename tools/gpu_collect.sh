@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything profiles/rNN holds for one tree, into gpurun_out/set_<tag>/ (copy into profiles/rNN/<tag>_*).
-# Usage: tools/gpu_collect.sh <tag> [lines|c2|c4|i4d|small]   (one part per gpurun call: the whole set is longer than one call's limit)
+# Usage: tools/gpu_collect.sh <tag> [lines|c2|c4|c4i|i4d|small]   (one part per gpurun call: the whole set is longer than one call's limit)
 set -u
 TAG=${1:-a}
 PART=${2:-lines}
@@ -11,14 +11,16 @@ cd $REPO
 Q="--no-cpu-baseline --no-extra-workloads"
 QQ="$Q --no-end-to-end --no-batch-sweep"
 if [ "$PART" = "lines" ]; then
-  python3 bench.py > $OUT/bench_B1024.json 2> $OUT/bench_B1024.err || exit 1
-  echo "default line done"
-  python3 bench.py --workload c3 $Q > $OUT/bench_c3_B1024.json 2>> $OUT/err.log || exit 1
-  python3 bench.py --dtype fp8 $QQ > $OUT/bench_fp8_B1024.json 2>> $OUT/err.log || exit 1
-  python3 bench.py --force-exchange --buckets two $QQ > $OUT/bench_rccl_one_rank_two_buckets.json 2>> $OUT/err.log || exit 1
-  python3 bench.py --force-exchange --buckets layer $QQ > $OUT/bench_rccl_one_rank_layer_buckets.json 2>> $OUT/err.log || exit 1
-  python3 bench.py $QQ > $OUT/bench_plain_after_rccl.json 2>> $OUT/err.log || exit 1
-  PMGT_BENCH_BACKEND=gloo PMGT_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 4 --steps 3 --warmup 1 --batch 256 $QQ > $OUT/bench_4rank_gloo_one_gpu_rehearsal.json 2>> $OUT/err.log || exit 1
+  # stdout = the ONE compact line the driver records (<name>.line.json), --detail-out = the full record (<name>.json)
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out $OUT/bench_B1024.json > $OUT/bench_B1024.line.json 2> /dev/null || exit 1
+  echo "default line done: $(wc -c < $OUT/bench_B1024.line.json) bytes"
+  python3 bench.py --workload c3 $Q --detail-out $OUT/bench_c3_B1024.json > $OUT/bench_c3_B1024.line.json 2>> $OUT/err.log || exit 1
+  python3 bench.py --dtype fp8 $QQ --detail-out $OUT/bench_fp8_B1024.json > /dev/null 2>> $OUT/err.log || exit 1
+  python3 bench.py --force-exchange --buckets two $QQ --detail-out $OUT/bench_rccl_one_rank_two_buckets.json > /dev/null 2>> $OUT/err.log || exit 1
+  python3 bench.py --force-exchange --buckets layer $QQ --detail-out $OUT/bench_rccl_one_rank_layer_buckets.json > /dev/null 2>> $OUT/err.log || exit 1
+  python3 bench.py --force-exchange --buckets one $QQ --detail-out $OUT/bench_rccl_one_rank_one_bucket.json > /dev/null 2>> $OUT/err.log || exit 1
+  python3 bench.py $QQ --detail-out $OUT/bench_plain_after_rccl.json > /dev/null 2>> $OUT/err.log || exit 1
+  PMGT_BENCH_BACKEND=gloo PMGT_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 4 --steps 3 --warmup 1 --batch 256 $QQ --detail-out $OUT/bench_4rank_gloo_one_gpu_rehearsal.json > $OUT/bench_4rank_gloo_one_gpu_rehearsal.line.json 2>> $OUT/err.log || exit 1
   echo "lines done"
 fi
 copy_set() {      # copy_set <prof tag> <prefix>
@@ -42,6 +44,11 @@ if [ "$PART" = "c4" ]; then
   BENCH_EXTRA="--workload c4 --batch 256" bash tools/gpu_profile.sh ${TAG}c4 > $OUT/profile_c4.log 2>&1 || exit 1
   copy_set ${TAG}c4 "c4_"
   echo "c4 profile done"
+fi
+if [ "$PART" = "c4i" ]; then
+  BENCH_EXTRA="--workload c4 --batch 256 --intermediate 2048" bash tools/gpu_profile.sh ${TAG}c4i2048 > $OUT/profile_c4_i2048.log 2>&1 || exit 1
+  copy_set ${TAG}c4i2048 "c4_i2048_"
+  echo "c4 i = 4d profile done"
 fi
 if [ "$PART" = "small" ]; then
   cd /tmp && export TMPDIR=/tmp
