@@ -462,6 +462,9 @@ def main():
         eng.profile_begin()
         for i in range(nprof):
             trainer.train_step(staged[i % n_stage])
+        seq = eng.profile_sequence()
+        # (launch order of the phases of one step: tools/make_traffic.py aligns the dispatches of a counter run with it)
+        out["phase_sequence"] = seq[: len(seq) // nprof] if len(seq) % nprof == 0 else None
         prof = eng.profile_end()
         torch.cuda.synchronize()
         tot = sum(ms for _, ms in prof.values())

@@ -177,6 +177,8 @@ void pmgt_engine_set_grad_ready_callback(pmgt_engine* e, pmgt_grad_ready_fn cb, 
  * "name count total_ms" line per phase into buf.  Off by default. */
 int pmgt_profile_begin(pmgt_engine* e);
 int pmgt_profile_end(pmgt_engine* e, char* buf, int cap);
+/* the phases recorded so far, in launch order, one name per line (between begin and end; no wait) */
+int pmgt_profile_sequence(pmgt_engine* e, char* buf, int cap);
 
 /* dtype plumbing */
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);

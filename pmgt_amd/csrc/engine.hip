@@ -1572,6 +1572,16 @@ int pmgt_profile_end(pmgt_engine* e, char* buf, int cap) {
     return 0;
 }
 
+// The recorded phases in LAUNCH ORDER, one name per line (call between pmgt_profile_begin and pmgt_profile_end; does not wait for anything):
+// tools/make_traffic.py walks the dispatch order of a rocprofv3 counter run next to it to attribute a kernel's launches to phases.
+int pmgt_profile_sequence(pmgt_engine* e, char* buf, int cap) {
+    std::string out;
+    for (auto& r : e->prof.recs) { out += r.name; out += '\n'; }
+    PMGT_CHECK(buf && cap > (int)out.size(), -4, "pmgt_profile_sequence: %d bytes needed", (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {
     if (dtype != PMGT_DTYPE_F32) return cast_f32<bf16>(src, (bf16*)dst, n, (hipStream_t)stream);
     return cast_f32<float>(src, (float*)dst, n, (hipStream_t)stream);

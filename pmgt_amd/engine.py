@@ -406,6 +406,12 @@ class Engine:
     def profile_begin(self):
         _lib.check(self.lib.pmgt_profile_begin(self.h))
 
+    def profile_sequence(self):
+        """Phase names recorded since profile_begin(), in launch order (no wait; call before profile_end())."""
+        buf = C.create_string_buffer(1 << 18)
+        _lib.check(self.lib.pmgt_profile_sequence(self.h, buf, len(buf)))
+        return buf.value.decode().split()
+
     def profile_end(self) -> Dict[str, tuple]:
         """{phase: (launch groups, total ms)} measured with HIP events on the launch stream."""
         buf = C.create_string_buffer(1 << 16)

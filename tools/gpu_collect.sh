@@ -26,6 +26,7 @@ fi
 copy_set() {      # copy_set <prof tag> <prefix>
   cp gpurun_out/prof_$1/kernel_stats.txt $OUT/$2kernel_stats.txt
   cp gpurun_out/prof_$1/kt_bench.json $OUT/$2bench_under_rocprof.json
+  cp gpurun_out/prof_$1/detail.json $OUT/$2detail.json
   for f in gpurun_out/prof_$1/pmc_*.txt; do cp $f $OUT/$2$(basename $f | sed 's/pmc_fetch.txt/pmc_fetch_size.txt/; s/pmc_write.txt/pmc_write_size.txt/; s/pmc_fetch_6steps.txt/pmc_fetch_size_6steps.txt/; s/pmc_write_6steps.txt/pmc_write_size_6steps.txt/'); done
 }
 if [ "$PART" = "c2" ]; then

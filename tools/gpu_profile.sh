@@ -16,6 +16,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/pmc_write.err
 python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_fetch FETCH_SIZE > $OUT/pmc_fetch.txt 2>&1
 python3 $REPO/tools/summarize_rocprof.py pmc $OUT/pmc_write WRITE_SIZE > $OUT/pmc_write.txt 2>&1
+# the same two runs dispatch by dispatch (order = launch order), and the phase order of one step of the same configuration
+python3 $REPO/tools/summarize_rocprof.py pmcseq $OUT/pmc_fetch FETCH_SIZE > $OUT/pmc_fetch_seq.txt 2>&1
+python3 $REPO/tools/summarize_rocprof.py pmcseq $OUT/pmc_write WRITE_SIZE > $OUT/pmc_write_seq.txt 2>&1
+python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-batch-sweep --no-extra-workloads ${BENCH_EXTRA:-} --detail-out $OUT/detail.json > /dev/null 2> $OUT/detail.err
 # the same two counters over SIX steps: the whole-step traffic is the DIFFERENCE of the two runs divided by the three extra steps
 # (tools/make_traffic.py), so that set-up kernels -- launched once, or a multiple of the step count -- never count as step traffic
 PMC_ARGS_B="--steps 5 --warmup 1 --no-cpu-baseline --no-phase-profile --no-end-to-end --no-batch-sweep --no-extra-workloads ${BENCH_EXTRA:-}"

@@ -41,6 +41,67 @@ def parse(path, counts=None):
     return rows
 
 
+def phase_class(phase):
+    """Which kernels a bench phase launches, as (must contain any of, must not contain any of); None = not attributed."""
+    if phase.startswith("bwd.wgrad_"):
+        return (("gemm_tn",), ())
+    if phase.startswith(("fwd.gemm_", "bwd.dgrad_", "loss.gemm_")):
+        return (("gemm_",), ("gemm_tn",))
+    return {"fwd.qkvc_attention": (("qkvc_attn_fwd",), ()), "fwd.attention": (("attn_fwd",), ()),
+            "bwd.attention_wgrad": (("attn_bwd_wgrad",), ()), "bwd.attention": (("attn_bwd",), ("attn_bwd_wgrad",)),
+            "fwd.layernorm": (("ln_fwd",), ()), "bwd.layernorm": (("ln_bwd",), ()),
+            "fwd.embed_mix": (("embed_mix_fwd", "embed_tok8_fwd"), ()), "bwd.embed_mix": (("embed_mix_bwd", "embed_tok8_bwd"), ())}.get(phase)
+
+
+def read_seq(path):
+    rows = []
+    for line in open(path).read().splitlines():
+        parts = line.split("\t")
+        if len(parts) == 3:
+            rows.append((parts[2], float(parts[1])))
+    return rows
+
+
+def steps_of(rows):
+    """The dispatch list of a bench run cut into training steps: a step ends with its adamw_kernel; what precedes the first step's weight
+    mirror (table casts, parameter init) is dropped.  The first step is the warm-up (first-touch page faults): not used."""
+    steps, cur = [], []
+    for name, v in rows:
+        cur.append((name, v))
+        if "adamw_kernel" in name:
+            steps.append(cur)
+            cur = []
+    if steps:
+        first = next((i for i, (n, _) in enumerate(steps[0]) if "mirror_kernel" in n), 0)
+        steps[0] = steps[0][first:]
+    return steps
+
+
+def attribute(seq_path, phase_sequence):
+    """{phase: [[counter value per launch, in launch order] per timed step]} -- every phase record takes the next dispatch of its class."""
+    per_phase = {}
+    classed = [c for c in (phase_class(p) for p in set(phase_sequence)) if c]
+    in_class = lambda n, c: any(a in n for a in c[0]) and not any(b in n for b in c[1])
+    for step in steps_of(read_seq(seq_path))[1:]:
+        k, got = 0, {}
+        for ph in phase_sequence:
+            c = phase_class(ph)
+            if c is None:
+                continue
+            while k < len(step) and not in_class(step[k][0], c):
+                k += 1
+            if k == len(step):
+                raise RuntimeError(f"{seq_path}: no dispatch left for phase {ph}")
+            got.setdefault(ph, []).append(step[k])
+            k += 1
+        left = [n for n, _ in step[k:] if any(in_class(n, c) for c in classed)]
+        if left:
+            raise RuntimeError(f"{seq_path}: {len(left)} classed dispatches not attributed to a phase (first: {left[0]})")
+        for ph, lst in got.items():
+            per_phase.setdefault(ph, []).append(lst)
+    return per_phase
+
+
 PMC_STEPS = 3        # tools/gpu_profile.sh runs the counter passes with --steps 2 --warmup 1 ...
 PMC_STEPS_B = 6      # ... and once more with --steps 5 --warmup 1 (the *_6steps.txt summaries)
 
@@ -62,7 +123,31 @@ def main():
         step_kib = sum(2.0 * fetch[k] * (nf[k] // PMC_STEPS) + write.get(k, 0.0) * (nw.get(k, 0) // PMC_STEPS) for k in fetch)
         step_how = "launch count // 3 dispatches of every kernel per step (three-step counter run)"
     phases = {}
-    for ph, sub in PHASE_KERNELS.items():
+    # exact attribution when the set holds the per-dispatch lists and the phase order of a step: a kernel that serves several phases with
+    # different shapes (the d = 512 tiles: one weight-gradient kernel for four GEMM shapes) is then split by phase instead of averaged
+    by_phase = None
+    try:
+        detail = json.load(open(prefix + "_detail.json"))
+        seq = detail.get("phase_sequence")
+        if seq:
+            f_ph, w_ph = attribute(prefix + "_pmc_fetch_seq.txt", seq), attribute(prefix + "_pmc_write_seq.txt", seq)
+            by_phase = {}
+            for ph in f_ph:
+                # per launch slot of the phase (launch order inside a step): mean over the timed steps of 2 x FETCH + WRITE
+                n_l = len(f_ph[ph][0])
+                mbs, kern = [], f_ph[ph][0][0][0]
+                for j in range(n_l):
+                    fs = [st[j][1] for st in f_ph[ph] if len(st) == n_l]
+                    ws = [st[j][1] for st in w_ph[ph] if len(st) == n_l]
+                    mbs.append((2.0 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024.0 / 1e6)
+                srt = sorted(mbs)
+                by_phase[ph] = {"kernel": kern, "launches_per_step": n_l, "hbm_mb_per_launch": round(srt[len(srt) // 2], 1),
+                                "hbm_mb_by_launch": [round(x, 1) for x in mbs]}
+    except (OSError, KeyError, ValueError, RuntimeError) as ex:
+        print("per-phase attribution not available:", ex, file=sys.stderr)
+    if by_phase is not None:
+        phases = by_phase
+    for ph, sub in ([] if by_phase is not None else PHASE_KERNELS.items()):
         kf = next((k for k in fetch if sub in k), None)
         kw = next((k for k in write if sub in k), None)
         if kf is None or kw is None:
@@ -83,6 +168,18 @@ def main():
                 phases[ph]["valu_per_mfma"] = round(valu[kv] / mfma[kv], 1)
         except OSError:
             pass
+    if by_phase is not None:      # SQ counters stay per KERNEL (summaries by name): the matrix-pipe share of the kernel that served the phase
+        try:
+            busy, cu = parse(prefix + "_pmc_SQ_VALU_MFMA_BUSY_CYCLES.txt"), parse(prefix + "_pmc_SQ_BUSY_CU_CYCLES.txt")
+            valu, mfma = parse(prefix + "_pmc_SQ_INSTS_VALU.txt"), parse(prefix + "_pmc_SQ_INSTS_MFMA.txt")
+            for ent in phases.values():
+                k = ent["kernel"]
+                if cu.get(k, 0) > 0 and k in busy:
+                    ent["matrix_pipe_busy"] = round(busy[k] / (4.0 * cu[k]), 4)
+                if mfma.get(k, 0) > 0 and k in valu:
+                    ent["valu_per_mfma"] = round(valu[k] / mfma[k], 1)
+        except OSError:
+            pass
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_sources_sha
     wkey = sys.argv[3] if len(sys.argv) > 3 else "c2"
@@ -96,6 +193,9 @@ def main():
         "correction": "HBM bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE; counters in KiB",
         "step_hbm_gb": round(step_kib * 1024.0 / 1e9, 2),
         "step_hbm_gb_method": step_how,
+        "phase_attribution": ("per dispatch: the launch order of the counter run walked next to the engine's phase order (pmgt_profile_sequence); "
+                              "hbm_mb_per_launch = median over the phase's launches of a step (the shortcut layer's launches are smaller), "
+                              "hbm_mb_by_launch = each of them" if by_phase is not None else "kernel average (one kernel name per phase)"),
         "phases": phases,
     }
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json" if wkey == "c2" else f"traffic_{wkey}.json")

@@ -61,8 +61,22 @@ def pmc(d, counter):
         print(f"{n:112s} {c:10d} {v / c:16.1f}")
 
 
+def pmcseq(d, counter):
+    """Every dispatch of the run in dispatch order: "<dispatch id>\t<counter value>\t<kernel>" (tools/make_traffic.py attributes them to
+    the bench's phases by walking this list next to the engine's phase sequence)."""
+    rows = []
+    for f in find(d, "*counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter:
+                rows.append((int(row["Dispatch_Id"]), float(row["Counter_Value"]), short(row.get("Kernel_Name", "?"))))
+    for did, v, n in sorted(rows):
+        print(f"{did}\t{v:.1f}\t{n}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmcseq":
+        pmcseq(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3])
