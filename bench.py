@@ -462,13 +462,21 @@ def main():
         eng.profile_begin()
         for i in range(nprof):
             trainer.train_step(staged[i % n_stage])
-        seq = eng.profile_sequence()
+        recs = eng.profile_records()
+        seq = [n for n, _ in recs]
         # (launch order of the phases of one step: tools/make_traffic.py aligns the dispatches of a counter run with it)
         out["phase_sequence"] = seq[: len(seq) // nprof] if len(seq) % nprof == 0 else None
+        # per phase: the MEDIAN launch (the last layer's dense blocks run on the compacted rows only: one launch in L is a fraction of the
+        # others, and a mean over all of them would price a full launch's bytes / flops on less than a full launch's time)
+        med_ms = {}
+        for n, t in recs:
+            med_ms.setdefault(n, []).append(t)
+        med_ms = {n: float(np.median(v)) for n, v in med_ms.items()}
         prof = eng.profile_end()
         torch.cuda.synchronize()
         tot = sum(ms for _, ms in prof.values())
-        phases = {k: {"launches_per_step": c // nprof, "ms_per_step": round(ms / nprof, 4), "share": round(ms / tot, 4)}
+        phases = {k: {"launches_per_step": c // nprof, "ms_per_step": round(ms / nprof, 4), "share": round(ms / tot, 4),
+                      "median_launch_ms": round(med_ms[k], 5)}
                   for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out["phases"] = phases
         esz = 4 if args.dtype == "fp32" else 2
@@ -476,8 +484,7 @@ def main():
         vc = dead_branch_skipped(args, d, H, S)
         dom = next((k for k in phases if phase_work(k, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc) is not None), next(iter(phases)))
         w = phase_work(dom, M, d, I, S, H, 1536, 768, B * (S - 1), esz, vc)
-        cnt, ms = prof[dom]
-        avg_s = ms / cnt / 1e3
+        avg_s = med_ms[dom] / 1e3
         if w is not None:
             flops, byts = w
             peak_t = MFMA_F32_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
@@ -503,7 +510,7 @@ def main():
             if wk is None or len(top) == 3:
                 continue
             c_k, ms_k = prof[k]
-            t_k = ms_k / c_k / 1e3
+            t_k = med_ms[k] / 1e3
             fl, by = wk
             mf = fl > 0 and fl / (peak_t * 1e12) >= by / (HBM_PEAK_GBS * 1e9)
             ach = fl / t_k / 1e12 if mf else by / t_k / 1e9

@@ -179,6 +179,8 @@ int pmgt_profile_begin(pmgt_engine* e);
 int pmgt_profile_end(pmgt_engine* e, char* buf, int cap);
 /* the phases recorded so far, in launch order, one name per line (between begin and end; no wait) */
 int pmgt_profile_sequence(pmgt_engine* e, char* buf, int cap);
+/* the same records with their times, "name ms" per line in launch order (waits for the events; the records stay for pmgt_profile_end) */
+int pmgt_profile_records(pmgt_engine* e, char* buf, int cap);
 
 /* dtype plumbing */
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);

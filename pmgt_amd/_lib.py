@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "pmgt_last_error", "pmgt_abi_version", "pmgt_engine_create", "pmgt_engine_destroy", "pmgt_param_count",
     "pmgt_param_num_entries", "pmgt_param_entry", "pmgt_workspace_bytes", "pmgt_pretrain_step", "pmgt_encode_ids",
     "pmgt_encode_feats", "pmgt_encode_train", "pmgt_encode_backward", "pmgt_optimizer_step", "pmgt_profile_begin",
-    "pmgt_profile_end", "pmgt_profile_sequence", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_quantize_e4m3", "pmgt_dequantize_e4m3",
+    "pmgt_profile_end", "pmgt_profile_sequence", "pmgt_profile_records", "pmgt_cast_from_f32", "pmgt_cast_to_f32", "pmgt_quantize_e4m3", "pmgt_dequantize_e4m3",
     "pmgt_engine_set_grad_ready_callback", "pmgt_engine_set_option", "pmgt_engine_get_option",
 ]
 OPS_SYMBOLS = [
@@ -124,6 +124,7 @@ def hip():
     L.pmgt_profile_begin.argtypes = [vp]
     L.pmgt_profile_end.argtypes = [vp, C.c_char_p, i]
     L.pmgt_profile_sequence.argtypes = [vp, C.c_char_p, i]
+    L.pmgt_profile_records.argtypes = [vp, C.c_char_p, i]
     L.pmgt_cast_from_f32.argtypes = [i, vp, vp, i64, vp]
     L.pmgt_cast_to_f32.argtypes = [i, vp, vp, i64, vp]
     L.pmgt_op_gemm_nt.argtypes = [i, vp, i64, vp, vp, i64, vp, i64, i, i, i, vp, i, vp, i64, vp, i64, f, u32, vp, vp, u32, vp]

@@ -1581,6 +1581,23 @@ int pmgt_profile_sequence(pmgt_engine* e, char* buf, int cap) {
     memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 }
+// The same records with their event times, "name ms" per line, in launch order (waits for the events; the records stay for pmgt_profile_end):
+// a phase whose launches differ in size -- the last layer's dense blocks run on the compacted rows only -- is then priced on its median
+// launch instead of on a mean that the small launch pulls down.
+int pmgt_profile_records(pmgt_engine* e, char* buf, int cap) {
+    std::string out;
+    for (auto& r : e->prof.recs) {
+        PMGT_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        PMGT_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        char line[160];
+        snprintf(line, sizeof(line), "%s %.6f\n", r.name, (double)t);
+        out += line;
+    }
+    PMGT_CHECK(buf && cap > (int)out.size(), -4, "pmgt_profile_records: %d bytes needed", (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
 
 int pmgt_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {
     if (dtype != PMGT_DTYPE_F32) return cast_f32<bf16>(src, (bf16*)dst, n, (hipStream_t)stream);

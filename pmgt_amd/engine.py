@@ -412,6 +412,12 @@ class Engine:
         _lib.check(self.lib.pmgt_profile_sequence(self.h, buf, len(buf)))
         return buf.value.decode().split()
 
+    def profile_records(self):
+        """[(phase, ms)] of every launch group recorded since profile_begin(), in launch order (waits for the events; call before profile_end())."""
+        buf = C.create_string_buffer(1 << 20)
+        _lib.check(self.lib.pmgt_profile_records(self.h, buf, len(buf)))
+        return [(ln.split()[0], float(ln.split()[1])) for ln in buf.value.decode().splitlines()]
+
     def profile_end(self) -> Dict[str, tuple]:
         """{phase: (launch groups, total ms)} measured with HIP events on the launch stream."""
         buf = C.create_string_buffer(1 << 16)

@@ -135,13 +135,15 @@ def main():
             for ph in f_ph:
                 # per launch slot of the phase (launch order inside a step): mean over the timed steps of 2 x FETCH + WRITE
                 n_l = len(f_ph[ph][0])
-                mbs, kern = [], f_ph[ph][0][0][0]
+                mbs = []
                 for j in range(n_l):
                     fs = [st[j][1] for st in f_ph[ph] if len(st) == n_l]
                     ws = [st[j][1] for st in w_ph[ph] if len(st) == n_l]
                     mbs.append((2.0 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024.0 / 1e6)
                 srt = sorted(mbs)
-                by_phase[ph] = {"kernel": kern, "launches_per_step": n_l, "hbm_mb_per_launch": round(srt[len(srt) // 2], 1),
+                med = srt[len(srt) // 2]
+                kern = f_ph[ph][0][mbs.index(med)][0]        # the kernel of the median launch (the shortcut layer's small launch may take another)
+                by_phase[ph] = {"kernel": kern, "launches_per_step": n_l, "hbm_mb_per_launch": round(med, 1),
                                 "hbm_mb_by_launch": [round(x, 1) for x in mbs]}
     except (OSError, KeyError, ValueError, RuntimeError) as ex:
         print("per-phase attribution not available:", ex, file=sys.stderr)
