@@ -156,9 +156,13 @@ def phase_work(name, M, d, I, S, H, Fv, Ft, cap_rows, esz, vc=False):
     return table.get(name)
 
 
-def traffic_key(workload, intermediate, beta):
+DEFAULT_BATCH = {"c4": 256}      # the batch a workload's bench lines quote (everything else: 1 024)
+
+
+def traffic_key(workload, intermediate, beta, batch=None):
     """Name of the committed PMC summary (profiles/traffic[_<key>].json) that belongs to a bench configuration."""
-    return workload + (f"_i{intermediate}" if intermediate else "") + ("_beta1" if beta == 1.0 else "")
+    b = "" if batch is None or batch == DEFAULT_BATCH.get(workload, 1024) else f"_b{batch}"
+    return workload + (f"_i{intermediate}" if intermediate else "") + ("_beta1" if beta == 1.0 else "") + b
 
 
 def dead_branch_skipped(args, d, H, S):
@@ -525,7 +529,7 @@ def main():
     # this workload, else traffic stays null.
     if "roofline" in out:
         try:
-            wl = traffic_key(args.workload, args.intermediate, args.beta)
+            wl = traffic_key(args.workload, args.intermediate, args.beta, B)
             tname = "traffic.json" if wl == "c2" else f"traffic_{wl}.json"
             tr = json.load(open(os.path.join(ROOT, "profiles", tname)))
             fresh = tr.get("kernel_sources_sha") == kernel_sources_sha()       # measured on THESE kernels, else it is stale: null

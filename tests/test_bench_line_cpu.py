@@ -118,6 +118,8 @@ def test_traffic_key_names_the_committed_summaries():
     assert bench.traffic_key("c2", 1024, 0.5) == "c2_i1024"
     assert bench.traffic_key("c2", 0, 1.0) == "c2_beta1"
     assert bench.traffic_key("c4", 2048, 0.5) == "c4_i2048"
+    assert bench.traffic_key("c4", 0, 0.5, 256) == "c4" and bench.traffic_key("c4", 0, 0.5, 1024) == "c4_b1024"
+    assert bench.traffic_key("c2", 0, 0.5, 1024) == "c2" and bench.traffic_key("c2", 0, 0.5, 256) == "c2_b256"
 
 
 def test_rehearsal_line_at_world_8_is_one_short_line():

@@ -46,6 +46,11 @@ if [ "$PART" = "c4" ]; then
   copy_set ${TAG}c4 "c4_"
   echo "c4 profile done"
 fi
+if [ "$PART" = "c4b" ]; then
+  BENCH_EXTRA="--workload c4 --batch 1024" bash tools/gpu_profile.sh ${TAG}c4b1024 > $OUT/profile_c4_b1024.log 2>&1 || exit 1
+  copy_set ${TAG}c4b1024 "c4_b1024_"
+  echo "c4 B = 1024 profile done"
+fi
 if [ "$PART" = "c4i" ]; then
   BENCH_EXTRA="--workload c4 --batch 256 --intermediate 2048" bash tools/gpu_profile.sh ${TAG}c4i2048 > $OUT/profile_c4_i2048.log 2>&1 || exit 1
   copy_set ${TAG}c4i2048 "c4_i2048_"

@@ -71,6 +71,39 @@ def table(pre, title, traffic_file, rows=22, lds=False):
     return out
 
 
+def phase_table(traffic_file, detail_file, title):
+    """Per PHASE of the bench (profiles/traffic*.json: the counter runs' dispatches attributed to the engine's phase order, round 6): median
+    launch time from the bench's own HIP events, PMC bytes of the median launch, the algorithmic bytes / flops of bench.phase_work."""
+    if not (os.path.exists(traffic_file) and os.path.exists(detail_file)):
+        return []
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    tr, d = json.load(open(traffic_file)), json.load(open(detail_file))
+    if "per dispatch" not in tr.get("phase_attribution", ""):
+        return []
+    wl = d["config"]["workload"]
+    g = lambda key: int(re.search(key + r"=(\d+)", wl).group(1))
+    L, H, dd, I, S, B = g("L"), g("H"), g("d"), g("I"), g("S"), g("B")
+    M = 12 * B * S
+    vc = "beta 1," in wl
+    out = [f"### {title}: per phase (`{os.path.basename(traffic_file)}`, `{os.path.basename(detail_file)}`)\n",
+           "| phase | launches / step | median launch us | PMC MB (median launch) | algorithmic MB | PMC / algorithmic | TB/s (algorithmic) | TFLOP/s | matrix pipe busy |",
+           "|---|---|---|---|---|---|---|---|---|"]
+    for ph, p in d["phases"].items():
+        t = tr["phases"].get(ph)
+        w = bench.phase_work(ph, M, dd, I, S, H, 1536, 768, B * (S - 1), 2, vc)
+        if t is None or w is None or p["median_launch_ms"] <= 0:
+            continue
+        fl, by = w
+        if t["hbm_mb_per_launch"] < 0.5 * by / 1e6:       # the per-token model does not describe this launch (table mode: once per node; compacted rows)
+            continue
+        us = p["median_launch_ms"] * 1e3
+        out.append(f"| `{ph}` | {p['launches_per_step']} | {us:.1f} | {t['hbm_mb_per_launch']:.0f} | {by / 1e6:.0f} | {t['hbm_mb_per_launch'] / (by / 1e6):.2f} | "
+                   f"{by / 1e6 / us:.2f} | {fl / 1e6 / us:.0f} | {t.get('matrix_pipe_busy', '-')} |")
+    out.append("")
+    return out
+
+
 def main():
     pre = sys.argv[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(pre)))
@@ -79,18 +112,26 @@ def main():
         "# %s -- one MI355X, bf16, dropout 0.1\n" % d,
         "Files: `a_kernel_stats.txt` (`rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3`: 13 steps), `a_pmc_*.txt` (separate "
         "`--pmc` passes of 3 steps, and of 6 steps for `*_6steps.txt`: FETCH_SIZE / WRITE_SIZE in KiB per launch; SQ counters), the same behind "
-        "`a_c2_i1024_` (C2 with I = 4d), `a_c2_beta1_` (C2 at beta = 1) and `a_c4_` (C4 shapes, B = 256), `a_bench_*.json` (bench lines: the default "
+        "`a_c2_i1024_` (C2 with I = 4d), `a_c2_beta1_` (C2 at beta = 1), `a_c4_` (C4 shapes, B = 256), `a_c4_i2048_`, `a_c4_b1024_` where collected; `*_pmc_{fetch,write}_seq.txt` = the same counter runs dispatch by dispatch and `*_detail.json` = a bench record with the phase order of a step (round 6: per-phase attribution, `tools/make_traffic.py`); `a_bench_*.json` (bench lines: the default "
         "line with its `workloads`, C3 graph, C2 in fp8 mode, the one-rank RCCL runs, a 4-rank gloo rehearsal on one GPU), `a_kernel_stats_B32.txt` / "
-        "`_B256.txt` (the reference's own batch sizes). Collected by `tools/gpu_collect.sh <tag> lines | c2 | i4d | c4 | small` -> `tools/gpu_profile.sh`; "
+        "`_B256.txt` (the reference's own batch sizes). Collected by `tools/gpu_collect.sh <tag> lines | c2 | i4d | c4 | c4i | c4b | small` -> `tools/gpu_profile.sh`; "
         "`profiles/traffic*.json` come from these sets (`tools/make_traffic.py`), the tables of this file from `tools/make_profile_readme.py`, the "
         "notes behind them from `NOTES.md`; `trace_*.txt` and the A/B files are named in the notes.\n",
         "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md). Matrix pipe busy = "
         "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES). Per-launch HBM bytes are what the counters saw DURING the launch: the 256-MB Infinity "
         "Cache moves write-backs of one launch into the next, so a writer can show fewer bytes than it produced.\n"]
     out += table(pre + "_", "C2 (7 252 nodes, L4 H8 d256 I256 S32), B = 1 024 -- the headline", os.path.join(root, "traffic.json"))
+    out += phase_table(os.path.join(root, "traffic.json"), pre + "_detail.json", "C2")
     out += table(pre + "_c2_i1024_", "C2 with I = 4d = 1 024, B = 1 024 (bench `c2_i1024`)", os.path.join(root, "traffic_c2_i1024.json"), rows=14)
-    out += table(pre + "_c2_beta1_", "C2 at beta = 1 (bench `c2_beta1`: the vc_only kernels)", None, rows=8)
+    out += phase_table(os.path.join(root, "traffic_c2_i1024.json"), pre + "_c2_i1024_detail.json", "C2, I = 4d")
+    out += table(pre + "_c2_beta1_", "C2 at beta = 1 (bench `c2_beta1`: the vc_only kernels)", os.path.join(root, "traffic_c2_beta1.json"), rows=8)
+    out += phase_table(os.path.join(root, "traffic_c2_beta1.json"), pre + "_c2_beta1_detail.json", "C2, beta = 1")
     out += table(pre + "_c4_", "C4 shapes (10^6 nodes, L6 H8 d512 I512 S64), B = 256", os.path.join(root, "traffic_c4.json"), rows=16, lds=True)
+    out += phase_table(os.path.join(root, "traffic_c4.json"), pre + "_c4_detail.json", "C4 shapes")
+    out += table(pre + "_c4_i2048_", "C4 shapes with I = 4d = 2 048, B = 256 (bench `c4_i2048`)", os.path.join(root, "traffic_c4_i2048.json"), rows=12)
+    out += phase_table(os.path.join(root, "traffic_c4_i2048.json"), pre + "_c4_i2048_detail.json", "C4 shapes, I = 4d")
+    out += table(pre + "_c4_b1024_", "C4 shapes, B = 1 024 (bench `c4_bf16_b1024`)", os.path.join(root, "traffic_c4_b1024.json"), rows=10)
+    out += phase_table(os.path.join(root, "traffic_c4_b1024.json"), pre + "_c4_b1024_detail.json", "C4 shapes, B = 1 024")
     notes = os.path.join(d, "NOTES.md")
     if os.path.exists(notes):
         out.append(open(notes).read())
