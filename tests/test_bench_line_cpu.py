@@ -133,3 +133,26 @@ def test_rehearsal_line_at_world_8_is_one_short_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["rank_sum"] == 28.0 and len(lines[0]) < bench.LINE_BUDGET
+
+
+def test_committed_traffic_files_were_measured_on_these_kernels():
+    """bench.py quotes `roofline.traffic` only while profiles/traffic*.json carry the fingerprint of pmgt_amd/csrc: the committed files are the ones
+    of THIS tree (a kernel edit without a new counter run would silently turn every `traffic` in the line into null), they are attributed per phase
+    launch, and there is one for every configuration the default line quotes."""
+    sha = bench.kernel_sources_sha()
+    want = {"c2": ("traffic.json", 1024), "c2_i1024": ("traffic_c2_i1024.json", 1024), "c2_beta1": ("traffic_c2_beta1.json", 1024),
+            "c4": ("traffic_c4.json", 256), "c4_i2048": ("traffic_c4_i2048.json", 256), "c4_b1024": ("traffic_c4_b1024.json", 1024)}
+    for key, (name, batch) in want.items():
+        tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert tr["kernel_sources_sha"] == sha, (name, "re-run tools/gpu_collect.sh + tools/publish_profiles.sh on this tree")
+        assert tr.get("workload_key", tr["workload"]) == key and tr["batch"] == batch
+        assert "per dispatch" in tr["phase_attribution"] and tr["step_hbm_gb"] > 0
+        dom = max(tr["phases"].values(), key=lambda e: e["hbm_mb_per_launch"] * e["launches_per_step"])
+        assert len(dom["hbm_mb_by_launch"]) == dom["launches_per_step"] and dom["hbm_mb_per_launch"] > 100
+    # every child of the default line has a file under the key bench.py derives for it
+    for name, extra in bench.EXTRA_WORKLOADS:
+        if "fp8" in extra:
+            continue
+        arg = lambda flag, dflt: extra[extra.index(flag) + 1] if flag in extra else dflt
+        key = bench.traffic_key(arg("--workload", "c2"), int(arg("--intermediate", 0)), float(arg("--beta", 0.5)), int(arg("--batch", 1024)))
+        assert key in want, (name, key)
