@@ -234,6 +234,38 @@ def test_fused_qkvc_attention_in_the_engine_matches_unfused(name):
     assert rel < 1e-2, rel
 
 
+def test_phase_records_are_the_launch_order_of_the_step():
+    """pmgt_profile_sequence / pmgt_profile_records (round 6): the phases in LAUNCH order -- what tools/make_traffic.py walks next to a counter
+    run's dispatch order, and what bench.py takes a phase's median launch from.  The sequence is the forward's phases, then the losses, then
+    the backward's in reverse layer order; records carry one non-negative time per entry; the totals of profile_end() are their sums; a second
+    identical step records the identical sequence."""
+    case = gu.model_case("m3")
+    batch = dev_batch(case["batch"])
+    inj, _ = inject_for(case)
+    eng = make_engine(case, dtype="bf16", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    seqs = []
+    for _ in range(2):
+        eng.profile_begin()
+        eng.pretrain_step(batch, training=True, backward=True, nfr_inject=inj, want_hidden=False)
+        seq = eng.profile_sequence()
+        recs = eng.profile_records()
+        prof = eng.profile_end()
+        assert [n for n, _ in recs] == seq and all(t >= 0 for _, t in recs)
+        for name, (cnt, ms) in prof.items():
+            mine = [t for n, t in recs if n == name]
+            assert len(mine) == cnt and abs(sum(mine) - ms) <= 1e-3 * max(ms, 1e-3), name
+        seqs.append(seq)
+    assert seqs[0] == seqs[1]
+    seq = seqs[0]
+    assert seq[0] == "mirror"
+    fwd = [i for i, n in enumerate(seq) if n.startswith("fwd.")]
+    loss = [i for i, n in enumerate(seq) if n.startswith("loss.")]
+    bwd = [i for i, n in enumerate(seq) if n.startswith("bwd.")]
+    assert max(fwd) < min(bwd) and min(loss) > min(fwd) and max(loss) < max(bwd)
+    L = case["cfg"]["num_hidden_layers"]
+    assert seq.count("fwd.qkvc_attention") == L and seq.count("bwd.attention_wgrad") + seq.count("bwd.attention") == L
+
+
 @pytest.mark.parametrize("name,dtype", [("m1", "fp32"), ("m3", "fp32"), ("m3", "bf16")])
 def test_table_projection_mode_matches_per_token_projection(name, dtype):
     """Small graphs: the engine projects the whole feature table once and gathers projected rows by node id
